@@ -1,0 +1,61 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'transformer-quantization_amd')
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container')
+    for it in items:
+        if 'gpu' in it.keywords:
+            it.add_marker(skip)
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    meta = json.loads(str(z['meta'])) if 'meta' in z.files else None
+    return z, meta
+
+
+@pytest.fixture(scope='session')
+def golden_fake_quant():
+    return load_golden('fake_quant')
+
+
+@pytest.fixture(scope='session')
+def golden_estimators():
+    return load_golden('estimators')
+
+
+@pytest.fixture(scope='session')
+def golden_toy():
+    return load_golden('toy_model')
+
+
+@pytest.fixture(scope='session')
+def golden_adaround():
+    return load_golden('adaround')
