@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- fake-quant forward throughput on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the fixed-range quantize->clip->dequantize op (W8A8 activation quantizer,
+asymmetric 8-bit, per-tensor, range from the running-min/max estimator) over one batch of synthetic
+BERT-base hidden states [B, S, 768] bf16 that is already resident in HBM.  The op is called through
+the drop-in class API (QuantizedActivation -> QuantizationManager -> AsymmetricUniformQuantizer ->
+ctypes -> libtq_hip.so), not through a private fast path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--seq S] [--sweep]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): each rank owns its own
+[B, S, 768] shard (weak scaling, no data-path collective in the fixed-range forward).  The
+calibration phase before the timed region DOES exchange statistics: one fused MAX all-reduce of
+[-min; max] per quantizer call; its throughput is reported under "calibration".
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'transformer-quantization_amd')
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_ELEM = 4             # bf16 in + bf16 out: algorithmic bytes of K1
+D_MODEL = 768
+
+
+def make_hidden(B, S, device, seed, dtype=torch.bfloat16):
+    """Synthetic BERT-base hidden state: unit normal, embedding dims 308 and 381
+    scaled x20 on every token and x60 on the last token."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn(B, S, D_MODEL, generator=g, device=device, dtype=torch.float32)
+    for d in (308, 381):
+        x[..., d] *= 20.0
+        x[:, -1, d] *= 3.0
+    return x.to(dtype)
+
+
+def cpu_baseline(budget_s=12.0):
+    """The reference's PyTorch-CPU quantizer path (oracle port, bit-identical to the reference per
+    tests/test_oracle_golden.py), fp32, on this box's host cores.  Bounded sample of the same
+    workload: [64, 512, 768] hidden states, repeated for ~budget_s seconds."""
+    from oracle import tq_oracle as O
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1000)
+    x = torch.randn(64, 512, D_MODEL, generator=g)
+    x[..., 308] *= 20.0
+    x[..., 381] *= 20.0
+    delta, zf = O.asym_params_from_range(x.min(), x.max(), 8)
+
+    def run(nthreads, budget):
+        torch.set_num_threads(nthreads)
+        for _ in range(2):
+            O.fake_quant(x, delta, zf, 8, False)
+        times = []
+        t_end = time.perf_counter() + budget
+        while time.perf_counter() < t_end and len(times) < 200:
+            t0 = time.perf_counter()
+            O.fake_quant(x, delta, zf, 8, False)
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        return x.numel() / times[len(times) // 2] / 1e6, len(times)
+
+    v_all, reps = run(threads, budget_s * 0.7)
+    v_one, _ = run(1, budget_s * 0.3)
+    torch.set_num_threads(threads)
+    return {
+        'value': round(v_all, 1), 'unit': 'M elems/s', 'cores': threads, 'kind': 'port',
+        'sample': f'[64,512,768] fp32 hidden states ({x.numel()} elems), fixed-range asym 8-bit '
+                  f'fake-quant, median of {reps} passes, torch {torch.__version__} CPU',
+        'single_thread_value': round(v_one, 1),
+        'cpu_model': _cpu_model(), 'host_logical_cpus': os.cpu_count(),
+    }
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor()
+
+
+def timed_region(fn, steps, world):
+    """barrier + sync, K steps with a HIP event pair around each, sync + barrier.
+    -> (wall seconds for the K steps, mean kernel-side milliseconds per step)."""
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        starts[i].record()
+        fn()
+        ends[i].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    ev_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / steps
+    return wall, ev_ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=1024)
+    ap.add_argument('--seq', type=int, default=512)
+    ap.add_argument('--sweep', action='store_true', help='also time the SURVEY.md 8d shape sweep')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU (there is no CPU fallback in the product path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from quantization import _hip, distributed as tq_dist
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from quantization.base_quantized_classes import QuantizedActivation
+    assert _hip.backend().name == 'hip'
+    if world > 1:
+        tq_dist.enable()
+
+    B, S = args.batch, args.seq
+    x = make_hidden(B, S, device, seed=1000 + rank)
+    n_elems = x.numel()
+
+    qa = QuantizedActivation(act_method=QMethods.asymmetric_uniform, n_bits_act=8,
+                             act_range_method=RangeEstimators.running_minmax).to(device)
+    qa.quantized_acts()
+    qa.eval()
+
+    # ---- calibration (untimed for `value`; reported separately): estimate + quantize ----------
+    calib_batches = [x, make_hidden(B, S, device, seed=2000 + rank)]
+    for xb in calib_batches:
+        qa(xb)
+    cal_wall, cal_ms = timed_region(lambda: qa(x), max(4, min(args.steps, 20)), world)
+    cal_steps = max(4, min(args.steps, 20))
+    qa.activation_quantizer.fix_ranges()
+    del calib_batches
+
+    # ---- the hot path: fixed-range fake-quant forward -------------------------------------------
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            qa(x)
+        wall, ev_ms = timed_region(lambda: qa(x), args.steps, world)
+
+    if world > 1:
+        tmax = torch.tensor([wall, cal_wall], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall, cal_wall = float(tmax[0]), float(tmax[1])
+
+    total_elems = n_elems * world * args.steps
+    value = total_elems / wall / 1e6
+    kernel_s = ev_ms / 1e3
+    achieved = n_elems * BYTES_PER_ELEM / kernel_s / 1e9
+
+    out = {
+        'metric': 'M elems/sec fake-quant fwd (BERT-base act tensor); achieved HBM GB/s vs peak',
+        'value': round(value, 1),
+        'unit': 'M elems/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': round(wall / args.steps * 1e3, 4),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',   # arithmetic type of the path: fp32 register math on bf16 storage
+        'data': 'synthetic',
+        'config': {
+            'workload': f'BERT-base W8A8 per-tensor asym 8-bit activation fake-quant, '
+                        f'running-minmax calibrated, fixed-range fwd, hidden [{B},{S},768] bf16 '
+                        f'per GPU (BASELINE configs[1])',
+            'storage_dtype': 'bf16', 'elems_per_gpu_per_step': n_elems,
+            'parallelism': f'dp{world} (independent shards, no data-path collective)',
+        },
+        'roofline': {
+            'bound': 'hbm',
+            'achieved': round(achieved, 1),
+            'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'traffic': None,
+            'kernel': 'tq::fq_tensor<bf16>',
+            'kernel_ms': round(ev_ms, 4),
+            'algorithmic_bytes_per_launch': n_elems * BYTES_PER_ELEM,
+        },
+        'calibration': {
+            'what': 'estimate (tq_minmax -> range_update -> set_range) + quantize per step; '
+                    + ('one fused MAX all-reduce of [-min;max] per step over RCCL' if world > 1
+                       else 'single GPU, no collective'),
+            'value': round(n_elems * world * cal_steps / cal_wall / 1e6, 1),
+            'unit': 'M elems/s',
+            'ms_per_step': round(cal_wall / cal_steps * 1e3, 4),
+        },
+    }
+
+    if args.sweep and rank == 0:
+        sweep = []
+        for (b, s) in [(8, 128), (64, 128), (256, 128), (256, 512), (1024, 512)]:
+            xs = make_hidden(b, s, device, seed=7)
+            with torch.no_grad():
+                for _ in range(5):
+                    qa(xs)
+                _, ms = timed_region(lambda: qa(xs), 30, 1)
+            sweep.append({'shape': [b, s, 768], 'kernel_ms': round(ms, 4),
+                          'M_elems_s': round(xs.numel() / ms / 1e3, 1),
+                          'GBps': round(xs.numel() * BYTES_PER_ELEM / ms / 1e6, 1)})
+        out['sweep'] = sweep
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out['cpu_baseline'] = cpu_baseline()
+    elif rank == 0:
+        out['cpu_baseline'] = None
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

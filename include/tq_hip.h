@@ -1,0 +1,196 @@
+/*
+ * tq_hip.h -- C ABI of libtq_hip.so: the MI355X (gfx950) fake-quantization hot path.
+ *
+ * The reference (Qualcomm-AI-research/transformer-quantization) is pure Python/PyTorch and has
+ * no FFI of its own; the interface each entry point replaces is therefore a Python method of
+ * the reference's quantization/ package, cited per function as file:line (paths relative to
+ * the upstream repository root).  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add to call these from the reference's own classes.
+ *
+ * Conventions
+ *   - Every pointer named x/y/idx/delta/... is a DEVICE pointer (HBM) unless the comment says
+ *     "host".  The library never allocates, frees or synchronises: the caller supplies every
+ *     buffer, including workspaces whose size is returned by the *_workspace_bytes() helpers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All work
+ *     is enqueued on it and is re-entrant per stream.
+ *   - Return value: 0 on success, a negative TQ_E* code otherwise; tq_last_error() returns a
+ *     thread-local, human readable description of the last failure.  No C++ exception crosses
+ *     the ABI.
+ *   - Tensor layout: contiguous row-major.  Quantization parameters are selected per element
+ *     i (flat index) as  p = (i / inner) % n_params :
+ *         per-tensor                n_params = 1            (inner ignored)
+ *         per-embedding / axis=-1   n_params = d, inner = 1
+ *         per-channel (dim 0)       n_params = C, inner = numel / C
+ *         any other axis            n_params = shape[axis], inner = prod(shape[axis+1:])
+ *   - Numerics contract: all arithmetic in IEEE fp32 with true division
+ *     and round-half-to-even; bf16/fp16 storage is widened to fp32 in registers and the
+ *     dequantised value rounded (RNE) on store.  Integer indices are bit-exact with the
+ *     reference's CPU path; clamp propagates NaN like torch.clamp.
+ */
+#ifndef TQ_HIP_H
+#define TQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TQ_ABI_VERSION 1
+
+/* storage dtype of x / y */
+enum { TQ_F32 = 0, TQ_BF16 = 1, TQ_F16 = 2 };
+/* storage dtype of the optional integer-index output */
+enum { TQ_IDX_NONE = 0, TQ_IDX_F32 = 1, TQ_IDX_I8 = 2, TQ_IDX_U8 = 3, TQ_IDX_I16 = 4,
+       TQ_IDX_I32 = 5 };
+/* error codes */
+enum { TQ_OK = 0, TQ_EINVAL = -1, TQ_ELAUNCH = -2, TQ_EWORKSPACE = -3, TQ_EUNSUPPORTED = -4 };
+/* range-estimator update rules for tq_range_update */
+enum { TQ_EST_CURRENT = 0, TQ_EST_ALL = 1, TQ_EST_RUNNING = 2 };
+/* AdaRound relaxations (quantization/adaround/utils.py:63-76) */
+enum { TQ_ADA_SIGMOID = 0, TQ_ADA_HARD_SIGMOID = 1, TQ_ADA_SIGMOID_TEMP = 2 };
+
+typedef void* tq_stream_t;
+
+/* Quantizer description shared by the entry points below.  Mirrors the state of
+ * AsymmetricUniformQuantizer / SymmetricUniformQuantizer (quantization/quantizers.py:96-107,
+ * 306-308): the raw `_delta`, `_zero_float` and `_signed` buffers stay on the device and are
+ * turned into (scale, zero_point, int_min, int_max) inside the kernels, exactly as the
+ * `scale` / `zero_point` / `int_min` / `int_max` properties do (:132-153, :321-332), so no host
+ * synchronisation is needed to launch.                                                        */
+typedef struct tq_quantizer {
+  const float*   delta;        /* [n_params] raw _delta (log-domain value if log_domain)      */
+  const float*   zero_float;   /* [n_params] raw _zero_float, NULL for symmetric               */
+  const uint8_t* signed_flag;  /* 1 byte (_signed), symmetric only; NULL = unsigned            */
+  int32_t        n_bits;       /* 1..24                                                        */
+  int32_t        symmetric;    /* 0 = asymmetric_uniform, 1 = symmetric_uniform                */
+  int32_t        log_domain;   /* scale_domain == 'log' (scale = exp(delta))                   */
+  float          eps;          /* quantizers.py:96 (default 1e-8)                              */
+  uint64_t       n_params;     /* see layout note above                                        */
+  uint64_t       inner;
+} tq_quantizer;
+
+int tq_abi_version(void);
+const char* tq_last_error(void);
+
+/* ---- K1/K2/K3: fused quantize -> clip -> dequantize ---------------------------------------
+ * Replaces AsymmetricUniformQuantizer.forward / to_integer_forward and the symmetric subclass
+ * (quantization/quantizers.py:172-211, 291-349): 6 ATen kernels become one.
+ * y (same dtype as x) and idx are both optional but not both NULL.                           */
+int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtype, uint64_t n, int dtype,
+                      const tq_quantizer* q, tq_stream_t stream);
+
+/* STE backward of the same op (autograd through quantizers.py:12-19,
+ * 184-185, 209): dx = ((g * scale) * mask) / scale with mask = [int_min <= round(x/s)+zp <=
+ * int_max].  Per-tensor parameters only accumulate d_delta / d_zero_float when the pointers
+ * are non-NULL (fp32 [1] each, must be zeroed by the caller).                                  */
+int tq_fake_quant_bwd(const void* x, const void* grad_y, void* grad_x, float* grad_delta,
+                      float* grad_zero_float, uint64_t n, int dtype, const tq_quantizer* q,
+                      tq_stream_t stream);
+
+/* ---- K4/K5: min / max statistics ------------------------------------------------------------
+ * Replaces torch.min/torch.max and the transpose+view+min(-1)/max(-1) chains of the range
+ * estimators (quantization/range_estimators.py:82-85,114-116,118-130,142-143,153-160,178-207).
+ * out_min/out_max: fp32 [n_params].  Two launches: block partials into `workspace`, then a
+ * finalize kernel; deterministic (no atomics).                                                */
+size_t tq_minmax_workspace_bytes(uint64_t n, uint64_t n_params, uint64_t inner);
+int tq_minmax(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner,
+              float* out_min, float* out_max, void* workspace, size_t workspace_bytes,
+              tq_stream_t stream);
+
+/* ---- estimator state update -------------------------------------------------------------------
+ * CurrentMinMaxEstimator (incl. per-embedding-group fold and the range-sorted permutation,
+ * range_estimators.py:87-112), AllMinMaxEstimator (:162-167) and RunningMinMaxEstimator's EMA
+ * (:209-214) applied to fresh batch statistics.
+ *   new_min/new_max [n]  batch statistics (per embedding dim when n_groups > 0)
+ *   cur_min/cur_max [n]  estimator state, updated in place
+ *   initialised          0 on the first batch (state is overwritten)
+ *   momentum             python float of the reference (double): the kernel narrows
+ *                        (1 - momentum) and momentum to fp32 exactly as ATen does
+ *   n_groups             0 = none; otherwise n % n_groups == 0 and every dim receives the
+ *                        min/max of its group.  order (int64 [n], may be NULL) is
+ *                        argsort(ranges): group g holds dims order[g*gs .. (g+1)*gs).          */
+int tq_range_update(int mode, const float* new_min, const float* new_max, float* cur_min,
+                    float* cur_max, uint64_t n, int initialised, double momentum,
+                    uint64_t n_groups, const int64_t* order, tq_stream_t stream);
+
+/* PEG phase 1 (range_estimators.py:68-80): ranges = max - min per embedding dim; on later
+ * batches the reference stores 0.1*r + 0.9*r of the NEW ranges (quirk q4).                    */
+int tq_axis_ranges(const float* new_min, const float* new_max, float* ranges, uint64_t n,
+                   int first, tq_stream_t stream);
+
+/* ---- range -> quantizer parameters ---------------------------------------------------------
+ * AsymmetricUniformQuantizer.set_quant_range (quantizers.py:234-282) and
+ * SymmetricUniformQuantizer.set_quant_range (:334-344), same fp32 operation order.            */
+int tq_set_range_asym(const float* x_min, const float* x_max, uint64_t n, int n_bits, float eps,
+                      int log_domain, float* delta, float* zero_float, tq_stream_t stream);
+int tq_set_range_sym(const float* x_min, const float* x_max, uint64_t n, int n_bits, float eps,
+                     int log_domain, float* delta, uint8_t* signed_flag, tq_stream_t stream);
+
+/* ---- K7/K8: MSE range search: loss of many candidate quantizers in one pass ---------------------
+ * Replaces the per-candidate deepcopy + set_quant_range + fake-quant + (x-y)^2 + sum loop of
+ * MSE_Estimator (range_estimators.py:248-256, 287-294, 356-420) and apply_mse_init
+ * (adaround/adaround.py:160-178).
+ *   x          [rows, row_len] contiguous (rows = 1 for per-tensor, = channels for per_channel)
+ *   cand       fp32 [C,4] = (scale, zero_point, int_min, int_max) per candidate
+ *   loss       fp64 [rows, C]; this batch's sum of squared errors is ADDED to it
+ *   workspace  tq_mse_workspace_bytes(...)                                                      */
+size_t tq_mse_workspace_bytes(uint64_t rows, uint64_t row_len, uint64_t n_cand);
+int tq_mse_candidates(const void* x, uint64_t rows, uint64_t row_len, int dtype,
+                      const float* cand, uint64_t n_cand, double* loss, void* workspace,
+                      size_t workspace_bytes, tq_stream_t stream);
+
+/* K9: CrossEntropyEstimator.loss_fx (range_estimators.py:498-502) for all candidates:
+ * loss[c] += -sum softmax(x,dim=1) * log_softmax(Q_c(x),dim=1), x fp32 [rows, cols].          */
+int tq_xent_candidates(const float* x, uint64_t rows, uint64_t cols, const float* cand,
+                       uint64_t n_cand, double* loss, tq_stream_t stream);
+
+/* argmin over candidates + threshold lookup, on the device (replaces the numpy argmin and
+ * host->device copies at range_estimators.py:370-376, 405-420):
+ * cur_min[r] = thr_min[argmin_c loss[r,c]], cur_max likewise; ties -> lowest c (np.argmin).   */
+int tq_argmin_select(const double* loss, uint64_t rows, uint64_t n_cand, const float* thr_min,
+                     const float* thr_max, float* cur_min, float* cur_max, int64_t* best,
+                     tq_stream_t stream);
+
+/* ---- K10/K11/K13: AdaRound --------------------------------------------------------------------
+ * K10: AdaRoundQuantizer.to_integer_forward + dequantise (adaround/quantizer.py:46-90,
+ *      quantizers.py:209): w_q = scale * (clamp(floor(w/s) + r (+zp), lo, hi) - zp),
+ *      r = h(alpha) if soft else [alpha >= 0].  w, alpha, w_q fp32 [n].                         */
+int tq_adaround_fwd(const float* w, const float* alpha, float* w_q, uint64_t n,
+                    const tq_quantizer* q, int mode, int soft, float temperature,
+                    tq_stream_t stream);
+/* backward of K10 alone (what autograd produces for alpha): grad_alpha = grad_wq * scale *
+ * h'(alpha) * [lo <= floor(w/s) + h(alpha) (+zp) <= hi].  Used when an external torch optimizer
+ * owns alpha; the fused path below is what apply_adaround_to_layer runs.                        */
+int tq_adaround_bwd(const float* w, const float* alpha, const float* grad_wq, float* grad_alpha,
+                    uint64_t n, const tq_quantizer* q, int mode, float temperature,
+                    tq_stream_t stream);
+/* alpha initialisation such that h(alpha) = frac(w/s) (adaround/quantizer.py:57-71).          */
+int tq_adaround_init_alpha(const float* w, float* alpha, uint64_t n, const tq_quantizer* q,
+                           int mode, float temperature, tq_stream_t stream);
+/* K11: fused backward of K10 + rounding regulariser + Adam step on alpha
+ *      (adaround/utils.py:159-162, adaround/adaround.py:98-99,260; torch.optim.Adam defaults):
+ *      g = grad_wq * scale * h'(alpha) * [lo <= floor(w/s)+h(+zp) <= hi]
+ *          + reg_weight * d/dalpha (1 - |2h-1|^beta)           (reg_weight = 0 during warm-up)
+ *      then m,v,alpha updated in place; `step` is the 1-based Adam step count.
+ *      grad_alpha_out (optional) receives g.                                                      */
+int tq_adaround_bwd_adam(const float* w, const float* grad_wq, float* alpha, float* exp_avg,
+                         float* exp_avg_sq, float* grad_alpha_out, uint64_t n,
+                         const tq_quantizer* q, int mode, float temperature, float reg_weight,
+                         float beta, float lr, float adam_b1, float adam_b2, float adam_eps,
+                         int step, tq_stream_t stream);
+/* regulariser value: out[0] += weight * sum(1 - |2h(alpha)-1|^beta)   (fp64 accumulate).        */
+int tq_adaround_reg(const float* alpha, uint64_t n, int mode, float temperature, float beta,
+                    float weight, double* out, void* workspace, size_t workspace_bytes,
+                    tq_stream_t stream);
+size_t tq_reduce_workspace_bytes(uint64_t n);
+/* K13: reconstruction loss (adaround/utils.py:150): mse(pred,tgt,'none').sum(1).mean() for
+ *      fp32 [d0, d1, rest]; out[0] (fp64) is overwritten.                                         */
+int tq_recon_loss(const float* pred, const float* tgt, uint64_t d0, uint64_t d1, uint64_t rest,
+                  double* out, void* workspace, size_t workspace_bytes, tq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TQ_HIP_H */

@@ -13,7 +13,8 @@ LAYOUT_ARGS = {
 
 
 def t(a):
-    return torch.from_numpy(np.ascontiguousarray(a))
+    a = np.asarray(a)
+    return torch.from_numpy(a.copy() if a.ndim else np.array(a))   # keeps 0-D shapes
 
 
 def bf16_from_bits(bits):

@@ -1,0 +1,185 @@
+"""A backend double for CPU-only tests: same method surface as quantization._hip.HipBackend, but
+every call is answered by the CPU oracle.  It exists so the host-side logic of the drop-in classes
+(state machines, shape bookkeeping, candidate tables, distributed hooks) can be exercised on a box
+without a GPU.  It is test infrastructure and is never importable from the product package."""
+import numpy as np
+import torch
+
+from oracle import tq_oracle as O
+
+EST_CURRENT, EST_ALL, EST_RUNNING = 0, 1, 2
+_MODES = {0: 'learned_sigmoid', 1: 'learned_hard_sigmoid', 2: 'sigmoid_temp_decay'}
+
+
+class OracleBackend:
+    name = 'oracle-double'
+
+    def to_device_f32(self, v, like=None):
+        if torch.is_tensor(v):
+            return v.detach().float()
+        return torch.tensor(v, dtype=torch.float64).float()
+
+    def _quant(self, x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params,
+               inner):
+        sgn = bool(signed.item()) if signed is not None else False
+        xf = x.float()
+        dom = 'log' if log_domain else 'linear'
+        if n_params == 1:
+            return O.fake_quant(xf, delta.reshape(()), None if zero_float is None else
+                                zero_float.reshape(()), n_bits, symmetric, sgn, eps, dom)
+        outer = x.numel() // (n_params * inner)
+        xv = xf.reshape(outer, n_params, inner)
+        d = delta.reshape(1, n_params, 1)
+        z = None if zero_float is None else zero_float.reshape(1, n_params, 1)
+        idx, y = O.fake_quant(xv, d, z, n_bits, symmetric, sgn, eps, dom)
+        return idx.reshape(x.shape), y.reshape(x.shape)
+
+    def fake_quant(self, x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps,
+                   n_params, inner, want_y=True, idx_dtype=None):
+        idx, y = self._quant(x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps,
+                             n_params, inner)
+        return (y.to(x.dtype) if want_y else None,
+                idx.to(idx_dtype) if idx_dtype is not None else None)
+
+    def fake_quant_bwd(self, x, grad_y, delta, zero_float, signed, n_bits, symmetric, log_domain,
+                       eps, n_params, inner, param_grads=False):
+        sgn = bool(signed.item()) if signed is not None else False
+        with torch.enable_grad():
+            return self._bwd(x, grad_y, delta, zero_float, sgn, n_bits, symmetric, eps, param_grads)
+
+    def _bwd(self, x, grad_y, delta, zero_float, sgn, n_bits, symmetric, eps, param_grads):
+        _, dx, dd, dz = O.fake_quant_with_grads(x.float(), delta.detach(), None if zero_float is None
+                                                else zero_float.detach(), n_bits, symmetric, sgn, eps,
+                                                grad_out=grad_y.float())
+        return dx.to(x.dtype), (dd.reshape(1) if param_grads else None), (
+            dz.reshape(1) if (param_grads and dz is not None) else
+            (torch.zeros(1) if param_grads else None))
+
+    def minmax(self, x, n_params=1, inner=1):
+        xf = x.detach().float()
+        if n_params == 1:
+            return xf.min(), xf.max()
+        outer = x.numel() // (n_params * inner)
+        v = xf.reshape(outer, n_params, inner).permute(1, 0, 2).reshape(n_params, -1)
+        return v.min(-1)[0], v.max(-1)[0]
+
+    def range_update(self, mode, new_min, new_max, cur_min, cur_max, momentum=0.9, n_groups=0,
+                     order=None):
+        if n_groups:
+            gs = new_min.numel() // n_groups
+            perm = order if order is not None else torch.arange(new_min.numel())
+            m = new_min[perm].view(n_groups, gs).min(-1)[0].repeat_interleave(gs)
+            M = new_max[perm].view(n_groups, gs).max(-1)[0].repeat_interleave(gs)
+            new_min, new_max = torch.empty_like(m), torch.empty_like(M)
+            new_min[perm], new_max[perm] = m, M
+        if mode == EST_CURRENT or cur_min is None:
+            return new_min.clone(), new_max.clone()
+        if mode == EST_ALL:
+            return O.allminmax_update(cur_min, cur_max, new_min, new_max)
+        return O.running_update(cur_min, cur_max, new_min, new_max, momentum)
+
+    def axis_ranges(self, new_min, new_max, first):
+        r = new_max - new_min
+        return r if first else 0.1 * r + (1 - 0.1) * r
+
+    def argsort(self, v):
+        return torch.argsort(v)
+
+    def set_range_asym(self, x_min, x_max, n_bits, eps, log_domain):
+        return O.asym_params_from_range(self.to_device_f32(x_min), self.to_device_f32(x_max), n_bits,
+                                        eps, 'log' if log_domain else 'linear')
+
+    def set_range_sym(self, x_min, x_max, n_bits, eps, log_domain):
+        return O.sym_params_from_range(self.to_device_f32(x_min), self.to_device_f32(x_max), n_bits,
+                                       eps, 'log' if log_domain else 'linear')
+
+    # ---- searches: direct evaluation of the (scale, zp, lo, hi) table in fp64 ----------------
+    @staticmethod
+    def _table_quant(x, c):
+        s, zp, lo, hi = (float(v) for v in c)
+        s = torch.tensor(s, dtype=torch.float32)
+        xi = torch.clamp(torch.round(x / s) + zp, lo, hi)
+        return s * (xi - zp)
+
+    def mse_candidates(self, x, rows, cand, loss):
+        # fp32 sums in the reference's own order (range_estimators.py:250-256) so that the
+        # scipy-driven searches see bit-identical loss values in the CPU tests
+        xf = x.detach().float()
+        for ci in range(cand.shape[0]):
+            y = self._table_quant(xf, cand[ci])
+            per_row = torch.sum(((xf - y) ** 2).view(len(xf), -1), dim=1)
+            if rows == 1:
+                loss[0, ci] += float(torch.sum(per_row))
+            else:
+                loss[:, ci] += per_row.double()
+        return loss
+
+    def xent_candidates(self, x, cand, loss):
+        xf = x.detach().float().reshape(x.shape[0], -1)
+        for ci in range(cand.shape[0]):
+            y = self._table_quant(xf, cand[ci])
+            v = torch.sum(-torch.softmax(xf, 1) * torch.log_softmax(y, 1))
+            loss[0, ci] += v.double()
+        return loss
+
+    def argmin_select(self, loss, thr_min, thr_max):
+        best = torch.from_numpy(np.argmin(loss.numpy(), axis=1))
+        return thr_min[best].clone(), thr_max[best].clone(), best
+
+    def candidate_table(self, table_np, device):
+        return torch.from_numpy(np.ascontiguousarray(table_np))
+
+    def zeros_f64(self, shape, device):
+        return torch.zeros(shape, dtype=torch.float64)
+
+    # ---- AdaRound ---------------------------------------------------------------------------
+    def _ada_args(self, w, qargs):
+        delta, zf, signed, n_bits, symmetric, log_domain, eps, n_params, inner = qargs
+        sgn = bool(signed.item()) if signed is not None else False
+        if n_params > 1:
+            delta = delta.reshape([-1] + [1] * (w.dim() - 1))
+            zf = None if zf is None else zf.reshape([-1] + [1] * (w.dim() - 1))
+        return delta, zf, n_bits, symmetric, sgn, eps
+
+    def adaround_fwd(self, w, alpha, qargs, mode, soft, temperature):
+        delta, zf, n_bits, symmetric, sgn, eps = self._ada_args(w, qargs)
+        return O.ada_fake_quant(w.detach(), alpha.detach(), delta, zf, n_bits, symmetric, sgn,
+                                _MODES[mode], soft, eps, temperature)[1]
+
+    def adaround_init_alpha(self, w, qargs, mode, temperature):
+        delta, zf, n_bits, symmetric, sgn, eps = self._ada_args(w, qargs)
+        return O.ada_alpha_init(w.detach(), O.effective_scale(delta, eps), _MODES[mode], temperature)
+
+    def adaround_bwd(self, w, alpha, grad_wq, qargs, mode, temperature):
+        delta, zf, n_bits, symmetric, sgn, eps = self._ada_args(w, qargs)
+        with torch.enable_grad():
+            a = alpha.detach().clone().requires_grad_(True)
+            _, wq = O.ada_fake_quant(w.detach(), a, delta, zf, n_bits, symmetric, sgn, _MODES[mode],
+                                     True, eps, temperature)
+            wq.backward(grad_wq)
+        return a.grad
+
+    def adaround_bwd_adam(self, w, grad_wq, alpha, exp_avg, exp_avg_sq, qargs, mode, temperature,
+                          reg_weight, beta, lr, b1, b2, adam_eps, step, want_grad=False):
+        delta, zf, n_bits, symmetric, sgn, eps = self._ada_args(w, qargs)
+        with torch.enable_grad():
+            a = alpha.detach().clone().requires_grad_(True)
+            _, wq = O.ada_fake_quant(w.detach(), a, delta, zf, n_bits, symmetric, sgn, _MODES[mode],
+                                     True, eps, temperature)
+            obj = (wq * grad_wq).sum()
+            if reg_weight:
+                obj = obj + O.ada_round_reg(a, _MODES[mode], beta, reg_weight, temperature)
+            obj.backward()
+        g = a.grad
+        exp_avg.lerp_(g, 1 - b1)
+        exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        denom = (exp_avg_sq.sqrt() / (bc2 ** 0.5)).add_(adam_eps)
+        alpha.addcdiv_(exp_avg, denom, value=-(lr / bc1))
+        return g if want_grad else None
+
+    def adaround_reg(self, alpha, mode, temperature, beta, weight):
+        return O.ada_round_reg(alpha.detach(), _MODES[mode], beta, weight, temperature).double()
+
+    def recon_loss(self, pred, tgt):
+        return O.ada_rec_loss(pred.detach().float(), tgt.detach().float()).double()

@@ -1,0 +1,83 @@
+"""The C-ABI library loads on a CPU-only box and exports exactly what include/tq_hip.h declares
+(no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests.conftest import ROOT, PKG
+
+HEADER = os.path.join(ROOT, 'include', 'tq_hip.h')
+LIB = os.path.join(PKG, 'lib', 'libtq_hip.so')
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(tq_[a-z0-9_]+)\s*\(', src)))
+
+
+@pytest.fixture(scope='module')
+def lib_path():
+    if not os.path.exists(LIB):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('tq_build', os.path.join(PKG, 'build.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build(verbose=False)
+    return LIB
+
+
+def test_header_symbols_are_exported(lib_path):
+    declared = _declared()
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(lib_path)
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in tq_hip.h but not exported'
+    out = subprocess.check_output(['nm', '-D', '--defined-only', lib_path], text=True)
+    exported = sorted(set(re.findall(r' T (tq_[a-z0-9_]+)', out)))
+    assert exported == declared, (set(exported) ^ set(declared))
+
+
+def test_python_binding_covers_header(lib_path):
+    from quantization import _hip
+    assert sorted(_hip.SIGNATURES) == _declared()
+    lib = _hip.load_library()
+    assert lib.tq_abi_version() == 1
+    assert lib.tq_last_error() is not None
+
+
+def test_gfx950_code_object_present(lib_path):
+    blob = open(lib_path, 'rb').read()
+    assert b'gfx950' in blob
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from quantization import _hip
+    with pytest.raises(_hip.TQError):
+        _hip.load_library(str(tmp_path / 'nope.so'))
+
+
+def test_argument_validation_without_gpu(lib_path):
+    """Validation happens before any HIP call, so it is testable without a device."""
+    from quantization import _hip
+    lib = _hip.load_library()
+    q = _hip.tq_quantizer(None, None, None, 8, 0, 0, 1e-8, 1, 1)
+    rc = lib.tq_fake_quant_fwd(None, None, None, 0, 16, 0, ctypes.byref(q), None)
+    assert rc == -1 and b'NULL' in lib.tq_last_error()
+    assert lib.tq_minmax_workspace_bytes(1 << 20, 1, 1) > 0
+    assert lib.tq_minmax_workspace_bytes(1024 * 768, 768, 1) >= 2 * 768 * 4
+    assert lib.tq_mse_workspace_bytes(1, 786432, 100) >= 100 * 8
+
+
+def test_product_package_never_imports_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith('.py'):
+                txt = open(os.path.join(dirpath, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M) or 'tq_oracle' in txt:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

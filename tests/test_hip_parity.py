@@ -1,0 +1,308 @@
+"""GPU parity: the HIP path (through the drop-in classes, i.e. ctypes -> C ABI -> gfx950 kernels)
+against the committed golden vectors and against the CPU oracle on seeded inputs.
+
+Bars: integer indices bit-exact; dequantised floats bit-exact for fp32 (asserted) and within
+1e-5 relative where transcendental functions are involved (AdaRound, cross-entropy).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tq_oracle as O
+from tests._cases import fq_case, est_inputs, t, LAYOUT_ARGS
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def q():
+    from quantization import _hip
+    assert _hip.backend().name == 'hip'
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators, OptMethod
+    from quantization.quantization_manager import QuantizationManager
+    from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+    import types
+    return types.SimpleNamespace(**locals())
+
+
+def _manager(q, m, init='current_minmax', init_params=None):
+    la = LAYOUT_ARGS[m['layout']]
+    mgr = q.QuantizationManager(qmethod=q.QMethods[m['method']], init=q.RangeEstimators[init],
+                                per_channel=la['per_channel'], qparams=dict(n_bits=m['n_bits']),
+                                init_params=dict(init_params or {}))
+    if la['axis'] is not None:
+        q.set_act_quant_axis_and_groups(mgr, axis=la['axis'], n_groups=la['n_groups'],
+                                        permute=m['layout'].endswith('_perm'))
+    return mgr
+
+
+def test_golden_fake_quant_through_manager(q, golden_fake_quant):
+    z, meta = golden_fake_quant
+    for m in meta:
+        c = fq_case(z, m)
+        x = c['x'].to(DEV)
+        mgr = _manager(q, m)
+        if m['layout'].endswith('_perm'):
+            assert mgr(x) is x                                   # phase 1 passes x through
+            assert torch.equal(mgr.range_estimator.ranges.cpu(), c['ranges']), m
+            mgr.range_estimator.per_group_range_estimation = False
+        y = mgr(x)
+        est, qz = mgr.range_estimator, mgr.quantizer
+        assert torch.equal(est.current_xmin.cpu().reshape(-1), c['xmin'].reshape(-1)), m
+        assert torch.equal(est.current_xmax.cpu().reshape(-1), c['xmax'].reshape(-1)), m
+        assert torch.equal(qz._delta.cpu().reshape(-1), c['delta'].reshape(-1)), m
+        if c['zero_float'] is not None:
+            assert torch.equal(qz._zero_float.cpu().reshape(-1), c['zero_float'].reshape(-1)), m
+        if c['symmetric']:
+            assert qz.signed == m['signed']
+            assert (float(qz.int_min), float(qz.int_max)) == (m['int_min'], m['int_max'])
+        idx = qz.to_integer_forward(x)
+        assert torch.equal(idx.cpu(), c['idx']), m
+        if m['io'] == 'bf16':
+            assert y.dtype == torch.bfloat16
+            assert torch.equal(y.cpu(), c['y_bf16']), m
+        else:
+            assert torch.equal(y.cpu(), c['y']), m
+        mgr.fix_ranges()
+        assert torch.equal(mgr(x), y)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(1,), (7,), (3, 5, 24), (8, 128, 768), (2, 3, 4099), (64, 1000)])
+def test_fake_quant_vs_oracle_per_tensor(q, dtype, shape):
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 3).to(dtype)
+    for sym, n_bits, rng in [(False, 8, (-2.5, 7.0)), (True, 8, (-3.0, 2.0)), (True, 4, (0.0, 5.0)),
+                             (False, 4, (-1.0, 1.0)), (False, 16, (-9.0, 9.0))]:
+        if sym:
+            delta, signed = O.sym_params_from_range(*rng, n_bits)
+            zf, sgn = None, bool(signed)
+        else:
+            delta, zf = O.asym_params_from_range(*rng, n_bits)
+            signed, sgn = None, False
+        ref_idx, ref_y = O.fake_quant_lowp(x, delta, zf, n_bits, sym, sgn)
+        y, idx = be.fake_quant(x.to(DEV), delta.to(DEV), None if zf is None else zf.to(DEV),
+                               None if signed is None else signed.to(DEV), n_bits, sym, False,
+                               1e-8, 1, 1, idx_dtype=torch.int32)
+        assert torch.equal(idx.cpu().float(), ref_idx), (dtype, shape, sym, n_bits)
+        assert torch.equal(y.cpu(), ref_y), (dtype, shape, sym, n_bits)
+
+
+def test_fake_quant_unaligned_and_index_dtypes(q):
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(5)
+    base = (torch.randn(4099, generator=g) * 4).to(DEV)
+    x = base[1:]                       # 4-byte aligned only -> scalar fallback kernel
+    delta, zf = O.asym_params_from_range(-3.0, 5.0, 8)
+    ref_idx, ref_y = O.fake_quant(x.cpu(), delta, zf, 8, False)
+    for idt in (torch.float32, torch.uint8, torch.int16, torch.int32):
+        y, idx = be.fake_quant(x, delta.to(DEV), zf.to(DEV), None, 8, False, False, 1e-8, 1, 1,
+                               idx_dtype=idt)
+        assert torch.equal(y.cpu(), ref_y)
+        assert torch.equal(idx.cpu().float(), ref_idx)
+    dlt, sg = O.sym_params_from_range(-3.0, 5.0, 8)
+    ref_idx, _ = O.fake_quant(base.cpu(), dlt, None, 8, True, True)
+    _, idx = be.fake_quant(base, dlt.to(DEV), None, sg.to(DEV), 8, True, False, 1e-8, 1, 1,
+                           want_y=False, idx_dtype=torch.int8)
+    assert torch.equal(idx.cpu().float(), ref_idx)
+
+
+def test_special_values_nan_inf(q):
+    from quantization import _hip
+    x = torch.tensor([float('nan'), float('inf'), -float('inf'), 0.0, -0.0, 1e-30, 0.5, 1.5, 2.5,
+                      -0.5, 3e38], dtype=torch.float32)
+    delta, zf = O.asym_params_from_range(-4.0, 4.0, 8)
+    ref_idx, ref_y = O.fake_quant(x, delta, zf, 8, False)
+    y, idx = _hip.backend().fake_quant(x.to(DEV), delta.to(DEV), zf.to(DEV), None, 8, False, False,
+                                       1e-8, 1, 1, idx_dtype=torch.float32)
+    assert torch.equal(torch.isnan(idx.cpu()), torch.isnan(ref_idx))
+    ok = ~torch.isnan(ref_idx)
+    assert torch.equal(idx.cpu()[ok], ref_idx[ok])
+    assert torch.equal(y.cpu()[ok], ref_y[ok])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape,axis', [((8, 128, 768), 2), ((4, 16, 3072), 2), ((8, 768), 1),
+                                        ((5, 7, 24), 2), ((3, 40, 6), 1), ((6, 10), 0)])
+def test_minmax_and_axis_quant_vs_oracle(q, dtype, shape, axis):
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(shape[-1] + axis)
+    x = (torch.randn(*shape, generator=g) * torch.linspace(0.5, 4, shape[-1])).to(dtype)
+    xf = x.float()
+    inner = int(np.prod(shape[axis + 1:]))
+    mn, mx = be.minmax(x.to(DEV), shape[axis], inner)
+    rmn, rmx = O.minmax_axis(xf, axis)
+    assert torch.equal(mn.cpu(), rmn) and torch.equal(mx.cpu(), rmx)
+    tmn, tmx = be.minmax(x.to(DEV), 1, 1)
+    assert float(tmn) == float(xf.min()) and float(tmx) == float(xf.max())
+    delta, zf = O.asym_params_from_range(rmn, rmx, 8)
+    d2, z2 = be.set_range_asym(mn, mx, 8, 1e-8, False)
+    assert torch.equal(d2.cpu(), delta) and torch.equal(z2.cpu(), zf)
+    ref_idx, ref_y = O.fake_quant_lowp(x, delta, zf, 8, False, axis=axis)
+    y, idx = be.fake_quant(x.to(DEV), d2, z2, None, 8, False, False, 1e-8, shape[axis], inner,
+                           idx_dtype=torch.float32)
+    assert torch.equal(idx.cpu(), ref_idx)
+    assert torch.equal(y.cpu(), ref_y)
+
+
+def _check_trace(q, m, z):
+    k = m['k']
+    xs = [x.to(DEV) for x in est_inputs(z, m)]
+    ip = dict(m['init_params'])
+    golden_section = ip.get('opt_method') == 'golden_section'
+    if 'opt_method' in ip:
+        ip['opt_method'] = q.OptMethod[ip['opt_method']]
+    mgr = _manager(q, m, init=m['init'], init_params=ip)
+    for b, x in enumerate(xs):
+        y = mgr(x)
+        est = mgr.range_estimator
+        got_min = est.current_xmin.cpu().reshape(-1)
+        got_max = est.current_xmax.cpu().reshape(-1)
+        ref_min, ref_max = t(z[f'e{k}_xmin'][b]), t(z[f'e{k}_xmax'][b])
+        if golden_section:
+            # scipy owns the iterate sequence; the device loss differs from the reference's fp32
+            # sum in the last bits, so thresholds agree to the optimiser's tolerance only
+            assert torch.allclose(got_min, ref_min, rtol=2e-3, atol=1e-4), (m, b)
+            assert torch.allclose(got_max, ref_max, rtol=2e-3, atol=1e-4), (m, b)
+        elif m['init'] == 'cross_entropy':
+            assert torch.allclose(got_max, ref_max, rtol=1e-6), (m, b)
+            assert torch.allclose(got_min, ref_min, rtol=1e-6), (m, b)
+        else:
+            assert torch.equal(got_min, ref_min), (m, b, got_min, ref_min)
+            assert torch.equal(got_max, ref_max), (m, b, got_max, ref_max)
+            assert torch.equal(mgr.quantizer._delta.cpu().reshape(-1), t(z[f'e{k}_delta'][b])), (m, b)
+    if not golden_section and m['init'] != 'cross_entropy':
+        assert torch.equal(y.cpu(), t(z[f'e{k}_y_last'])), m
+    la = getattr(mgr.range_estimator, 'loss_array', None)
+    if la is not None and f'e{k}_loss_array' in z.files and not golden_section:
+        ref = z[f'e{k}_loss_array']
+        fin = np.isfinite(ref)
+        assert np.allclose(la[fin], ref[fin], rtol=2e-5, atol=1e-6), m
+        assert np.array_equal(np.isfinite(la), fin)
+
+
+def test_estimator_traces(q, golden_estimators):
+    z, meta = golden_estimators
+    for m in meta:
+        _check_trace(q, m, z)
+
+
+def test_permuted_peg_trace(q, golden_estimators):
+    z, _ = golden_estimators
+    xs = [t(b).to(DEV) for b in z['batches']]
+    mgr = q.QuantizationManager(qmethod=q.QMethods.asymmetric_uniform,
+                                init=q.RangeEstimators.current_minmax, qparams=dict(n_bits=8))
+    q.set_act_quant_axis_and_groups(mgr, axis=2, n_groups=4, permute=True)
+    for x in xs:
+        assert mgr(x) is x
+    assert torch.equal(mgr.range_estimator.ranges.cpu(), t(z['perm_ranges']))
+    mgr.range_estimator.per_group_range_estimation = False
+    y = mgr(xs[0])
+    assert torch.equal(mgr.range_estimator.current_xmin.cpu(), t(z['perm_xmin']))
+    assert torch.equal(mgr.range_estimator.current_xmax.cpu(), t(z['perm_xmax']))
+    assert torch.equal(y.cpu(), t(z['perm_y']))
+
+
+def test_mse_losses_vs_oracle_large_grid(q):
+    """1-D (101 candidates) and 2-D (8-bit: 20 x 64 x 2) searches on a BERT-shaped tensor:
+    same argmin as the oracle's per-candidate loop, losses within 1e-5 relative."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(4, 32, 96, generator=g)
+    x[..., 7] *= 15
+    for method, n_bits, C in (('symmetric_uniform', 8, 100), ('asymmetric_uniform', 8, 6),
+                              ('asymmetric_uniform', 4, 30)):
+        m = dict(method=method, n_bits=n_bits, layout='per_tensor')
+        mgr = _manager(q, m, init='MSE', init_params=dict(num_candidates=C))
+        mgr(x.to(DEV))
+        qs = O.QSpec(n_bits, method == 'symmetric_uniform')
+        s = O.MSESearch(qs, num_candidates=C)
+        rmin, rmax = s.step_batch(x)
+        got = mgr.range_estimator.loss_array
+        fin = np.isfinite(s.loss_array)
+        assert np.allclose(got[fin], s.loss_array[fin], rtol=1e-5), method
+        assert torch.equal(mgr.range_estimator.current_xmin.cpu(), rmin), method
+        assert torch.equal(mgr.range_estimator.current_xmax.cpu(), rmax), method
+
+
+def test_ste_backward_matches_autograd(q):
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(33, 65, generator=g) * 3)
+    go = torch.randn(33, 65, generator=g)
+    for method in ('asymmetric_uniform', 'symmetric_uniform'):
+        mgr = q.QuantizationManager(qmethod=q.QMethods[method], qparams=dict(n_bits=4),
+                                    x_min=-2.0, x_max=2.5)
+        qz = mgr.quantizer
+        sym = method == 'symmetric_uniform'
+        ref_y, ref_dx, ref_dd, ref_dz = O.fake_quant_with_grads(
+            x, qz._delta.cpu(), None if sym else qz._zero_float.cpu(), 4, sym,
+            signed=(qz.signed if sym else False), grad_out=go)
+        xd = x.to(DEV).requires_grad_(True)
+        mgr.learn_ranges()
+        y = mgr(xd)
+        y.backward(go.to(DEV))
+        assert torch.equal(y.detach().cpu(), ref_y)
+        assert torch.allclose(xd.grad.cpu(), ref_dx, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(qz._delta.grad.cpu(), ref_dd, rtol=1e-4, atol=1e-3), method
+        if not sym:
+            assert torch.allclose(qz._zero_float.grad.cpu(), ref_dz, rtol=1e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE.json's full size: [B, S, 768] bf16 hidden states
+# ------------------------------------------------------------------------------------------
+def test_full_size_properties(q):
+    B, S, D = 1024, 512, 768
+    torch.manual_seed(1000)
+    x = torch.randn(B, S, D, device=DEV, dtype=torch.bfloat16)
+    x[..., 308] *= 20
+    x[..., 381] *= 20
+    mgr = q.QuantizationManager(qmethod=q.QMethods.asymmetric_uniform,
+                                init=q.RangeEstimators.running_minmax, qparams=dict(n_bits=8))
+    y = mgr(x)
+    est, qz = mgr.range_estimator, mgr.quantizer
+    # statistics equal torch's own reductions
+    assert float(est.current_xmin) == float(x.min()) and float(est.current_xmax) == float(x.max())
+    mgr.fix_ranges()
+    # deterministic + idempotent: Q(Q(x)) == Q(x) once the grid is fixed
+    assert torch.equal(mgr(x), y)
+    assert torch.equal(mgr(y), y)
+    # indices live on the grid and reproduce y when dequantised
+    idx = qz.to_integer_forward(x)
+    assert float(idx.min()) >= 0 and float(idx.max()) <= 255
+    assert torch.equal(idx, torch.round(idx))
+    deq = (qz.scale * (idx - qz.zero_point)).to(torch.bfloat16)
+    assert torch.equal(deq, y)
+    # a slab of the big tensor agrees bit-for-bit with the CPU oracle
+    sl = x[5, :64].cpu()
+    ref_idx, ref_y = O.fake_quant_lowp(sl, qz._delta.cpu(), qz._zero_float.cpu(), 8, False)
+    assert torch.equal(idx[5, :64].cpu(), ref_idx)
+    assert torch.equal(y[5, :64].cpu(), ref_y)
+    # per-embedding statistics at full size: column-owned kernel == torch reductions
+    from quantization import _hip
+    mn, mx = _hip.backend().minmax(x, D, 1)
+    assert torch.equal(mn, x.view(-1, D).float().amin(0)) and torch.equal(mx, x.view(-1, D).float().amax(0))
+
+
+def test_empty_tensor(q):
+    from quantization import _hip
+    be = _hip.backend()
+    delta, zf = O.asym_params_from_range(-1.0, 1.0, 8)
+    y, _ = be.fake_quant(torch.empty(0, 768, device=DEV), delta.to(DEV), zf.to(DEV), None, 8, False,
+                         False, 1e-8, 1, 1)
+    assert y.shape == (0, 768)
+    with pytest.raises(_hip.TQError):
+        be.minmax(torch.empty(0, device=DEV), 1, 1)     # like torch.min of an empty tensor
+
+
+def test_cpu_tensor_is_refused(q):
+    from quantization import _hip
+    mgr = q.QuantizationManager(qmethod=q.QMethods.asymmetric_uniform, qparams=dict(n_bits=8))
+    with pytest.raises(_hip.TQError):
+        mgr(torch.randn(4, 4))

@@ -1,0 +1,355 @@
+"""Host-side logic of the drop-in classes on a CPU-only box.
+
+The HIP backend is replaced by tests/_oracle_backend.OracleBackend (the CPU oracle), so what is
+under test here is everything ABOVE the C ABI: state machines, buffer names/shapes, parameter
+layout inference, candidate-table construction, estimator bookkeeping, AdaRound loop, errors.
+"""
+import copy
+import json
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from tests._cases import fq_case, est_inputs, t, LAYOUT_ARGS
+from tests._oracle_backend import OracleBackend
+
+torch.set_num_threads(1)
+
+
+@pytest.fixture(autouse=True)
+def oracle_backend():
+    from quantization import _hip
+    prev = _hip.set_backend(OracleBackend())
+    yield
+    _hip.set_backend(prev)
+
+
+def _api():
+    from quantization.quantizers import QMethods, QuantizerNotInitializedError
+    from quantization.range_estimators import RangeEstimators, OptMethod, NoDataPassedError
+    from quantization.quantization_manager import QuantizationManager, Qstates
+    from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+    import types
+    return types.SimpleNamespace(**locals())
+
+
+def _manager(q, m, init='current_minmax', init_params=None):
+    la = LAYOUT_ARGS[m['layout']]
+    mgr = q.QuantizationManager(qmethod=q.QMethods[m['method']], init=q.RangeEstimators[init],
+                                per_channel=la['per_channel'], qparams=dict(n_bits=m['n_bits']),
+                                init_params=dict(init_params or {}))
+    if la['axis'] is not None:
+        q.set_act_quant_axis_and_groups(mgr, axis=la['axis'], n_groups=la['n_groups'],
+                                        permute=m['layout'].endswith('_perm'))
+    return mgr
+
+
+def test_golden_fake_quant_through_manager(golden_fake_quant):
+    q = _api()
+    z, meta = golden_fake_quant
+    for m in meta:
+        c = fq_case(z, m)
+        x = c['x']
+        mgr = _manager(q, m)
+        if m['layout'].endswith('_perm'):
+            assert mgr(x) is x
+            assert torch.equal(mgr.range_estimator.ranges, c['ranges'])
+            mgr.range_estimator.per_group_range_estimation = False
+        y = mgr(x)
+        est, qz = mgr.range_estimator, mgr.quantizer
+        assert torch.equal(est.current_xmin.reshape(-1), c['xmin'].reshape(-1)), m
+        assert torch.equal(est.current_xmax.reshape(-1), c['xmax'].reshape(-1)), m
+        assert torch.equal(qz._delta.reshape(-1), c['delta'].reshape(-1)), m
+        assert qz._delta.shape == c['delta'].shape, m           # [1,1,d] / [C,1] views like upstream
+        if c['zero_float'] is not None:
+            assert torch.equal(qz._zero_float.reshape(-1), c['zero_float'].reshape(-1)), m
+        assert torch.equal(qz.to_integer_forward(x), c['idx']), m
+        assert torch.equal(y, c['y_bf16'] if m['io'] == 'bf16' else c['y']), m
+        if c['symmetric']:
+            assert qz.signed == m['signed']
+            assert (float(qz.int_min), float(qz.int_max)) == (m['int_min'], m['int_max'])
+
+
+def test_estimator_traces(golden_estimators):
+    q = _api()
+    z, meta = golden_estimators
+    for m in meta:
+        k = m['k']
+        ip = dict(m['init_params'])
+        golden_section = ip.get('opt_method') == 'golden_section'
+        if 'opt_method' in ip:
+            ip['opt_method'] = q.OptMethod[ip['opt_method']]
+        mgr = _manager(q, m, init=m['init'], init_params=ip)
+        for b, x in enumerate(est_inputs(z, m)):
+            y = mgr(x)
+            est = mgr.range_estimator
+            gmin, gmax = est.current_xmin.reshape(-1), est.current_xmax.reshape(-1)
+            rmin, rmax = t(z[f'e{k}_xmin'][b]), t(z[f'e{k}_xmax'][b])
+            if golden_section or m['init'] == 'cross_entropy':
+                assert torch.allclose(gmin, rmin, rtol=2e-3, atol=1e-4), (m, b)
+                assert torch.allclose(gmax, rmax, rtol=2e-3, atol=1e-4), (m, b)
+            else:
+                assert torch.equal(gmin, rmin), (m, b)
+                assert torch.equal(gmax, rmax), (m, b)
+        if not golden_section and m['init'] != 'cross_entropy':
+            assert torch.equal(y, t(z[f'e{k}_y_last'])), m
+        la = getattr(mgr.range_estimator, 'loss_array', None)
+        if la is not None and f'e{k}_loss_array' in z.files and not golden_section:
+            ref = z[f'e{k}_loss_array']
+            assert la.shape == ref.shape, m
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(la), fin)
+            assert np.allclose(la[fin], ref[fin], rtol=1e-5, atol=1e-7), m
+
+
+def test_candidate_table_matches_reference_set_quant_range():
+    """candidate_params (numpy fp32) == oracle set_quant_range + scale/zero_point properties."""
+    from quantization.range_estimators import candidate_params
+    from oracle import tq_oracle as O
+    rng = np.random.RandomState(0)
+    neg = -np.abs(rng.randn(200)) * 5
+    pos = np.abs(rng.randn(200)) * 5
+    neg[:20] = 0.0
+    for n_bits in (2, 4, 8, 16):
+        for sym in (False, True):
+            tab = candidate_params(neg, pos, n_bits, sym)
+            for i in range(len(neg)):
+                if sym:
+                    d, s = O.sym_params_from_range(float(neg[i]), float(pos[i]), n_bits)
+                    lo, hi = O.grid_limits(n_bits, True, bool(s))
+                    exp = [float(O.effective_scale(d)), 0.0, lo, hi]
+                else:
+                    d, zf = O.asym_params_from_range(float(neg[i]), float(pos[i]), n_bits)
+                    exp = [float(O.effective_scale(d)), float(O.effective_zero_point(zf, n_bits)),
+                           0.0, 2.0 ** n_bits - 1]
+                assert tab[i].tolist() == [np.float32(v) for v in exp], (n_bits, sym, i)
+
+
+class ToyNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(24, 32)
+        self.act = nn.GELU()
+        self.ln = nn.LayerNorm(32)
+        self.fc2 = nn.Linear(32, 24)
+
+
+def _quant_toy(org, **qp):
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.base_quantized_classes import QuantizedActivation
+    from quantization.autoquant_utils import quantize_model
+
+    class QuantToy(QuantizedModel):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = quantize_model(org.fc1, **qp)
+            self.act = org.act
+            self.act_q = QuantizedActivation(**qp)
+            self.ln = quantize_model(org.ln, **qp)
+            self.fc2 = quantize_model(org.fc2, **qp)
+            self.res_q = QuantizedActivation(**qp)
+
+        def forward(self, x):
+            h = self.act_q(self.act(self.fc1(x)))
+            h = self.ln(h)
+            return self.res_q(self.fc2(h) + x)
+
+    return QuantToy()
+
+
+def test_toy_model_calibration_state_dict(golden_toy):
+    """pass_data_for_range_estimation + fix_ranges on a 2-layer QuantizedModel reproduces the
+    reference's state_dict (names, shapes, values) and output."""
+    q = _api()
+    from utils.utils import pass_data_for_range_estimation
+    z, _ = golden_toy
+    org = ToyNet()
+    org.load_state_dict({k[2:]: t(z[k]) for k in z.files if k.startswith('w_')})
+    qp = dict(method=q.QMethods.symmetric_uniform, act_method=q.QMethods.asymmetric_uniform,
+              n_bits=8, n_bits_act=8, weight_range_method=q.RangeEstimators.current_minmax,
+              act_range_method=q.RangeEstimators.running_minmax)
+    model = _quant_toy(org, **qp)
+    loader = [(t(b),) for b in z['loader']]
+    pass_data_for_range_estimation(loader, model, act_quant=True, weight_quant=True,
+                                   max_num_batches=3)
+    model.fix_ranges()
+    model.eval()
+    out = model(loader[3][0])
+    sd = model.state_dict()
+    names = json.loads(str(z['sd_names']))
+    assert len(names) == 48
+    for name in names:
+        assert name in sd, name
+        ref = torch.from_numpy(z['sd_' + name])
+        assert sd[name].shape == ref.shape, name
+        assert torch.equal(sd[name].cpu().to(ref.dtype), ref), name
+    assert torch.equal(out, t(z['out']))
+    # eval-mode weight cache is populated and invalidated like upstream
+    assert model.fc1.cached_params is not None
+    model.train()
+    assert model.fc1.cached_params is None
+    # state machine
+    for mod in model.modules():
+        if isinstance(mod, q.QuantizationManager):
+            assert mod.state == q.Qstates.fix_ranges
+
+
+def test_errors_and_states():
+    q = _api()
+    mgr = q.QuantizationManager(qmethod=q.QMethods.asymmetric_uniform, qparams=dict(n_bits=8))
+    with pytest.raises(q.QuantizerNotInitializedError):
+        mgr.fix_ranges()
+    with pytest.raises(q.QuantizerNotInitializedError):
+        _ = mgr.quantizer.delta
+    with pytest.raises(q.QuantizerNotInitializedError):
+        _ = q.QMethods.symmetric_uniform.cls(n_bits=8).signed
+    with pytest.raises(ValueError):
+        mgr.quantizer.set_quant_range(torch.zeros(3), torch.ones(3))   # vector on per-tensor
+    est = q.RangeEstimators.MSE.cls(quantizer=mgr.quantizer)
+    with pytest.raises(q.NoDataPassedError):
+        _ = est.step_size
+    with pytest.raises(NotImplementedError):
+        q.RangeEstimators.MSE.cls(quantizer=None)
+    x = torch.randn(4, 8)
+    mgr(x)
+    assert mgr.quantizer.is_initialized
+    mgr.fix_ranges()
+    d0 = mgr.quantizer._delta.clone()
+    mgr(x * 10)
+    assert torch.equal(mgr.quantizer._delta, d0)                  # fixed
+    mgr.estimate_ranges_train()
+    mgr.eval()
+    mgr(x * 10)
+    assert torch.equal(mgr.quantizer._delta, d0)                  # eval: frozen
+    mgr.train()
+    mgr(x * 10)
+    assert not torch.equal(mgr.quantizer._delta, d0)              # train: follows the data
+    mgr.reset_ranges()
+    assert not mgr.quantizer.is_initialized and mgr.state == q.Qstates.estimate_ranges
+    # fixed-range constructor
+    m2 = q.QuantizationManager(qmethod=q.QMethods.symmetric_uniform, qparams=dict(n_bits=4),
+                               x_min=-1.0, x_max=2.0)
+    assert m2.state == q.Qstates.fix_ranges and m2.range_estimator is None
+    assert m2.quantizer.signed is True and m2.quantizer.int_min == -8 and m2.quantizer.int_max == 7
+    y = m2(x)
+    assert y.shape == x.shape
+    assert q.QMethods.list() == ['symmetric_uniform', 'asymmetric_uniform']
+    assert q.RangeEstimators.list() == ['current_minmax', 'allminmax', 'running_minmax', 'MSE',
+                                        'cross_entropy']
+    # state_dict key names (checkpoint compatibility)
+    keys = set(mgr.state_dict().keys()) | set(m2.state_dict().keys())
+    assert 'quantizer._delta' in keys and 'quantizer._signed' in keys
+
+
+def test_quant_dict_hijack():
+    q = _api()
+    from quantization.base_quantized_classes import QuantizedActivation, FP32Acts
+    from utils.per_embd_quant_utils import hijack_act_quant
+    mods = {n: QuantizedActivation(n_bits_act=8) for n in 'abcde'}
+    qd = dict(a=4, b='fp32', c='per_embd', d='ng6', e='ngp3')
+    for n, m in mods.items():
+        hijack_act_quant(qd, n, m)
+    assert mods['a'].activation_quantizer.quantizer.n_bits == 4
+    assert isinstance(mods['b'].activation_quantizer, FP32Acts)
+    c = mods['c'].activation_quantizer
+    assert (c.axis, c.quantizer.axis, c.range_estimator.axis, c.n_groups) == (2, 2, 2, None)
+    d = mods['d'].activation_quantizer
+    assert d.n_groups == 6 and d.range_estimator.n_groups == 6
+    assert not d.range_estimator.per_group_range_estimation
+    assert mods['e'].activation_quantizer.range_estimator.per_group_range_estimation
+    with pytest.raises(NotImplementedError):
+        hijack_act_quant(dict(a='bogus'), 'a', QuantizedActivation())
+
+
+def test_adaround_quantizer_and_fused_loop(golden_adaround):
+    """AdaRoundQuantizer (alpha init, soft/hard) and the fused optimisation loop on the recorded
+    batch-index sequence track the reference's autograd + torch.optim.Adam trace."""
+    q = _api()
+    from quantization.autoquant_utils import QuantLinear
+    from quantization.adaround.quantizer import ADAROUND_QUANTIZER_MAP
+    from quantization.adaround.utils import AdaRoundMode, CombinedLoss, MODE_TO_LOSS_TYPE, \
+        AdaRoundTempDecayType
+    from quantization.adaround.adaround import FusedAlphaAdam, optimize_local_loss
+    z, meta = golden_adaround
+    for m in meta:
+        k = m['k']
+        layer = QuantLinear(16, 12, method=q.QMethods[m['method']], n_bits=4,
+                            weight_range_method=q.RangeEstimators.current_minmax)
+        layer.weight.data = t(z[f'a{k}_w']).clone()
+        layer.bias.data = t(z[f'a{k}_b']).clone()
+        layer.quantized_weights()
+        layer.caching = False
+        X, tgt = t(z[f'a{k}_X']), t(z[f'a{k}_tgt'])
+        with torch.no_grad():
+            layer(X[:4])
+        oq = layer.weight_quantizer.quantizer
+        assert torch.equal(oq._delta, t(z[f'a{k}_delta']))
+        wq = ADAROUND_QUANTIZER_MAP[oq.__class__](n_bits=oq.n_bits, scale_domain=oq.scale_domain,
+                                                  per_channel=oq.per_channel, eps=oq.eps)
+        for name in ('_delta', '_zero_float', '_signed'):
+            if hasattr(oq, name):
+                wq.register_buffer(name, getattr(oq, name))
+        layer.weight_quantizer.quantizer = wq
+        layer.weight_quantizer.fix_ranges()
+        wq.round_mode = AdaRoundMode[m['mode']]
+        wq.temperature = 20
+        wq.soft_targets = True
+        with torch.no_grad():
+            soft0 = wq(layer.weight)
+        assert torch.equal(wq.alpha.detach(), t(z[f'a{k}_alpha0'])), m
+        assert torch.equal(soft0, t(z[f'a{k}_wq_soft0'])), m
+        wq.soft_targets = False
+        with torch.no_grad():
+            assert torch.equal(wq(layer.weight), t(z[f'a{k}_wq_hard0'])), m
+            assert torch.allclose(wq.to_integer_forward(layer.weight), t(z[f'a{k}_idx_hard0']),
+                                  atol=1e-4), m
+        wq.soft_targets = True
+        loss_fn = CombinedLoss(quantizer=wq, loss_type=MODE_TO_LOSS_TYPE[wq.round_mode], weight=0.01,
+                               max_count=m['iters'], b_range=(20, 2), warmup=0.2,
+                               decay_type=AdaRoundTempDecayType.cosine, decay_shape=1.0,
+                               decay_start=0.0)
+        opt = FusedAlphaAdam(wq, lr=m['lr'])
+        batch_idx = z[f'a{k}_batch_idx']
+
+        class _IO:      # stands in for GetLayerInpOut: the cached I/O is (X, tgt) itself
+            def __call__(self, data):
+                return data, tgt[self.pos:self.pos + data.size(0)]
+        io = _IO()
+
+        def get_inp_out(data):
+            pos = int((X == data[0]).all(-1).all(-1).nonzero()[0])
+            return data, tgt[pos:pos + data.size(0)]
+
+        optimize_local_loss(layer, get_inp_out, X, opt, loss_fn, m['bs'], m['iters'],
+                            batch_indices=batch_idx)
+        ref_alpha = t(z[f'a{k}_alphas'][-1])
+        assert torch.allclose(wq.alpha.detach(), ref_alpha, rtol=1e-4, atol=1e-5), m
+        wq.soft_targets = False
+        with torch.no_grad():
+            assert torch.equal(wq(layer.weight), t(z[f'a{k}_wq_hard1'])), m
+
+
+def test_adaround_generic_autograd_path(golden_adaround):
+    """An external torch optimizer over quantizer.alpha (the reference's way of driving it) goes
+    through _AdaRoundFn's backward and reproduces the recorded gradients."""
+    q = _api()
+    from quantization.adaround.quantizer import ADAROUND_QUANTIZER_MAP
+    from quantization.adaround.utils import AdaRoundMode
+    z, meta = golden_adaround
+    m = meta[0]
+    k = m['k']
+    wq = ADAROUND_QUANTIZER_MAP[q.QMethods[m['method']].cls](n_bits=4)
+    wq.set_quant_range(t(z[f'a{k}_w']).min(), t(z[f'a{k}_w']).max())
+    assert torch.equal(wq._delta, t(z[f'a{k}_delta']))
+    wq.round_mode = AdaRoundMode[m['mode']]
+    wq.temperature = 20
+    wq.soft_targets = True
+    w, b = t(z[f'a{k}_w']), t(z[f'a{k}_b'])
+    X, tgt = t(z[f'a{k}_X']), t(z[f'a{k}_tgt'])
+    idx = torch.from_numpy(z[f'a{k}_batch_idx'][0])
+    out = torch.nn.functional.linear(X[idx], wq(w), b)
+    loss = torch.nn.functional.mse_loss(out, tgt[idx], reduction='none').sum(1).mean()
+    loss.backward()
+    assert torch.allclose(wq.alpha.grad, t(z[f'a{k}_grads'][0]), rtol=1e-5, atol=1e-7)

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Build libtq_hip.so (gfx950) in-tree with hipcc.  No torch involved: the library is plain C ABI.
+
+    python transformer-quantization_amd/build.py [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libtq_hip.so')
+OBJDIR = os.path.join(HERE, 'build')
+
+FLAGS = [
+    '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+    '-ffp-contract=off',            # bit-exact parity: never fuse mul+add into fma
+    '-fno-fast-math',
+    '-fhip-fp32-correctly-rounded-divide-sqrt',   # IEEE division (x / scale)
+    '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
+]
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hs.append(os.path.join(os.path.dirname(HERE), 'include', 'tq_hip.h'))
+    return hs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = _headers()
+    objs, procs = [], []
+    for src in _sources():
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f'hipcc failed on {src}')
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,273 @@
+// K10/K11/K13: AdaRound kernels for gfx950 (fp32 weights, like the reference).
+//
+//   ada_fwd_k      w_q = s * (clamp(floor(w/s) + r (+zp), lo, hi) - zp), r = h(alpha) | [alpha >= 0]
+//                  (reference adaround/quantizer.py:46-90 + quantizers.py:209): ~8 ATen kernels -> 1
+//   ada_init_k     alpha such that h(alpha) = frac(w/s)  (adaround/quantizer.py:57-71)
+//   ada_bwd_adam_k autograd through ada_fwd + rounding regulariser (adaround/utils.py:159-162)
+//                  + torch.optim.Adam step on alpha (adaround/adaround.py:98-99, 260): ~25 -> 1,
+//                  28 B/element (read g, w, alpha, m, v; write alpha, m, v)
+//   ada_reg_k      value of the regulariser; recon_k: mse(pred,tgt,'none').sum(1).mean()
+#include <algorithm>
+
+#include "tq_device.h"
+#include "tq_host.h"
+
+namespace tq {
+
+// python-double constants of adaround/quantizer.py:27-34 as ATen narrows them for fp32 tensors
+constexpr float kZeta = 1.1f;
+constexpr float kGamma = -0.1f;
+constexpr float kStretch = (float)(1.1 - (-0.1));   // zeta - gamma evaluated in double, then fp32
+
+__device__ __forceinline__ float sigmoidf_(float a) { return 1.0f / (1.0f + expf(-a)); }
+
+// h(alpha) and dh/dalpha
+__device__ __forceinline__ float ada_h(float a, int mode, float temp, float* dh) {
+  if (mode == TQ_ADA_SIGMOID) {
+    const float s = sigmoidf_(a);
+    if (dh) *dh = s * (1.0f - s);
+    return s;
+  }
+  if (mode == TQ_ADA_HARD_SIGMOID) {
+    const float s = sigmoidf_(a);
+    const float u = s * kStretch + kGamma;
+    if (dh) *dh = (u >= 0.0f && u <= 1.0f) ? kStretch * (s * (1.0f - s)) : 0.0f;   // clamp mask is inclusive
+    return clamp_nanprop(u, 0.0f, 1.0f);
+  }
+  const float s = sigmoidf_(a / temp);
+  if (dh) *dh = (s * (1.0f - s)) / temp;
+  return s;
+}
+
+__device__ __forceinline__ uint64_t par_index(const tq_quantizer& q, uint64_t i) {
+  return q.n_params == 1 ? 0 : (i / q.inner) % q.n_params;
+}
+
+__global__ __launch_bounds__(kBlock) void ada_fwd_k(const float* __restrict__ w, const float* __restrict__ alpha,
+                                                    float* __restrict__ out, uint64_t n, tq_quantizer q, int mode,
+                                                    int soft, float temp) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const QP p = make_qp(q, par_index(q, i));
+    const float fl = floorf(w[i] / p.scale);
+    const float a = alpha[i];
+    const float r = soft ? ada_h(a, mode, temp, nullptr) : (a >= 0.0f ? 1.0f : 0.0f);
+    float xi = fl + r;
+    if (!q.symmetric) xi += p.zp;
+    xi = clamp_nanprop(xi, p.lo, p.hi);
+    out[i] = q_dequant(xi, p);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ada_init_k(const float* __restrict__ w, float* __restrict__ alpha, uint64_t n,
+                                                     tq_quantizer q, int mode, float temp) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const QP p = make_qp(q, par_index(q, i));
+    const float x = w[i] / p.scale;
+    const float rest = x - floorf(x);
+    float a;
+    if (mode == TQ_ADA_HARD_SIGMOID) {
+      a = -logf((kZeta - rest) / (rest - kGamma));                 // hard_logit, quantizer.py:32-34
+    } else {
+      const float pr = clamp_nanprop(rest, 1e-16f, (float)(1.0 - 1e-16));
+      a = -logf(1.0f / pr - 1.0f);                                 // logit, quantizer.py:22-24
+      if (mode == TQ_ADA_SIGMOID_TEMP) a = temp * a;
+    }
+    alpha[i] = a;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ada_bwd_k(const float* __restrict__ w, const float* __restrict__ alpha,
+                                                    const float* __restrict__ g_wq, float* __restrict__ g_alpha,
+                                                    uint64_t n, tq_quantizer q, int mode, float temp) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const QP p = make_qp(q, par_index(q, i));
+    float dh;
+    const float h = ada_h(alpha[i], mode, temp, &dh);
+    float xi = floorf(w[i] / p.scale) + h;
+    if (!q.symmetric) xi += p.zp;
+    const bool in = (xi >= p.lo) && (xi <= p.hi);
+    g_alpha[i] = in ? (g_wq[i] * p.scale) * dh : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ada_bwd_adam_k(const float* __restrict__ w, const float* __restrict__ g_wq,
+                                                         float* __restrict__ alpha, float* __restrict__ m,
+                                                         float* __restrict__ v, float* __restrict__ g_out, uint64_t n,
+                                                         tq_quantizer q, int mode, float temp, float reg_w, float beta,
+                                                         float lr, float b1, float b2, float adam_eps, float bc1,
+                                                         float bc2_sqrt) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const QP p = make_qp(q, par_index(q, i));
+    const float a = alpha[i];
+    float dh;
+    const float h = ada_h(a, mode, temp, &dh);
+    float xi = floorf(w[i] / p.scale) + h;
+    if (!q.symmetric) xi += p.zp;
+    const bool in = (xi >= p.lo) && (xi <= p.hi);
+    // d loss / d alpha through w_q = s * (x_int - zp)
+    float g = in ? (g_wq[i] * p.scale) * dh : 0.0f;
+    if (reg_w != 0.0f) {
+      // d/dalpha [ reg_w * (1 - (2|h - 0.5|)^beta) ]
+      const float c = h - 0.5f;
+      const float u = fabsf(c) * 2.0f;
+      const float sgn = c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f);
+      const float dpow = (u == 0.0f && beta >= 1.0f) ? 0.0f : beta * powf(u, beta - 1.0f);
+      g += -reg_w * dpow * 2.0f * sgn * dh;
+    }
+    if (g_out) g_out[i] = g;
+    // torch.optim.Adam (no weight decay / amsgrad)
+    const float mi = m[i] + (g - m[i]) * (1.0f - b1);       // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (1.0f - b2) * g * g;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + adam_eps;
+    alpha[i] = a - (lr / bc1) * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+// block partial sums -> ws[blockIdx.x]; finalize adds/sets out[0]
+__global__ __launch_bounds__(kBlock) void ada_reg_k(const float* __restrict__ alpha, uint64_t n, int mode, float temp,
+                                                    float beta, double* __restrict__ ws) {
+  __shared__ double s_w[kBlock / kWave];
+  double acc = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const float h = ada_h(alpha[i], mode, temp, nullptr);
+    acc += (double)(1.0f - powf(fabsf(h - 0.5f) * 2.0f, beta));
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kBlock / kWave; ++k) t += s_w[k];
+    ws[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sqdiff_k(const float* __restrict__ a, const float* __restrict__ b, uint64_t n,
+                                                   double* __restrict__ ws) {
+  __shared__ double s_w[kBlock / kWave];
+  double acc = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const float d = a[i] - b[i];
+    acc += (double)(d * d);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kBlock / kWave; ++k) t += s_w[k];
+    ws[blockIdx.x] = t;
+  }
+}
+
+__global__ void reduce_final_k(const double* __restrict__ ws, uint32_t nb, double scale, int accumulate,
+                               double* __restrict__ out) {
+  __shared__ double s_w[kBlock / kWave];
+  double acc = 0.0;
+  for (uint32_t i = threadIdx.x; i < nb; i += kBlock) acc += ws[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kBlock / kWave; ++k) t += s_w[k];
+    out[0] = accumulate ? out[0] + t * scale : t * scale;
+  }
+}
+
+static unsigned ew_grid(uint64_t n) {
+  return (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, kBlock), 1), kMaxGrid);
+}
+
+static int check_mode(int mode, float temp, const char* who) {
+  if (mode < TQ_ADA_SIGMOID || mode > TQ_ADA_SIGMOID_TEMP) return set_error(TQ_EINVAL, "%s: unknown round mode %d", who, mode);
+  if (mode == TQ_ADA_SIGMOID_TEMP && !(temp > 0.0f)) return set_error(TQ_EINVAL, "%s: temperature must be > 0", who);
+  return TQ_OK;
+}
+
+}  // namespace tq
+
+using namespace tq;
+
+extern "C" int tq_adaround_fwd(const float* w, const float* alpha, float* w_q, uint64_t n, const tq_quantizer* q,
+                               int mode, int soft, float temperature, tq_stream_t stream) {
+  TQ_REQUIRE(w && alpha && w_q, "tq_adaround_fwd: NULL pointer");
+  if (int e = check_quantizer(q, n, "tq_adaround_fwd")) return e;
+  if (int e = check_mode(mode, temperature, "tq_adaround_fwd")) return e;
+  if (n == 0) return TQ_OK;
+  hipLaunchKernelGGL(ada_fwd_k, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, alpha, w_q, n, *q,
+                     mode, soft, temperature);
+  return check_launch("ada_fwd_k");
+}
+
+extern "C" int tq_adaround_init_alpha(const float* w, float* alpha, uint64_t n, const tq_quantizer* q, int mode,
+                                      float temperature, tq_stream_t stream) {
+  TQ_REQUIRE(w && alpha, "tq_adaround_init_alpha: NULL pointer");
+  if (int e = check_quantizer(q, n, "tq_adaround_init_alpha")) return e;
+  if (int e = check_mode(mode, temperature, "tq_adaround_init_alpha")) return e;
+  if (n == 0) return TQ_OK;
+  hipLaunchKernelGGL(ada_init_k, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, alpha, n, *q, mode,
+                     temperature);
+  return check_launch("ada_init_k");
+}
+
+extern "C" int tq_adaround_bwd(const float* w, const float* alpha, const float* grad_wq, float* grad_alpha, uint64_t n,
+                               const tq_quantizer* q, int mode, float temperature, tq_stream_t stream) {
+  TQ_REQUIRE(w && alpha && grad_wq && grad_alpha, "tq_adaround_bwd: NULL pointer");
+  if (int e = check_quantizer(q, n, "tq_adaround_bwd")) return e;
+  if (int e = check_mode(mode, temperature, "tq_adaround_bwd")) return e;
+  if (n == 0) return TQ_OK;
+  hipLaunchKernelGGL(ada_bwd_k, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, alpha, grad_wq,
+                     grad_alpha, n, *q, mode, temperature);
+  return check_launch("ada_bwd_k");
+}
+
+extern "C" int tq_adaround_bwd_adam(const float* w, const float* grad_wq, float* alpha, float* exp_avg,
+                                    float* exp_avg_sq, float* grad_alpha_out, uint64_t n, const tq_quantizer* q,
+                                    int mode, float temperature, float reg_weight, float beta, float lr,
+                                    float adam_b1, float adam_b2, float adam_eps, int step, tq_stream_t stream) {
+  TQ_REQUIRE(w && grad_wq && alpha && exp_avg && exp_avg_sq, "tq_adaround_bwd_adam: NULL pointer");
+  TQ_REQUIRE(step >= 1, "tq_adaround_bwd_adam: step must be >= 1");
+  if (int e = check_quantizer(q, n, "tq_adaround_bwd_adam")) return e;
+  if (int e = check_mode(mode, temperature, "tq_adaround_bwd_adam")) return e;
+  if (n == 0) return TQ_OK;
+  // bias corrections in double like python, narrowed once (torch computes them as python floats)
+  const double bc1 = 1.0 - pow((double)adam_b1, (double)step);
+  const double bc2 = 1.0 - pow((double)adam_b2, (double)step);
+  hipLaunchKernelGGL(ada_bwd_adam_k, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq, alpha,
+                     exp_avg, exp_avg_sq, grad_alpha_out, n, *q, mode, temperature, reg_weight, beta, lr, adam_b1,
+                     adam_b2, adam_eps, (float)bc1, (float)sqrt(bc2));
+  return check_launch("ada_bwd_adam_k");
+}
+
+extern "C" size_t tq_reduce_workspace_bytes(uint64_t n) { return (size_t)kMaxGrid * sizeof(double); }
+
+extern "C" int tq_adaround_reg(const float* alpha, uint64_t n, int mode, float temperature, float beta, float weight,
+                               double* out, void* workspace, size_t workspace_bytes, tq_stream_t stream) {
+  TQ_REQUIRE(alpha && out, "tq_adaround_reg: NULL pointer");
+  TQ_REQUIRE(workspace && workspace_bytes >= (size_t)kMaxGrid * sizeof(double), "tq_adaround_reg: workspace too small");
+  if (int e = check_mode(mode, temperature, "tq_adaround_reg")) return e;
+  if (n == 0) return TQ_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned g = ew_grid(n);
+  hipLaunchKernelGGL(ada_reg_k, dim3(g), dim3(kBlock), 0, st, alpha, n, mode, temperature, beta, static_cast<double*>(workspace));
+  hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(kBlock), 0, st, static_cast<const double*>(workspace), g, (double)weight, 1, out);
+  return check_launch("tq_adaround_reg");
+}
+
+extern "C" int tq_recon_loss(const float* pred, const float* tgt, uint64_t d0, uint64_t d1, uint64_t rest, double* out,
+                             void* workspace, size_t workspace_bytes, tq_stream_t stream) {
+  TQ_REQUIRE(pred && tgt && out, "tq_recon_loss: NULL pointer");
+  TQ_REQUIRE(d0 >= 1 && d1 >= 1 && rest >= 1, "tq_recon_loss: empty tensor");
+  TQ_REQUIRE(workspace && workspace_bytes >= (size_t)kMaxGrid * sizeof(double), "tq_recon_loss: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint64_t n = d0 * d1 * rest;
+  const unsigned g = ew_grid(n);
+  hipLaunchKernelGGL(sqdiff_k, dim3(g), dim3(kBlock), 0, st, pred, tgt, n, static_cast<double*>(workspace));
+  // sum over dim 1, mean over the remaining d0 * rest positions
+  hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(kBlock), 0, st, static_cast<const double*>(workspace), g,
+                     1.0 / (double)(d0 * rest), 0, out);
+  return check_launch("tq_recon_loss");
+}

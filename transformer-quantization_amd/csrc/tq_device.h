@@ -1,0 +1,182 @@
+// Device-side helpers shared by the gfx950 kernels of libtq_hip.so.
+// Wave = 64 lanes, 16-byte vector memory ops, fp32 register math (see include/tq_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/tq_hip.h"
+
+namespace tq {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;          // 4 waves, one per SIMD
+constexpr int kMaxGrid = 256 * 8;    // 256 CUs x 8 resident 256-thread blocks
+
+// ------------------------------------------------------------------ quantizer parameters
+// (scale, zero_point, int_min, int_max) exactly as the reference's properties compute them
+// from the raw buffers: quantizers.py:132-153 (asym) and :321-332 (sym).
+struct QP {
+  float scale, zp, lo, hi;
+};
+
+__device__ __forceinline__ float grid_top(int n_bits) {
+  // 2.0 ** n_bits - 1 evaluated in double like the python float, then narrowed to fp32
+  return (float)(ldexp(1.0, n_bits) - 1.0);
+}
+
+__device__ __forceinline__ float clamp_nanprop(float v, float lo, float hi) {
+  // torch.clamp semantics: NaN stays NaN (both comparisons are false)
+  v = v < lo ? lo : v;
+  v = v > hi ? hi : v;
+  return v;
+}
+
+__device__ __forceinline__ QP make_qp(const tq_quantizer& q, uint64_t p) {
+  QP r;
+  const float d = q.delta[p];
+  r.scale = q.log_domain ? expf(d) : (d < q.eps ? q.eps : d);    // quantizers.py:142-147
+  if (q.symmetric) {
+    const bool sgn = q.signed_flag != nullptr && q.signed_flag[0] != 0;
+    r.zp = 0.0f;                                                  // :330-332
+    r.lo = sgn ? -(float)ldexp(1.0, q.n_bits - 1) : 0.0f;         // :321-323
+    r.hi = grid_top(q.n_bits - (sgn ? 1 : 0));                    // :325-328
+  } else {
+    r.lo = 0.0f;                                                  // :132-135
+    r.hi = grid_top(q.n_bits);                                    // :137-140
+    r.zp = clamp_nanprop(rintf(q.zero_float[p]), r.lo, r.hi);     // :149-153
+  }
+  return r;
+}
+
+// x_int = clamp(round(x / scale) + zp, lo, hi)   (quantizers.py:184-185)
+__device__ __forceinline__ float q_index(float x, const QP& p) {
+  return clamp_nanprop(rintf(x / p.scale) + p.zp, p.lo, p.hi);
+}
+// y = scale * (x_int - zp)                        (quantizers.py:209)
+__device__ __forceinline__ float q_dequant(float xi, const QP& p) {
+  return p.scale * (xi - p.zp);
+}
+
+// ------------------------------------------------------------------ storage <-> fp32
+template <int DT> struct Store;   // DT = TQ_F32 / TQ_BF16 / TQ_F16
+
+template <> struct Store<TQ_F32> {
+  typedef float elem_t;
+  static constexpr int kVec = 4;   // elements per 16-byte vector
+  static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, v[i]);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[4]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(uint32_t, f[i]);
+    return v;
+  }
+  static __device__ __forceinline__ float load1(const elem_t* p) { return *p; }
+  static __device__ __forceinline__ void store1(elem_t* p, float f) { *p = f; }
+};
+
+template <> struct Store<TQ_BF16> {
+  typedef uint16_t elem_t;
+  static constexpr int kVec = 8;
+  static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x2 t = {f[2 * i], f[2 * i + 1]};
+      v[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
+    }
+    return v;
+  }
+  static __device__ __forceinline__ float load1(const elem_t* p) {
+    return __builtin_bit_cast(float, (uint32_t)(*p) << 16);
+  }
+  static __device__ __forceinline__ void store1(elem_t* p, float f) {
+    *p = __builtin_bit_cast(uint16_t, (__bf16)f);
+  }
+};
+
+template <> struct Store<TQ_F16> {
+  typedef uint16_t elem_t;
+  static constexpr int kVec = 8;
+  static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f16x2 h = __builtin_bit_cast(f16x2, v[i]);
+      f[2 * i] = (float)h[0];
+      f[2 * i + 1] = (float)h[1];
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f16x2 h = {(_Float16)f[2 * i], (_Float16)f[2 * i + 1]};
+      v[i] = __builtin_bit_cast(uint32_t, h);
+    }
+    return v;
+  }
+  static __device__ __forceinline__ float load1(const elem_t* p) {
+    return (float)__builtin_bit_cast(_Float16, *p);
+  }
+  static __device__ __forceinline__ void store1(elem_t* p, float f) {
+    *p = __builtin_bit_cast(uint16_t, (_Float16)f);
+  }
+};
+
+// streaming (read-once / write-once) 16-byte accesses
+__device__ __forceinline__ u32x4 ld_stream(const u32x4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
+
+// ------------------------------------------------------------------ index output
+template <int IT> struct Idx;
+template <> struct Idx<TQ_IDX_F32> { typedef float t; static __device__ __forceinline__ t cv(float f) { return f; } };
+template <> struct Idx<TQ_IDX_I8>  { typedef int8_t t; static __device__ __forceinline__ t cv(float f) { return (int8_t)(int)f; } };
+template <> struct Idx<TQ_IDX_U8>  { typedef uint8_t t; static __device__ __forceinline__ t cv(float f) { return (uint8_t)(int)f; } };
+template <> struct Idx<TQ_IDX_I16> { typedef int16_t t; static __device__ __forceinline__ t cv(float f) { return (int16_t)(int)f; } };
+template <> struct Idx<TQ_IDX_I32> { typedef int32_t t; static __device__ __forceinline__ t cv(float f) { return (int32_t)f; } };
+
+// ------------------------------------------------------------------ wave / block reductions
+// torch.min / torch.max propagate NaN; so do these.
+__device__ __forceinline__ float min_nanprop(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
+__device__ __forceinline__ float max_nanprop(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b > a ? b : a)); }
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min_nanprop(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max_nanprop(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace tq

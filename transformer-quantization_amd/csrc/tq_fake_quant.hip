@@ -1,0 +1,334 @@
+// K1/K2/K3: fused quantize -> clip -> dequantize for gfx950 (MI355X).
+//
+// One pass over HBM: 16-byte vector loads (8 x bf16 / 4 x fp32 per lane), everything else in
+// registers, 16-byte vector stores.  Replaces the 6 un-fused ATen kernels (~12 sweeps) behind
+// AsymmetricUniformQuantizer.forward (reference quantization/quantizers.py:172-211).
+//
+// Kernel family
+//   fq_tensor : one (scale, zp) for the whole tensor; parameters live in SGPRs.
+//   fq_axis   : parameters indexed by the LAST axis (per-embedding / PEG); the per-column table
+//               (scale, zp) is staged once per block in LDS; lanes read their 8 columns with
+//               ds_read_b128.
+//   fq_rows   : parameters constant along contiguous rows of `inner` elements (per-channel
+//               weights, any non-last axis); one row per blockIdx.y, SGPR parameters.
+//   fq_scalar : element-wise fallback for unaligned pointers / odd shapes.
+#include <algorithm>
+
+#include "tq_device.h"
+#include "tq_host.h"
+
+namespace tq {
+
+template <int N, typename T> struct alignas(N * sizeof(T)) PackN { T e[N]; };
+
+template <int V>
+__device__ __forceinline__ void store_idx(void* idx, int idx_dtype, uint64_t off, const float (&xi)[V]) {
+  switch (idx_dtype) {  // wave-uniform
+    case TQ_IDX_F32: { PackN<V, float> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.e[j] = xi[j];
+      *reinterpret_cast<PackN<V, float>*>(static_cast<float*>(idx) + off) = o; break; }
+    case TQ_IDX_I8: { PackN<V, int8_t> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.e[j] = (int8_t)(int)xi[j];
+      *reinterpret_cast<PackN<V, int8_t>*>(static_cast<int8_t*>(idx) + off) = o; break; }
+    case TQ_IDX_U8: { PackN<V, uint8_t> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.e[j] = (uint8_t)(int)xi[j];
+      *reinterpret_cast<PackN<V, uint8_t>*>(static_cast<uint8_t*>(idx) + off) = o; break; }
+    case TQ_IDX_I16: { PackN<V, int16_t> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.e[j] = (int16_t)(int)xi[j];
+      *reinterpret_cast<PackN<V, int16_t>*>(static_cast<int16_t*>(idx) + off) = o; break; }
+    default: { PackN<V, int32_t> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.e[j] = (int32_t)xi[j];
+      *reinterpret_cast<PackN<V, int32_t>*>(static_cast<int32_t*>(idx) + off) = o; break; }
+  }
+}
+
+__device__ __forceinline__ void store_idx1(void* idx, int idx_dtype, uint64_t off, float xi) {
+  switch (idx_dtype) {
+    case TQ_IDX_F32: static_cast<float*>(idx)[off] = xi; break;
+    case TQ_IDX_I8: static_cast<int8_t*>(idx)[off] = (int8_t)(int)xi; break;
+    case TQ_IDX_U8: static_cast<uint8_t*>(idx)[off] = (uint8_t)(int)xi; break;
+    case TQ_IDX_I16: static_cast<int16_t*>(idx)[off] = (int16_t)(int)xi; break;
+    default: static_cast<int32_t*>(idx)[off] = (int32_t)xi; break;
+  }
+}
+
+// one 16-byte vector: widen, quantize, (store indices), dequantize, narrow
+template <int DT, bool HAS_IDX>
+__device__ __forceinline__ u32x4 fq_vec(const u32x4& in, const QP& p, void* idx, int idx_dtype, uint64_t elem_off) {
+  constexpr int V = Store<DT>::kVec;
+  float f[V];
+  Store<DT>::unpack(in, f);
+#pragma unroll
+  for (int j = 0; j < V; ++j) f[j] = q_index(f[j], p);
+  if (HAS_IDX) store_idx<V>(idx, idx_dtype, elem_off, f);
+#pragma unroll
+  for (int j = 0; j < V; ++j) f[j] = q_dequant(f[j], p);
+  return Store<DT>::pack(f);
+}
+
+// ------------------------------------------------------------------------------ per tensor
+template <int DT, bool HAS_IDX, bool NT>
+__global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x, u32x4* __restrict__ y,
+                                                    void* __restrict__ idx, int idx_dtype, uint64_t n,
+                                                    tq_quantizer q) {
+  constexpr int V = Store<DT>::kVec;
+  constexpr int U = 4;
+  const QP p = make_qp(q, 0);
+  const uint64_t n_vec = n / V;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+
+  for (; i + (U - 1) * stride < n_vec; i += U * stride) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? ld_stream(x + i + u * stride) : x[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u32x4 o = fq_vec<DT, HAS_IDX>(v[u], p, idx, idx_dtype, (i + u * stride) * V);
+      if (y) { if (NT) st_stream(y + i + u * stride, o); else y[i + u * stride] = o; }
+    }
+  }
+  for (; i < n_vec; i += stride) {
+    const u32x4 o = fq_vec<DT, HAS_IDX>(x[i], p, idx, idx_dtype, i * V);
+    if (y) y[i] = o;
+  }
+  // ragged tail (< V elements)
+  const uint64_t tail0 = n_vec * V;
+  if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
+    typedef typename Store<DT>::elem_t E;
+    const uint64_t k = tail0 + threadIdx.x;
+    const float xi = q_index(Store<DT>::load1(reinterpret_cast<const E*>(x) + k), p);
+    if (HAS_IDX) store_idx1(idx, idx_dtype, k, xi);
+    if (y) Store<DT>::store1(reinterpret_cast<E*>(y) + k, q_dequant(xi, p));
+  }
+}
+
+// ------------------------------------------------------------------------------ last axis
+// x viewed as [rows, d]; d % V == 0.  LDS: scale[d], zp[d].
+template <int DT, bool HAS_IDX, bool NT>
+__global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u32x4* __restrict__ y,
+                                                  void* __restrict__ idx, int idx_dtype, uint64_t n,
+                                                  tq_quantizer q) {
+  constexpr int V = Store<DT>::kVec;
+  extern __shared__ __attribute__((aligned(16))) float s_par[];
+  const uint32_t d = (uint32_t)q.n_params;
+  float* s_scale = s_par;
+  float* s_zp = s_par + d;
+  float lo = 0.f, hi = 0.f;
+  for (uint32_t c = threadIdx.x; c < d; c += kBlock) {
+    const QP p = make_qp(q, c);
+    s_scale[c] = p.scale;
+    s_zp[c] = p.zp;
+  }
+  {
+    const QP p0 = make_qp(q, 0);   // int_min / int_max do not depend on the column
+    lo = p0.lo;
+    hi = p0.hi;
+  }
+  __syncthreads();
+
+  const uint32_t vpr = d / V;                       // vectors per row
+  const uint64_t n_vec = n / V;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const uint32_t stride_mod = (uint32_t)(stride % vpr);
+  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  uint32_t cv = (uint32_t)(i % vpr);                // this lane's vector column
+
+  for (; i < n_vec; i += stride) {
+    const u32x4 in = NT ? ld_stream(x + i) : x[i];
+    float f[V], sc[V], zp[V];
+    Store<DT>::unpack(in, f);
+#pragma unroll
+    for (int j = 0; j < V; j += 4) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(s_scale + cv * V + j);
+      const f32x4 z4 = *reinterpret_cast<const f32x4*>(s_zp + cv * V + j);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { sc[j + k] = s4[k]; zp[j + k] = z4[k]; }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const QP p = {sc[j], zp[j], lo, hi};
+      f[j] = q_index(f[j], p);
+    }
+    if (HAS_IDX) store_idx<V>(idx, idx_dtype, i * V, f);
+    if (y) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) f[j] = sc[j] * (f[j] - zp[j]);
+      const u32x4 o = Store<DT>::pack(f);
+      if (NT) st_stream(y + i, o); else y[i] = o;
+    }
+    cv += stride_mod;
+    if (cv >= vpr) cv -= vpr;
+  }
+}
+
+// ------------------------------------------------------------------------------ rows
+// x viewed as [n_rows, inner]; parameter index = row % n_params; inner % V == 0.
+template <int DT, bool HAS_IDX>
+__global__ __launch_bounds__(kBlock) void fq_rows(const u32x4* __restrict__ x, u32x4* __restrict__ y,
+                                                  void* __restrict__ idx, int idx_dtype, uint64_t n_rows,
+                                                  tq_quantizer q) {
+  constexpr int V = Store<DT>::kVec;
+  const uint64_t vec_per_row = q.inner / V;
+  for (uint64_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
+    const QP p = make_qp(q, row % q.n_params);
+    const uint64_t base = row * vec_per_row;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < vec_per_row;
+         i += (uint64_t)gridDim.x * kBlock) {
+      const u32x4 o = fq_vec<DT, HAS_IDX>(x[base + i], p, idx, idx_dtype, (base + i) * V);
+      if (y) y[base + i] = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ fallback
+template <int DT, bool HAS_IDX>
+__global__ __launch_bounds__(kBlock) void fq_scalar(const void* __restrict__ x, void* __restrict__ y,
+                                                    void* __restrict__ idx, int idx_dtype, uint64_t n,
+                                                    tq_quantizer q) {
+  typedef typename Store<DT>::elem_t E;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t pi = q.n_params == 1 ? 0 : (i / q.inner) % q.n_params;
+    const QP p = make_qp(q, pi);
+    const float xi = q_index(Store<DT>::load1(static_cast<const E*>(x) + i), p);
+    if (HAS_IDX) store_idx1(idx, idx_dtype, i, xi);
+    if (y) Store<DT>::store1(static_cast<E*>(y) + i, q_dequant(xi, p));
+  }
+}
+
+template <int DT, bool HAS_IDX>
+static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t n, const tq_quantizer& q,
+                     hipStream_t st) {
+  constexpr int V = Store<DT>::kVec;
+  const size_t idx_es = idx_dtype == TQ_IDX_F32 || idx_dtype == TQ_IDX_I32 ? 4 : (idx_dtype == TQ_IDX_I16 ? 2 : 1);
+  const bool vec_ok = aligned16(x) && (y == nullptr || aligned16(y)) &&
+                      (!HAS_IDX || (reinterpret_cast<uintptr_t>(idx) % (V * idx_es)) == 0);
+  static const int nt_min_mb = tuning("TQ_NT_MIN_MB", 64);   // streaming hint above this footprint
+  const bool nt = (n * elem_size(DT)) >= ((uint64_t)nt_min_mb << 20);
+  const auto xv = static_cast<const u32x4*>(x);
+  auto yv = static_cast<u32x4*>(y);
+
+  if (vec_ok && q.n_params == 1) {
+    const uint64_t n_vec = n / V;
+    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n_vec, kBlock), 1), kMaxGrid);
+    if (nt) hipLaunchKernelGGL((fq_tensor<DT, HAS_IDX, true>), dim3(grid), dim3(kBlock), 0, st, xv, yv, idx, idx_dtype, n, q);
+    else    hipLaunchKernelGGL((fq_tensor<DT, HAS_IDX, false>), dim3(grid), dim3(kBlock), 0, st, xv, yv, idx, idx_dtype, n, q);
+    return check_launch("fq_tensor");
+  }
+  if (vec_ok && q.n_params > 1 && q.inner == 1 && q.n_params % V == 0 && q.n_params * 8 <= 128 * 1024) {
+    const uint64_t n_vec = n / V;
+    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n_vec, kBlock), 1), kMaxGrid);
+    const size_t lds = q.n_params * 2 * sizeof(float);
+    if (nt) hipLaunchKernelGGL((fq_axis<DT, HAS_IDX, true>), dim3(grid), dim3(kBlock), lds, st, xv, yv, idx, idx_dtype, n, q);
+    else    hipLaunchKernelGGL((fq_axis<DT, HAS_IDX, false>), dim3(grid), dim3(kBlock), lds, st, xv, yv, idx, idx_dtype, n, q);
+    return check_launch("fq_axis");
+  }
+  if (vec_ok && q.n_params > 1 && q.inner > 1 && q.inner % V == 0) {
+    const uint64_t n_rows = n / q.inner;
+    const uint64_t vpr = q.inner / V;
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(vpr, kBlock), 1), 64);
+    const unsigned gy = (unsigned)std::min<uint64_t>(n_rows, 65535);
+    hipLaunchKernelGGL((fq_rows<DT, HAS_IDX>), dim3(gx, gy), dim3(kBlock), 0, st, xv, yv, idx, idx_dtype, n_rows, q);
+    return check_launch("fq_rows");
+  }
+  const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, kBlock), 1), kMaxGrid);
+  hipLaunchKernelGGL((fq_scalar<DT, HAS_IDX>), dim3(grid), dim3(kBlock), 0, st, x, y, idx, idx_dtype, n, q);
+  return check_launch("fq_scalar");
+}
+
+// ------------------------------------------------------------------------------ STE backward
+// dx = ((g * scale) * mask) / scale      (autograd of mul / clamp / STE-round / div in order)
+// d_delta, d_zero_float (per-tensor only): chain rule through scale = clamp(delta, eps),
+//   zp = clamp(round_ste(zero_float), lo, hi), x_int = clamp(round_ste(x/s) + zp, lo, hi),
+//   y = s * (x_int - zp).
+template <int DT>
+__global__ __launch_bounds__(kBlock) void fq_bwd(const void* __restrict__ x, const void* __restrict__ gy,
+                                                 void* __restrict__ gx, float* __restrict__ g_delta,
+                                                 float* __restrict__ g_zf, uint64_t n, tq_quantizer q) {
+  typedef typename Store<DT>::elem_t E;
+  __shared__ float s_red[2][kBlock / kWave];
+  float acc_d = 0.f, acc_z = 0.f;
+  const bool per_tensor = q.n_params == 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t pi = per_tensor ? 0 : (i / q.inner) % q.n_params;
+    const QP p = make_qp(q, pi);
+    const float xv = Store<DT>::load1(static_cast<const E*>(x) + i);
+    const float g = Store<DT>::load1(static_cast<const E*>(gy) + i);
+    const float r = rintf(xv / p.scale) + p.zp;
+    const bool in = (r >= p.lo) && (r <= p.hi);          // torch.clamp backward mask (inclusive)
+    const float gs = g * p.scale;                         // grad wrt (x_int - zp)
+    Store<DT>::store1(static_cast<E*>(gx) + i, in ? gs / p.scale : 0.0f);
+    if (per_tensor && g_delta != nullptr) {
+      const float xi = clamp_nanprop(r, p.lo, p.hi);
+      // d y / d scale = (x_int - zp) + s * mask * d(x/s)/ds = (x_int - zp) - mask * x / s
+      float dd = g * (xi - p.zp);
+      if (in) dd -= (gs * xv) / (p.scale * p.scale);
+      acc_d += dd;
+      // d y / d zp = s * (mask - 1)
+      acc_z += in ? 0.0f : -gs;
+    }
+  }
+  if (per_tensor && g_delta != nullptr) {
+    acc_d = wave_sum(acc_d);
+    acc_z = wave_sum(acc_z);
+    const int w = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) { s_red[0][w] = acc_d; s_red[1][w] = acc_z; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float d = 0.f, z = 0.f;
+      for (int k = 0; k < kBlock / kWave; ++k) { d += s_red[0][k]; z += s_red[1][k]; }
+      const float delta = q.delta[0];
+      // scale = clamp(delta, min=eps): gradient passes when delta >= eps; log domain: * scale
+      const float pass = q.log_domain ? expf(delta) : (delta >= q.eps ? 1.0f : 0.0f);
+      atomicAdd(g_delta, d * pass);
+      if (g_zf != nullptr && !q.symmetric) {
+        const float zf = rintf(q.zero_float[0]);
+        const QP p = make_qp(q, 0);
+        atomicAdd(g_zf, (zf >= p.lo && zf <= p.hi) ? z : 0.0f);
+      }
+    }
+  }
+}
+
+}  // namespace tq
+
+using namespace tq;
+
+extern "C" int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtype, uint64_t n, int dtype,
+                                 const tq_quantizer* q, tq_stream_t stream) {
+  TQ_REQUIRE(x != nullptr, "tq_fake_quant_fwd: x is NULL");
+  TQ_REQUIRE(y != nullptr || (idx != nullptr && idx_dtype != TQ_IDX_NONE), "tq_fake_quant_fwd: no output requested");
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_fake_quant_fwd: bad dtype %d", dtype);
+  TQ_REQUIRE(idx_dtype >= TQ_IDX_NONE && idx_dtype <= TQ_IDX_I32, "tq_fake_quant_fwd: bad idx_dtype %d", idx_dtype);
+  if (int e = check_quantizer(q, n, "tq_fake_quant_fwd")) return e;
+  if (n == 0) return TQ_OK;
+  const bool has_idx = idx != nullptr && idx_dtype != TQ_IDX_NONE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case TQ_F32: return has_idx ? launch_fq<TQ_F32, true>(x, y, idx, idx_dtype, n, *q, st) : launch_fq<TQ_F32, false>(x, y, idx, idx_dtype, n, *q, st);
+    case TQ_BF16: return has_idx ? launch_fq<TQ_BF16, true>(x, y, idx, idx_dtype, n, *q, st) : launch_fq<TQ_BF16, false>(x, y, idx, idx_dtype, n, *q, st);
+    default: return has_idx ? launch_fq<TQ_F16, true>(x, y, idx, idx_dtype, n, *q, st) : launch_fq<TQ_F16, false>(x, y, idx, idx_dtype, n, *q, st);
+  }
+}
+
+extern "C" int tq_fake_quant_bwd(const void* x, const void* grad_y, void* grad_x, float* grad_delta,
+                                 float* grad_zero_float, uint64_t n, int dtype, const tq_quantizer* q,
+                                 tq_stream_t stream) {
+  TQ_REQUIRE(x && grad_y && grad_x, "tq_fake_quant_bwd: NULL tensor");
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_fake_quant_bwd: bad dtype %d", dtype);
+  if (int e = check_quantizer(q, n, "tq_fake_quant_bwd")) return e;
+  if (n == 0) return TQ_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, kBlock), 1), kMaxGrid);
+  switch (dtype) {
+    case TQ_F32: hipLaunchKernelGGL((fq_bwd<TQ_F32>), dim3(grid), dim3(kBlock), 0, st, x, grad_y, grad_x, grad_delta, grad_zero_float, n, *q); break;
+    case TQ_BF16: hipLaunchKernelGGL((fq_bwd<TQ_BF16>), dim3(grid), dim3(kBlock), 0, st, x, grad_y, grad_x, grad_delta, grad_zero_float, n, *q); break;
+    default: hipLaunchKernelGGL((fq_bwd<TQ_F16>), dim3(grid), dim3(kBlock), 0, st, x, grad_y, grad_x, grad_delta, grad_zero_float, n, *q); break;
+  }
+  return check_launch("fq_bwd");
+}

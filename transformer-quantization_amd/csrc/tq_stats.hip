@@ -1,0 +1,390 @@
+// K4/K5 + estimator state + range->parameter kernels for gfx950.
+//
+//   mm_cols   : statistics per index of the LAST axis (per-embedding).  No transpose copy (the
+//               reference does transpose+contiguous+view+min/max, range_estimators.py:82-85,
+//               114-116): a 2-D block owns a fixed set of 16-byte column vectors and walks down the
+//               rows keeping 8 (bf16) / 4 (fp32) running minima and maxima per lane in registers.
+//   mm_rows   : statistics per contiguous row (per-tensor = one row, per-channel = dim 0, any
+//               other axis); wave __shfl_xor reduction, LDS across the 4 waves.
+//   mm_final  : reduces the block partials ([P][2][n_params] in the caller's workspace).
+//   Deterministic: no atomics anywhere.
+#include <algorithm>
+
+#include "tq_device.h"
+#include "tq_host.h"
+
+namespace tq {
+
+constexpr float kInf = __builtin_huge_valf();
+
+// ------------------------------------------------------------------------------ last axis
+// blockDim = (CX, RY): CX lanes side by side cover CX 16-byte vectors of a row, RY rows at a time.
+// grid = (col_chunks, row_blocks).  partial layout: ws[(row_block) * 2 * d + {0,1} * d + col]
+template <int DT>
+__global__ void mm_cols(const u32x4* __restrict__ x, uint64_t rows, uint32_t d, float* __restrict__ ws) {
+  constexpr int V = Store<DT>::kVec;
+  extern __shared__ __attribute__((aligned(16))) float s_mm[];   // [RY][2][CX*V]
+  const uint32_t vpr = d / V;
+  const uint32_t cx = blockIdx.x * blockDim.x + threadIdx.x;    // vector column
+  const bool live = cx < vpr;
+  float mn[V], mx[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { mn[j] = kInf; mx[j] = -kInf; }
+
+  const uint64_t row_stride = (uint64_t)gridDim.y * blockDim.y;
+  uint64_t r = (uint64_t)blockIdx.y * blockDim.y + threadIdx.y;
+  if (live) {
+    constexpr int U = 4;
+    for (; r + (U - 1) * row_stride < rows; r += U * row_stride) {
+      u32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = ld_stream(x + (r + u * row_stride) * vpr + cx);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f[V];
+        Store<DT>::unpack(v[u], f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { mn[j] = min_nanprop(mn[j], f[j]); mx[j] = max_nanprop(mx[j], f[j]); }
+      }
+    }
+    for (; r < rows; r += row_stride) {
+      float f[V];
+      Store<DT>::unpack(x[r * vpr + cx], f);
+#pragma unroll
+      for (int j = 0; j < V; ++j) { mn[j] = min_nanprop(mn[j], f[j]); mx[j] = max_nanprop(mx[j], f[j]); }
+    }
+  }
+  // combine the RY row-lanes of this block through LDS
+  const uint32_t cw = blockDim.x * V;
+  float* my = s_mm + (size_t)threadIdx.y * 2 * cw;
+#pragma unroll
+  for (int j = 0; j < V; ++j) { my[threadIdx.x * V + j] = mn[j]; my[cw + threadIdx.x * V + j] = mx[j]; }
+  __syncthreads();
+  if (threadIdx.y == 0 && live) {
+    for (uint32_t k = 1; k < blockDim.y; ++k) {
+      const float* o = s_mm + (size_t)k * 2 * cw;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        mn[j] = min_nanprop(mn[j], o[threadIdx.x * V + j]);
+        mx[j] = max_nanprop(mx[j], o[cw + threadIdx.x * V + j]);
+      }
+    }
+    float* out = ws + (size_t)blockIdx.y * 2 * d;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { out[cx * V + j] = mn[j]; out[d + cx * V + j] = mx[j]; }
+  }
+}
+
+// ------------------------------------------------------------------------------ rows
+// x viewed as [n_rows, inner]; parameter = row % n_params; grid = (chunks, rows_in_grid).
+// partial layout: ws[((row / n_params) * chunks + chunk) * 2 * n_params + {0,1} * n_params + param]
+template <int DT, bool VEC>
+__global__ __launch_bounds__(kBlock) void mm_rows(const void* __restrict__ x, uint64_t n_rows, uint64_t inner,
+                                                  uint64_t n_params, float* __restrict__ ws) {
+  constexpr int V = Store<DT>::kVec;
+  typedef typename Store<DT>::elem_t E;
+  __shared__ float s_red[2][kBlock / kWave];
+  for (uint64_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
+    float mn = kInf, mx = -kInf;
+    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    if (VEC) {
+      const u32x4* xv = static_cast<const u32x4*>(x) + row * (inner / V);
+      const uint64_t n_vec = inner / V;
+      constexpr int U = 4;
+      uint64_t i = tid;
+      for (; i + (U - 1) * stride < n_vec; i += U * stride) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld_stream(xv + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float f[V];
+          Store<DT>::unpack(v[u], f);
+#pragma unroll
+          for (int j = 0; j < V; ++j) { mn = min_nanprop(mn, f[j]); mx = max_nanprop(mx, f[j]); }
+        }
+      }
+      for (; i < n_vec; i += stride) {
+        float f[V];
+        Store<DT>::unpack(xv[i], f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { mn = min_nanprop(mn, f[j]); mx = max_nanprop(mx, f[j]); }
+      }
+    } else {
+      const E* xs = static_cast<const E*>(x) + row * inner;
+      for (uint64_t i = tid; i < inner; i += stride) {
+        const float f = Store<DT>::load1(xs + i);
+        mn = min_nanprop(mn, f);
+        mx = max_nanprop(mx, f);
+      }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int w = threadIdx.x / kWave;
+    __syncthreads();   // s_red reuse across row iterations
+    if ((threadIdx.x & (kWave - 1)) == 0) { s_red[0][w] = mn; s_red[1][w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int k = 1; k < kBlock / kWave; ++k) { mn = min_nanprop(mn, s_red[0][k]); mx = max_nanprop(mx, s_red[1][k]); }
+      const uint64_t outer = row / n_params, p = row % n_params;
+      float* out = ws + ((outer * gridDim.x) + blockIdx.x) * 2 * n_params;
+      out[p] = mn;
+      out[n_params + p] = mx;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ finalize
+// ws [P][2][n_params] -> out_min[n_params], out_max[n_params].  block = (cx, sy): cx adjacent
+// parameters, sy slices of P.
+__global__ void mm_final(const float* __restrict__ ws, uint64_t P, uint64_t n_params, float* __restrict__ out_min,
+                         float* __restrict__ out_max) {
+  extern __shared__ float s_f[];   // [2][sy][cx]
+  const uint32_t cx = blockDim.x, sy = blockDim.y;
+  const uint64_t col = (uint64_t)blockIdx.x * cx + threadIdx.x;
+  float mn = kInf, mx = -kInf;
+  if (col < n_params) {
+    for (uint64_t p = threadIdx.y; p < P; p += sy) {
+      mn = min_nanprop(mn, ws[p * 2 * n_params + col]);
+      mx = max_nanprop(mx, ws[p * 2 * n_params + n_params + col]);
+    }
+  }
+  s_f[threadIdx.y * cx + threadIdx.x] = mn;
+  s_f[(sy + threadIdx.y) * cx + threadIdx.x] = mx;
+  __syncthreads();
+  if (threadIdx.y == 0 && col < n_params) {
+    for (uint32_t k = 1; k < sy; ++k) {
+      mn = min_nanprop(mn, s_f[k * cx + threadIdx.x]);
+      mx = max_nanprop(mx, s_f[(sy + k) * cx + threadIdx.x]);
+    }
+    out_min[col] = mn;
+    out_max[col] = mx;
+  }
+}
+
+struct MMPlan {
+  bool cols;          // mm_cols path
+  unsigned bx, by, gx, gy;
+  uint64_t P;         // number of partial records of 2*n_params floats
+};
+
+static MMPlan plan_minmax(uint64_t n, uint64_t n_params, uint64_t inner, int V, bool aligned) {
+  MMPlan pl{};
+  if (n_params > 1 && inner == 1 && n_params % V == 0 && aligned) {
+    const uint64_t vpr = n_params / V, rows = n / n_params;
+    pl.cols = true;
+    pl.bx = (unsigned)std::min<uint64_t>(vpr, 128);
+    pl.by = std::max(1u, 256u / pl.bx);
+    pl.gx = (unsigned)ceil_div(vpr, pl.bx);
+    // enough row-blocks to fill the chip, each walking >= 8 rows per lane
+    const uint64_t want = std::max<uint64_t>(1, (uint64_t)kMaxGrid / 2 / pl.gx);
+    pl.gy = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, ceil_div(rows, (uint64_t)pl.by * 8)));
+    pl.P = pl.gy;
+    return pl;
+  }
+  const uint64_t eff_inner = n_params == 1 ? n : inner;
+  const uint64_t n_rows = n_params == 1 ? 1 : n / inner;
+  const uint64_t per_block = (uint64_t)kBlock * V * 4;
+  pl.cols = false;
+  pl.gy = (unsigned)std::min<uint64_t>(n_rows, 65535);
+  const uint64_t max_gx = std::max<uint64_t>(1, (uint64_t)kMaxGrid / std::max<uint64_t>(1, std::min<uint64_t>(n_rows, kMaxGrid)));
+  pl.gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(eff_inner, per_block), max_gx));
+  const uint64_t outer = n_params == 1 ? 1 : n_rows / n_params;
+  pl.P = outer * pl.gx;
+  return pl;
+}
+
+template <int DT>
+static int launch_minmax(const void* x, uint64_t n, uint64_t n_params, uint64_t inner, float* out_min,
+                         float* out_max, float* ws, size_t ws_bytes, hipStream_t st) {
+  constexpr int V = Store<DT>::kVec;
+  const bool al = aligned16(x);
+  const MMPlan pl = plan_minmax(n, n_params, inner, V, al);
+  const size_t need = pl.P * 2 * n_params * sizeof(float);
+  if (ws == nullptr || ws_bytes < need)
+    return set_error(TQ_EWORKSPACE, "tq_minmax: workspace %zu < %zu bytes", ws_bytes, need);
+  if (pl.cols) {
+    const size_t lds = (size_t)pl.by * 2 * pl.bx * V * sizeof(float);
+    hipLaunchKernelGGL((mm_cols<DT>), dim3(pl.gx, pl.gy), dim3(pl.bx, pl.by), lds, st,
+                       static_cast<const u32x4*>(x), n / n_params, (uint32_t)n_params, ws);
+  } else {
+    const uint64_t eff_inner = n_params == 1 ? n : inner;
+    const uint64_t n_rows = n_params == 1 ? 1 : n / inner;
+    const bool vec = al && (eff_inner % V == 0);
+    if (vec) hipLaunchKernelGGL((mm_rows<DT, true>), dim3(pl.gx, pl.gy), dim3(kBlock), 0, st, x, n_rows, eff_inner, n_params, ws);
+    else     hipLaunchKernelGGL((mm_rows<DT, false>), dim3(pl.gx, pl.gy), dim3(kBlock), 0, st, x, n_rows, eff_inner, n_params, ws);
+  }
+  if (int e = check_launch("tq_minmax partial")) return e;
+  const unsigned cx = (unsigned)std::min<uint64_t>(n_params, 64);
+  const unsigned sy = 256 / cx;
+  hipLaunchKernelGGL(mm_final, dim3((unsigned)ceil_div(n_params, cx)), dim3(cx, sy), 2 * sy * cx * sizeof(float), st,
+                     ws, pl.P, n_params, out_min, out_max);
+  return check_launch("tq_minmax final");
+}
+
+// ------------------------------------------------------------------------------ estimator state
+// One block.  Step 1 (optional): fold per-dimension statistics into per-group statistics
+// (range_estimators.py:87-112 / :183-193).  Step 2: current / all / running update.
+__global__ void range_update_k(int mode, const float* __restrict__ new_min, const float* __restrict__ new_max,
+                               float* __restrict__ cur_min, float* __restrict__ cur_max, uint64_t n, int initialised,
+                               double momentum_d, uint64_t n_groups, const int64_t* __restrict__ order) {
+  extern __shared__ float s_g[];   // [2][n_groups]
+  if (n_groups > 0) {
+    const uint64_t gs = n / n_groups;
+    for (uint64_t g = threadIdx.x; g < n_groups; g += blockDim.x) {
+      float mn = kInf, mx = -kInf;
+      for (uint64_t k = 0; k < gs; ++k) {
+        const uint64_t dim = order ? (uint64_t)order[g * gs + k] : g * gs + k;
+        mn = min_nanprop(mn, new_min[dim]);
+        mx = max_nanprop(mx, new_max[dim]);
+      }
+      s_g[g] = mn;
+      s_g[n_groups + g] = mx;
+    }
+    __syncthreads();
+  }
+  // (1 - momentum) as the reference evaluates it: python double, narrowed by the fp32 multiply
+  const float om = (float)(1.0 - momentum_d);
+  const float momentum = (float)momentum_d;
+  for (uint64_t j = threadIdx.x; j < n; j += blockDim.x) {
+    float a, b;
+    if (n_groups > 0) {
+      // position j of the (permuted) layout belongs to group j / gs and is dimension order[j]
+      const uint64_t gs = n / n_groups;
+      const uint64_t dim = order ? (uint64_t)order[j] : j;
+      a = s_g[j / gs];
+      b = s_g[n_groups + j / gs];
+      // writes go to `dim`
+      if (mode == TQ_EST_CURRENT || !initialised) { cur_min[dim] = a; cur_max[dim] = b; }
+      else if (mode == TQ_EST_ALL) { cur_min[dim] = min_nanprop(cur_min[dim], a); cur_max[dim] = max_nanprop(cur_max[dim], b); }
+      else { cur_min[dim] = om * a + momentum * cur_min[dim]; cur_max[dim] = om * b + momentum * cur_max[dim]; }
+      continue;
+    }
+    a = new_min[j];
+    b = new_max[j];
+    if (mode == TQ_EST_CURRENT || !initialised) { cur_min[j] = a; cur_max[j] = b; }
+    else if (mode == TQ_EST_ALL) { cur_min[j] = min_nanprop(cur_min[j], a); cur_max[j] = max_nanprop(cur_max[j], b); }
+    else { cur_min[j] = om * a + momentum * cur_min[j]; cur_max[j] = om * b + momentum * cur_max[j]; }
+  }
+}
+
+__global__ void axis_ranges_k(const float* __restrict__ new_min, const float* __restrict__ new_max,
+                              float* __restrict__ ranges, uint64_t n, int first) {
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+    const float r = new_max[j] - new_min[j];
+    // range_estimators.py:75-79: momentum * ranges + (1 - momentum) * ranges with momentum = 0.1
+    ranges[j] = first ? r : (0.1f * r + 0.9f * r);
+  }
+}
+
+// ------------------------------------------------------------------------------ range -> params
+__global__ void set_range_asym_k(const float* __restrict__ x_min, const float* __restrict__ x_max, uint64_t n,
+                                 int n_bits, float eps, int log_domain, float* __restrict__ delta,
+                                 float* __restrict__ zero_float) {
+  const float top = grid_top(n_bits);
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+    const float lo = min_nanprop(x_min[j], 0.0f);       // quantizers.py:258
+    const float hi = max_nanprop(x_max[j], eps);        // :259  (ones_like * eps == eps in fp32)
+    const float d = (hi - lo) / top;                    // :276
+    zero_float[j] = (-lo) / d;                          // :277
+    delta[j] = log_domain ? logf(d) : d;                // :279-280
+  }
+}
+
+// single block: `signed` is a property of the whole range vector (quantizers.py:336)
+__global__ void set_range_sym_k(const float* __restrict__ x_min, const float* __restrict__ x_max, uint64_t n,
+                                int n_bits, float eps, int log_domain, float* __restrict__ delta,
+                                uint8_t* __restrict__ signed_flag) {
+  __shared__ int s_neg;
+  if (threadIdx.x == 0) s_neg = 0;
+  __syncthreads();
+  int neg = 0;
+  for (uint64_t j = threadIdx.x; j < n; j += blockDim.x) neg |= (min_nanprop(x_min[j], 0.0f) < 0.0f) ? 1 : 0;
+  if (neg) atomicOr(&s_neg, 1);
+  __syncthreads();
+  const bool sgn = s_neg != 0;
+  if (threadIdx.x == 0) signed_flag[0] = sgn ? 1 : 0;
+  const float top = grid_top(n_bits - (sgn ? 1 : 0));   // :325-328
+  for (uint64_t j = threadIdx.x; j < n; j += blockDim.x) {
+    const float lo = min_nanprop(x_min[j], 0.0f);
+    const float hi = max_nanprop(x_max[j], eps);
+    const float d = max_nanprop(fabsf(lo), hi) / top;   // :338-339
+    delta[j] = log_domain ? logf(d) : d;
+  }
+}
+
+}  // namespace tq
+
+using namespace tq;
+
+extern "C" size_t tq_minmax_workspace_bytes(uint64_t n, uint64_t n_params, uint64_t inner) {
+  if (n == 0 || n_params == 0) return 0;
+  // the larger of the plans over dtypes / alignment (vector width 4 or 8)
+  size_t best = 0;
+  for (int V : {4, 8})
+    for (bool al : {true, false}) {
+      const MMPlan pl = plan_minmax(n, n_params, n_params > 1 && inner == 0 ? 1 : inner, V, al);
+      best = std::max(best, (size_t)(pl.P * 2 * n_params * sizeof(float)));
+    }
+  return best;
+}
+
+extern "C" int tq_minmax(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner, float* out_min,
+                         float* out_max, void* workspace, size_t workspace_bytes, tq_stream_t stream) {
+  TQ_REQUIRE(x && out_min && out_max, "tq_minmax: NULL pointer");
+  TQ_REQUIRE(n > 0, "tq_minmax: empty tensor has no min/max");
+  TQ_REQUIRE(n_params >= 1, "tq_minmax: n_params == 0");
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_minmax: bad dtype %d", dtype);
+  if (n_params > 1) {
+    TQ_REQUIRE(inner >= 1, "tq_minmax: inner == 0");
+    TQ_REQUIRE(n % (n_params * inner) == 0, "tq_minmax: n not a multiple of n_params*inner");
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* ws = static_cast<float*>(workspace);
+  switch (dtype) {
+    case TQ_F32: return launch_minmax<TQ_F32>(x, n, n_params, inner, out_min, out_max, ws, workspace_bytes, st);
+    case TQ_BF16: return launch_minmax<TQ_BF16>(x, n, n_params, inner, out_min, out_max, ws, workspace_bytes, st);
+    default: return launch_minmax<TQ_F16>(x, n, n_params, inner, out_min, out_max, ws, workspace_bytes, st);
+  }
+}
+
+extern "C" int tq_range_update(int mode, const float* new_min, const float* new_max, float* cur_min, float* cur_max,
+                               uint64_t n, int initialised, double momentum, uint64_t n_groups, const int64_t* order,
+                               tq_stream_t stream) {
+  TQ_REQUIRE(new_min && new_max && cur_min && cur_max, "tq_range_update: NULL pointer");
+  TQ_REQUIRE(mode >= TQ_EST_CURRENT && mode <= TQ_EST_RUNNING, "tq_range_update: bad mode %d", mode);
+  TQ_REQUIRE(n > 0, "tq_range_update: n == 0");
+  TQ_REQUIRE(n_groups == 0 || n % n_groups == 0, "tq_range_update: n %% n_groups != 0");
+  TQ_REQUIRE(n_groups * 2 * sizeof(float) <= 64 * 1024, "tq_range_update: too many groups");
+  hipLaunchKernelGGL(range_update_k, dim3(1), dim3(n >= 256 ? 1024 : 256), n_groups * 2 * sizeof(float),
+                     static_cast<hipStream_t>(stream), mode, new_min, new_max, cur_min, cur_max, n, initialised,
+                     momentum, n_groups, order);
+  return check_launch("tq_range_update");
+}
+
+extern "C" int tq_axis_ranges(const float* new_min, const float* new_max, float* ranges, uint64_t n, int first,
+                              tq_stream_t stream) {
+  TQ_REQUIRE(new_min && new_max && ranges && n > 0, "tq_axis_ranges: bad argument");
+  hipLaunchKernelGGL(axis_ranges_k, dim3((unsigned)std::min<uint64_t>(ceil_div(n, 256), 1024)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), new_min, new_max, ranges, n, first);
+  return check_launch("tq_axis_ranges");
+}
+
+extern "C" int tq_set_range_asym(const float* x_min, const float* x_max, uint64_t n, int n_bits, float eps,
+                                 int log_domain, float* delta, float* zero_float, tq_stream_t stream) {
+  TQ_REQUIRE(x_min && x_max && delta && zero_float && n > 0, "tq_set_range_asym: bad argument");
+  TQ_REQUIRE(n_bits >= 1 && n_bits <= 24, "tq_set_range_asym: n_bits=%d", n_bits);
+  hipLaunchKernelGGL(set_range_asym_k, dim3((unsigned)std::min<uint64_t>(ceil_div(n, 256), 1024)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x_min, x_max, n, n_bits, eps, log_domain, delta, zero_float);
+  return check_launch("tq_set_range_asym");
+}
+
+extern "C" int tq_set_range_sym(const float* x_min, const float* x_max, uint64_t n, int n_bits, float eps,
+                                int log_domain, float* delta, uint8_t* signed_flag, tq_stream_t stream) {
+  TQ_REQUIRE(x_min && x_max && delta && signed_flag && n > 0, "tq_set_range_sym: bad argument");
+  TQ_REQUIRE(n_bits >= 1 && n_bits <= 24, "tq_set_range_sym: n_bits=%d", n_bits);
+  hipLaunchKernelGGL(set_range_sym_k, dim3(1), dim3(n >= 256 ? 1024 : 256), 0, static_cast<hipStream_t>(stream),
+                     x_min, x_max, n, n_bits, eps, log_domain, delta, signed_flag);
+  return check_launch("tq_set_range_sym");
+}

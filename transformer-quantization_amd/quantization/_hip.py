@@ -1,0 +1,370 @@
+"""ctypes binding of libtq_hip.so (include/tq_hip.h) + the tensor-level backend the
+quantization classes call.
+
+There is NO CPU implementation here or anywhere else in this package: if the shared library is
+missing, or a tensor is not resident on a ROCm device, the call raises.  (The test-suite swaps
+`backend()` for an oracle-backed double to exercise the host-side state machines on a box
+without a GPU; that double lives under tests/, not here.)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libtq_hip.so')
+
+TQ_F32, TQ_BF16, TQ_F16 = 0, 1, 2
+IDX_NONE, IDX_F32, IDX_I8, IDX_U8, IDX_I16, IDX_I32 = range(6)
+EST_CURRENT, EST_ALL, EST_RUNNING = 0, 1, 2
+ADA_SIGMOID, ADA_HARD_SIGMOID, ADA_SIGMOID_TEMP = 0, 1, 2
+
+_DTYPES = {torch.float32: TQ_F32, torch.bfloat16: TQ_BF16, torch.float16: TQ_F16}
+_IDX_DTYPES = {torch.float32: IDX_F32, torch.int8: IDX_I8, torch.uint8: IDX_U8,
+               torch.int16: IDX_I16, torch.int32: IDX_I32}
+
+
+class TQError(RuntimeError):
+    pass
+
+
+class tq_quantizer(C.Structure):
+    _fields_ = [('delta', C.c_void_p), ('zero_float', C.c_void_p), ('signed_flag', C.c_void_p),
+                ('n_bits', C.c_int32), ('symmetric', C.c_int32), ('log_domain', C.c_int32),
+                ('eps', C.c_float), ('n_params', C.c_uint64), ('inner', C.c_uint64)]
+
+
+_u64, _vp, _int, _sz, _f, _d = C.c_uint64, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double
+_QP = C.POINTER(tq_quantizer)
+
+# name -> (restype, argtypes); must list every symbol include/tq_hip.h declares
+SIGNATURES = {
+    'tq_abi_version': (_int, []),
+    'tq_last_error': (C.c_char_p, []),
+    'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
+    'tq_fake_quant_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _int, _QP, _vp]),
+    'tq_minmax_workspace_bytes': (_sz, [_u64, _u64, _u64]),
+    'tq_minmax': (_int, [_vp, _u64, _int, _u64, _u64, _vp, _vp, _vp, _sz, _vp]),
+    'tq_range_update': (_int, [_int, _vp, _vp, _vp, _vp, _u64, _int, _d, _u64, _vp, _vp]),
+    'tq_axis_ranges': (_int, [_vp, _vp, _vp, _u64, _int, _vp]),
+    'tq_set_range_asym': (_int, [_vp, _vp, _u64, _int, _f, _int, _vp, _vp, _vp]),
+    'tq_set_range_sym': (_int, [_vp, _vp, _u64, _int, _f, _int, _vp, _vp, _vp]),
+    'tq_mse_workspace_bytes': (_sz, [_u64, _u64, _u64]),
+    'tq_mse_candidates': (_int, [_vp, _u64, _u64, _int, _vp, _u64, _vp, _vp, _sz, _vp]),
+    'tq_xent_candidates': (_int, [_vp, _u64, _u64, _vp, _u64, _vp, _vp]),
+    'tq_argmin_select': (_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'tq_adaround_fwd': (_int, [_vp, _vp, _vp, _u64, _QP, _int, _int, _f, _vp]),
+    'tq_adaround_init_alpha': (_int, [_vp, _vp, _u64, _QP, _int, _f, _vp]),
+    'tq_adaround_bwd': (_int, [_vp, _vp, _vp, _vp, _u64, _QP, _int, _f, _vp]),
+    'tq_adaround_bwd_adam': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _QP, _int, _f, _f, _f, _f,
+                                    _f, _f, _f, _int, _vp]),
+    'tq_adaround_reg': (_int, [_vp, _u64, _int, _f, _f, _f, _vp, _vp, _sz, _vp]),
+    'tq_reduce_workspace_bytes': (_sz, [_u64]),
+    'tq_recon_loss': (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libtq_hip.so and declare every prototype.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise TQError(
+            f'{p} not found: build it with `python transformer-quantization_amd/build.py` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tq_abi_version() != 1:
+        raise TQError('libtq_hip.so ABI version mismatch')
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc, lib):
+    if rc != 0:
+        raise TQError(f'libtq_hip: {lib.tq_last_error().decode()} (code {rc})')
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_device(t, what):
+    if not t.is_cuda:
+        raise TQError(f'{what}: tensor lives on {t.device}; the fake-quant path only runs on a '
+                      'ROCm device (no CPU fallback)')
+
+
+def _dtype_code(t, what):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise TQError(f'{what}: dtype {t.dtype} not supported (fp32 / bf16 / fp16)') from None
+
+
+class HipBackend:
+    """Tensor-level wrappers; one instance per process.  All work goes to torch's current stream."""
+
+    name = 'hip'
+
+    def __init__(self):
+        self.lib = load_library()
+        self._ws = {}
+
+    # -- helpers -------------------------------------------------------------------------
+    def _workspace(self, device, nbytes):
+        key = (device.index, _stream())
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    def to_device_f32(self, v, like=None):
+        """python scalar / numpy / CPU tensor -> fp32 tensor on the active ROCm device."""
+        if torch.is_tensor(v):
+            if v.is_cuda:
+                return v if v.dtype == torch.float32 else v.float()
+            dev = like.device if (like is not None and like.is_cuda) else torch.device(
+                'cuda', torch.cuda.current_device())
+            return v.detach().to(device=dev, dtype=torch.float32)
+        dev = like.device if (like is not None and like.is_cuda) else torch.device(
+            'cuda', torch.cuda.current_device())
+        return torch.tensor(v, dtype=torch.float64).float().to(dev)
+
+    def _qdesc(self, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner):
+        return tq_quantizer(_ptr(delta), _ptr(zero_float), _ptr(signed), int(n_bits),
+                            int(bool(symmetric)), int(bool(log_domain)), float(eps),
+                            int(n_params), int(inner))
+
+    # -- K1/K2/K3 ------------------------------------------------------------------------
+    def fake_quant(self, x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps,
+                   n_params, inner, want_y=True, idx_dtype=None):
+        _need_device(x, 'fake_quant')
+        x = x.contiguous()
+        y = torch.empty_like(x) if want_y else None
+        idx = torch.empty(x.shape, dtype=idx_dtype, device=x.device) if idx_dtype is not None else None
+        q = self._qdesc(delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner)
+        rc = self.lib.tq_fake_quant_fwd(_ptr(x), _ptr(y), _ptr(idx),
+                                        _IDX_DTYPES[idx_dtype] if idx_dtype is not None else IDX_NONE,
+                                        x.numel(), _dtype_code(x, 'fake_quant'), C.byref(q), _stream())
+        _check(rc, self.lib)
+        return y, idx
+
+    def fake_quant_bwd(self, x, grad_y, delta, zero_float, signed, n_bits, symmetric, log_domain, eps,
+                       n_params, inner, param_grads=False):
+        _need_device(x, 'fake_quant_bwd')
+        x = x.contiguous()
+        grad_y = grad_y.contiguous().to(x.dtype)
+        gx = torch.empty_like(x)
+        gd = gz = None
+        if param_grads:
+            gd = torch.zeros(1, dtype=torch.float32, device=x.device)
+            gz = torch.zeros(1, dtype=torch.float32, device=x.device)
+        q = self._qdesc(delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner)
+        rc = self.lib.tq_fake_quant_bwd(_ptr(x), _ptr(grad_y), _ptr(gx), _ptr(gd), _ptr(gz), x.numel(),
+                                        _dtype_code(x, 'fake_quant_bwd'), C.byref(q), _stream())
+        _check(rc, self.lib)
+        return gx, gd, gz
+
+    # -- K4/K5 ---------------------------------------------------------------------------
+    def minmax(self, x, n_params=1, inner=1):
+        """-> (min, max) fp32; 0-D for n_params == 1 else [n_params]."""
+        _need_device(x, 'minmax')
+        x = x.detach().contiguous()
+        n = x.numel()
+        out = torch.empty(2, n_params, dtype=torch.float32, device=x.device)
+        nbytes = self.lib.tq_minmax_workspace_bytes(n, n_params, inner)
+        ws = self._workspace(x.device, nbytes)
+        rc = self.lib.tq_minmax(_ptr(x), n, _dtype_code(x, 'minmax'), n_params, inner, _ptr(out[0]),
+                                _ptr(out[1]), _ptr(ws), ws.numel(), _stream())
+        _check(rc, self.lib)
+        if n_params == 1:
+            return out[0, 0], out[1, 0]
+        return out[0], out[1]
+
+    def range_update(self, mode, new_min, new_max, cur_min, cur_max, momentum=0.9, n_groups=0,
+                     order=None):
+        """Estimator state update; allocates the state on the first batch. -> (cur_min, cur_max)"""
+        _need_device(new_min, 'range_update')
+        new_min, new_max = new_min.contiguous(), new_max.contiguous()
+        initialised = cur_min is not None
+        if not initialised or mode == EST_CURRENT:
+            cur_min, cur_max = torch.empty_like(new_min), torch.empty_like(new_max)
+        else:
+            # the reference rebinds fresh tensors every batch; keep earlier results un-aliased
+            cur_min, cur_max = cur_min.clone(), cur_max.clone()
+        rc = self.lib.tq_range_update(mode, _ptr(new_min), _ptr(new_max), _ptr(cur_min), _ptr(cur_max),
+                                      new_min.numel(), int(initialised), float(momentum),
+                                      int(n_groups or 0), _ptr(order), _stream())
+        _check(rc, self.lib)
+        return cur_min, cur_max
+
+    def axis_ranges(self, new_min, new_max, first):
+        _need_device(new_min, 'axis_ranges')
+        r = torch.empty_like(new_min)
+        rc = self.lib.tq_axis_ranges(_ptr(new_min.contiguous()), _ptr(new_max.contiguous()), _ptr(r),
+                                     r.numel(), int(first), _stream())
+        _check(rc, self.lib)
+        return r
+
+    def argsort(self, v):
+        return torch.argsort(v).contiguous()
+
+    # -- range -> params -------------------------------------------------------------------
+    def set_range_asym(self, x_min, x_max, n_bits, eps, log_domain):
+        x_min = self.to_device_f32(x_min).contiguous()
+        x_max = self.to_device_f32(x_max, like=x_min).contiguous()
+        delta, zf = torch.empty_like(x_min), torch.empty_like(x_min)
+        rc = self.lib.tq_set_range_asym(_ptr(x_min), _ptr(x_max), max(x_min.numel(), 1), int(n_bits),
+                                        float(eps), int(log_domain), _ptr(delta), _ptr(zf), _stream())
+        _check(rc, self.lib)
+        return delta, zf
+
+    def set_range_sym(self, x_min, x_max, n_bits, eps, log_domain):
+        x_min = self.to_device_f32(x_min).contiguous()
+        x_max = self.to_device_f32(x_max, like=x_min).contiguous()
+        delta = torch.empty_like(x_min)
+        signed = torch.empty((), dtype=torch.bool, device=x_min.device)
+        rc = self.lib.tq_set_range_sym(_ptr(x_min), _ptr(x_max), max(x_min.numel(), 1), int(n_bits),
+                                       float(eps), int(log_domain), _ptr(delta), _ptr(signed), _stream())
+        _check(rc, self.lib)
+        return delta, signed
+
+    # -- K7/K8/K9 --------------------------------------------------------------------------
+    def mse_candidates(self, x, rows, cand, loss):
+        """loss[rows, C] (fp64, device) += sum of squared quantisation error per candidate."""
+        _need_device(x, 'mse_candidates')
+        x = x.detach().contiguous()
+        row_len = x.numel() // rows
+        n_cand = cand.shape[0]
+        nbytes = self.lib.tq_mse_workspace_bytes(rows, row_len, n_cand)
+        ws = self._workspace(x.device, nbytes)
+        rc = self.lib.tq_mse_candidates(_ptr(x), rows, row_len, _dtype_code(x, 'mse_candidates'),
+                                        _ptr(cand), n_cand, _ptr(loss), _ptr(ws), ws.numel(), _stream())
+        _check(rc, self.lib)
+        return loss
+
+    def xent_candidates(self, x, cand, loss):
+        _need_device(x, 'xent_candidates')
+        x = x.detach().float().contiguous()
+        rows = x.shape[0]
+        cols = x.numel() // rows
+        rc = self.lib.tq_xent_candidates(_ptr(x), rows, cols, _ptr(cand), cand.shape[0], _ptr(loss),
+                                         _stream())
+        _check(rc, self.lib)
+        return loss
+
+    def argmin_select(self, loss, thr_min, thr_max):
+        rows, n_cand = loss.shape
+        cur_min = torch.empty(rows, dtype=torch.float32, device=loss.device)
+        cur_max = torch.empty(rows, dtype=torch.float32, device=loss.device)
+        best = torch.empty(rows, dtype=torch.int64, device=loss.device)
+        rc = self.lib.tq_argmin_select(_ptr(loss), rows, n_cand, _ptr(thr_min), _ptr(thr_max),
+                                       _ptr(cur_min), _ptr(cur_max), _ptr(best), _stream())
+        _check(rc, self.lib)
+        return cur_min, cur_max, best
+
+    def candidate_table(self, table_np, device):
+        """host numpy [C,k] fp32 -> device tensor (one async H2D copy)."""
+        return torch.from_numpy(table_np).to(device, non_blocking=True)
+
+    def zeros_f64(self, shape, device):
+        return torch.zeros(shape, dtype=torch.float64, device=device)
+
+    # -- K10/K11/K13 -----------------------------------------------------------------------
+    def adaround_fwd(self, w, alpha, qargs, mode, soft, temperature):
+        _need_device(w, 'adaround_fwd')
+        w = w.detach().contiguous()
+        out = torch.empty_like(w)
+        q = self._qdesc(*qargs)
+        rc = self.lib.tq_adaround_fwd(_ptr(w), _ptr(alpha), _ptr(out), w.numel(), C.byref(q), mode,
+                                      int(soft), float(temperature or 0.0), _stream())
+        _check(rc, self.lib)
+        return out
+
+    def adaround_init_alpha(self, w, qargs, mode, temperature):
+        _need_device(w, 'adaround_init_alpha')
+        w = w.detach().contiguous()
+        alpha = torch.empty_like(w)
+        q = self._qdesc(*qargs)
+        rc = self.lib.tq_adaround_init_alpha(_ptr(w), _ptr(alpha), w.numel(), C.byref(q), mode,
+                                             float(temperature or 0.0), _stream())
+        _check(rc, self.lib)
+        return alpha
+
+    def adaround_bwd(self, w, alpha, grad_wq, qargs, mode, temperature):
+        _need_device(w, 'adaround_bwd')
+        g = torch.empty_like(alpha)
+        q = self._qdesc(*qargs)
+        rc = self.lib.tq_adaround_bwd(_ptr(w.detach().contiguous()), _ptr(alpha.detach().contiguous()),
+                                      _ptr(grad_wq.contiguous()), _ptr(g), alpha.numel(), C.byref(q),
+                                      mode, float(temperature or 0.0), _stream())
+        _check(rc, self.lib)
+        return g
+
+    def adaround_bwd_adam(self, w, grad_wq, alpha, exp_avg, exp_avg_sq, qargs, mode, temperature,
+                          reg_weight, beta, lr, b1, b2, adam_eps, step, want_grad=False):
+        _need_device(w, 'adaround_bwd_adam')
+        g = torch.empty_like(alpha) if want_grad else None
+        q = self._qdesc(*qargs)
+        rc = self.lib.tq_adaround_bwd_adam(_ptr(w.detach().contiguous()), _ptr(grad_wq.contiguous()),
+                                           _ptr(alpha), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(g),
+                                           alpha.numel(), C.byref(q), mode, float(temperature or 0.0),
+                                           float(reg_weight), float(beta), float(lr), float(b1),
+                                           float(b2), float(adam_eps), int(step), _stream())
+        _check(rc, self.lib)
+        return g
+
+    def adaround_reg(self, alpha, mode, temperature, beta, weight):
+        _need_device(alpha, 'adaround_reg')
+        out = torch.zeros(1, dtype=torch.float64, device=alpha.device)
+        ws = self._workspace(alpha.device, self.lib.tq_reduce_workspace_bytes(alpha.numel()))
+        rc = self.lib.tq_adaround_reg(_ptr(alpha.detach().contiguous()), alpha.numel(), mode,
+                                      float(temperature or 0.0), float(beta), float(weight), _ptr(out),
+                                      _ptr(ws), ws.numel(), _stream())
+        _check(rc, self.lib)
+        return out[0]
+
+    def recon_loss(self, pred, tgt):
+        _need_device(pred, 'recon_loss')
+        pred, tgt = pred.detach().float().contiguous(), tgt.detach().float().contiguous()
+        d0 = pred.shape[0]
+        d1 = pred.shape[1] if pred.dim() > 1 else 1
+        rest = pred.numel() // (d0 * d1)
+        out = torch.empty(1, dtype=torch.float64, device=pred.device)
+        ws = self._workspace(pred.device, self.lib.tq_reduce_workspace_bytes(pred.numel()))
+        rc = self.lib.tq_recon_loss(_ptr(pred), _ptr(tgt), d0, d1, rest, _ptr(out), _ptr(ws), ws.numel(),
+                                    _stream())
+        _check(rc, self.lib)
+        return out[0]
+
+
+_backend = None
+
+
+def backend():
+    """The active backend (HipBackend unless a test installed a double with set_backend)."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend(b):
+    """Test hook: install a backend double (or None to go back to HIP)."""
+    global _backend
+    prev, _backend = _backend, b
+    return prev

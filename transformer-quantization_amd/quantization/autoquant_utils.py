@@ -1,0 +1,186 @@
+"""Quantized drop-ins for nn.Linear / nn.LayerNorm / nn.Embedding and the recursive
+``quantize_model`` rewriter (counterpart of the reference's quantization/autoquant_utils.py).
+
+``run_forward`` stays the per-op hook of the reference (:20-21, :59-66, :76-85); it is also where a
+fused GEMM + fake-quant epilogue would plug in.
+"""
+import copy
+import warnings
+
+from torch import nn
+from torch.nn import functional as F
+from torch.nn.modules.pooling import _AdaptiveAvgPoolNd, _AvgPoolNd
+
+from quantization.base_quantized_classes import FP32Acts, QuantizedActivation, QuantizedModule
+from quantization.hijacker import QuantizationHijacker, activations_list
+from quantization.quantization_manager import QuantizationManager
+
+
+class QuantLinear(QuantizationHijacker, nn.Linear):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+
+    def run_forward(self, x, weight, bias, offsets=None):
+        return F.linear(x.contiguous(), weight.contiguous(), bias=bias)
+
+
+class QuantLayerNorm(QuantizationHijacker, nn.LayerNorm):
+    def __init__(self, *args, activation=None, **kwargs):
+        super().__init__(*args, activation=activation, **kwargs)
+
+    def run_forward(self, x, weight, bias, offsets=None):
+        return F.layer_norm(input=x.contiguous(), normalized_shape=self.normalized_shape,
+                            weight=weight.contiguous(), bias=bias.contiguous(), eps=self.eps)
+
+
+class QuantEmbedding(QuantizationHijacker, nn.Embedding):
+    def __init__(self, *args, activation=None, **kwargs):
+        super().__init__(*args, activation=activation, **kwargs)
+        # a lookup in an already-quantized table needs no output quantizer
+        self.activation_quantizer = FP32Acts()
+
+    def run_forward(self, x, weight, bias, offsets=None):
+        return F.embedding(input=x.contiguous(), weight=weight.contiguous(),
+                           padding_idx=self.padding_idx, max_norm=self.max_norm,
+                           norm_type=self.norm_type, scale_grad_by_freq=self.scale_grad_by_freq,
+                           sparse=self.sparse)
+
+
+class QuantizedActivationWrapper(QuantizedActivation):
+    """Runs `layer` and quantizes its output; can share ("tie") the quantizer of the layer
+    before it, in which case the range is not updated here (useful for average pooling)."""
+
+    def __init__(self, layer, tie_activation_quantizers=False,
+                 input_quantizer: QuantizationManager = None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.tie_activation_quantizers = tie_activation_quantizers
+        if input_quantizer:
+            assert isinstance(input_quantizer, QuantizationManager)
+            self.activation_quantizer = input_quantizer
+        self.layer = layer
+
+    def quantize_activations_no_range_update(self, x):
+        return self.activation_quantizer.quantizer(x) if self._quant_a else x
+
+    def forward(self, x):
+        x = self.layer(x)
+        if self.tie_activation_quantizers:
+            return self.quantize_activations_no_range_update(x)
+        return self.quantize_activations(x)
+
+
+module_map = {nn.Linear: QuantLinear, nn.LayerNorm: QuantLayerNorm, nn.Embedding: QuantEmbedding}
+
+non_param_modules = (_AdaptiveAvgPoolNd, _AvgPoolNd)
+
+
+def get_act(module, i):
+    """First activation function after position i of a Sequential, and its index."""
+    for j in range(i + 1, len(module)):
+        if isinstance(module[j], tuple(activations_list)):
+            return module[j], j
+    return None, None
+
+
+def get_linear_args(module):
+    return dict(in_features=module.in_features, out_features=module.out_features,
+                bias=module.bias is not None)
+
+
+def get_layernorm_args(module):
+    return dict(normalized_shape=module.normalized_shape, eps=module.eps)
+
+
+def get_embedding_args(module):
+    return {k: getattr(module, k) for k in (
+        'num_embeddings', 'embedding_dim', 'padding_idx', 'max_norm', 'norm_type',
+        'scale_grad_by_freq', 'sparse')}
+
+
+def get_module_args(mod, act):
+    if isinstance(mod, nn.Linear):
+        kwargs = get_linear_args(mod)
+    elif isinstance(mod, nn.LayerNorm):
+        kwargs = get_layernorm_args(mod)
+    elif isinstance(mod, nn.Embedding):
+        kwargs = get_embedding_args(mod)
+    else:
+        raise ValueError
+    kwargs['activation'] = act
+    return kwargs
+
+
+def quant_module(module, i, **quant_params):
+    """Quantized copy of module[i], folding a following activation function into it."""
+    act, _ = get_act(module, i)
+    src = module[i]
+    new_module = module_map[type(src)](**get_module_args(src, act), **quant_params)
+    new_module.weight.data = src.weight.data.clone()
+    if src.bias is not None:
+        new_module.bias.data = src.bias.data.clone()
+    return new_module, i + int(bool(act)) + 1
+
+
+def quantize_sequence(model, specials=None, tie_activation_quantizers=False, **quant_params):
+    specials = specials or dict()
+    out = []
+    i = 0
+    while i < len(model):
+        m = model[i]
+        if isinstance(m, QuantizedModule):
+            out.append(m)
+        elif type(m) in module_map:
+            new_module, i = quant_module(model, i, **quant_params)
+            out.append(new_module)
+            continue
+        elif type(m) in specials:
+            out.append(specials[type(m)](m, **quant_params))
+        elif isinstance(m, non_param_modules):
+            input_quantizer = None
+            if out and isinstance(out[-1], QuantizedModule) and tie_activation_quantizers:
+                input_quantizer = out[-1].activation_quantizer
+                warnings.warn(f'Tying input quantizer {i}^th layer of type {type(out[-1])} to the '
+                              f'quantized {type(m)} following it')
+            out.append(QuantizedActivationWrapper(
+                m, tie_activation_quantizers=tie_activation_quantizers,
+                input_quantizer=input_quantizer, **quant_params))
+        else:
+            out.append(quantize_model(m, specials=specials, **quant_params))
+        i += 1
+    return out
+
+
+def quantize_sequential(model, specials=None, tie_activation_quantizers=False, **quant_params):
+    return nn.Sequential(*quantize_sequence(model, specials, tie_activation_quantizers,
+                                            **quant_params))
+
+
+def quantize_module_list(model, specials=None, tie_activation_quantizers=False, **quant_params):
+    return nn.ModuleList(quantize_sequence(model, specials, tie_activation_quantizers,
+                                           **quant_params))
+
+
+def quantize_model(model, specials=None, tie_activation_quantizers=False, **quant_params):
+    """Recursively replace Linear / LayerNorm / Embedding (and `specials`) by quantized versions."""
+    specials = specials or dict()
+
+    if isinstance(model, nn.Sequential):
+        return quantize_sequential(model, specials, tie_activation_quantizers, **quant_params)
+    if type(model) in specials:
+        return specials[type(model)](model, **quant_params)
+    if isinstance(model, non_param_modules):
+        return QuantizedActivationWrapper(model, **quant_params)
+    if type(model) in module_map:
+        # exact type match on purpose: subclasses of these layers are treated as containers
+        quant_model = module_map[type(model)](**get_module_args(model, None), **quant_params)
+        quant_model.weight.data = model.weight.data
+        if getattr(model, 'bias', None) is not None:
+            quant_model.bias.data = model.bias.data
+        return quant_model
+
+    quant_model = copy.deepcopy(model)
+    for name, child in quant_model._modules.items():
+        new_child = quantize_model(child, specials=specials, **quant_params)
+        if new_child is not None:
+            setattr(quant_model, name, new_child)
+    return quant_model

@@ -1,0 +1,80 @@
+"""Sharded calibration: all-reduce of per-rank range statistics over RCCL / xGMI.
+
+The reference has no distributed code at all; this module is new.  Calibration
+batches are split along the batch dimension across ranks (one process per GPU, identical weights).
+Every range estimator computes its statistic on the local shard and calls one of the two hooks
+below *inline* -- the freshly estimated range is needed to quantize the tensor that feeds the next
+layer, so the exchange cannot be deferred to the end of the forward:
+
+* ``sync_minmax``: min and max are fused into ONE ``MAX`` all-reduce on ``[-min ; max]``
+  (2 floats per tensor, 2*768 per-embedding).  min/max are associative, so the result is
+  bit-identical to the single-rank statistic of the concatenated batch; the EMA / all-time update
+  is then applied identically on every rank.
+* ``sync_sum``: ``SUM`` all-reduce of the fp64 candidate-loss vector of the MSE / cross-entropy
+  search (808 B for the 1-D grid, 103 KB for the 2-D grid); the argmin is computed redundantly.
+
+Messages are tiny, so the collectives are latency-bound: one fused buffer per call, no barrier,
+issued on the current stream through ``torch.distributed`` (backend ``nccl`` == RCCL on ROCm;
+``gloo`` in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+_group = None
+_enabled = False
+_stats = {'minmax_calls': 0, 'sum_calls': 0, 'bytes': 0}
+
+
+def enable(group=None):
+    """Turn on statistic all-reduce (requires an initialised default process group)."""
+    global _group, _enabled
+    if not dist.is_available() or not dist.is_initialized():
+        raise RuntimeError('torch.distributed is not initialised')
+    _group, _enabled = group, True
+
+
+def disable():
+    global _group, _enabled
+    _group, _enabled = None, False
+
+
+def is_enabled():
+    return _enabled and dist.is_initialized() and dist.get_world_size(_group) > 1
+
+
+def stats():
+    return dict(_stats)
+
+
+def sync_minmax(mn, mx):
+    """-> (min, max) over all ranks; one MAX all-reduce of cat(-min, max)."""
+    if not is_enabled():
+        return mn, mx
+    shape = mn.shape
+    buf = torch.cat([(-mn).reshape(-1), mx.reshape(-1)])
+    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=_group)
+    n = buf.numel() // 2
+    _stats['minmax_calls'] += 1
+    _stats['bytes'] += buf.numel() * buf.element_size()
+    return (-buf[:n]).reshape(shape), buf[n:].reshape(shape)
+
+
+def sync_sum(t):
+    """-> element-wise sum over all ranks (fp64 candidate losses, AdaRound gradients)."""
+    if not is_enabled():
+        return t
+    t = t.contiguous()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_group)
+    _stats['sum_calls'] += 1
+    _stats['bytes'] += t.numel() * t.element_size()
+    return t
+
+
+def shard_batch(x, dim=0):
+    """The slice of a calibration batch this rank owns."""
+    if not is_enabled():
+        return x
+    ws, rk = dist.get_world_size(_group), dist.get_rank(_group)
+    n = x.shape[dim]
+    per = (n + ws - 1) // ws
+    return x.narrow(dim, min(rk * per, n), max(0, min(per, n - rk * per)))
