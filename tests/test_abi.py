@@ -67,6 +67,7 @@ def test_argument_validation_without_gpu(lib_path):
     q = _hip.tq_quantizer(None, None, None, 8, 0, 0, 1e-8, 1, 1)
     rc = lib.tq_fake_quant_fwd(None, None, None, 0, 16, 0, ctypes.byref(q), None)
     assert rc == -1 and b'NULL' in lib.tq_last_error()
+    assert lib.tq_fake_quant_fwd(None, None, None, 0, 0, 0, ctypes.byref(q), None) == 0   # empty
     assert lib.tq_minmax_workspace_bytes(1 << 20, 1, 1) > 0
     assert lib.tq_minmax_workspace_bytes(1024 * 768, 768, 1) >= 2 * 768 * 4
     assert lib.tq_mse_workspace_bytes(1, 786432, 100) >= 100 * 8

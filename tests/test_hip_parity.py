@@ -167,10 +167,21 @@ def _check_trace(q, m, z):
         got_max = est.current_xmax.cpu().reshape(-1)
         ref_min, ref_max = t(z[f'e{k}_xmin'][b]), t(z[f'e{k}_xmax'][b])
         if golden_section:
-            # scipy owns the iterate sequence; the device loss differs from the reference's fp32
-            # sum in the last bits, so thresholds agree to the optimiser's tolerance only
-            assert torch.allclose(got_min, ref_min, rtol=2e-3, atol=1e-4), (m, b)
-            assert torch.allclose(got_max, ref_max, rtol=2e-3, atol=1e-4), (m, b)
+            # scipy owns the iterate sequence.  The device loss is an fp64-accumulated sum, the
+            # reference's an fp32 torch.sum: last-bit differences can steer Brent's method into a
+            # different local minimum of the (multi-modal, 4-bit) shift loss.  Accept either the
+            # same thresholds or an optimum that is at least as good under the oracle's loss.
+            same = torch.allclose(got_min, ref_min, rtol=2e-3, atol=1e-4) and \
+                torch.allclose(got_max, ref_max, rtol=2e-3, atol=1e-4)
+            if not same:
+                sym = m['method'] == 'symmetric_uniform'
+                qs = O.QSpec(m['n_bits'], sym)
+                xc = x.cpu()
+                rows = xc if LAYOUT_ARGS[m['layout']]['per_channel'] else xc.unsqueeze(0)
+                for r in range(got_min.numel()):
+                    ours = O.mse_loss_value(qs, rows[r], float(got_min[r]), float(got_max[r]))
+                    ref = O.mse_loss_value(qs, rows[r], float(ref_min[r]), float(ref_max[r]))
+                    assert ours <= ref * (1 + 1e-3), (m, b, r, ours, ref)
         elif m['init'] == 'cross_entropy':
             assert torch.allclose(got_max, ref_max, rtol=1e-6), (m, b)
             assert torch.allclose(got_min, ref_min, rtol=1e-6), (m, b)

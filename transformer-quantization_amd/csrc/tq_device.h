@@ -67,6 +67,11 @@ __device__ __forceinline__ float q_dequant(float xi, const QP& p) {
 }
 
 // ------------------------------------------------------------------ storage <-> fp32
+// NB: always bit-cast a by-value scalar.  clang (ROCm 7.2) mis-compiles
+// __builtin_bit_cast(T, vec[i]) on an ext_vector element lvalue: every i reads element 0.
+__device__ __forceinline__ float bits_to_f32(uint32_t w) { return __builtin_bit_cast(float, w); }
+__device__ __forceinline__ uint32_t f32_to_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
 template <int DT> struct Store;   // DT = TQ_F32 / TQ_BF16 / TQ_F16
 
 template <> struct Store<TQ_F32> {
@@ -74,12 +79,12 @@ template <> struct Store<TQ_F32> {
   static constexpr int kVec = 4;   // elements per 16-byte vector
   static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, v[i]);
+    for (int i = 0; i < 4; ++i) { const uint32_t w = v[i]; f[i] = bits_to_f32(w); }
   }
   static __device__ __forceinline__ u32x4 pack(const float (&f)[4]) {
     u32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(uint32_t, f[i]);
+    for (int i = 0; i < 4; ++i) v[i] = f32_to_bits(f[i]);
     return v;
   }
   static __device__ __forceinline__ float load1(const elem_t* p) { return *p; }
@@ -92,8 +97,9 @@ template <> struct Store<TQ_BF16> {
   static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
-      f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+      const uint32_t w = v[i];
+      f[2 * i] = bits_to_f32(w << 16);
+      f[2 * i + 1] = bits_to_f32(w & 0xffff0000u);
     }
   }
   static __device__ __forceinline__ u32x4 pack(const float (&f)[8]) {
@@ -119,7 +125,8 @@ template <> struct Store<TQ_F16> {
   static __device__ __forceinline__ void unpack(const u32x4& v, float (&f)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f16x2 h = __builtin_bit_cast(f16x2, v[i]);
+      const uint32_t w = v[i];
+      const f16x2 h = __builtin_bit_cast(f16x2, w);
       f[2 * i] = (float)h[0];
       f[2 * i + 1] = (float)h[1];
     }
@@ -155,8 +162,14 @@ template <> struct Idx<TQ_IDX_I32> { typedef int32_t t; static __device__ __forc
 
 // ------------------------------------------------------------------ wave / block reductions
 // torch.min / torch.max propagate NaN; so do these.
-__device__ __forceinline__ float min_nanprop(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
-__device__ __forceinline__ float max_nanprop(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b > a ? b : a)); }
+__device__ __forceinline__ float min_nanprop(float a, float b) {
+  const float m = b < a ? b : a;   // a NaN -> compare false -> m = a (NaN)
+  return (b != b) ? b : m;
+}
+__device__ __forceinline__ float max_nanprop(float a, float b) {
+  const float m = b > a ? b : a;
+  return (b != b) ? b : m;
+}
 
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll

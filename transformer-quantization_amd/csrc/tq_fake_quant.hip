@@ -301,6 +301,7 @@ using namespace tq;
 
 extern "C" int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtype, uint64_t n, int dtype,
                                  const tq_quantizer* q, tq_stream_t stream) {
+  if (n == 0) return TQ_OK;   // empty tensors are legal (torch semantics) and carry NULL pointers
   TQ_REQUIRE(x != nullptr, "tq_fake_quant_fwd: x is NULL");
   TQ_REQUIRE(y != nullptr || (idx != nullptr && idx_dtype != TQ_IDX_NONE), "tq_fake_quant_fwd: no output requested");
   TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_fake_quant_fwd: bad dtype %d", dtype);
@@ -319,6 +320,7 @@ extern "C" int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtyp
 extern "C" int tq_fake_quant_bwd(const void* x, const void* grad_y, void* grad_x, float* grad_delta,
                                  float* grad_zero_float, uint64_t n, int dtype, const tq_quantizer* q,
                                  tq_stream_t stream) {
+  if (n == 0) return TQ_OK;
   TQ_REQUIRE(x && grad_y && grad_x, "tq_fake_quant_bwd: NULL tensor");
   TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_fake_quant_bwd: bad dtype %d", dtype);
   if (int e = check_quantizer(q, n, "tq_fake_quant_bwd")) return e;

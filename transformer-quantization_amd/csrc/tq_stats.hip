@@ -17,6 +17,21 @@ namespace tq {
 
 constexpr float kInf = __builtin_huge_valf();
 
+// Branch-free running min/max with torch's NaN propagation: the compares ignore NaN, a third
+// lane-local word remembers the largest |bits| seen (> 0x7f800000 <=> some input was NaN).
+struct MinMax {
+  float mn = kInf, mx = -kInf;
+  uint32_t top = 0;
+  __device__ __forceinline__ void add(float x) {
+    mn = x < mn ? x : mn;
+    mx = x > mx ? x : mx;
+    const uint32_t a = f32_to_bits(x) & 0x7fffffffu;
+    top = a > top ? a : top;
+  }
+  __device__ __forceinline__ float lo() const { return top > 0x7f800000u ? __builtin_nanf("") : mn; }
+  __device__ __forceinline__ float hi() const { return top > 0x7f800000u ? __builtin_nanf("") : mx; }
+};
+
 // ------------------------------------------------------------------------------ last axis
 // blockDim = (CX, RY): CX lanes side by side cover CX 16-byte vectors of a row, RY rows at a time.
 // grid = (col_chunks, row_blocks).  partial layout: ws[(row_block) * 2 * d + {0,1} * d + col]
@@ -27,9 +42,8 @@ __global__ void mm_cols(const u32x4* __restrict__ x, uint64_t rows, uint32_t d, 
   const uint32_t vpr = d / V;
   const uint32_t cx = blockIdx.x * blockDim.x + threadIdx.x;    // vector column
   const bool live = cx < vpr;
+  MinMax acc[V];
   float mn[V], mx[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) { mn[j] = kInf; mx[j] = -kInf; }
 
   const uint64_t row_stride = (uint64_t)gridDim.y * blockDim.y;
   uint64_t r = (uint64_t)blockIdx.y * blockDim.y + threadIdx.y;
@@ -44,16 +58,18 @@ __global__ void mm_cols(const u32x4* __restrict__ x, uint64_t rows, uint32_t d, 
         float f[V];
         Store<DT>::unpack(v[u], f);
 #pragma unroll
-        for (int j = 0; j < V; ++j) { mn[j] = min_nanprop(mn[j], f[j]); mx[j] = max_nanprop(mx[j], f[j]); }
+        for (int j = 0; j < V; ++j) acc[j].add(f[j]);
       }
     }
     for (; r < rows; r += row_stride) {
       float f[V];
       Store<DT>::unpack(x[r * vpr + cx], f);
 #pragma unroll
-      for (int j = 0; j < V; ++j) { mn[j] = min_nanprop(mn[j], f[j]); mx[j] = max_nanprop(mx[j], f[j]); }
+      for (int j = 0; j < V; ++j) acc[j].add(f[j]);
     }
   }
+#pragma unroll
+  for (int j = 0; j < V; ++j) { mn[j] = acc[j].lo(); mx[j] = acc[j].hi(); }
   // combine the RY row-lanes of this block through LDS
   const uint32_t cw = blockDim.x * V;
   float* my = s_mm + (size_t)threadIdx.y * 2 * cw;
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void mm_rows(const void* __restrict__ x, ui
   typedef typename Store<DT>::elem_t E;
   __shared__ float s_red[2][kBlock / kWave];
   for (uint64_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
-    float mn = kInf, mx = -kInf;
+    MinMax acc;
     const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     if (VEC) {
@@ -102,25 +118,21 @@ __global__ __launch_bounds__(kBlock) void mm_rows(const void* __restrict__ x, ui
           float f[V];
           Store<DT>::unpack(v[u], f);
 #pragma unroll
-          for (int j = 0; j < V; ++j) { mn = min_nanprop(mn, f[j]); mx = max_nanprop(mx, f[j]); }
+          for (int j = 0; j < V; ++j) acc.add(f[j]);
         }
       }
       for (; i < n_vec; i += stride) {
         float f[V];
         Store<DT>::unpack(xv[i], f);
 #pragma unroll
-        for (int j = 0; j < V; ++j) { mn = min_nanprop(mn, f[j]); mx = max_nanprop(mx, f[j]); }
+        for (int j = 0; j < V; ++j) acc.add(f[j]);
       }
     } else {
       const E* xs = static_cast<const E*>(x) + row * inner;
-      for (uint64_t i = tid; i < inner; i += stride) {
-        const float f = Store<DT>::load1(xs + i);
-        mn = min_nanprop(mn, f);
-        mx = max_nanprop(mx, f);
-      }
+      for (uint64_t i = tid; i < inner; i += stride) acc.add(Store<DT>::load1(xs + i));
     }
-    mn = wave_min(mn);
-    mx = wave_max(mx);
+    float mn = wave_min(acc.lo());
+    float mx = wave_max(acc.hi());
     const int w = threadIdx.x / kWave;
     __syncthreads();   // s_red reuse across row iterations
     if ((threadIdx.x & (kWave - 1)) == 0) { s_red[0][w] = mn; s_red[1][w] = mx; }
