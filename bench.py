@@ -85,6 +85,21 @@ def cpu_baseline(budget_s=12.0):
     }
 
 
+def pmc_traffic(n_elems):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes).
+    None when no PMC summary exists for this exact workload size."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if t.get('workload_elems') != n_elems:
+        return None
+    return t.get('traffic_bytes_per_launch')
+
+
 def _cpu_model():
     try:
         with open('/proc/cpuinfo') as f:
@@ -207,7 +222,9 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4),
-            'traffic': None,
+            'traffic': pmc_traffic(n_elems),
+            'traffic_note': 'bytes per launch from profiles/pmc_traffic.json (rocprofv3 PMC, separate '
+                            'passes, gfx950 FETCH_SIZE x2); null if not collected for this size',
             'kernel': 'tq::fq_tensor<bf16>',
             'kernel_ms': round(ev_ms, 4),
             'algorithmic_bytes_per_launch': n_elems * BYTES_PER_ELEM,

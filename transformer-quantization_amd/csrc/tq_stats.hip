@@ -45,11 +45,15 @@ __global__ void mm_cols(const u32x4* __restrict__ x, uint64_t rows, uint32_t d, 
   MinMax acc[V];
   float mn[V], mx[V];
 
-  const uint64_t row_stride = (uint64_t)gridDim.y * blockDim.y;
-  uint64_t r = (uint64_t)blockIdx.y * blockDim.y + threadIdx.y;
+  // block (., by) owns the contiguous rows [by * chunk, (by + 1) * chunk): the resident blocks
+  // then sweep one contiguous window of HBM instead of gridDim.y windows that lie MBs apart
+  const uint64_t chunk = (rows + gridDim.y - 1) / gridDim.y;
+  const uint64_t row_end = min(rows, ((uint64_t)blockIdx.y + 1) * chunk);
+  const uint64_t row_stride = blockDim.y;
+  uint64_t r = (uint64_t)blockIdx.y * chunk + threadIdx.y;
   if (live) {
     constexpr int U = 4;
-    for (; r + (U - 1) * row_stride < rows; r += U * row_stride) {
+    for (; r + (U - 1) * row_stride < row_end; r += U * row_stride) {
       u32x4 v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = ld_stream(x + (r + u * row_stride) * vpr + cx);
@@ -61,7 +65,7 @@ __global__ void mm_cols(const u32x4* __restrict__ x, uint64_t rows, uint32_t d, 
         for (int j = 0; j < V; ++j) acc[j].add(f[j]);
       }
     }
-    for (; r < rows; r += row_stride) {
+    for (; r < row_end; r += row_stride) {
       float f[V];
       Store<DT>::unpack(x[r * vpr + cx], f);
 #pragma unroll
@@ -102,13 +106,15 @@ __global__ __launch_bounds__(kBlock) void mm_rows(const void* __restrict__ x, ui
   __shared__ float s_red[2][kBlock / kWave];
   for (uint64_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
     MinMax acc;
-    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t stride = kBlock;
     if (VEC) {
+      // block bx owns the contiguous vectors [bx * chunk, (bx + 1) * chunk) of the row
       const u32x4* xv = static_cast<const u32x4*>(x) + row * (inner / V);
-      const uint64_t n_vec = inner / V;
+      const uint64_t n_all = inner / V;
+      const uint64_t chunk = (n_all + gridDim.x - 1) / gridDim.x;
+      const uint64_t n_vec = min(n_all, ((uint64_t)blockIdx.x + 1) * chunk);
       constexpr int U = 4;
-      uint64_t i = tid;
+      uint64_t i = (uint64_t)blockIdx.x * chunk + threadIdx.x;
       for (; i + (U - 1) * stride < n_vec; i += U * stride) {
         u32x4 v[U];
 #pragma unroll
@@ -129,7 +135,8 @@ __global__ __launch_bounds__(kBlock) void mm_rows(const void* __restrict__ x, ui
       }
     } else {
       const E* xs = static_cast<const E*>(x) + row * inner;
-      for (uint64_t i = tid; i < inner; i += stride) acc.add(Store<DT>::load1(xs + i));
+      for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < inner; i += (uint64_t)gridDim.x * kBlock)
+        acc.add(Store<DT>::load1(xs + i));
     }
     float mn = wave_min(acc.lo());
     float mx = wave_max(acc.hi());
@@ -157,7 +164,20 @@ __global__ void mm_final(const float* __restrict__ ws, uint64_t P, uint64_t n_pa
   const uint64_t col = (uint64_t)blockIdx.x * cx + threadIdx.x;
   float mn = kInf, mx = -kInf;
   if (col < n_params) {
-    for (uint64_t p = threadIdx.y; p < P; p += sy) {
+    // 4 independent loads in flight per lane: a single dependent chain over P records is
+    // latency-bound (33 us for 16384 records before this unroll)
+    uint64_t p = threadIdx.y;
+    for (; p + 3 * (uint64_t)sy < P; p += 4 * (uint64_t)sy) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = ws[(p + u * sy) * 2 * n_params + col];
+        b[u] = ws[(p + u * sy) * 2 * n_params + n_params + col];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { mn = min_nanprop(mn, a[u]); mx = max_nanprop(mx, b[u]); }
+    }
+    for (; p < P; p += sy) {
       mn = min_nanprop(mn, ws[p * 2 * n_params + col]);
       mx = max_nanprop(mx, ws[p * 2 * n_params + n_params + col]);
     }
@@ -165,13 +185,19 @@ __global__ void mm_final(const float* __restrict__ ws, uint64_t P, uint64_t n_pa
   s_f[threadIdx.y * cx + threadIdx.x] = mn;
   s_f[(sy + threadIdx.y) * cx + threadIdx.x] = mx;
   __syncthreads();
-  if (threadIdx.y == 0 && col < n_params) {
-    for (uint32_t k = 1; k < sy; ++k) {
-      mn = min_nanprop(mn, s_f[k * cx + threadIdx.x]);
-      mx = max_nanprop(mx, s_f[(sy + k) * cx + threadIdx.x]);
+  // tree over the sy slices
+  for (uint32_t h = 1; h < sy; h <<= 1) {
+    if ((threadIdx.y % (2 * h)) == 0 && threadIdx.y + h < sy) {
+      float* a = s_f + threadIdx.y * cx + threadIdx.x;
+      float* b = s_f + (sy + threadIdx.y) * cx + threadIdx.x;
+      *a = min_nanprop(*a, a[h * cx]);
+      *b = max_nanprop(*b, b[h * cx]);
     }
-    out_min[col] = mn;
-    out_max[col] = mx;
+    __syncthreads();
+  }
+  if (threadIdx.y == 0 && col < n_params) {
+    out_min[col] = s_f[threadIdx.x];
+    out_max[col] = s_f[sy * cx + threadIdx.x];
   }
 }
 
@@ -197,10 +223,11 @@ static MMPlan plan_minmax(uint64_t n, uint64_t n_params, uint64_t inner, int V, 
   }
   const uint64_t eff_inner = n_params == 1 ? n : inner;
   const uint64_t n_rows = n_params == 1 ? 1 : n / inner;
-  const uint64_t per_block = (uint64_t)kBlock * V * 4;
+  const uint64_t per_block = (uint64_t)kBlock * V * 4 * 2;      // two 4-vector rounds per lane
   pl.cols = false;
   pl.gy = (unsigned)std::min<uint64_t>(n_rows, 65535);
-  const uint64_t max_gx = std::max<uint64_t>(1, (uint64_t)kMaxGrid / std::max<uint64_t>(1, std::min<uint64_t>(n_rows, kMaxGrid)));
+  constexpr uint64_t kMaxBlocks = 16384;                        // partial records stay <= 128 KiB
+  const uint64_t max_gx = std::max<uint64_t>(1, kMaxBlocks / std::max<uint64_t>(1, std::min<uint64_t>(n_rows, kMaxBlocks)));
   pl.gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(eff_inner, per_block), max_gx));
   const uint64_t outer = n_params == 1 ? 1 : n_rows / n_params;
   pl.P = outer * pl.gx;
@@ -229,7 +256,7 @@ static int launch_minmax(const void* x, uint64_t n, uint64_t n_params, uint64_t 
   }
   if (int e = check_launch("tq_minmax partial")) return e;
   const unsigned cx = (unsigned)std::min<uint64_t>(n_params, 64);
-  const unsigned sy = 256 / cx;
+  const unsigned sy = std::max(1u, std::min<unsigned>(1024 / cx, (unsigned)std::max<uint64_t>(1, pl.P)));
   hipLaunchKernelGGL(mm_final, dim3((unsigned)ceil_div(n_params, cx)), dim3(cx, sy), 2 * sy * cx * sizeof(float), st,
                      ws, pl.P, n_params, out_min, out_max);
   return check_launch("tq_minmax final");
