@@ -1,0 +1,255 @@
+"""N > 1 path on CPU: world_size-2 `gloo` process groups (the same torch.distributed calls go to
+RCCL on the GPU box).  The backend is the oracle-backed double, so what is verified here is the
+sharding logic: per-rank statistics all-reduced inline give every rank the statistics of the
+concatenated batch (exact for min/max; equal argmin for the MSE search), and data-parallel AdaRound
+reproduces the single-rank step on the same global batch.
+"""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.conftest import ROOT, PKG
+
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _setup(rank, port):
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    from quantization import _hip, distributed as tq_dist
+    from tests._oracle_backend import OracleBackend
+    _hip.set_backend(OracleBackend())
+    tq_dist.enable()
+    return tq_dist
+
+
+def _batches(n=3, B=4, T=6, D=24, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        x = torch.randn(B, T, D, generator=g) * (1.0 + 0.5 * i)
+        x[..., 3] *= 15
+        out.append(x)
+    return out
+
+
+def _run_managers(xs, shard):
+    """Drive a set of managers over batches; `shard(x)` picks the local slice."""
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from quantization.quantization_manager import QuantizationManager
+    from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+    cfgs = [('asymmetric_uniform', 'running_minmax', None, {}),
+            ('symmetric_uniform', 'allminmax', None, {}),
+            ('asymmetric_uniform', 'current_minmax', 'per_embd', {}),
+            ('asymmetric_uniform', 'running_minmax', 'peg4', {}),
+            ('symmetric_uniform', 'MSE', None, dict(num_candidates=40)),
+            ('asymmetric_uniform', 'MSE', None, dict(num_candidates=8))]
+    res = []
+    for method, init, layout, ip in cfgs:
+        mgr = QuantizationManager(qmethod=QMethods[method], init=RangeEstimators[init],
+                                  qparams=dict(n_bits=4 if init == 'MSE' else 8), init_params=ip)
+        if layout == 'per_embd':
+            set_act_quant_axis_and_groups(mgr, axis=2, n_groups=None)
+        elif layout == 'peg4':
+            set_act_quant_axis_and_groups(mgr, axis=2, n_groups=4)
+        for x in xs:
+            mgr(shard(x))
+        est = mgr.range_estimator
+        rec = dict(xmin=est.current_xmin.clone(), xmax=est.current_xmax.clone(),
+                   delta=mgr.quantizer._delta.clone())
+        if init == 'MSE':
+            rec['loss'] = est.loss_array.copy()
+        res.append(rec)
+    return res
+
+
+def _worker_calibration(rank, port, outdir):
+    tq_dist = _setup(rank, port)
+    xs = _batches()
+    res = _run_managers(xs, tq_dist.shard_batch)
+    torch.save(res, os.path.join(outdir, f'calib_{rank}.pt'))
+    torch.save(tq_dist.stats(), os.path.join(outdir, f'stats_{rank}.pt'))
+    # ragged shard: 5 samples over 2 ranks -> 3 + 2
+    x = torch.arange(5.0).view(5, 1)
+    assert tq_dist.shard_batch(x).shape[0] == (3 if rank == 0 else 2)
+    dist.destroy_process_group()
+
+
+def test_sharded_calibration_equals_single_rank(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_calibration, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    # single-rank reference on the full batches (same backend double, collectives off)
+    from quantization import _hip, distributed as tq_dist
+    from tests._oracle_backend import OracleBackend
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        tq_dist.disable()
+        ref = _run_managers(_batches(), lambda x: x)
+    finally:
+        _hip.set_backend(prev)
+    for rank in range(WORLD):
+        got = torch.load(os.path.join(tmp_path, f'calib_{rank}.pt'), weights_only=False)
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert torch.equal(g['xmin'], r['xmin']), (rank, i)
+            assert torch.equal(g['xmax'], r['xmax']), (rank, i)
+            assert torch.equal(g['delta'], r['delta']), (rank, i)
+            if 'loss' in r:
+                fin = np.isfinite(r['loss'])
+                assert np.allclose(g['loss'][fin], r['loss'][fin], rtol=1e-6), (rank, i)
+        st = torch.load(os.path.join(tmp_path, f'stats_{rank}.pt'), weights_only=False)
+        assert st['minmax_calls'] > 0 and st['sum_calls'] > 0
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc1 = torch.nn.Linear(24, 32)
+        self.fc2 = torch.nn.Linear(32, 24)
+
+
+def _quant_toy(org):
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.base_quantized_classes import QuantizedActivation
+    from quantization.autoquant_utils import quantize_model
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8,
+              act_range_method=RangeEstimators.running_minmax)
+
+    class Q(QuantizedModel):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = quantize_model(org.fc1, **qp)
+            self.fc2 = quantize_model(org.fc2, **qp)
+            self.res = QuantizedActivation(**qp)
+
+        def forward(self, x):
+            return self.res(self.fc2(torch.relu(self.fc1(x))) + x)
+    return Q()
+
+
+def _calibrated_state(shard_loader):
+    from utils.utils import pass_data_for_range_estimation
+    torch.manual_seed(5)
+    model = _quant_toy(_Toy())
+    loader = [(b,) for b in _batches(n=3, B=8)]
+    pass_data_for_range_estimation(loader, model, act_quant=True, weight_quant=True, max_num_batches=3)
+    model.fix_ranges()
+    return {k: v.clone() for k, v in model.state_dict().items()
+            if any(s in k for s in ('_delta', '_zero_float', 'current_x'))}
+
+
+def _worker_model(rank, port, outdir):
+    _setup(rank, port)
+    torch.save(_calibrated_state(None), os.path.join(outdir, f'model_{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_sharded_pass_data_for_range_estimation(tmp_path):
+    """The calibration driver shards every batch along dim 0; the resulting quantizer state is the
+    single-rank state (activation ranges within fp32 GEMM round-off of the batch split, weight
+    ranges exactly)."""
+    port = _free_port()
+    mp.spawn(_worker_model, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    from quantization import _hip, distributed as tq_dist
+    from tests._oracle_backend import OracleBackend
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        tq_dist.disable()
+        ref = _calibrated_state(None)
+    finally:
+        _hip.set_backend(prev)
+    for rank in range(WORLD):
+        got = torch.load(os.path.join(tmp_path, f'model_{rank}.pt'), weights_only=False)
+        assert got.keys() == ref.keys()
+        for k in ref:
+            if 'weight_quantizer' in k:
+                assert torch.equal(got[k], ref[k]), k
+            else:
+                assert torch.allclose(got[k], ref[k], rtol=1e-5, atol=1e-6), k
+
+
+def _ada_problem():
+    from quantization.quantizers import QMethods
+    from quantization.autoquant_utils import QuantLinear
+    from quantization.adaround.quantizer import ADAROUND_QUANTIZER_MAP
+    from quantization.adaround.utils import AdaRoundMode, CombinedLoss, AdaRoundLossType
+    from quantization.adaround.adaround import FusedAlphaAdam
+    g = torch.Generator().manual_seed(31)
+    layer = QuantLinear(16, 12, method=QMethods.symmetric_uniform, n_bits=4)
+    layer.weight.data = torch.randn(12, 16, generator=g) * 0.3
+    layer.bias.data = torch.randn(12, generator=g) * 0.1
+    layer.quantized_weights()
+    layer.caching = False
+    X = torch.randn(16, 5, 16, generator=g)
+    tgt = torch.randn(16, 5, 12, generator=g)
+    with torch.no_grad():
+        layer(X)
+    oq = layer.weight_quantizer.quantizer
+    wq = ADAROUND_QUANTIZER_MAP[oq.__class__](n_bits=4)
+    for name in ('_delta', '_zero_float', '_signed'):
+        wq.register_buffer(name, getattr(oq, name))
+    layer.weight_quantizer.quantizer = wq
+    layer.weight_quantizer.fix_ranges()
+    wq.round_mode = AdaRoundMode.learned_hard_sigmoid
+    wq.soft_targets = True
+    with torch.no_grad():
+        wq(layer.weight)
+    loss_fn = CombinedLoss(quantizer=wq, loss_type=AdaRoundLossType.relaxation, weight=0.01,
+                           max_count=6, b_range=(20, 2), warmup=0.2)
+    idx = [torch.randperm(16, generator=g)[:8].numpy() for _ in range(6)]
+
+    def get_inp_out(data):
+        pos = [int((X == d).all(-1).all(-1).nonzero()[0]) for d in data]
+        return data, tgt[pos]
+    return layer, wq, X, get_inp_out, loss_fn, FusedAlphaAdam(wq, lr=1e-2), idx
+
+
+def _worker_adaround(rank, port, outdir):
+    _setup(rank, port)
+    from quantization.adaround.adaround import optimize_local_loss
+    layer, wq, X, gio, loss_fn, opt, idx = _ada_problem()
+    optimize_local_loss(layer, gio, X, opt, loss_fn, 8, 6, batch_indices=idx)
+    torch.save(wq.alpha.detach().clone(), os.path.join(outdir, f'alpha_{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_adaround_equals_single_rank(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_adaround, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    from quantization import _hip, distributed as tq_dist
+    from quantization.adaround.adaround import optimize_local_loss
+    from tests._oracle_backend import OracleBackend
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        tq_dist.disable()
+        layer, wq, X, gio, loss_fn, opt, idx = _ada_problem()
+        optimize_local_loss(layer, gio, X, opt, loss_fn, 8, 6, batch_indices=idx)
+        ref = wq.alpha.detach().clone()
+    finally:
+        _hip.set_backend(prev)
+    a0 = torch.load(os.path.join(tmp_path, 'alpha_0.pt'), weights_only=False)
+    a1 = torch.load(os.path.join(tmp_path, 'alpha_1.pt'), weights_only=False)
+    assert torch.equal(a0, a1)                                    # replicas stay in lock-step
+    assert torch.allclose(a0, ref, rtol=1e-4, atol=1e-5)          # and follow the 1-rank trajectory
