@@ -73,14 +73,24 @@ def cpu_baseline(budget_s=12.0):
         times.sort()
         return x.numel() / times[len(times) // 2] / 1e6, len(times)
 
-    v_all, reps = run(threads, budget_s * 0.7)
-    v_one, _ = run(1, budget_s * 0.3)
+    # torch's default (all logical cores / 2) is page-fault bound on this op chain (every ATen op
+    # allocates a fresh 100 MB tensor), so sweep thread counts and report the best one as `value`
+    counts = sorted({c for c in (1, 8, 16, 32, 64, threads) if c <= threads})
+    per = {}
+    reps_best = 0
+    for c in counts:
+        v, reps = run(c, budget_s / len(counts))
+        per[str(c)] = round(v, 1)
+        if v >= max(per.values()):
+            reps_best = reps
+    best = max(per, key=lambda k: per[k])
     torch.set_num_threads(threads)
     return {
-        'value': round(v_all, 1), 'unit': 'M elems/s', 'cores': threads, 'kind': 'port',
+        'value': per[best], 'unit': 'M elems/s', 'cores': int(best), 'kind': 'port',
         'sample': f'[64,512,768] fp32 hidden states ({x.numel()} elems), fixed-range asym 8-bit '
-                  f'fake-quant, median of {reps} passes, torch {torch.__version__} CPU',
-        'single_thread_value': round(v_one, 1),
+                  f'fake-quant (reference op chain, oracle port), median of {reps_best} passes, '
+                  f'torch {torch.__version__} CPU; best of thread counts {counts}',
+        'by_threads': per,
         'cpu_model': _cpu_model(), 'host_logical_cpus': os.cpu_count(),
     }
 
