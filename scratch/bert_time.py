@@ -1,0 +1,35 @@
+import sys, time
+sys.path.insert(0,'/root/repo/transformer-quantization_amd'); sys.path.insert(0,'/root/repo')
+import numpy as np, torch
+from tests.test_bert_e2e import _build, _fixture
+from utils.utils import pass_data_for_range_estimation
+z=_fixture()
+model,hf=_build('cuda')
+ids=torch.from_numpy(z['input_ids']).cuda()
+def t(fn,n=10,w=2):
+    for _ in range(w): fn()
+    torch.cuda.synchronize(); t0=time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter()-t0)/n*1e3
+with torch.no_grad():
+    model.set_quant_state(False, False); model.eval()
+    print('fp32 forward ms', t(lambda: model(ids)))
+    model.set_quant_state(True, True)
+    print('calibrating forward ms', t(lambda: model(ids)))
+    model.fix_ranges()
+    print('fixed-range forward ms (eager)', t(lambda: model(ids)))
+    # hipGraph capture of the fixed-range forward
+    g=torch.cuda.CUDAGraph()
+    s=torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3): model(ids)
+    torch.cuda.current_stream().wait_stream(s)
+    try:
+        with torch.cuda.graph(g):
+            out=model(ids)
+        print('fixed-range forward ms (hipGraph replay)', t(lambda: g.replay()))
+        ref=model(ids)
+        print('graph == eager', torch.equal(out, ref))
+    except Exception as e:
+        print('graph capture failed:', repr(e)[:300])

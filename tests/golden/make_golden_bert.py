@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Whole-model fixture (BASELINE configs[0]/[1]): random-init BERT-base, W8A8 per-tensor
+(symmetric 8-bit weights / current min-max, asymmetric 8-bit activations / running min-max),
+one calibration batch, then a fixed-range forward -- produced by the REFERENCE's own
+models/quantized_bert.py sub-modules, imported here (build container only).
+
+The reference targets transformers 4.1; its HF *container* forwards (BertEncoder, BertAttention)
+no longer match, so the script drives the reference's quantized blocks directly in the order the
+4.1 containers did (self-attention -> self-output -> intermediate -> output).  No reference file is
+modified; shims: HF layers get the 4.1-style functional GELU, `utils` namespace package with no-op TensorBoard hooks, and
+transformers.modeling_utils.apply_chunking_to_forward re-exported from pytorch_utils.
+
+Stores: logits, the 161 activation ranges (call order) and the 102 weight-quantizer deltas.
+Weights are NOT stored (440 MB): the test rebuilds them from the same seed with the same
+transformers / torch versions (same container image on the GPU box).
+
+    python tests/golden/make_golden_bert.py
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = '/root/reference'
+sys.path.insert(0, REF)
+_u = types.ModuleType('utils')
+_u.__path__ = [os.path.join(REF, 'utils')]
+for _name in ('_tb_advance_global_step', '_tb_advance_token_counters', '_tb_hist'):
+    setattr(_u, _name, lambda *a, **k: None)
+sys.modules['utils'] = _u
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import transformers  # noqa: E402
+import transformers.modeling_utils as _mu  # noqa: E402
+from transformers.pytorch_utils import apply_chunking_to_forward  # noqa: E402
+_mu.apply_chunking_to_forward = apply_chunking_to_forward
+from transformers import BertConfig, BertForSequenceClassification  # noqa: E402
+
+from utils.utils import DotDict  # noqa: E402
+_u.DotDict = DotDict
+from quantization.quantizers import QMethods  # noqa: E402
+from quantization.range_estimators import RangeEstimators  # noqa: E402
+from quantization.quantization_manager import QuantizationManager  # noqa: E402
+from quantization.autoquant_utils import quantize_model  # noqa: E402
+from models.quantized_bert import (  # noqa: E402
+    QuantizedBertEmbeddings, QuantizedBertLayer, QuantizedBertPooler)
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+SEED = 1000
+
+
+def build_hf():
+    torch.manual_seed(SEED)
+    cfg = BertConfig(num_labels=2)
+    model = BertForSequenceClassification(cfg)
+    model.eval()
+    # transformers 4.1 semantics: ACT2FN['gelu'] was torch.nn.functional.gelu, which the reference
+    # turns into nn.GELU() and folds into the intermediate QuantLinear (quantized_bert.py:283-291);
+    # today's GELUActivation module would silently escape that folding.
+    for layer in model.bert.encoder.layer:
+        del layer.intermediate.intermediate_act_fn          # registered sub-module today
+        object.__setattr__(layer.intermediate, 'intermediate_act_fn', torch.nn.functional.gelu)
+    return model
+
+
+def inputs():
+    g = torch.Generator().manual_seed(SEED)
+    return torch.randint(0, 30522, (8, 128), generator=g)
+
+
+def main():
+    torch.set_num_threads(8)
+    hf = build_hf()
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8,
+              n_bits_act=8, weight_range_method=RangeEstimators.current_minmax,
+              act_range_method=RangeEstimators.running_minmax, quant_dict={})
+    emb = QuantizedBertEmbeddings(hf.bert.embeddings, **qp)
+    layers = [QuantizedBertLayer(l, **qp) for l in hf.bert.encoder.layer]
+    pooler = QuantizedBertPooler(hf.bert.pooler, **qp)
+    qp2 = dict(qp)
+    qp2.pop('quant_dict')
+    classifier = quantize_model(hf.classifier, **qp2)
+    blocks = torch.nn.ModuleList([emb] + layers + [pooler, classifier])
+
+    def apply(fn):
+        for m in blocks.modules():
+            if hasattr(m, fn) and not isinstance(m, QuantizationManager):
+                getattr(m, fn)()
+
+    def forward(ids):
+        mask = torch.zeros(ids.shape[0], 1, 1, ids.shape[1])          # all-ones attention mask
+        h = emb(input_ids=ids)
+        for L in layers:
+            att = L.attention
+            ctx = att.self(h, mask)[0]
+            a_out = att.output(ctx, h)
+            h = L.output(L.intermediate(a_out), a_out)
+        pooled = hf.dropout(pooler(h))
+        return classifier(pooled)
+
+    blocks.eval()
+    apply('quantized')
+    ids = inputs()
+    with torch.no_grad():
+        forward(ids)                         # calibration batch (estimate_ranges state)
+        for m in blocks.modules():
+            if isinstance(m, QuantizationManager) and m.quantizer.is_initialized:
+                m.fix_ranges()
+        logits = forward(ids)
+
+    act, wts = [], []
+    for name, m in blocks.named_modules():
+        if isinstance(m, QuantizationManager) and m.quantizer.is_initialized:
+            if name.endswith('activation_quantizer'):
+                act.append((name, float(m.range_estimator.current_xmin),
+                            float(m.range_estimator.current_xmax)))
+            elif name.endswith('weight_quantizer'):
+                wts.append((name, float(m.quantizer._delta)))
+    print('activation quantizers:', len(act), 'weight quantizers:', len(wts))
+    print('logits', logits)
+    np.savez_compressed(
+        os.path.join(OUT, 'bert_base_w8a8.npz'),
+        logits=logits.numpy(), input_ids=ids.numpy(),
+        act_names=np.array([a[0] for a in act]), act_min=np.array([a[1] for a in act], np.float32),
+        act_max=np.array([a[2] for a in act], np.float32),
+        w_names=np.array([w[0] for w in wts]), w_delta=np.array([w[1] for w in wts], np.float32),
+        versions=np.array(f'torch {torch.__version__} transformers {transformers.__version__}'),
+        first_weight_sum=np.array(float(hf.bert.encoder.layer[0].attention.self.query.weight.double().sum())))
+
+
+if __name__ == '__main__':
+    main()

@@ -24,15 +24,15 @@ constexpr int kCandTile = 128;
 template <int DT, int E>
 __global__ __launch_bounds__(kBlock) void mse_cand_k(const void* __restrict__ x, uint64_t row_len, bool vec_ok,
                                                      const float4* __restrict__ cand, uint32_t n_cand,
-                                                     double* __restrict__ partial) {
+                                                     uint32_t cand_tile, double* __restrict__ partial) {
   constexpr int V = Store<DT>::kVec;
   constexpr int NV = E / V;   // 16-byte vectors per lane per tile
   typedef typename Store<DT>::elem_t T;
   __shared__ float4 s_c[kCandTile];
   __shared__ double s_acc[kBlock / kWave][kCandTile];
 
-  const uint32_t c0 = blockIdx.y * kCandTile;
-  const uint32_t nc = min((uint32_t)kCandTile, n_cand - c0);
+  const uint32_t c0 = blockIdx.y * cand_tile;
+  const uint32_t nc = min(cand_tile, n_cand - c0);
   for (uint32_t c = threadIdx.x; c < kCandTile; c += kBlock) {
     if (c < nc) s_c[c] = cand[c0 + c];
 #pragma unroll
@@ -97,15 +97,18 @@ __global__ void mse_final_k(const double* __restrict__ partial, uint32_t nb, uin
   loss[row * n_cand + c] += tot;
 }
 
-struct MsePlan { unsigned gx, gy; int e; };
+struct MsePlan { unsigned gx, gy; int e; unsigned cand_tile; };
 
 static MsePlan plan_mse(uint64_t rows, uint64_t row_len, uint64_t n_cand) {
   MsePlan p;
   p.e = row_len <= 2048 ? 4 : 16;
   if (row_len > 2048 && row_len < (uint64_t)kBlock * 16 * 256) p.e = 8;   // more, smaller tiles for mid sizes
   const uint64_t tile = (uint64_t)kBlock * p.e;
-  p.gy = (unsigned)ceil_div(n_cand, kCandTile);
   const uint64_t tiles = ceil_div(row_len, tile);
+  // small tensors: split the candidates over more blocks (x is re-read from L2) until the chip is full
+  p.cand_tile = kCandTile;
+  while (p.cand_tile > 16 && tiles * rows * ceil_div(n_cand, p.cand_tile) < 2048) p.cand_tile /= 2;
+  p.gy = (unsigned)ceil_div(n_cand, p.cand_tile);
   const uint64_t budget = std::max<uint64_t>(1, (uint64_t)4096 / std::max<uint64_t>(1, (uint64_t)p.gy * rows));
   p.gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(tiles, budget));
   return p;
@@ -194,9 +197,9 @@ static int launch_mse(const void* x, uint64_t rows, uint64_t row_len, const floa
   const bool vec_ok = aligned16(x) && ((row_len * elem_size(DT)) % 16 == 0 || rows == 1) && (row_len % V == 0 || rows == 1);
   const dim3 grid(pl.gx, pl.gy, (unsigned)rows);
   const float4* c4 = reinterpret_cast<const float4*>(cand);
-  if (pl.e == 16) hipLaunchKernelGGL((mse_cand_k<DT, 16>), grid, dim3(kBlock), 0, st, x, row_len, vec_ok, c4, (uint32_t)n_cand, ws);
-  else if (pl.e == 8) hipLaunchKernelGGL((mse_cand_k<DT, 8>), grid, dim3(kBlock), 0, st, x, row_len, vec_ok, c4, (uint32_t)n_cand, ws);
-  else hipLaunchKernelGGL((mse_cand_k<DT, 4>), grid, dim3(kBlock), 0, st, x, row_len, vec_ok && V <= 4, c4, (uint32_t)n_cand, ws);
+  if (pl.e == 16) hipLaunchKernelGGL((mse_cand_k<DT, 16>), grid, dim3(kBlock), 0, st, x, row_len, vec_ok, c4, (uint32_t)n_cand, pl.cand_tile, ws);
+  else if (pl.e == 8) hipLaunchKernelGGL((mse_cand_k<DT, 8>), grid, dim3(kBlock), 0, st, x, row_len, vec_ok, c4, (uint32_t)n_cand, pl.cand_tile, ws);
+  else hipLaunchKernelGGL((mse_cand_k<DT, 4>), grid, dim3(kBlock), 0, st, x, row_len, vec_ok && V <= 4, c4, (uint32_t)n_cand, pl.cand_tile, ws);
   if (int e = check_launch("mse_cand_k")) return e;
   hipLaunchKernelGGL(mse_final_k, dim3((unsigned)ceil_div(n_cand, 256), (unsigned)rows), dim3(256), 0, st, ws, pl.gx,
                      (uint32_t)n_cand, loss);
