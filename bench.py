@@ -158,11 +158,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (there is no CPU fallback in the product path)')
+    # TQ_BENCH_SAME_DEVICE=1 + TQ_BENCH_BACKEND=gloo: control-flow test of the N>1 path on a
+    # 1-GPU box (every rank on cuda:0, host-staged collectives).  Never used for reported numbers.
+    if os.environ.get('TQ_BENCH_SAME_DEVICE') == '1':
+        local_rank = 0
+    backend = os.environ.get('TQ_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from quantization import _hip, distributed as tq_dist
     from quantization.quantizers import QMethods
@@ -192,6 +200,13 @@ def main():
 
     # ---- the hot path: fixed-range fake-quant forward -------------------------------------------
     with torch.no_grad():
+        # untimed: let the power management settle (the first ~100 ms after an idle period run at a
+        # lower clock: 280-340 us per launch vs 255-265 us steady state for this kernel)
+        t_settle = time.perf_counter() + 0.4
+        while time.perf_counter() < t_settle:
+            for _ in range(20):
+                qa(x)
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             qa(x)
         wall, ev_ms = timed_region(lambda: qa(x), args.steps, world)

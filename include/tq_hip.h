@@ -81,6 +81,13 @@ const char* tq_last_error(void);
 int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtype, uint64_t n, int dtype,
                       const tq_quantizer* q, tq_stream_t stream);
 
+/* Fused NoNorm + output quantizer (MobileBERT; reference models/quantized_mobilebert.py:58-72,
+ * QuantNoNorm.forward followed by quantize_activations): y = Q(x * w[col] + b[col]) for x viewed
+ * as [n / d, d]; w, b fp32 [d] (the already fake-quantized affine parameters); per-tensor output
+ * quantizer.  mul and add are separate fp32 operations like the reference's `x * weight + bias`. */
+int tq_affine_fake_quant_fwd(const void* x, const float* w, const float* b, void* y, uint64_t n,
+                             uint64_t d, int dtype, const tq_quantizer* q, tq_stream_t stream);
+
 /* STE backward of the same op (autograd through quantizers.py:12-19,
  * 184-185, 209): dx = ((g * scale) * mask) / scale with mask = [int_min <= round(x/s)+zp <=
  * int_max].  Per-tensor parameters only accumulate d_delta / d_zero_float when the pointers
@@ -114,6 +121,22 @@ int tq_minmax(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t 
 int tq_range_update(int mode, const float* new_min, const float* new_max, float* cur_min,
                     float* cur_max, uint64_t n, int initialised, double momentum,
                     uint64_t n_groups, const int64_t* order, tq_stream_t stream);
+
+/* ---- fused calibration step ----------------------------------------------------------------------
+ * The estimating branch of QuantizationManager.forward (quantization_manager.py:99-106) for the
+ * min/max estimators in ONE call: batch statistics (tq_minmax) -> estimator update
+ * (tq_range_update) -> range-to-parameters (tq_set_range_*) [-> quantize, if y != NULL]; the middle
+ * two steps are a single launch.  prev_min/prev_max: estimator state before this batch (NULL on the
+ * first batch); cur_min/cur_max/delta/zero_float|signed_flag: fresh outputs [n_params].
+ * n_params <= 4096; single-rank only (sharded calibration needs the all-reduce between the steps
+ * and uses the separate entry points).                                                           */
+size_t tq_calibrate_workspace_bytes(uint64_t n, uint64_t n_params, uint64_t inner);
+int tq_calibrate_minmax(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner,
+                        int mode, const float* prev_min, const float* prev_max, float* cur_min,
+                        float* cur_max, double momentum, uint64_t n_groups, const int64_t* order,
+                        int n_bits, int symmetric, float eps, int log_domain, float* delta,
+                        float* zero_float, uint8_t* signed_flag, void* y, void* workspace,
+                        size_t workspace_bytes, tq_stream_t stream);
 
 /* PEG phase 1 (range_estimators.py:68-80): ranges = max - min per embedding dim; on later
  * batches the reference stores 0.1*r + 0.9*r of the NEW ranges (quirk q4).                    */

@@ -1,0 +1,133 @@
+// Tuning harness for the per-embedding (last-axis) fake-quant kernel.  Not part of the library.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include "../transformer-quantization_amd/csrc/tq_device.h"
+using namespace tq;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+// A: LDS table, table computed in the prologue from (delta, zf)  [current library kernel shape]
+template <int U, bool PREFILLED>
+__global__ __launch_bounds__(256) void k_lds(const u32x4* __restrict__ x, u32x4* __restrict__ y, uint64_t n_vec,
+                                             const float* __restrict__ delta, const float* __restrict__ zf,
+                                             const float* __restrict__ table, uint32_t d, uint32_t tpb) {
+  constexpr int V = 8; constexpr uint32_t TILE = 256 * U;
+  extern __shared__ __attribute__((aligned(16))) float s_par[];
+  float* s_scale = s_par; float* s_zp = s_par + d;
+  const uint32_t vpr = d / V;
+  if (PREFILLED) {
+    for (uint32_t c = threadIdx.x; c < 2 * d / 4; c += 256) reinterpret_cast<f32x4*>(s_par)[c] = reinterpret_cast<const f32x4*>(table)[c];
+  } else {
+    for (uint32_t c = threadIdx.x; c < d; c += 256) {
+      const float dl = delta[c];
+      s_scale[c] = dl < 1e-8f ? 1e-8f : dl;
+      s_zp[c] = clamp_nanprop(rintf(zf[c]), 0.f, 255.f);
+    }
+  }
+  __syncthreads();
+  const uint32_t tid_mod = threadIdx.x % vpr, blk_mod = 256 % vpr, tile_mod = TILE % vpr;
+  const uint64_t n_tiles = (n_vec + TILE - 1) / TILE;
+  for (uint64_t tile = (uint64_t)blockIdx.x * tpb; tile < n_tiles; tile += (uint64_t)gridDim.x * tpb)
+    for (uint32_t t = 0; t < tpb && tile + t < n_tiles; ++t) {
+      const uint64_t cur = tile + t, i0 = cur * TILE + threadIdx.x;
+      uint32_t cv = ((uint32_t)(cur % vpr) * tile_mod) % vpr + tid_mod; if (cv >= vpr) cv -= vpr;
+      u32x4 v[U];
+      const bool full = (cur + 1) * TILE <= n_vec;
+      if (full) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld_stream(x + i0 + (uint64_t)u * 256);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const uint64_t k = i0 + (uint64_t)u * 256; v[u] = u32x4{0,0,0,0}; if (k < n_vec) v[u] = ld_stream(x + k); }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t k = i0 + (uint64_t)u * 256;
+        float f[V], sc[V], zp[V];
+        Store<TQ_BF16>::unpack(v[u], f);
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(s_scale + cv * V + j);
+          const f32x4 z4 = *reinterpret_cast<const f32x4*>(s_zp + cv * V + j);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { sc[j + m] = s4[m]; zp[j + m] = z4[m]; }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const QP p = {sc[j], zp[j], 0.f, 255.f}; f[j] = q_dequant(q_index(f[j], p), p); }
+        if (full || k < n_vec) st_stream(y + k, Store<TQ_BF16>::pack(f));
+        cv += blk_mod; if (cv >= vpr) cv -= vpr;
+      }
+    }
+}
+
+// B: register-resident parameters: TILE = 256*U is a multiple of vpr, so slot (tid,u) always sees
+// the same 8 columns.
+template <int U>
+__global__ __launch_bounds__(256) void k_reg(const u32x4* __restrict__ x, u32x4* __restrict__ y, uint64_t n_vec,
+                                             const float* __restrict__ delta, const float* __restrict__ zf, uint32_t d, uint32_t tpb) {
+  constexpr int V = 8; constexpr uint32_t TILE = 256 * U;
+  const uint32_t vpr = d / V;
+  float sc[U][V], zp[U][V];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t cv = (threadIdx.x + u * 256) % vpr;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float dl = delta[cv * V + j];
+      sc[u][j] = dl < 1e-8f ? 1e-8f : dl;
+      zp[u][j] = clamp_nanprop(rintf(zf[cv * V + j]), 0.f, 255.f);
+    }
+  }
+  const uint64_t n_tiles = (n_vec + TILE - 1) / TILE;
+  for (uint64_t tile = (uint64_t)blockIdx.x * tpb; tile < n_tiles; tile += (uint64_t)gridDim.x * tpb)
+    for (uint32_t t = 0; t < tpb && tile + t < n_tiles; ++t) {
+      const uint64_t i0 = (tile + t) * TILE + threadIdx.x;
+      u32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const uint64_t k = i0 + (uint64_t)u * 256; v[u] = u32x4{0,0,0,0}; if (k < n_vec) v[u] = ld_stream(x + k); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t k = i0 + (uint64_t)u * 256;
+        float f[V];
+        Store<TQ_BF16>::unpack(v[u], f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const QP p = {sc[u][j], zp[u][j], 0.f, 255.f}; f[j] = q_dequant(q_index(f[j], p), p); }
+        if (k < n_vec) st_stream(y + k, Store<TQ_BF16>::pack(f));
+      }
+    }
+}
+
+int main() {
+  const uint32_t d = 768;
+  for (uint64_t rows : {(uint64_t)256 * 512, (uint64_t)1024 * 512}) {
+    const uint64_t n = rows * d, n_vec = n / 8;
+    u32x4 *x, *y; float *delta, *zf, *table;
+    CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&y, n * 2)); CK(hipMalloc(&delta, d * 4)); CK(hipMalloc(&zf, d * 4)); CK(hipMalloc(&table, 2 * d * 4));
+    std::vector<uint16_t> h(1 << 20);
+    for (size_t i = 0; i < h.size(); ++i) { float f = (float)((int)(rand() % 2001) - 1000) / 300.0f; uint32_t b; memcpy(&b, &f, 4); h[i] = b >> 16; }
+    for (uint64_t off = 0; off < n * 2; off += h.size() * 2) CK(hipMemcpy((char*)x + off, h.data(), std::min<uint64_t>(h.size() * 2, n * 2 - off), hipMemcpyHostToDevice));
+    std::vector<float> hd(d, 0.03f), hz(d, 128.f), ht(2 * d);
+    for (uint32_t i = 0; i < d; ++i) { ht[i] = 0.03f; ht[d + i] = 128.f; }
+    CK(hipMemcpy(delta, hd.data(), d * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(zf, hz.data(), d * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(table, ht.data(), 2 * d * 4, hipMemcpyHostToDevice));
+    hipStream_t st; CK(hipStreamCreate(&st)); hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto run = [&](const char* name, auto fn) {
+      for (int w = 0; w < 3; ++w) fn(); CK(hipStreamSynchronize(st));
+      CK(hipEventRecord(e0, st)); for (int r = 0; r < 10; ++r) fn(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("rows=%-8llu %-34s %8.1f us  %6.0f GB/s\n", (unsigned long long)rows, name, ms / 10 * 1e3, n * 4.0 / (ms / 10 * 1e-3) / 1e9);
+    };
+    for (uint32_t tpb : {1u, 2u, 4u, 8u}) {
+      char nm[64];
+      const unsigned g4 = (unsigned)((n_vec + 1023) / 1024 + tpb - 1) / tpb, g3 = (unsigned)((n_vec + 767) / 768 + tpb - 1) / tpb;
+      snprintf(nm, 64, "lds U=4 tpb=%u", tpb); run(nm, [&] { hipLaunchKernelGGL((k_lds<4, false>), dim3(g4), dim3(256), 2 * d * 4, st, x, y, n_vec, delta, zf, table, d, tpb); });
+      snprintf(nm, 64, "lds-prefilled U=4 tpb=%u", tpb); run(nm, [&] { hipLaunchKernelGGL((k_lds<4, true>), dim3(g4), dim3(256), 2 * d * 4, st, x, y, n_vec, delta, zf, table, d, tpb); });
+      snprintf(nm, 64, "lds U=3 tpb=%u", tpb); run(nm, [&] { hipLaunchKernelGGL((k_lds<3, false>), dim3(g3), dim3(256), 2 * d * 4, st, x, y, n_vec, delta, zf, table, d, tpb); });
+      snprintf(nm, 64, "reg U=3 tpb=%u", tpb); run(nm, [&] { hipLaunchKernelGGL((k_reg<3>), dim3(g3), dim3(256), 0, st, x, y, n_vec, delta, zf, d, tpb); });
+    }
+    CK(hipFree(x)); CK(hipFree(y));
+  }
+  return 0;
+}

@@ -41,6 +41,11 @@ class OracleBackend:
         return (y.to(x.dtype) if want_y else None,
                 idx.to(idx_dtype) if idx_dtype is not None else None)
 
+    def affine_fake_quant(self, x, w, b, delta, zero_float, signed, n_bits, symmetric, log_domain, eps):
+        r = x.float() * w.float() + b.float()
+        _, y = self._quant(r, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, 1, 1)
+        return y.to(x.dtype)
+
     def fake_quant_bwd(self, x, grad_y, delta, zero_float, signed, n_bits, symmetric, log_domain,
                        eps, n_params, inner, param_grads=False):
         sgn = bool(signed.item()) if signed is not None else False

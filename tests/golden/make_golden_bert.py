@@ -129,5 +129,42 @@ def main():
         first_weight_sum=np.array(float(hf.bert.encoder.layer[0].attention.self.query.weight.double().sum())))
 
 
+def gen_nonorm():
+    """QuantNoNorm (MobileBERT's affine 'LayerNorm', reference models/quantized_mobilebert.py:58-72):
+    one weight quantizer is applied to the weight and then to the bias, so in the estimating state
+    the bias call overwrites the range (quirk q9).  3-batch trace on MobileBERT widths."""
+    from models.quantized_mobilebert import QuantNoNorm
+    from transformers.models.mobilebert.modeling_mobilebert import NoNorm
+    data = {}
+    for k, (d, w_bits, a_bits) in enumerate(((512, 4, 4), (128, 8, 8))):
+        g = torch.Generator().manual_seed(500 + k)
+        nn_ = NoNorm(d)
+        nn_.weight.data = 1.0 + 0.3 * torch.randn(d, generator=g)
+        nn_.bias.data = 0.2 * torch.randn(d, generator=g)
+        m = QuantNoNorm(nn_, method=QMethods.symmetric_uniform, n_bits=w_bits,
+                        act_method=QMethods.asymmetric_uniform, n_bits_act=a_bits)
+        m.quantized()
+        xs = [torch.randn(4, 16, d, generator=g) * (1 + 0.5 * i) for i in range(3)]
+        ys = [m(x) for x in xs]
+        m.weight_quantizer.fix_ranges()
+        m.activation_quantizer.fix_ranges()
+        y_fixed = m(xs[0])
+        data[f'n{k}_w'] = nn_.weight.detach().numpy().copy()
+        data[f'n{k}_b'] = nn_.bias.detach().numpy().copy()
+        data[f'n{k}_x'] = np.stack([x.numpy() for x in xs])
+        data[f'n{k}_y'] = np.stack([y.detach().numpy() for y in ys])
+        data[f'n{k}_y_fixed'] = y_fixed.detach().numpy()
+        data[f'n{k}_w_delta'] = m.weight_quantizer.quantizer._delta.numpy().copy()
+        data[f'n{k}_a_delta'] = m.activation_quantizer.quantizer._delta.numpy().copy()
+        data[f'n{k}_a_zf'] = m.activation_quantizer.quantizer._zero_float.numpy().copy()
+        data[f'n{k}_cfg'] = np.array([d, w_bits, a_bits])
+    np.savez_compressed(os.path.join(OUT, 'nonorm.npz'), **data)
+    print('nonorm cases: 2')
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'nonorm':
+        gen_nonorm()
+    else:
+        main()
+        gen_nonorm()

@@ -28,6 +28,17 @@ def q():
     return types.SimpleNamespace(**locals())
 
 
+@pytest.fixture(params=[True, False], ids=['fused-calibration', 'layered-calibration'])
+def calib_path(request):
+    """Run calibration-state tests through both the one-call fused path (tq_calibrate_minmax) and
+    the layered estimator -> set_quant_range -> quantizer path."""
+    from quantization import quantization_manager as qm
+    prev = qm.FUSED_CALIBRATION
+    qm.FUSED_CALIBRATION = request.param
+    yield request.param
+    qm.FUSED_CALIBRATION = prev
+
+
 def _manager(q, m, init='current_minmax', init_params=None):
     la = LAYOUT_ARGS[m['layout']]
     mgr = q.QuantizationManager(qmethod=q.QMethods[m['method']], init=q.RangeEstimators[init],
@@ -39,7 +50,7 @@ def _manager(q, m, init='current_minmax', init_params=None):
     return mgr
 
 
-def test_golden_fake_quant_through_manager(q, golden_fake_quant):
+def test_golden_fake_quant_through_manager(q, golden_fake_quant, calib_path):
     z, meta = golden_fake_quant
     for m in meta:
         c = fq_case(z, m)
@@ -201,13 +212,13 @@ def _check_trace(q, m, z):
         assert np.array_equal(np.isfinite(la), fin)
 
 
-def test_estimator_traces(q, golden_estimators):
+def test_estimator_traces(q, golden_estimators, calib_path):
     z, meta = golden_estimators
     for m in meta:
         _check_trace(q, m, z)
 
 
-def test_permuted_peg_trace(q, golden_estimators):
+def test_permuted_peg_trace(q, golden_estimators, calib_path):
     z, _ = golden_estimators
     xs = [t(b).to(DEV) for b in z['batches']]
     mgr = q.QuantizationManager(qmethod=q.QMethods.asymmetric_uniform,
@@ -270,7 +281,7 @@ def test_ste_backward_matches_autograd(q):
 # ------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE.json's full size: [B, S, 768] bf16 hidden states
 # ------------------------------------------------------------------------------------------
-def test_full_size_properties(q):
+def test_full_size_properties(q, calib_path):
     B, S, D = 1024, 512, 768
     torch.manual_seed(1000)
     x = torch.randn(B, S, D, device=DEV, dtype=torch.bfloat16)
@@ -524,7 +535,7 @@ def test_apply_adaround_to_layer_end_to_end(q):
         assert hard.soft_targets is False and layer.caching is True
 
 
-def test_toy_model_calibration_on_gpu(q, golden_toy):
+def test_toy_model_calibration_on_gpu(q, golden_toy, calib_path):
     """pass_data_for_range_estimation on the GPU: weight-side state is exact; activation ranges
     depend on GEMM outputs (hipBLASLt vs CPU) and are compared at 1e-4 relative."""
     import json

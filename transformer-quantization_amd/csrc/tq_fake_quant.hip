@@ -123,18 +123,44 @@ __global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x,
 }
 
 // ------------------------------------------------------------------------------ last axis
-// x viewed as [rows, d]; d % V == 0.  LDS: scale[d], zp[d].  Same tiling as fq_tensor; the vector
-// column of lane/slot (tid, u) is (tile_start + tid + u * kBlock) mod (d / V), kept incrementally.
+// x viewed as [rows, d]; d % V == 0.  LDS: scale[d], zp[d].  Same tiling as fq_tensor, but a block
+// owns TPB consecutive tiles so that the table fill (6 KB for d = 768) is paid once per 64 KiB of
+// input, and the first tile's HBM loads are issued BEFORE the fill + barrier so their latency
+// overlaps it.  The vector column of lane/slot (tid, u) is (tile_start + tid + u * kBlock) mod (d / V),
+// kept incrementally.
 template <int DT, bool HAS_IDX, bool NT, int U>
 __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u32x4* __restrict__ y,
                                                   void* __restrict__ idx, int idx_dtype, uint64_t n,
-                                                  tq_quantizer q) {
+                                                  tq_quantizer q, uint32_t tpb) {
   constexpr int V = Store<DT>::kVec;
   constexpr uint32_t TILE = kBlock * U;
   extern __shared__ __attribute__((aligned(16))) float s_par[];
   const uint32_t d = (uint32_t)q.n_params;
   float* s_scale = s_par;
   float* s_zp = s_par + d;
+  const uint64_t n_vec = n / V;
+  const uint32_t vpr = d / V;                       // vectors per row (<= 2048)
+
+  auto load_tile = [&](uint64_t tile, u32x4 (&v)[U]) {
+    const uint64_t i0 = tile * TILE + threadIdx.x;
+    if ((tile + 1) * TILE <= n_vec) {           // full tile: no per-lane predicates
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = NT ? ld_stream(x + i0 + (uint64_t)u * kBlock) : x[i0 + (uint64_t)u * kBlock];
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t k = i0 + (uint64_t)u * kBlock;
+        v[u] = u32x4{0, 0, 0, 0};
+        if (k < n_vec) v[u] = x[k];
+      }
+    }
+  };
+
+  const uint64_t n_tiles = (n_vec + TILE - 1) / TILE;
+  uint64_t tile = (uint64_t)blockIdx.x * tpb;
+  u32x4 v[U];
+  if (tile < n_tiles) load_tile(tile, v);
+
   for (uint32_t c = threadIdx.x; c < d; c += kBlock) {
     const QP p = make_qp(q, c);
     s_scale[c] = p.scale;
@@ -144,52 +170,101 @@ __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u
   const float lo = p0.lo, hi = p0.hi;
   __syncthreads();
 
-  const uint32_t vpr = d / V;                       // vectors per row (<= 2048)
-  const uint64_t n_vec = n / V;
   const uint32_t tid_mod = threadIdx.x % vpr;
   const uint32_t blk_mod = kBlock % vpr;
   const uint32_t tile_mod = TILE % vpr;
 
-  for (uint64_t tile = blockIdx.x; tile * TILE < n_vec; tile += gridDim.x) {
-    const uint64_t i0 = tile * TILE + threadIdx.x;
-    uint32_t cv = ((uint32_t)(tile % vpr) * tile_mod) % vpr + tid_mod;
-    if (cv >= vpr) cv -= vpr;
-    u32x4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t k = i0 + (uint64_t)u * kBlock;
-      v[u] = u32x4{0, 0, 0, 0};
-      if (k < n_vec) v[u] = NT ? ld_stream(x + k) : x[k];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t k = i0 + (uint64_t)u * kBlock;
-      float f[V], sc[V], zp[V];
-      Store<DT>::unpack(v[u], f);
-#pragma unroll
-      for (int j = 0; j < V; j += 4) {
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(s_scale + cv * V + j);
-        const f32x4 z4 = *reinterpret_cast<const f32x4*>(s_zp + cv * V + j);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { sc[j + m] = s4[m]; zp[j + m] = z4[m]; }
-      }
-#pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const QP p = {sc[j], zp[j], lo, hi};
-        f[j] = q_index(f[j], p);
-      }
-      if (k < n_vec) {
-        if (HAS_IDX) store_idx<V>(idx, idx_dtype, k * V, f);
-        if (y) {
-#pragma unroll
-          for (int j = 0; j < V; ++j) f[j] = sc[j] * (f[j] - zp[j]);
-          const u32x4 o = Store<DT>::pack(f);
-          if (NT) st_stream(y + k, o); else y[k] = o;
-        }
-      }
-      cv += blk_mod;
+  for (; tile < n_tiles; tile += (uint64_t)gridDim.x * tpb) {
+    for (uint32_t t = 0; t < tpb && tile + t < n_tiles; ++t) {
+      const uint64_t cur = tile + t;
+      if (t > 0 || cur != (uint64_t)blockIdx.x * tpb) load_tile(cur, v);
+      const uint64_t i0 = cur * TILE + threadIdx.x;
+      const bool full = (cur + 1) * TILE <= n_vec;
+      uint32_t cv = ((uint32_t)(cur % vpr) * tile_mod) % vpr + tid_mod;
       if (cv >= vpr) cv -= vpr;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t k = i0 + (uint64_t)u * kBlock;
+        float f[V], sc[V], zp[V];
+        Store<DT>::unpack(v[u], f);
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(s_scale + cv * V + j);
+          const f32x4 z4 = *reinterpret_cast<const f32x4*>(s_zp + cv * V + j);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { sc[j + m] = s4[m]; zp[j + m] = z4[m]; }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const QP p = {sc[j], zp[j], lo, hi};
+          f[j] = q_index(f[j], p);
+        }
+        if (full || k < n_vec) {
+          if (HAS_IDX) store_idx<V>(idx, idx_dtype, k * V, f);
+          if (y) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) f[j] = sc[j] * (f[j] - zp[j]);
+            const u32x4 o = Store<DT>::pack(f);
+            if (NT) st_stream(y + k, o); else y[k] = o;
+          }
+        }
+        cv += blk_mod;
+        if (cv >= vpr) cv -= vpr;
+      }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------ affine + quant
+// MobileBERT's NoNorm followed by its output quantizer (reference models/quantized_mobilebert.py:
+// 58-72): y = Q(x * w[col] + b[col]) with a per-tensor quantizer.  The reference runs mul, add and
+// the 6 quantizer kernels as separate sweeps (~16 tensor passes); here it is 1 read + 1 write.
+// x viewed as [rows, d], d % V == 0; w, b (fp32 [d], already fake-quantized) staged in LDS.
+template <int DT, bool NT, int U>
+__global__ __launch_bounds__(kBlock) void fq_affine(const u32x4* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ b, u32x4* __restrict__ y, uint64_t n,
+                                                    uint32_t d, tq_quantizer q) {
+  constexpr int V = Store<DT>::kVec;
+  constexpr uint32_t TILE = kBlock * U;
+  extern __shared__ __attribute__((aligned(16))) float s_par[];
+  float* s_w = s_par;
+  float* s_b = s_par + d;
+  const uint64_t n_vec = n / V;
+  const uint32_t vpr = d / V;
+  const uint64_t tile = blockIdx.x;
+  const uint64_t i0 = tile * TILE + threadIdx.x;
+  const bool full = (tile + 1) * TILE <= n_vec;
+  u32x4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint64_t k = i0 + (uint64_t)u * kBlock;
+    v[u] = u32x4{0, 0, 0, 0};
+    if (full || k < n_vec) v[u] = NT ? ld_stream(x + k) : x[k];
+  }
+  for (uint32_t c = threadIdx.x; c < d; c += kBlock) { s_w[c] = w[c]; s_b[c] = b[c]; }
+  const QP p = make_qp(q, 0);
+  __syncthreads();
+  uint32_t cv = ((uint32_t)(tile % vpr) * (TILE % vpr)) % vpr + threadIdx.x % vpr;
+  if (cv >= vpr) cv -= vpr;
+  const uint32_t blk_mod = kBlock % vpr;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint64_t k = i0 + (uint64_t)u * kBlock;
+    float f[V];
+    Store<DT>::unpack(v[u], f);
+#pragma unroll
+    for (int j = 0; j < V; j += 4) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_w + cv * V + j);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_b + cv * V + j);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float r = f[j + m] * w4[m] + b4[m];          // mul, then add (no fma: -ffp-contract=off)
+        f[j + m] = q_dequant(q_index(r, p), p);
+      }
+    }
+    if (full || k < n_vec) { const u32x4 o = Store<DT>::pack(f); if (NT) st_stream(y + k, o); else y[k] = o; }
+    cv += blk_mod;
+    if (cv >= vpr) cv -= vpr;
   }
 }
 
@@ -255,11 +330,15 @@ static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t 
   if (vec_ok && q.n_params > 1 && q.inner == 1 && q.n_params % V == 0 && q.n_params <= 16384) {
     const size_t lds = q.n_params * 2 * sizeof(float);
 #define TQ_LAUNCH_AXIS(NTV, UV)                                                                            \
-    hipLaunchKernelGGL((fq_axis<DT, HAS_IDX, NTV, UV>),                                                     \
-                       dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n_vec_all, kBlock * UV), 1), kMaxTiles)), \
-                       dim3(kBlock), lds, st, xv, yv, idx, idx_dtype, n, q)
-    if (big) { if (nt) TQ_LAUNCH_AXIS(true, 4); else TQ_LAUNCH_AXIS(false, 4); }
-    else     { if (nt) TQ_LAUNCH_AXIS(true, 1); else TQ_LAUNCH_AXIS(false, 1); }
+    {                                                                                                      \
+      const uint64_t n_tiles = std::max<uint64_t>(ceil_div(n_vec_all, kBlock * UV), 1);                    \
+      const uint32_t tpb = n_tiles >= 32768 ? 2 : 1;                                                       \
+      hipLaunchKernelGGL((fq_axis<DT, HAS_IDX, NTV, UV>),                                                   \
+                         dim3((unsigned)std::min<uint64_t>(ceil_div(n_tiles, tpb), kMaxTiles)),            \
+                         dim3(kBlock), lds, st, xv, yv, idx, idx_dtype, n, q, tpb);                         \
+    }
+    if (big) { if (nt) TQ_LAUNCH_AXIS(true, 4) else TQ_LAUNCH_AXIS(false, 4) }
+    else     { if (nt) TQ_LAUNCH_AXIS(true, 1) else TQ_LAUNCH_AXIS(false, 1) }
 #undef TQ_LAUNCH_AXIS
     return check_launch("fq_axis");
   }
@@ -349,6 +428,42 @@ extern "C" int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtyp
     case TQ_F32: return has_idx ? launch_fq<TQ_F32, true>(x, y, idx, idx_dtype, n, *q, st) : launch_fq<TQ_F32, false>(x, y, idx, idx_dtype, n, *q, st);
     case TQ_BF16: return has_idx ? launch_fq<TQ_BF16, true>(x, y, idx, idx_dtype, n, *q, st) : launch_fq<TQ_BF16, false>(x, y, idx, idx_dtype, n, *q, st);
     default: return has_idx ? launch_fq<TQ_F16, true>(x, y, idx, idx_dtype, n, *q, st) : launch_fq<TQ_F16, false>(x, y, idx, idx_dtype, n, *q, st);
+  }
+}
+
+template <int DT>
+static int launch_affine(const void* x, const float* w, const float* b, void* y, uint64_t n, uint64_t d,
+                         const tq_quantizer& q, hipStream_t st) {
+  constexpr int V = Store<DT>::kVec;
+  const uint64_t n_vec = n / V;
+  const bool nt = (n * elem_size(DT)) >= ((uint64_t)64 << 20);
+  const bool big = n_vec >= (uint64_t)kBlock * 4 * 2048;
+  const size_t lds = d * 2 * sizeof(float);
+  const auto xv = static_cast<const u32x4*>(x);
+  auto yv = static_cast<u32x4*>(y);
+#define TQ_LAUNCH_AFF(NTV, UV) hipLaunchKernelGGL((fq_affine<DT, NTV, UV>), dim3((unsigned)std::max<uint64_t>(ceil_div(n_vec, kBlock * UV), 1)), dim3(kBlock), lds, st, xv, w, b, yv, n, (uint32_t)d, q)
+  if (big) { if (nt) TQ_LAUNCH_AFF(true, 4); else TQ_LAUNCH_AFF(false, 4); }
+  else     { if (nt) TQ_LAUNCH_AFF(true, 1); else TQ_LAUNCH_AFF(false, 1); }
+#undef TQ_LAUNCH_AFF
+  return check_launch("fq_affine");
+}
+
+extern "C" int tq_affine_fake_quant_fwd(const void* x, const float* w, const float* b, void* y, uint64_t n, uint64_t d,
+                                        int dtype, const tq_quantizer* q, tq_stream_t stream) {
+  if (n == 0) return TQ_OK;
+  TQ_REQUIRE(x && w && b && y, "tq_affine_fake_quant_fwd: NULL pointer");
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_affine_fake_quant_fwd: bad dtype %d", dtype);
+  if (int e = check_quantizer(q, n, "tq_affine_fake_quant_fwd")) return e;
+  TQ_REQUIRE(q->n_params == 1, "tq_affine_fake_quant_fwd: per-tensor output quantizer only");
+  const uint64_t V = dtype == TQ_F32 ? 4 : 8;
+  TQ_REQUIRE(d >= V && d % V == 0 && d <= 16384 && n % d == 0, "tq_affine_fake_quant_fwd: d=%llu unsupported", (unsigned long long)d);
+  TQ_REQUIRE(aligned16(x) && aligned16(y), "tq_affine_fake_quant_fwd: x / y must be 16-byte aligned");
+  TQ_REQUIRE(n / V / (kBlock) < (1ull << 31), "tq_affine_fake_quant_fwd: tensor too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case TQ_F32: return launch_affine<TQ_F32>(x, w, b, y, n, d, *q, st);
+    case TQ_BF16: return launch_affine<TQ_BF16>(x, w, b, y, n, d, *q, st);
+    default: return launch_affine<TQ_F16>(x, w, b, y, n, d, *q, st);
   }
 }
 

@@ -353,6 +353,85 @@ __global__ void set_range_sym_k(const float* __restrict__ x_min, const float* __
   }
 }
 
+// ------------------------------------------------------------------------------ fused calibration step
+// group fold + estimator update + range -> quantizer parameters in ONE single-block launch
+// (range_update_k followed by set_range_*_k); n <= kCalibMaxN so the new state fits in LDS.
+constexpr uint32_t kCalibMaxN = 4096;
+
+__global__ __launch_bounds__(1024) void calib_update_k(int mode, const float* __restrict__ new_min,
+                                                       const float* __restrict__ new_max, const float* __restrict__ prev_min,
+                                                       const float* __restrict__ prev_max, float* __restrict__ cur_min,
+                                                       float* __restrict__ cur_max, uint32_t n, double momentum_d,
+                                                       uint32_t n_groups, const int64_t* __restrict__ order, int n_bits,
+                                                       int symmetric, float eps, int log_domain, float* __restrict__ delta,
+                                                       float* __restrict__ zero_float, uint8_t* __restrict__ signed_flag) {
+  extern __shared__ float s_c[];          // [2][n] new state, then [2][n_groups]
+  float* s_lo = s_c;
+  float* s_hi = s_c + n;
+  float* s_g = s_c + 2 * n;
+  __shared__ int s_neg;
+  if (threadIdx.x == 0) s_neg = 0;
+  if (n_groups > 0) {
+    const uint32_t gs = n / n_groups;
+    for (uint32_t g = threadIdx.x; g < n_groups; g += blockDim.x) {
+      float mn = kInf, mx = -kInf;
+      for (uint32_t k = 0; k < gs; ++k) {
+        const uint32_t dim = order ? (uint32_t)order[g * gs + k] : g * gs + k;
+        mn = min_nanprop(mn, new_min[dim]);
+        mx = max_nanprop(mx, new_max[dim]);
+      }
+      s_g[g] = mn;
+      s_g[n_groups + g] = mx;
+    }
+  }
+  __syncthreads();
+  const bool first = prev_min == nullptr;
+  const float om = (float)(1.0 - momentum_d), mom = (float)momentum_d;
+  for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+    uint32_t dim = j;
+    float a, b;
+    if (n_groups > 0) {
+      const uint32_t gs = n / n_groups;
+      dim = order ? (uint32_t)order[j] : j;
+      a = s_g[j / gs];
+      b = s_g[n_groups + j / gs];
+    } else {
+      a = new_min[j];
+      b = new_max[j];
+    }
+    if (!(mode == TQ_EST_CURRENT || first)) {
+      const float pa = prev_min[dim], pb = prev_max[dim];
+      if (mode == TQ_EST_ALL) { a = min_nanprop(pa, a); b = max_nanprop(pb, b); }
+      else { a = om * a + mom * pa; b = om * b + mom * pb; }
+    }
+    cur_min[dim] = a;
+    cur_max[dim] = b;
+    s_lo[dim] = min_nanprop(a, 0.0f);            // quantizers.py:258
+    s_hi[dim] = max_nanprop(b, eps);             // :259
+  }
+  __syncthreads();
+  if (symmetric) {
+    int neg = 0;
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) neg |= s_lo[j] < 0.0f ? 1 : 0;
+    if (neg) atomicOr(&s_neg, 1);
+    __syncthreads();
+    const bool sgn = s_neg != 0;
+    if (threadIdx.x == 0) signed_flag[0] = sgn ? 1 : 0;
+    const float top = grid_top(n_bits - (sgn ? 1 : 0));
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+      const float d = max_nanprop(fabsf(s_lo[j]), s_hi[j]) / top;
+      delta[j] = log_domain ? logf(d) : d;
+    }
+  } else {
+    const float top = grid_top(n_bits);
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+      const float d = (s_hi[j] - s_lo[j]) / top;
+      zero_float[j] = (-s_lo[j]) / d;
+      delta[j] = log_domain ? logf(d) : d;
+    }
+  }
+}
+
 }  // namespace tq
 
 using namespace tq;
@@ -426,4 +505,39 @@ extern "C" int tq_set_range_sym(const float* x_min, const float* x_max, uint64_t
   hipLaunchKernelGGL(set_range_sym_k, dim3(1), dim3(n >= 256 ? 1024 : 256), 0, static_cast<hipStream_t>(stream),
                      x_min, x_max, n, n_bits, eps, log_domain, delta, signed_flag);
   return check_launch("tq_set_range_sym");
+}
+
+extern "C" size_t tq_calibrate_workspace_bytes(uint64_t n, uint64_t n_params, uint64_t inner) {
+  return tq_minmax_workspace_bytes(n, n_params, inner) + 2 * n_params * sizeof(float) + 256;
+}
+
+extern "C" int tq_calibrate_minmax(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner, int mode,
+                                   const float* prev_min, const float* prev_max, float* cur_min, float* cur_max,
+                                   double momentum, uint64_t n_groups, const int64_t* order, int n_bits, int symmetric,
+                                   float eps, int log_domain, float* delta, float* zero_float, uint8_t* signed_flag,
+                                   void* y, void* workspace, size_t workspace_bytes, tq_stream_t stream) {
+  TQ_REQUIRE(cur_min && cur_max && delta, "tq_calibrate_minmax: NULL output");
+  TQ_REQUIRE((prev_min == nullptr) == (prev_max == nullptr), "tq_calibrate_minmax: prev_min / prev_max mismatch");
+  TQ_REQUIRE(symmetric ? signed_flag != nullptr : zero_float != nullptr, "tq_calibrate_minmax: missing parameter output");
+  TQ_REQUIRE(mode >= TQ_EST_CURRENT && mode <= TQ_EST_RUNNING, "tq_calibrate_minmax: bad mode %d", mode);
+  TQ_REQUIRE(n_params >= 1 && n_params <= kCalibMaxN, "tq_calibrate_minmax: n_params=%llu > %u (use the separate calls)",
+             (unsigned long long)n_params, kCalibMaxN);
+  TQ_REQUIRE(n_groups == 0 || n_params % n_groups == 0, "tq_calibrate_minmax: n_params %% n_groups != 0");
+  TQ_REQUIRE(n_bits >= 1 && n_bits <= 24, "tq_calibrate_minmax: n_bits=%d", n_bits);
+  const size_t stats_bytes = (2 * n_params * sizeof(float) + 255) / 256 * 256;
+  TQ_REQUIRE(workspace && workspace_bytes >= stats_bytes, "tq_calibrate_minmax: workspace too small");
+  float* stats = static_cast<float*>(workspace);
+  char* rest = static_cast<char*>(workspace) + stats_bytes;
+  if (int e = tq_minmax(x, n, dtype, n_params, inner, stats, stats + n_params, rest, workspace_bytes - stats_bytes, stream))
+    return e;
+  const size_t lds = (2 * n_params + 2 * n_groups) * sizeof(float);
+  hipLaunchKernelGGL(calib_update_k, dim3(1), dim3(n_params >= 256 ? 1024 : 256), lds, static_cast<hipStream_t>(stream), mode,
+                     stats, stats + n_params, prev_min, prev_max, cur_min, cur_max, (uint32_t)n_params, momentum,
+                     (uint32_t)n_groups, order, n_bits, symmetric, eps, log_domain, delta, zero_float, signed_flag);
+  if (int e = check_launch("calib_update_k")) return e;
+  if (y != nullptr) {
+    tq_quantizer q{delta, zero_float, signed_flag, n_bits, symmetric, log_domain, eps, n_params, inner};
+    return tq_fake_quant_fwd(x, y, nullptr, TQ_IDX_NONE, n, dtype, &q, stream);
+  }
+  return TQ_OK;
 }

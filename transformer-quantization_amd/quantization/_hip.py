@@ -42,9 +42,13 @@ SIGNATURES = {
     'tq_abi_version': (_int, []),
     'tq_last_error': (C.c_char_p, []),
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
+    'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
     'tq_fake_quant_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _int, _QP, _vp]),
     'tq_minmax_workspace_bytes': (_sz, [_u64, _u64, _u64]),
     'tq_minmax': (_int, [_vp, _u64, _int, _u64, _u64, _vp, _vp, _vp, _sz, _vp]),
+    'tq_calibrate_workspace_bytes': (_sz, [_u64, _u64, _u64]),
+    'tq_calibrate_minmax': (_int, [_vp, _u64, _int, _u64, _u64, _int, _vp, _vp, _vp, _vp, _d, _u64, _vp, _int,
+                                   _int, _f, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'tq_range_update': (_int, [_int, _vp, _vp, _vp, _vp, _u64, _int, _d, _u64, _vp, _vp]),
     'tq_axis_ranges': (_int, [_vp, _vp, _vp, _u64, _int, _vp]),
     'tq_set_range_asym': (_int, [_vp, _vp, _u64, _int, _f, _int, _vp, _vp, _vp]),
@@ -163,6 +167,19 @@ class HipBackend:
         _check(rc, self.lib)
         return y, idx
 
+    def affine_fake_quant(self, x, w, b, delta, zero_float, signed, n_bits, symmetric, log_domain, eps):
+        """y = Q(x * w + b) (w, b fp32 [d] over the last axis), per-tensor output quantizer."""
+        _need_device(x, 'affine_fake_quant')
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        q = self._qdesc(delta, zero_float, signed, n_bits, symmetric, log_domain, eps, 1, 1)
+        rc = self.lib.tq_affine_fake_quant_fwd(_ptr(x), _ptr(w.detach().float().contiguous()),
+                                               _ptr(b.detach().float().contiguous()), _ptr(y), x.numel(),
+                                               x.shape[-1], _dtype_code(x, 'affine_fake_quant'),
+                                               C.byref(q), _stream())
+        _check(rc, self.lib)
+        return y
+
     def fake_quant_bwd(self, x, grad_y, delta, zero_float, signed, n_bits, symmetric, log_domain, eps,
                        n_params, inner, param_grads=False):
         _need_device(x, 'fake_quant_bwd')
@@ -194,6 +211,31 @@ class HipBackend:
         if n_params == 1:
             return out[0, 0], out[1, 0]
         return out[0], out[1]
+
+    CALIB_MAX_PARAMS = 4096
+
+    def calibrate_minmax(self, x, n_params, inner, mode, prev_min, prev_max, momentum, n_groups, order,
+                         n_bits, symmetric, eps, log_domain, want_y=True):
+        """Fused estimating step (statistics -> estimator update -> quantizer parameters -> y).
+        -> (cur_min, cur_max, delta, zero_float | None, signed | None, y | None); 0-D for n_params == 1."""
+        _need_device(x, 'calibrate_minmax')
+        x = x.contiguous()
+        dev = x.device
+        cur = torch.empty(2, n_params, dtype=torch.float32, device=dev)
+        par = torch.empty(1 if symmetric else 2, n_params, dtype=torch.float32, device=dev)
+        signed = torch.empty((), dtype=torch.bool, device=dev) if symmetric else None
+        y = torch.empty_like(x) if want_y else None
+        ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), n_params, inner))
+        rc = self.lib.tq_calibrate_minmax(
+            _ptr(x), x.numel(), _dtype_code(x, 'calibrate_minmax'), n_params, inner, mode,
+            _ptr(prev_min), _ptr(prev_max), _ptr(cur[0]), _ptr(cur[1]), float(momentum), int(n_groups or 0),
+            _ptr(order), int(n_bits), int(bool(symmetric)), float(eps), int(bool(log_domain)),
+            _ptr(par[0]), None if symmetric else _ptr(par[1]), _ptr(signed), _ptr(y), _ptr(ws), ws.numel(),
+            _stream())
+        _check(rc, self.lib)
+        if n_params == 1:
+            return (cur[0, 0], cur[1, 0], par[0, 0], None if symmetric else par[1, 0], signed, y)
+        return (cur[0], cur[1], par[0], None if symmetric else par[1], signed, y)
 
     def range_update(self, mode, new_min, new_max, cur_min, cur_max, momentum=0.9, n_groups=0,
                      order=None):

@@ -7,10 +7,12 @@ fused GEMM + fake-quant epilogue would plug in.
 import copy
 import warnings
 
+import torch
 from torch import nn
 from torch.nn import functional as F
 from torch.nn.modules.pooling import _AdaptiveAvgPoolNd, _AvgPoolNd
 
+from quantization import _hip
 from quantization.base_quantized_classes import FP32Acts, QuantizedActivation, QuantizedModule
 from quantization.hijacker import QuantizationHijacker, activations_list
 from quantization.quantization_manager import QuantizationManager
@@ -44,6 +46,43 @@ class QuantEmbedding(QuantizationHijacker, nn.Embedding):
                            padding_idx=self.padding_idx, max_norm=self.max_norm,
                            norm_type=self.norm_type, scale_grad_by_freq=self.scale_grad_by_freq,
                            sparse=self.sparse)
+
+
+class QuantNoNorm(QuantizationHijacker):
+    """MobileBERT's element-wise affine "LayerNorm" with quantized parameters and output
+    (counterpart of the reference's models/quantized_mobilebert.py:58-72).
+
+    One weight quantizer is applied to the weight and then to the bias; while it is estimating,
+    the bias call therefore overwrites the range found for the weight (upstream quirk, kept).
+    With fixed ranges the whole layer -- x * Q(w) + Q(b) followed by the output quantizer -- is one
+    fused launch (``tq_affine_fake_quant_fwd``) instead of ~8 element-wise kernels."""
+
+    def __init__(self, org_model, *args, activation=None, **kwargs):
+        super().__init__(*args, activation=activation, **kwargs)
+        self.weight = org_model.weight
+        self.bias = org_model.bias
+
+    def _fusable(self, x):
+        from quantization.quantization_manager import Qstates
+        mgr = self.activation_quantizer
+        return (self._quant_a and self.activation_function is None
+                and self.activation_save_target is None
+                and isinstance(mgr, QuantizationManager) and mgr.state == Qstates.fix_ranges
+                and mgr.quantizer.is_initialized and mgr.quantizer._delta.numel() == 1
+                and not torch.is_grad_enabled() and x.dim() >= 1
+                and x.shape[-1] == self.weight.numel() and x.shape[-1] % 8 == 0)
+
+    def forward(self, x, offsets=None):
+        weight, bias = self.weight, self.bias
+        if self._quant_w:
+            weight = self.weight_quantizer(weight)
+            bias = self.weight_quantizer(bias)
+        if self._fusable(x):
+            q = self.activation_quantizer.quantizer
+            return _hip.backend().affine_fake_quant(
+                x, weight, bias, q._delta, q._zero_float, getattr(q, '_signed', None), q.n_bits,
+                q.symmetric, q.scale_domain == 'log', q.eps)
+        return self.quantize_activations(x * weight + bias)
 
 
 class QuantizedActivationWrapper(QuantizedActivation):

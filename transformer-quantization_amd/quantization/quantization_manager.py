@@ -12,10 +12,31 @@ on the current HIP stream with no host synchronisation; in ``fix_ranges`` only t
 """
 from enum import Enum
 
+import torch
 from torch import nn
 
-from quantization.quantizers import QMethods, QuantizerNotInitializedError
-from quantization.range_estimators import RangeEstimators
+from quantization import _hip
+from quantization import distributed as tq_dist
+from quantization.quantizers import (
+    AsymmetricUniformQuantizer,
+    QMethods,
+    QuantizerNotInitializedError,
+    SymmetricUniformQuantizer,
+)
+from quantization.range_estimators import (
+    AllMinMaxEstimator,
+    CurrentMinMaxEstimator,
+    RangeEstimators,
+    RunningMinMaxEstimator,
+)
+
+# Estimating forwards of these (estimator, quantizer) pairs run as ONE C call
+# (tq_calibrate_minmax: 4 launches) instead of estimator -> set_quant_range -> quantizer
+# (3 calls, 5 launches).  Exact types only: subclasses keep the layered path.
+FUSED_CALIBRATION = True
+_FUSED_ESTIMATORS = {CurrentMinMaxEstimator: _hip.EST_CURRENT, AllMinMaxEstimator: _hip.EST_ALL,
+                     RunningMinMaxEstimator: _hip.EST_RUNNING}
+_FUSED_QUANTIZERS = (AsymmetricUniformQuantizer, SymmetricUniformQuantizer)
 
 
 class Qstates(Enum):
@@ -91,6 +112,56 @@ class QuantizationManager(nn.Module):
         return self.state == Qstates.estimate_ranges or (
             self.state == Qstates.estimate_ranges_train and self.training)
 
+    def _fused_estimating_forward(self, x):
+        """estimator(x) -> set_quant_range -> quantizer(x) as one backend call, or None when the
+        configuration needs the layered path (sharded calibration, percentiles, custom classes,
+        autograd, CPU tensors, > 4096 ranges).  Leaves exactly the state the layered path leaves."""
+        est, q = self.range_estimator, self.quantizer
+        mode = _FUSED_ESTIMATORS.get(type(est))
+        be = _hip.backend()
+        if (mode is None or type(q) not in _FUSED_QUANTIZERS or not FUSED_CALIBRATION
+                or not hasattr(be, 'calibrate_minmax') or not x.is_cuda or tq_dist.is_enabled()
+                or getattr(est, 'percentile', None)
+                or (torch.is_grad_enabled() and x.requires_grad)):
+            return None
+        axis = None if mode == _hip.EST_ALL else est.axis
+        n_groups = 0
+        if axis is not None:
+            n_params, inner = x.shape[axis], 1
+            for s in x.shape[axis + 1:]:
+                inner *= s
+            if est.n_groups is not None:
+                assert est.n_groups > 0 and n_params % est.n_groups == 0
+                n_groups = est.n_groups
+        elif est.per_channel:
+            n_params, inner = x.shape[0], x.numel() // max(x.shape[0], 1)
+        else:
+            n_params, inner = 1, 1
+        if n_params > be.CALIB_MAX_PARAMS or x.numel() == 0:
+            return None
+        if n_params > 1 and not q.per_channel and q.axis is None:
+            return None                      # layered path raises the reference's ValueError
+        order = None
+        if n_groups and mode == _hip.EST_CURRENT and est.ranges is not None:
+            order = be.argsort(est.ranges)
+        prev_min = est.current_xmin if mode != _hip.EST_CURRENT else None
+        prev_max = est.current_xmax if mode != _hip.EST_CURRENT else None
+        cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_minmax(
+            x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0), n_groups, order,
+            q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log')
+        est.current_xmin, est.current_xmax = cur_min, cur_max
+        q._delta = delta
+        if q.symmetric:
+            q._signed = signed
+        else:
+            q._zero_float = zero_float
+        # same buffer shapes as quantizer.forward leaves behind ([1,1,d] / [C,1,..] views)
+        if q.axis is not None:
+            q._adjust_params_per_axis(x)
+        if q.per_channel:
+            q._adjust_params_per_channel(x)
+        return y
+
     def forward(self, x):
         est = self.range_estimator
         if est is not None and est.per_group_range_estimation:
@@ -99,6 +170,9 @@ class QuantizationManager(nn.Module):
         if self._estimating():
             if est is None:
                 raise RuntimeError('this manager was built with a fixed range: no estimator to run')
+            y = self._fused_estimating_forward(x)
+            if y is not None:
+                return y
             cur_xmin, cur_xmax = est(x)
             self.set_quant_range(cur_xmin, cur_xmax)
         return self.quantizer(x)
