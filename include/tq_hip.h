@@ -90,11 +90,14 @@ int tq_affine_fake_quant_fwd(const void* x, const float* w, const float* b, void
 
 /* STE backward of the same op (autograd through quantizers.py:12-19,
  * 184-185, 209): dx = ((g * scale) * mask) / scale with mask = [int_min <= round(x/s)+zp <=
- * int_max].  Per-tensor parameters only accumulate d_delta / d_zero_float when the pointers
- * are non-NULL (fp32 [1] each, must be zeroed by the caller).                                  */
+ * int_max]: 3 streams, 6 B/elem bf16.  For a per-tensor quantizer, non-NULL grad_delta /
+ * grad_zero_float (fp32 [1], overwritten) also receive d loss / d _delta and d loss / d _zero_float
+ * (make_range_trainable, quantizers.py:284-288, 346-349) through deterministic block partials in
+ * `workspace` (tq_fake_quant_bwd_workspace_bytes).                                                */
+size_t tq_fake_quant_bwd_workspace_bytes(uint64_t n);
 int tq_fake_quant_bwd(const void* x, const void* grad_y, void* grad_x, float* grad_delta,
                       float* grad_zero_float, uint64_t n, int dtype, const tq_quantizer* q,
-                      tq_stream_t stream);
+                      void* workspace, size_t workspace_bytes, tq_stream_t stream);
 
 /* ---- K4/K5: min / max statistics ------------------------------------------------------------
  * Replaces torch.min/torch.max and the transpose+view+min(-1)/max(-1) chains of the range

@@ -24,6 +24,8 @@ for dt,es in ((torch.bfloat16,2),(torch.float32,4)):
         r['fq_tensor']=(timeit(lambda: be.fake_quant(x,delta,zf,None,8,False,False,1e-8,1,1)), 2*es)
         r['fq_axis']=(timeit(lambda: be.fake_quant(x,dv,zv,None,8,False,False,1e-8,d,1)), 2*es)
         r['fq_idx8']=(timeit(lambda: be.fake_quant(x,delta,zf,None,8,False,False,1e-8,1,1,want_y=False,idx_dtype=torch.uint8)), es+1)
+        gy=torch.randn_like(x)
+        r['fq_bwd']=(timeit(lambda: be.fake_quant_bwd(x,gy,delta,zf,None,8,False,False,1e-8,1,1)), 3*es)
         r['mm_tensor']=(timeit(lambda: be.minmax(x,1,1)), es)
         r['mm_axis']=(timeit(lambda: be.minmax(x,d,1)), es)
         print(str(dt).split('.')[-1], shape, '  '.join(f'{k}: {ms*1e3:.1f}us {n*b/ms/1e6:.0f}GB/s' for k,(ms,b) in r.items()), flush=True)

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Per-config measurements (BASELINE.json `configs`) on one MI355X; writes one JSON document.
+
+    python scripts/config_bench.py > gpurun_out/config_bench.json
+"""
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, 'transformer-quantization_amd'), ROOT):
+    sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+from quantization import _hip
+from quantization.quantizers import QMethods
+from quantization.range_estimators import RangeEstimators, OptMethod
+from quantization.quantization_manager import QuantizationManager
+from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+
+dev = 'cuda'
+out = {}
+
+
+def wall(fn, n=10, w=2):
+    for _ in range(w):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def hidden(B, S, d=768, dtype=torch.float32, seed=1000):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn(B, S, d, generator=g, device=dev)
+    x[..., 308 % d] *= 20
+    x[..., 381 % d] *= 20
+    return x.to(dtype)
+
+
+# ---- configs 0/1: whole BERT-base W8A8 (B=8, T=128) -------------------------------------------
+from tests.test_bert_e2e import _build, _fixture
+z = _fixture()
+model, hf = _build(dev)
+ids = torch.from_numpy(z['input_ids']).to(dev)
+with torch.no_grad():
+    model.set_quant_state(False, False)
+    c = {'fp32_forward_ms': wall(lambda: model(ids))}
+    model.set_quant_state(True, True)
+    c['calibrating_forward_ms'] = wall(lambda: model(ids))
+    model.fix_ranges()
+    c['fixed_range_forward_eager_ms'] = wall(lambda: model(ids))
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            model(ids)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        o = model(ids)
+    c['fixed_range_forward_hipgraph_ms'] = wall(lambda: g.replay(), n=30)
+    c['graph_equals_eager'] = bool(torch.equal(o, model(ids)))
+c['activation_elems_per_forward'] = 172234768
+c['reference_cpu_8thr_ms'] = {'fp32': 239, 'fixed_range': 368, 'calibrating': 5100,
+                              'source': 'BASELINE.md section 2 (survey container, 8 vCPU)'}
+out['config0_1_bert_base_w8a8_b8_t128'] = c
+del model, hf
+
+# ---- config 2: per-tensor running min/max, [8,128,768] and [1024,512,768] --------------------------
+c = {}
+for shape in ((8, 128), (1024, 512)):
+    for dt in (torch.bfloat16, torch.float32):
+        x = hidden(*shape, dtype=dt)
+        mgr = QuantizationManager(qmethod=QMethods.asymmetric_uniform, init=RangeEstimators.running_minmax,
+                                  qparams=dict(n_bits=8))
+        mgr(x)
+        est_ms = wall(lambda: mgr(x), n=30)
+        mgr.fix_ranges()
+        fix_ms = wall(lambda: mgr(x), n=30)
+        c[f'{list(x.shape)}_{str(dt)[6:]}'] = {
+            'estimate_plus_quantize_ms': est_ms, 'fixed_ms': fix_ms,
+            'estimate_GBps_at_6B_per_elem_bf16_or_12_fp32': x.numel() * 3 * x.element_size() / est_ms / 1e6,
+            'fixed_GBps': x.numel() * 2 * x.element_size() / fix_ms / 1e6}
+out['config2_per_tensor_running_minmax'] = c
+
+# ---- config 3: per-embedding-group (PEG-6, permuted) + MSE search ---------------------------------
+c = {}
+for shape in ((8, 128), (256, 512)):
+    x = hidden(*shape)
+    for layout in ('per_embd', 'ng6', 'ngp6'):
+        mgr = QuantizationManager(qmethod=QMethods.asymmetric_uniform, init=RangeEstimators.current_minmax,
+                                  qparams=dict(n_bits=8))
+        set_act_quant_axis_and_groups(mgr, axis=2, n_groups=None if layout == 'per_embd' else 6,
+                                      permute=layout == 'ngp6')
+        if layout == 'ngp6':
+            mgr(x)
+            mgr.range_estimator.per_group_range_estimation = False
+        mgr(x)
+        est_ms = wall(lambda: mgr(x), n=20)
+        mgr.fix_ranges()
+        fix_ms = wall(lambda: mgr(x), n=20)
+        c[f'{list(x.shape)}_{layout}'] = {'estimate_plus_quantize_ms': est_ms, 'fixed_ms': fix_ms}
+x = hidden(8, 128)
+for name, method, n_bits, params in (
+        ('mse_1d_grid_sym8_100cand', 'symmetric_uniform', 8, dict(num_candidates=100)),
+        ('mse_2d_grid_asym8_100x64x2', 'asymmetric_uniform', 8, dict(num_candidates=100)),
+        ('mse_golden_section_sym8', 'symmetric_uniform', 8, dict(opt_method=OptMethod.golden_section)),
+        ('mse_peg6_degenerate_2d_asym8', 'asymmetric_uniform', 8, dict(num_candidates=100))):
+    def one():
+        mgr = QuantizationManager(qmethod=QMethods[method], init=RangeEstimators.MSE,
+                                  qparams=dict(n_bits=n_bits), init_params=params)
+        if 'peg6' in name:
+            set_act_quant_axis_and_groups(mgr, axis=2, n_groups=6)
+        mgr(x)
+    c[name + '_[8,128,768]_ms'] = wall(one, n=3, w=1)
+c['reference_cpu_8thr_ms'] = {'mse_1d': 170, 'mse_2d': 13800, 'source': 'BASELINE.md section 2'}
+out['config3_peg_and_mse'] = c
+
+# ---- config 4: AdaRound W4 on BERT-base layer shapes ------------------------------------------------
+from quantization.base_quantized_model import QuantizedModel
+from quantization.autoquant_utils import quantize_model
+from quantization.adaround import apply_adaround_to_layer
+from quantization.adaround.config import DEFAULT_ADAROUND_CONFIG
+c = {}
+for (fin, fout) in ((768, 3072), (768, 768)):
+    class Net(QuantizedModel):
+        def __init__(self):
+            super().__init__()
+            self.fc = quantize_model(torch.nn.Linear(fin, fout), method=QMethods.symmetric_uniform, n_bits=4)
+
+        def forward(self, x):
+            return self.fc(x)
+    torch.manual_seed(1000)
+    net = Net().to(dev)
+    data = torch.randn(256, 128, fin, device=dev)
+    net.set_quant_state(True, False)
+    net.eval()
+    with torch.no_grad():
+        net(data[:8])
+    cfg = copy.deepcopy(DEFAULT_ADAROUND_CONFIG)
+    cfg.iters = 300
+    net.full_precision()
+    net.fc.quantized_weights()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = apply_adaround_to_layer(net, net.fc, data, batch_size=8, act_quant=False, adaround_config=cfg)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    c[f'linear_{fin}x{fout}'] = {'iters': cfg.iters, 'cached_samples': 256, 'batch': '8x128 tokens',
+                                 'total_s': total, 'ms_per_iter_incl_caching': total / cfg.iters * 1e3,
+                                 'loss_hard_before': res.loss_hard_before, 'loss_hard_after': res.loss_hard_after}
+c['reference_cpu_8thr'] = {'linear_768x3072_20iters_64samples_s': 3.9, 'per_iter_ms': '<= 200',
+                           'source': 'BASELINE.md section 2'}
+out['config4_adaround_w4'] = c
+
+# ---- config 5 building blocks: MobileBERT W4A4 shapes ----------------------------------------------
+be = _hip.backend()
+c = {}
+for rows, d in ((1024, 512), (1024, 128), (131072, 512)):
+    for dt in (torch.bfloat16, torch.float32):
+        x = torch.randn(rows, d, device=dev).to(dt)
+        w = torch.randn(d, device=dev)
+        b = torch.randn(d, device=dev)
+        delta = torch.tensor(0.4, device=dev)
+        zf = torch.tensor(7.0, device=dev)
+        ms = wall(lambda: be.affine_fake_quant(x, w, b, delta, zf, None, 4, False, False, 1e-8), n=30)
+        c[f'nonorm_quant_[{rows},{d}]_{str(dt)[6:]}'] = {'ms': ms, 'GBps': x.numel() * 2 * x.element_size() / ms / 1e6}
+out['config5_mobilebert_w4a4_blocks'] = c
+
+print(json.dumps(out, indent=1))

@@ -565,3 +565,32 @@ def test_toy_model_calibration_on_gpu(q, golden_toy, calib_path):
     # outputs sit on an 8-bit grid: allow one quantisation step of the final quantizer
     step = float(sd['res_q.activation_quantizer.quantizer._delta'])
     assert float((out.cpu() - t(z['out'])).abs().max()) <= step * 1.001
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_ste_backward_large_and_layouts(q, dtype):
+    """Vectorised STE backward at a BERT-sized tensor, plus per-embedding params and a ragged,
+    unaligned tensor through the scalar kernel; dx against autograd on the CPU oracle."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(64, 128, 768, generator=g) * 3).to(dtype)
+    go = torch.randn(64, 128, 768, generator=g).to(dtype)
+    delta, zf = O.asym_params_from_range(-4.0, 5.0, 8)
+    gx, gd, gz = be.fake_quant_bwd(x.to(DEV), go.to(DEV), delta.to(DEV), zf.to(DEV), None, 8, False, False,
+                                   1e-8, 1, 1, param_grads=True)
+    _, ref_dx, ref_dd, ref_dz = O.fake_quant_with_grads(x.float(), delta, zf, 8, False, grad_out=go.float())
+    assert torch.equal(gx.cpu(), ref_dx.to(dtype))
+    assert torch.allclose(gd.cpu().reshape(()), ref_dd, rtol=2e-4, atol=1e-2)
+    assert torch.allclose(gz.cpu().reshape(()), ref_dz, rtol=2e-4, atol=1e-2)
+    # per-embedding parameters (scalar kernel), ragged + unaligned view
+    xs, gs = x[:3, :5].contiguous(), go[:3, :5].contiguous()
+    dv, zv = O.asym_params_from_range(xs.float().amin((0, 1)), xs.float().amax((0, 1)), 4)
+    gx2, _, _ = be.fake_quant_bwd(xs.to(DEV), gs.to(DEV), dv.to(DEV), zv.to(DEV), None, 4, False, False, 1e-8,
+                                  768, 1)
+    _, ref2, _, _ = O.fake_quant_with_grads(xs.float(), dv, zv, 4, False, grad_out=gs.float(), axis=2)
+    assert torch.equal(gx2.cpu(), ref2.to(dtype))
+    flat = x.reshape(-1)[1:4098].to(DEV)
+    gflat = go.reshape(-1)[1:4098].to(DEV)
+    gx3, _, _ = be.fake_quant_bwd(flat, gflat, delta.to(DEV), zf.to(DEV), None, 8, False, False, 1e-8, 1, 1)
+    assert torch.equal(gx3.cpu(), ref_dx.reshape(-1)[1:4098].to(dtype))

@@ -152,14 +152,6 @@ template <> struct Store<TQ_F16> {
 __device__ __forceinline__ u32x4 ld_stream(const u32x4* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_stream(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
 
-// ------------------------------------------------------------------ index output
-template <int IT> struct Idx;
-template <> struct Idx<TQ_IDX_F32> { typedef float t; static __device__ __forceinline__ t cv(float f) { return f; } };
-template <> struct Idx<TQ_IDX_I8>  { typedef int8_t t; static __device__ __forceinline__ t cv(float f) { return (int8_t)(int)f; } };
-template <> struct Idx<TQ_IDX_U8>  { typedef uint8_t t; static __device__ __forceinline__ t cv(float f) { return (uint8_t)(int)f; } };
-template <> struct Idx<TQ_IDX_I16> { typedef int16_t t; static __device__ __forceinline__ t cv(float f) { return (int16_t)(int)f; } };
-template <> struct Idx<TQ_IDX_I32> { typedef int32_t t; static __device__ __forceinline__ t cv(float f) { return (int32_t)f; } };
-
 // ------------------------------------------------------------------ wave / block reductions
 // torch.min / torch.max propagate NaN; so do these.
 __device__ __forceinline__ float min_nanprop(float a, float b) {

@@ -360,53 +360,160 @@ static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t 
 // d_delta, d_zero_float (per-tensor only): chain rule through scale = clamp(delta, eps),
 //   zp = clamp(round_ste(zero_float), lo, hi), x_int = clamp(round_ste(x/s) + zp, lo, hi),
 //   y = s * (x_int - zp).
-template <int DT>
-__global__ __launch_bounds__(kBlock) void fq_bwd(const void* __restrict__ x, const void* __restrict__ gy,
-                                                 void* __restrict__ gx, float* __restrict__ g_delta,
-                                                 float* __restrict__ g_zf, uint64_t n, tq_quantizer q) {
-  typedef typename Store<DT>::elem_t E;
-  __shared__ float s_red[2][kBlock / kWave];
-  float acc_d = 0.f, acc_z = 0.f;
-  const bool per_tensor = q.n_params == 1;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    const uint64_t pi = per_tensor ? 0 : (i / q.inner) % q.n_params;
-    const QP p = make_qp(q, pi);
-    const float xv = Store<DT>::load1(static_cast<const E*>(x) + i);
-    const float g = Store<DT>::load1(static_cast<const E*>(gy) + i);
-    const float r = rintf(xv / p.scale) + p.zp;
-    const bool in = (r >= p.lo) && (r <= p.hi);          // torch.clamp backward mask (inclusive)
-    const float gs = g * p.scale;                         // grad wrt (x_int - zp)
-    Store<DT>::store1(static_cast<E*>(gx) + i, in ? gs / p.scale : 0.0f);
-    if (per_tensor && g_delta != nullptr) {
-      const float xi = clamp_nanprop(r, p.lo, p.hi);
-      // d y / d scale = (x_int - zp) + s * mask * d(x/s)/ds = (x_int - zp) - mask * x / s
-      float dd = g * (xi - p.zp);
-      if (in) dd -= (gs * xv) / (p.scale * p.scale);
-      acc_d += dd;
-      // d y / d zp = s * (mask - 1)
-      acc_z += in ? 0.0f : -gs;
-    }
+struct BwdAcc { float d, z; };
+
+__device__ __forceinline__ float ste_bwd_elem(float xv, float g, const QP& p, bool pgrad, BwdAcc& acc) {
+  const float r = rintf(xv / p.scale) + p.zp;
+  const bool in = (r >= p.lo) && (r <= p.hi);          // torch.clamp backward mask (inclusive)
+  const float gs = g * p.scale;                         // grad wrt (x_int - zp)
+  if (pgrad) {
+    const float xi = clamp_nanprop(r, p.lo, p.hi);
+    // d y / d scale = (x_int - zp) - mask * x / s ;  d y / d zp = s * (mask - 1)
+    float dd = g * (xi - p.zp);
+    if (in) dd -= (gs * xv) / (p.scale * p.scale);
+    acc.d += dd;
+    acc.z += in ? 0.0f : -gs;
   }
-  if (per_tensor && g_delta != nullptr) {
-    acc_d = wave_sum(acc_d);
-    acc_z = wave_sum(acc_z);
-    const int w = threadIdx.x / kWave;
-    if ((threadIdx.x & (kWave - 1)) == 0) { s_red[0][w] = acc_d; s_red[1][w] = acc_z; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float d = 0.f, z = 0.f;
-      for (int k = 0; k < kBlock / kWave; ++k) { d += s_red[0][k]; z += s_red[1][k]; }
-      const float delta = q.delta[0];
-      // scale = clamp(delta, min=eps): gradient passes when delta >= eps; log domain: * scale
-      const float pass = q.log_domain ? expf(delta) : (delta >= q.eps ? 1.0f : 0.0f);
-      atomicAdd(g_delta, d * pass);
-      if (g_zf != nullptr && !q.symmetric) {
-        const float zf = rintf(q.zero_float[0]);
-        const QP p = make_qp(q, 0);
-        atomicAdd(g_zf, (zf >= p.lo && zf <= p.hi) ? z : 0.0f);
+  return in ? gs / p.scale : 0.0f;
+}
+
+__device__ __forceinline__ void bwd_block_reduce(BwdAcc acc, float* __restrict__ partial) {
+  __shared__ float s_red[2][kBlock / kWave];
+  acc.d = wave_sum(acc.d);
+  acc.z = wave_sum(acc.z);
+  const int w = threadIdx.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_red[0][w] = acc.d; s_red[1][w] = acc.z; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float d = 0.f, z = 0.f;
+    for (int k = 0; k < kBlock / kWave; ++k) { d += s_red[0][k]; z += s_red[1][k]; }
+    partial[2 * blockIdx.x] = d;
+    partial[2 * blockIdx.x + 1] = z;
+  }
+}
+
+// per-tensor, vectorised: 3 streams (x, g in; gx out) = 6 B/elem bf16; same one-shot tiling as K1
+template <int DT, bool PGRAD, bool NT, int U>
+__global__ __launch_bounds__(kBlock) void fq_bwd_tensor(const u32x4* __restrict__ x, const u32x4* __restrict__ gy,
+                                                        u32x4* __restrict__ gx, float* __restrict__ partial,
+                                                        uint64_t n, tq_quantizer q) {
+  constexpr int V = Store<DT>::kVec;
+  constexpr uint64_t TILE = (uint64_t)kBlock * U;
+  const QP p = make_qp(q, 0);
+  const uint64_t n_vec = n / V;
+  BwdAcc acc = {0.f, 0.f};
+  for (uint64_t t0 = (uint64_t)blockIdx.x * TILE; t0 < n_vec; t0 += (uint64_t)gridDim.x * TILE) {
+    const uint64_t i = t0 + threadIdx.x;
+    const bool full = t0 + TILE <= n_vec;
+    u32x4 vx[U], vg[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t k = i + u * kBlock;
+      vx[u] = u32x4{0, 0, 0, 0};
+      vg[u] = u32x4{0, 0, 0, 0};
+      if (full || k < n_vec) { vx[u] = NT ? ld_stream(x + k) : x[k]; vg[u] = NT ? ld_stream(gy + k) : gy[k]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t k = i + u * kBlock;
+      float fx[V], fg[V];
+      Store<DT>::unpack(vx[u], fx);
+      Store<DT>::unpack(vg[u], fg);
+      if (full || k < n_vec) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) fg[j] = ste_bwd_elem(fx[j], fg[j], p, PGRAD, acc);
+        const u32x4 o = Store<DT>::pack(fg);
+        if (NT) st_stream(gx + k, o); else gx[k] = o;
       }
     }
   }
+  const uint64_t tail0 = n_vec * V;
+  if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
+    typedef typename Store<DT>::elem_t E;
+    const uint64_t k = tail0 + threadIdx.x;
+    const float r = ste_bwd_elem(Store<DT>::load1(reinterpret_cast<const E*>(x) + k),
+                                 Store<DT>::load1(reinterpret_cast<const E*>(gy) + k), p, PGRAD, acc);
+    Store<DT>::store1(reinterpret_cast<E*>(gx) + k, r);
+  }
+  if (PGRAD) bwd_block_reduce(acc, partial);
+}
+
+// any layout / alignment (scalar loads); parameter gradients only for per-tensor quantizers
+template <int DT, bool PGRAD>
+__global__ __launch_bounds__(kBlock) void fq_bwd(const void* __restrict__ x, const void* __restrict__ gy,
+                                                 void* __restrict__ gx, float* __restrict__ partial, uint64_t n,
+                                                 tq_quantizer q) {
+  typedef typename Store<DT>::elem_t E;
+  BwdAcc acc = {0.f, 0.f};
+  const bool per_tensor = q.n_params == 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const QP p = make_qp(q, per_tensor ? 0 : (i / q.inner) % q.n_params);
+    const float r = ste_bwd_elem(Store<DT>::load1(static_cast<const E*>(x) + i),
+                                 Store<DT>::load1(static_cast<const E*>(gy) + i), p, PGRAD && per_tensor, acc);
+    Store<DT>::store1(static_cast<E*>(gx) + i, r);
+  }
+  if (PGRAD) bwd_block_reduce(acc, partial);
+}
+
+// sum the block partials and apply the chain rule through scale = clamp(delta, eps) | exp(delta)
+// and zp = clamp(round_ste(zero_float), lo, hi)
+__global__ void fq_bwd_final(const float* __restrict__ partial, uint32_t nb, tq_quantizer q, float* __restrict__ g_delta,
+                             float* __restrict__ g_zf) {
+  __shared__ double s_red[2][kBlock / kWave];
+  double d = 0.0, z = 0.0;
+  for (uint32_t i = threadIdx.x; i < nb; i += kBlock) { d += (double)partial[2 * i]; z += (double)partial[2 * i + 1]; }
+  d = wave_sum(d);
+  z = wave_sum(z);
+  const int w = threadIdx.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_red[0][w] = d; s_red[1][w] = z; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    d = z = 0.0;
+    for (int k = 0; k < kBlock / kWave; ++k) { d += s_red[0][k]; z += s_red[1][k]; }
+    const float delta = q.delta[0];
+    const float pass = q.log_domain ? expf(delta) : (delta >= q.eps ? 1.0f : 0.0f);
+    g_delta[0] = (float)d * pass;
+    if (g_zf != nullptr && !q.symmetric) {
+      const QP p = make_qp(q, 0);
+      const float zf = rintf(q.zero_float[0]);
+      g_zf[0] = (zf >= p.lo && zf <= p.hi) ? (float)z : 0.0f;
+    }
+  }
+}
+
+template <int DT>
+static int launch_bwd(const void* x, const void* gy, void* gx, float* g_delta, float* g_zf, uint64_t n,
+                      const tq_quantizer& q, float* ws, size_t ws_bytes, hipStream_t st) {
+  constexpr int V = Store<DT>::kVec;
+  const bool pgrad = g_delta != nullptr;
+  if (pgrad && q.n_params != 1) return set_error(TQ_EUNSUPPORTED, "tq_fake_quant_bwd: parameter gradients need a per-tensor quantizer");
+  const bool vec_ok = q.n_params == 1 && aligned16(x) && aligned16(gy) && aligned16(gx);
+  const uint64_t n_vec = n / V;
+  constexpr int U = 2;
+  unsigned grid;
+  if (vec_ok) grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n_vec, kBlock * U), 1), pgrad ? 65536 : kMaxTiles);
+  else grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, kBlock), 1), kMaxGrid);
+  if (pgrad && (ws == nullptr || ws_bytes < (size_t)grid * 2 * sizeof(float)))
+    return set_error(TQ_EWORKSPACE, "tq_fake_quant_bwd: workspace %zu < %zu bytes", ws_bytes, (size_t)grid * 2 * sizeof(float));
+  const bool nt = (n * elem_size(DT)) >= ((uint64_t)64 << 20);
+  if (vec_ok) {
+    const auto xv = static_cast<const u32x4*>(x);
+    const auto gv = static_cast<const u32x4*>(gy);
+    auto ov = static_cast<u32x4*>(gx);
+    if (pgrad) { if (nt) hipLaunchKernelGGL((fq_bwd_tensor<DT, true, true, U>), dim3(grid), dim3(kBlock), 0, st, xv, gv, ov, ws, n, q);
+                 else    hipLaunchKernelGGL((fq_bwd_tensor<DT, true, false, U>), dim3(grid), dim3(kBlock), 0, st, xv, gv, ov, ws, n, q); }
+    else       { if (nt) hipLaunchKernelGGL((fq_bwd_tensor<DT, false, true, U>), dim3(grid), dim3(kBlock), 0, st, xv, gv, ov, ws, n, q);
+                 else    hipLaunchKernelGGL((fq_bwd_tensor<DT, false, false, U>), dim3(grid), dim3(kBlock), 0, st, xv, gv, ov, ws, n, q); }
+  } else {
+    if (pgrad) hipLaunchKernelGGL((fq_bwd<DT, true>), dim3(grid), dim3(kBlock), 0, st, x, gy, gx, ws, n, q);
+    else       hipLaunchKernelGGL((fq_bwd<DT, false>), dim3(grid), dim3(kBlock), 0, st, x, gy, gx, ws, n, q);
+  }
+  if (int e = check_launch("fq_bwd")) return e;
+  if (pgrad) {
+    hipLaunchKernelGGL(fq_bwd_final, dim3(1), dim3(kBlock), 0, st, ws, grid, q, g_delta, g_zf);
+    return check_launch("fq_bwd_final");
+  }
+  return TQ_OK;
 }
 
 }  // namespace tq
@@ -467,20 +574,20 @@ extern "C" int tq_affine_fake_quant_fwd(const void* x, const float* w, const flo
   }
 }
 
+extern "C" size_t tq_fake_quant_bwd_workspace_bytes(uint64_t n) { return (size_t)65536 * 2 * sizeof(float); }
+
 extern "C" int tq_fake_quant_bwd(const void* x, const void* grad_y, void* grad_x, float* grad_delta,
                                  float* grad_zero_float, uint64_t n, int dtype, const tq_quantizer* q,
-                                 tq_stream_t stream) {
+                                 void* workspace, size_t workspace_bytes, tq_stream_t stream) {
   if (n == 0) return TQ_OK;
   TQ_REQUIRE(x && grad_y && grad_x, "tq_fake_quant_bwd: NULL tensor");
   TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_fake_quant_bwd: bad dtype %d", dtype);
   if (int e = check_quantizer(q, n, "tq_fake_quant_bwd")) return e;
-  if (n == 0) return TQ_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, kBlock), 1), kMaxGrid);
+  float* ws = static_cast<float*>(workspace);
   switch (dtype) {
-    case TQ_F32: hipLaunchKernelGGL((fq_bwd<TQ_F32>), dim3(grid), dim3(kBlock), 0, st, x, grad_y, grad_x, grad_delta, grad_zero_float, n, *q); break;
-    case TQ_BF16: hipLaunchKernelGGL((fq_bwd<TQ_BF16>), dim3(grid), dim3(kBlock), 0, st, x, grad_y, grad_x, grad_delta, grad_zero_float, n, *q); break;
-    default: hipLaunchKernelGGL((fq_bwd<TQ_F16>), dim3(grid), dim3(kBlock), 0, st, x, grad_y, grad_x, grad_delta, grad_zero_float, n, *q); break;
+    case TQ_F32: return launch_bwd<TQ_F32>(x, grad_y, grad_x, grad_delta, grad_zero_float, n, *q, ws, workspace_bytes, st);
+    case TQ_BF16: return launch_bwd<TQ_BF16>(x, grad_y, grad_x, grad_delta, grad_zero_float, n, *q, ws, workspace_bytes, st);
+    default: return launch_bwd<TQ_F16>(x, grad_y, grad_x, grad_delta, grad_zero_float, n, *q, ws, workspace_bytes, st);
   }
-  return check_launch("fq_bwd");
 }

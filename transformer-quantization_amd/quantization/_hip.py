@@ -43,7 +43,8 @@ SIGNATURES = {
     'tq_last_error': (C.c_char_p, []),
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
     'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
-    'tq_fake_quant_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _int, _QP, _vp]),
+    'tq_fake_quant_bwd_workspace_bytes': (_sz, [_u64]),
+    'tq_fake_quant_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _int, _QP, _vp, _sz, _vp]),
     'tq_minmax_workspace_bytes': (_sz, [_u64, _u64, _u64]),
     'tq_minmax': (_int, [_vp, _u64, _int, _u64, _u64, _vp, _vp, _vp, _sz, _vp]),
     'tq_calibrate_workspace_bytes': (_sz, [_u64, _u64, _u64]),
@@ -187,12 +188,15 @@ class HipBackend:
         grad_y = grad_y.contiguous().to(x.dtype)
         gx = torch.empty_like(x)
         gd = gz = None
+        ws = None
         if param_grads:
             gd = torch.zeros(1, dtype=torch.float32, device=x.device)
             gz = torch.zeros(1, dtype=torch.float32, device=x.device)
+            ws = self._workspace(x.device, self.lib.tq_fake_quant_bwd_workspace_bytes(x.numel()))
         q = self._qdesc(delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner)
         rc = self.lib.tq_fake_quant_bwd(_ptr(x), _ptr(grad_y), _ptr(gx), _ptr(gd), _ptr(gz), x.numel(),
-                                        _dtype_code(x, 'fake_quant_bwd'), C.byref(q), _stream())
+                                        _dtype_code(x, 'fake_quant_bwd'), C.byref(q), _ptr(ws),
+                                        ws.numel() if ws is not None else 0, _stream())
         _check(rc, self.lib)
         return gx, gd, gz
 
