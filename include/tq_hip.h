@@ -167,6 +167,16 @@ int tq_mse_candidates(const void* x, uint64_t rows, uint64_t row_len, int dtype,
                       const float* cand, uint64_t n_cand, double* loss, void* workspace,
                       size_t workspace_bytes, tq_stream_t stream);
 
+/* Extension: true per-embedding-group search.  The reference's MSE estimator
+ * ignores axis / n_groups, so "PEG + MSE" degenerates to a per-tensor search; this entry point
+ * evaluates the candidates per group of embedding dimensions of x [n_tokens, d] in place
+ * (group g = columns [g*d/n_groups, (g+1)*d/n_groups)), loss fp64 [n_groups, C] accumulated.
+ * Oracle: the reference's MSE_Estimator(per_channel=True) on the transposed [n_groups, -1] view.
+ * Workspace: tq_mse_workspace_bytes(n_groups, n_tokens * d / n_groups, n_cand).                  */
+int tq_mse_candidates_grouped(const void* x, uint64_t n_tokens, uint64_t d, uint64_t n_groups,
+                              int dtype, const float* cand, uint64_t n_cand, double* loss,
+                              void* workspace, size_t workspace_bytes, tq_stream_t stream);
+
 /* K9: CrossEntropyEstimator.loss_fx (range_estimators.py:498-502) for all candidates:
  * loss[c] += -sum softmax(x,dim=1) * log_softmax(Q_c(x),dim=1), x fp32 [rows, cols].          */
 int tq_xent_candidates(const float* x, uint64_t rows, uint64_t cols, const float* cand,

@@ -119,6 +119,12 @@ class OracleBackend:
                 loss[:, ci] += per_row.double()
         return loss
 
+    def mse_candidates_grouped(self, x, n_groups, cand, loss):
+        # the [n_groups, -1] view the reference's per-channel estimator would see
+        xf = x.detach().float()
+        xg = xf.transpose(0, xf.dim() - 1).contiguous().view(xf.shape[-1], -1).view(n_groups, -1)
+        return self.mse_candidates(xg, n_groups, cand, loss)
+
     def xent_candidates(self, x, cand, loss):
         xf = x.detach().float().reshape(x.shape[0], -1)
         for ci in range(cand.shape[0]):

@@ -240,6 +240,26 @@ def gen_estimators():
     data['perm_xmax'] = np32(mgr.range_estimator.current_xmax)
     data['perm_y'] = np32(y)
 
+    # Oracle of the per-group MSE EXTENSION: the reference's own per-channel MSE
+    # estimator applied to the [n_groups, -1] view of each batch, then repeat_interleave(gs).
+    from quantization.quantizers import AsymmetricUniformQuantizer, SymmetricUniformQuantizer
+    ng = 4
+    for tag, qcls, n_bits, inputs_, ip_ in (('asym4', AsymmetricUniformQuantizer, 4, batches, dict(num_candidates=12)),
+                                            ('sym8', SymmetricUniformQuantizer, 8, batches, dict(num_candidates=50)),
+                                            ('onesided6', AsymmetricUniformQuantizer, 6, pos_batches, dict(num_candidates=30))):
+        qz = qcls(n_bits=n_bits)
+        est = RangeEstimators.MSE.cls(per_channel=True, quantizer=qz, **ip_)
+        mins, maxs = [], []
+        for x in inputs_:
+            xg = x.transpose(0, 2).contiguous().view(x.size(2), -1).view(ng, -1)
+            mn, mx = est(xg)
+            gs = x.size(2) // ng
+            mins.append(np32(mn.repeat_interleave(gs)))
+            maxs.append(np32(mx.repeat_interleave(gs)))
+        data[f'pg_{tag}_xmin'] = np.stack(mins)
+        data[f'pg_{tag}_xmax'] = np.stack(maxs)
+        data[f'pg_{tag}_loss'] = np.asarray(est.loss_array, dtype=np.float64)
+
     data['meta'] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, 'estimators.npz'), **data)
     print('estimator cases:', k)

@@ -21,8 +21,14 @@ namespace tq {
 
 constexpr int kCandTile = 128;
 
+// A "row" (one loss vector) is either contiguous (seg == row_len) or the union of segments of `seg`
+// elements that repeat every `seg_stride` elements: row r, element e lives at
+//   (e / seg) * seg_stride + r * seg + (e % seg)
+// which is how a group of embedding dimensions [r*seg, (r+1)*seg) of a [tokens, d] tensor is laid out
+// (seg = d / n_groups, seg_stride = d): per-group searches need no transpose copy.
 template <int DT, int E>
-__global__ __launch_bounds__(kBlock) void mse_cand_k(const void* __restrict__ x, uint64_t row_len, bool vec_ok,
+__global__ __launch_bounds__(kBlock) void mse_cand_k(const void* __restrict__ x, uint64_t row_len, uint64_t seg,
+                                                     uint64_t seg_stride, bool vec_ok,
                                                      const float4* __restrict__ cand, uint32_t n_cand,
                                                      uint32_t cand_tile, double* __restrict__ partial) {
   constexpr int V = Store<DT>::kVec;
@@ -41,13 +47,14 @@ __global__ __launch_bounds__(kBlock) void mse_cand_k(const void* __restrict__ x,
   __syncthreads();
 
   const uint64_t row = blockIdx.z;
-  const T* xr = static_cast<const T*>(x) + row * row_len;
+  const bool contiguous = seg == row_len;
+  const T* xr = static_cast<const T*>(x) + row * seg;
   const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
   constexpr uint64_t kTile = (uint64_t)kBlock * E;
 
   for (uint64_t t0 = (uint64_t)blockIdx.x * kTile; t0 < row_len; t0 += (uint64_t)gridDim.x * kTile) {
     float f[E];
-    if (vec_ok && t0 + kTile <= row_len) {
+    if (vec_ok && contiguous && t0 + kTile <= row_len) {
       const u32x4* xv = reinterpret_cast<const u32x4*>(xr + t0);
 #pragma unroll
       for (int u = 0; u < NV; ++u) {
@@ -55,6 +62,28 @@ __global__ __launch_bounds__(kBlock) void mse_cand_k(const void* __restrict__ x,
         Store<DT>::unpack(xv[u * kBlock + threadIdx.x], g);
 #pragma unroll
         for (int j = 0; j < V; ++j) f[u * V + j] = g[j];
+      }
+    } else if (vec_ok && !contiguous) {
+      // segmented row: seg % V == 0, so a 16-byte vector never straddles two segments
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const uint64_t e = t0 + ((uint64_t)u * kBlock + threadIdx.x) * V;
+        float g[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) g[j] = 0.0f;
+        if (e < row_len) {
+          const uint64_t sidx = e / seg, off = e - sidx * seg;
+          Store<DT>::unpack(*reinterpret_cast<const u32x4*>(xr + sidx * seg_stride + off), g);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) f[u * V + j] = g[j];
+      }
+    } else if (!contiguous) {
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const uint64_t e = t0 + (uint64_t)j * kBlock + threadIdx.x;
+        const uint64_t sidx = e / seg, off = e - sidx * seg;
+        f[j] = e < row_len ? Store<DT>::load1(xr + sidx * seg_stride + off) : 0.0f;
       }
     } else {
       // ragged / unaligned tile: zero padding contributes exactly 0 to every candidate's loss
@@ -188,18 +217,21 @@ __global__ void argmin_select_k(const double* __restrict__ loss, uint32_t n_cand
 }
 
 template <int DT>
-static int launch_mse(const void* x, uint64_t rows, uint64_t row_len, const float* cand, uint64_t n_cand, double* loss,
-                      double* ws, size_t ws_bytes, hipStream_t st) {
+static int launch_mse(const void* x, uint64_t rows, uint64_t row_len, uint64_t seg, uint64_t seg_stride,
+                      const float* cand, uint64_t n_cand, double* loss, double* ws, size_t ws_bytes, hipStream_t st) {
   constexpr int V = Store<DT>::kVec;
   const MsePlan pl = plan_mse(rows, row_len, n_cand);
   const size_t need = (size_t)rows * pl.gx * n_cand * sizeof(double);
   if (ws == nullptr || ws_bytes < need) return set_error(TQ_EWORKSPACE, "tq_mse_candidates: workspace %zu < %zu", ws_bytes, need);
-  const bool vec_ok = aligned16(x) && ((row_len * elem_size(DT)) % 16 == 0 || rows == 1) && (row_len % V == 0 || rows == 1);
+  const bool contiguous = seg == row_len;
+  const bool vec_ok = contiguous
+      ? aligned16(x) && ((row_len * elem_size(DT)) % 16 == 0 || rows == 1) && (row_len % V == 0 || rows == 1)
+      : aligned16(x) && seg % V == 0 && seg_stride % V == 0;
   const dim3 grid(pl.gx, pl.gy, (unsigned)rows);
   const float4* c4 = reinterpret_cast<const float4*>(cand);
-  if (pl.e == 16) hipLaunchKernelGGL((mse_cand_k<DT, 16>), grid, dim3(kBlock), 0, st, x, row_len, vec_ok, c4, (uint32_t)n_cand, pl.cand_tile, ws);
-  else if (pl.e == 8) hipLaunchKernelGGL((mse_cand_k<DT, 8>), grid, dim3(kBlock), 0, st, x, row_len, vec_ok, c4, (uint32_t)n_cand, pl.cand_tile, ws);
-  else hipLaunchKernelGGL((mse_cand_k<DT, 4>), grid, dim3(kBlock), 0, st, x, row_len, vec_ok && V <= 4, c4, (uint32_t)n_cand, pl.cand_tile, ws);
+  if (pl.e == 16) hipLaunchKernelGGL((mse_cand_k<DT, 16>), grid, dim3(kBlock), 0, st, x, row_len, seg, seg_stride, vec_ok, c4, (uint32_t)n_cand, pl.cand_tile, ws);
+  else if (pl.e == 8) hipLaunchKernelGGL((mse_cand_k<DT, 8>), grid, dim3(kBlock), 0, st, x, row_len, seg, seg_stride, vec_ok, c4, (uint32_t)n_cand, pl.cand_tile, ws);
+  else hipLaunchKernelGGL((mse_cand_k<DT, 4>), grid, dim3(kBlock), 0, st, x, row_len, seg, seg_stride, vec_ok && V <= 4, c4, (uint32_t)n_cand, pl.cand_tile, ws);
   if (int e = check_launch("mse_cand_k")) return e;
   hipLaunchKernelGGL(mse_final_k, dim3((unsigned)ceil_div(n_cand, 256), (unsigned)rows), dim3(256), 0, st, ws, pl.gx,
                      (uint32_t)n_cand, loss);
@@ -228,9 +260,28 @@ extern "C" int tq_mse_candidates(const void* x, uint64_t rows, uint64_t row_len,
   hipStream_t st = static_cast<hipStream_t>(stream);
   double* ws = static_cast<double*>(workspace);
   switch (dtype) {
-    case TQ_F32: return launch_mse<TQ_F32>(x, rows, row_len, cand, n_cand, loss, ws, workspace_bytes, st);
-    case TQ_BF16: return launch_mse<TQ_BF16>(x, rows, row_len, cand, n_cand, loss, ws, workspace_bytes, st);
-    default: return launch_mse<TQ_F16>(x, rows, row_len, cand, n_cand, loss, ws, workspace_bytes, st);
+    case TQ_F32: return launch_mse<TQ_F32>(x, rows, row_len, row_len, row_len, cand, n_cand, loss, ws, workspace_bytes, st);
+    case TQ_BF16: return launch_mse<TQ_BF16>(x, rows, row_len, row_len, row_len, cand, n_cand, loss, ws, workspace_bytes, st);
+    default: return launch_mse<TQ_F16>(x, rows, row_len, row_len, row_len, cand, n_cand, loss, ws, workspace_bytes, st);
+  }
+}
+
+extern "C" int tq_mse_candidates_grouped(const void* x, uint64_t n_tokens, uint64_t d, uint64_t n_groups, int dtype,
+                                         const float* cand, uint64_t n_cand, double* loss, void* workspace,
+                                         size_t workspace_bytes, tq_stream_t stream) {
+  TQ_REQUIRE(x && cand && loss, "tq_mse_candidates_grouped: NULL pointer");
+  TQ_REQUIRE(n_groups >= 1 && n_groups <= 65535 && d % n_groups == 0, "tq_mse_candidates_grouped: d %% n_groups != 0");
+  TQ_REQUIRE(n_cand >= 1 && n_cand < (1ull << 31), "tq_mse_candidates_grouped: bad candidate count");
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_mse_candidates_grouped: bad dtype %d", dtype);
+  TQ_REQUIRE((reinterpret_cast<uintptr_t>(cand) & 15u) == 0, "tq_mse_candidates_grouped: candidate table must be 16-byte aligned");
+  if (n_tokens == 0) return TQ_OK;
+  const uint64_t gs = d / n_groups;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* ws = static_cast<double*>(workspace);
+  switch (dtype) {
+    case TQ_F32: return launch_mse<TQ_F32>(x, n_groups, n_tokens * gs, gs, d, cand, n_cand, loss, ws, workspace_bytes, st);
+    case TQ_BF16: return launch_mse<TQ_BF16>(x, n_groups, n_tokens * gs, gs, d, cand, n_cand, loss, ws, workspace_bytes, st);
+    default: return launch_mse<TQ_F16>(x, n_groups, n_tokens * gs, gs, d, cand, n_cand, loss, ws, workspace_bytes, st);
   }
 }
 

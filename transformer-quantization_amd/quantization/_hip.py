@@ -56,6 +56,7 @@ SIGNATURES = {
     'tq_set_range_sym': (_int, [_vp, _vp, _u64, _int, _f, _int, _vp, _vp, _vp]),
     'tq_mse_workspace_bytes': (_sz, [_u64, _u64, _u64]),
     'tq_mse_candidates': (_int, [_vp, _u64, _u64, _int, _vp, _u64, _vp, _vp, _sz, _vp]),
+    'tq_mse_candidates_grouped': (_int, [_vp, _u64, _u64, _u64, _int, _vp, _u64, _vp, _vp, _sz, _vp]),
     'tq_xent_candidates': (_int, [_vp, _u64, _u64, _vp, _u64, _vp, _vp]),
     'tq_argmin_select': (_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'tq_adaround_fwd': (_int, [_vp, _vp, _vp, _u64, _QP, _int, _int, _f, _vp]),
@@ -300,6 +301,21 @@ class HipBackend:
         ws = self._workspace(x.device, nbytes)
         rc = self.lib.tq_mse_candidates(_ptr(x), rows, row_len, _dtype_code(x, 'mse_candidates'),
                                         _ptr(cand), n_cand, _ptr(loss), _ptr(ws), ws.numel(), _stream())
+        _check(rc, self.lib)
+        return loss
+
+    def mse_candidates_grouped(self, x, n_groups, cand, loss):
+        """loss[n_groups, C] += per-group (of the LAST axis) squared quantisation error per candidate."""
+        _need_device(x, 'mse_candidates_grouped')
+        x = x.detach().contiguous()
+        d = x.shape[-1]
+        n_tokens = x.numel() // d
+        n_cand = cand.shape[0]
+        nbytes = self.lib.tq_mse_workspace_bytes(n_groups, n_tokens * (d // n_groups), n_cand)
+        ws = self._workspace(x.device, nbytes)
+        rc = self.lib.tq_mse_candidates_grouped(_ptr(x), n_tokens, d, n_groups,
+                                                _dtype_code(x, 'mse_candidates_grouped'), _ptr(cand), n_cand,
+                                                _ptr(loss), _ptr(ws), ws.numel(), _stream())
         _check(rc, self.lib)
         return loss
 

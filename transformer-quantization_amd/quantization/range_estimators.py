@@ -248,6 +248,11 @@ class MSE_Estimator(RangeEstimatorBase):
                 'A Quantizer must be given as an argument to the MSE Range' 'Estimator')
         self.max_int_skew = (2 ** self.quantizer.n_bits) // 4  # for asymmetric quantization
 
+        # Extension, off by default (the reference ignores axis / n_groups here, quirk q5): search one
+        # range per embedding group, like MSE_Estimator(per_channel=True) applied to the
+        # [n_groups, -1] view of the tensor.  Enable per instance (`est.per_group_search = True`).
+        self.per_group_search = False
+
         self._loss_dev = None      # fp64 [groups, n_cand] on the device
         self._cand_dev = None      # fp32 [n_cand, 4]
         self._thr_dev = None       # fp32 [2, n_cand]
@@ -292,7 +297,17 @@ class MSE_Estimator(RangeEstimatorBase):
         raise NotImplementedError('Optimization Method not Implemented')
 
     # ---- loss evaluation on the device -------------------------------------------------------
+    def _grouped(self, data):
+        if not (self.per_group_search and self.axis is not None and self.n_groups):
+            return False
+        if self.axis != data.dim() - 1:
+            raise NotImplementedError('per-group MSE search needs the grouped axis to be the last one')
+        assert data.shape[-1] % self.n_groups == 0
+        return True
+
     def _rows(self, data):
+        if self._grouped(data):
+            return self.n_groups
         return len(data) if self.per_channel else 1
 
     def _batch_losses(self, data, cand_dev, rows):
@@ -303,7 +318,10 @@ class MSE_Estimator(RangeEstimatorBase):
         return tq_dist.sync_sum(loss)
 
     def _launch_loss(self, be, data, rows, cand_dev, loss):
-        be.mse_candidates(data, rows, cand_dev, loss)
+        if self._grouped(data) and rows == self.n_groups:
+            be.mse_candidates_grouped(data, self.n_groups, cand_dev, loss)
+        else:
+            be.mse_candidates(data, rows, cand_dev, loss)
 
     def _cand_table(self, neg_thr, pos_thr):
         q = self.quantizer
@@ -336,7 +354,7 @@ class MSE_Estimator(RangeEstimatorBase):
     # ---- search space ----------------------------------------------------------------------
     def _define_search_range(self, data):
         be = _hip.backend()
-        self.channel_groups = len(data) if self.per_channel else 1
+        self.channel_groups = self._rows(data)
         mn, mx = self._tensor_stats(data)
         data_min, data_max = float(mn), float(mx)            # one host sync, first batch only
         if self._one_dimensional:
@@ -383,6 +401,9 @@ class MSE_Estimator(RangeEstimatorBase):
         self._loss_dev = self._loss_dev + self._batch_losses(data, self._cand_dev,
                                                              self.channel_groups)
         xmin, xmax, _ = be.argmin_select(self._loss_dev, self._thr_dev[0], self._thr_dev[1])
+        if self._grouped(data):
+            gs = data.shape[-1] // self.n_groups
+            xmin, xmax = xmin.repeat_interleave(gs), xmax.repeat_interleave(gs)
         self.current_xmin, self.current_xmax = xmin, xmax
 
     def _perform_1D_search(self, data):
@@ -407,8 +428,19 @@ class MSE_Estimator(RangeEstimatorBase):
         return result.fun
 
     def _segments(self, data):
+        if self._grouped(data):
+            gs = data.shape[-1] // self.n_groups
+            for g in range(self.n_groups):
+                yield g, data[..., g * gs:(g + 1) * gs].contiguous()
+            return
         for g in range(self.channel_groups):
             yield g, (data if (g == 0 and not self.per_channel) else data[g])
+
+    def _expand_groups(self, data, xmin, xmax):
+        if self._grouped(data):
+            gs = data.shape[-1] // self.n_groups
+            return xmin.repeat_interleave(gs), xmax.repeat_interleave(gs)
+        return xmin, xmax
 
     def _golden_section_symmetric(self, data):
         xmin = torch.zeros(self.channel_groups)
@@ -419,6 +451,7 @@ class MSE_Estimator(RangeEstimatorBase):
                 bounds=(0.01 * self.max_search_range, self.max_search_range), method='Bounded')
             xmax[g] = torch.tensor(self.result.x)
             xmin[g] = torch.tensor(0.0) if self.one_sided_dist else -xmax[g]
+        xmin, xmax = self._expand_groups(data, xmin, xmax)
         self.current_xmax = xmax.to(data.device)
         self.current_xmin = xmin.to(data.device)
 
@@ -438,6 +471,7 @@ class MSE_Estimator(RangeEstimatorBase):
             self.final_shift = self.subresult.x
             xmax[g] = torch.tensor(self.final_range + self.final_shift)
             xmin[g] = torch.tensor(-self.final_range + self.final_shift)
+        xmin, xmax = self._expand_groups(data, xmin, xmax)
         self.current_xmax = xmax.to(data.device)
         self.current_xmin = xmin.to(data.device)
 
