@@ -88,6 +88,19 @@ int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtype, uint64_t
 int tq_affine_fake_quant_fwd(const void* x, const float* w, const float* b, void* y, uint64_t n,
                              uint64_t d, int dtype, const tq_quantizer* q, tq_stream_t stream);
 
+/* (f2) Fused tail of BertSelfOutput / BertOutput with fixed ranges (reference
+ * models/quantized_bert.py:238-248, 264-280):
+ *     y = Q_out( layer_norm( Q_sum( Q_dense(dense_out) + residual ); ln_weight, ln_bias, eps ) )
+ * for [rows, d] tensors: 2 reads + 1 write instead of 5 + 4.  Each quantizer is per-tensor and may be
+ * NULL (= identity).  ln_weight / ln_bias: fp32 [d], already fake-quantized.  Statistics (mean,
+ * biased centred variance) are fp32 two-pass over the row held in registers.  Supported row lengths:
+ * d / (16-byte vector width) in {16,32,64,96,128,192,256,384,512,768}.                              */
+int tq_residual_layernorm_quant_fwd(const void* dense_out, const void* residual, void* y,
+                                    uint64_t rows, uint64_t d, int dtype,
+                                    const tq_quantizer* q_dense, const tq_quantizer* q_sum,
+                                    const float* ln_weight, const float* ln_bias, float ln_eps,
+                                    const tq_quantizer* q_out, tq_stream_t stream);
+
 /* STE backward of the same op (autograd through quantizers.py:12-19,
  * 184-185, 209): dx = ((g * scale) * mask) / scale with mask = [int_min <= round(x/s)+zp <=
  * int_max]: 3 streams, 6 B/elem bf16.  For a per-tensor quantizer, non-NULL grad_delta /

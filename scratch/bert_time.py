@@ -33,3 +33,15 @@ with torch.no_grad():
         print('graph == eager', torch.equal(out, ref))
     except Exception as e:
         print('graph capture failed:', repr(e)[:300])
+from tests.harness_bert import QResidualBlock
+QResidualBlock.fuse=True
+with torch.no_grad():
+    print('fixed-range forward ms (eager, fused tails)', t(lambda: model(ids)))
+    g2=torch.cuda.CUDAGraph()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3): model(ids)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g2):
+        out2=model(ids)
+    print('fixed-range forward ms (hipGraph, fused tails)', t(lambda: g2.replay(), n=30))

@@ -46,6 +46,13 @@ class OracleBackend:
         _, y = self._quant(r, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, 1, 1)
         return y.to(x.dtype)
 
+    def residual_layernorm_quant(self, dense_out, residual, q_dense, q_sum, ln_weight, ln_bias, ln_eps, q_out):
+        def q(v, a):
+            return v if a is None else self._quant(v, *a, 1, 1)[1]
+        u = q(q(dense_out.float(), q_dense) + residual.float(), q_sum)
+        v = torch.nn.functional.layer_norm(u, (u.shape[-1],), ln_weight.float(), ln_bias.float(), ln_eps)
+        return q(v, q_out).to(dense_out.dtype)
+
     def fake_quant_bwd(self, x, grad_y, delta, zero_float, signed, n_bits, symmetric, log_domain,
                        eps, n_params, inner, param_grads=False):
         sgn = bool(signed.item()) if signed is not None else False

@@ -78,7 +78,12 @@ class QResidualBlock(QuantizedModel):
         self.res_act_quantizer = QuantizedActivation(**qp)
         self.LayerNorm = quantize_model(hf.LayerNorm, **qp)
 
+    fuse = False   # set True to run the fixed-range tail as one kernel (quantization/fused.py)
+
     def forward(self, h, residual):
+        if self.fuse:
+            from quantization.fused import residual_layernorm_quant
+            return residual_layernorm_quant(self.dense, self.res_act_quantizer, self.LayerNorm, h, residual)
         return self.LayerNorm(self.res_act_quantizer(self.dense(h) + residual))
 
 

@@ -594,3 +594,19 @@ def test_ste_backward_large_and_layouts(q, dtype):
     gflat = go.reshape(-1)[1:4098].to(DEV)
     gx3, _, _ = be.fake_quant_bwd(flat, gflat, delta.to(DEV), zf.to(DEV), None, 8, False, False, 1e-8, 1, 1)
     assert torch.equal(gx3.cpu(), ref_dx.reshape(-1)[1:4098].to(dtype))
+
+
+def test_percentile_ranges_on_gpu(q):
+    g = torch.Generator().manual_seed(12)
+    w = torch.randn(768, 3072, generator=g) * 0.05
+    for p in (0.01, 1.0):
+        est = q.RangeEstimators.current_minmax.cls(percentile=p, per_channel=True)
+        lo, hi = est(w.to(DEV))
+        r_lo, r_hi = np.percentile(w.numpy(), (p, 100 - p), axis=-1)
+        assert torch.equal(lo.cpu(), torch.Tensor(r_lo)) and torch.equal(hi.cpu(), torch.Tensor(r_hi))
+        mgr = q.QuantizationManager(qmethod=q.QMethods.symmetric_uniform, init=q.RangeEstimators.current_minmax,
+                                    per_channel=True, qparams=dict(n_bits=4), init_params=dict(percentile=p))
+        y = mgr(w.to(DEV))
+        d, s = O.sym_params_from_range(torch.Tensor(r_lo), torch.Tensor(r_hi), 4)
+        _, ref = O.fake_quant(w, d, None, 4, True, bool(s), per_channel=True)
+        assert torch.equal(y.cpu(), ref)

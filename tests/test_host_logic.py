@@ -375,3 +375,21 @@ def test_golden_section_is_chaotic_in_the_reference(golden_estimators):
         got[name] = (float(mn), float(mx))
     assert got['fp32'] == (float(z[f"e{m['k']}_xmin"][0][0]), float(z[f"e{m['k']}_xmax"][0][0]))
     assert got['fp64'] != got['fp32']
+
+
+def test_percentile_ranges_match_numpy():
+    """percentile option of CurrentMinMaxEstimator (reference range_estimators.py:118-140): numpy is
+    the arithmetic owner upstream; the device sort + float64 lerp reproduces it bit for bit,
+    including the (p, 100) asymmetry of the per-tensor branch (quirk q6)."""
+    q = _api()
+    g = torch.Generator().manual_seed(12)
+    w = torch.randn(24, 333, generator=g) * 2
+    for p in (0.01, 1.0, 5.0):
+        est = q.RangeEstimators.current_minmax.cls(percentile=p, per_channel=True)
+        lo, hi = est(w)
+        r_lo, r_hi = np.percentile(w.numpy(), (p, 100 - p), axis=-1)
+        assert torch.equal(lo, torch.Tensor(r_lo)) and torch.equal(hi, torch.Tensor(r_hi))
+        est = q.RangeEstimators.current_minmax.cls(percentile=p)
+        lo, hi = est(w)
+        r = np.percentile(w.numpy(), (p, 100))
+        assert lo.shape == (1,) and float(lo) == np.float32(r[0]) and float(hi) == np.float32(r[1])

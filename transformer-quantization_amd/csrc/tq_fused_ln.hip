@@ -1,0 +1,149 @@
+// (f2) Fused residual-add -> quantize -> LayerNorm -> quantize for gfx950.
+//
+// The tail of BertSelfOutput / BertOutput in the reference (models/quantized_bert.py:238-248,
+// 264-280 with quantization/hijacker.py:98-116 and autoquant_utils.py:55-66) is five separate
+// tensor sweeps after the GEMM:
+//     t = Q1(dense_out)        activation quantizer of the QuantLinear
+//     s = t + residual
+//     u = Q2(s)                res_act_quantizer
+//     v = layer_norm(u; Q(w), Q(b), eps)
+//     y = Q3(v)                activation quantizer of the QuantLayerNorm
+// = 5 reads + 4 writes of [B*T, d] plus ~20 launches.  With fixed ranges the chain only needs the
+// row it is working on, so it collapses to 2 reads + 1 write (6 B/elem bf16, 12 B/elem fp32):
+// LPR lanes (16/32/64) own one row, keep it in registers (d/LPR values per lane), do the two
+// row reductions (mean, centred variance) with __shfl_xor inside the lane group, and stream out.
+// Any of the three quantizers may be absent (NULL).
+#include <algorithm>
+
+#include "tq_device.h"
+#include "tq_host.h"
+
+namespace tq {
+
+struct FusedQ {
+  QP p;
+  int on;
+};
+
+__device__ __forceinline__ float apply_q(float v, const FusedQ& q) {
+  return q.on ? q_dequant(q_index(v, q.p), q.p) : v;
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR);
+  return v;
+}
+
+// NV = 16-byte vectors per lane per row (d == LPR * NV * V)
+template <int DT, int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
+                                                         u32x4* __restrict__ y, uint64_t rows,
+                                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                         float ln_eps, tq_quantizer q1, tq_quantizer q2, tq_quantizer q3,
+                                                         int on1, int on2, int on3) {
+  constexpr int V = Store<DT>::kVec;
+  constexpr int RPB = kBlock / LPR;                 // rows per block iteration
+  constexpr uint32_t d = LPR * NV * V;
+  const FusedQ f1 = {on1 ? make_qp(q1, 0) : QP{1.f, 0.f, 0.f, 0.f}, on1};
+  const FusedQ f2 = {on2 ? make_qp(q2, 0) : QP{1.f, 0.f, 0.f, 0.f}, on2};
+  const FusedQ f3 = {on3 ? make_qp(q3, 0) : QP{1.f, 0.f, 0.f, 0.f}, on3};
+  const int lane = threadIdx.x % LPR;
+  const int sub = threadIdx.x / LPR;
+  const float inv_d = 1.0f / (float)d;
+
+  // this lane's slice of the affine parameters stays in registers for every row it handles
+  float w[NV][V], b[NV][V];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      w[v][j] = ln_w[(v * LPR + lane) * V + j];
+      b[v][j] = ln_b[(v * LPR + lane) * V + j];
+    }
+
+  for (uint64_t row = (uint64_t)blockIdx.x * RPB + sub; row < rows; row += (uint64_t)gridDim.x * RPB) {
+    const uint64_t base = row * (d / V);
+    u32x4 va[NV], vr[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { va[v] = ld_stream(a + base + v * LPR + lane); vr[v] = ld_stream(r + base + v * LPR + lane); }
+    float u[NV][V];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      float fa[V], fr[V];
+      Store<DT>::unpack(va[v], fa);
+      Store<DT>::unpack(vr[v], fr);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        u[v][j] = apply_q(apply_q(fa[j], f1) + fr[j], f2);
+        s += u[v][j];
+      }
+    }
+    const float mean = group_sum<LPR>(s) * inv_d;
+    float ss = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int j = 0; j < V; ++j) { const float c = u[v][j] - mean; ss += c * c; }
+    const float rstd = 1.0f / sqrtf(group_sum<LPR>(ss) * inv_d + ln_eps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      float o[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = apply_q((u[v][j] - mean) * rstd * w[v][j] + b[v][j], f3);
+      st_stream(y + base + v * LPR + lane, Store<DT>::pack(o));
+    }
+  }
+}
+
+template <int DT>
+static int launch_res_ln(const void* a, const void* r, void* y, uint64_t rows, uint64_t d, const float* w, const float* b,
+                         float eps, const tq_quantizer* q1, const tq_quantizer* q2, const tq_quantizer* q3, hipStream_t st) {
+  constexpr int V = Store<DT>::kVec;
+  const tq_quantizer none{};
+  const tq_quantizer &c1 = q1 ? *q1 : none, &c2 = q2 ? *q2 : none, &c3 = q3 ? *q3 : none;
+  const auto av = static_cast<const u32x4*>(a);
+  const auto rv = static_cast<const u32x4*>(r);
+  auto yv = static_cast<u32x4*>(y);
+  const uint64_t vpr = d / V;
+#define TQ_LN(LPR, NV)                                                                                          \
+  if (vpr == (uint64_t)(LPR) * (NV)) {                                                                          \
+    const unsigned rpb = kBlock / (LPR);                                                                        \
+    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(rows, rpb), 1), 1u << 20);   \
+    hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, rows, w, b, eps, \
+                       c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr);                                \
+    return check_launch("res_ln_quant_k");                                                                      \
+  }
+  // d (bf16 | fp32): 768 -> 96 | 192 vectors, 3072 -> 384 | 768, 512 -> 64 | 128, 128 -> 16 | 32, 1024 -> 128 | 256
+  TQ_LN(32, 3) TQ_LN(64, 3) TQ_LN(64, 6) TQ_LN(64, 12) TQ_LN(64, 1) TQ_LN(64, 2) TQ_LN(64, 4) TQ_LN(16, 1) TQ_LN(32, 1) TQ_LN(64, 8)
+#undef TQ_LN
+  return set_error(TQ_EUNSUPPORTED, "tq_residual_layernorm_quant_fwd: row length %llu has no instantiation",
+                   (unsigned long long)d);
+}
+
+}  // namespace tq
+
+using namespace tq;
+
+extern "C" int tq_residual_layernorm_quant_fwd(const void* dense_out, const void* residual, void* y, uint64_t rows,
+                                               uint64_t d, int dtype, const tq_quantizer* q_dense,
+                                               const tq_quantizer* q_sum, const float* ln_weight, const float* ln_bias,
+                                               float ln_eps, const tq_quantizer* q_out, tq_stream_t stream) {
+  if (rows == 0) return TQ_OK;
+  TQ_REQUIRE(dense_out && residual && y && ln_weight && ln_bias, "tq_residual_layernorm_quant_fwd: NULL pointer");
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_residual_layernorm_quant_fwd: bad dtype %d", dtype);
+  TQ_REQUIRE(aligned16(dense_out) && aligned16(residual) && aligned16(y), "tq_residual_layernorm_quant_fwd: 16-byte alignment required");
+  for (const tq_quantizer* q : {q_dense, q_sum, q_out})
+    if (q != nullptr) {
+      if (int e = check_quantizer(q, rows * d, "tq_residual_layernorm_quant_fwd")) return e;
+      TQ_REQUIRE(q->n_params == 1, "tq_residual_layernorm_quant_fwd: per-tensor quantizers only");
+    }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case TQ_F32: return launch_res_ln<TQ_F32>(dense_out, residual, y, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
+    case TQ_BF16: return launch_res_ln<TQ_BF16>(dense_out, residual, y, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
+    default: return launch_res_ln<TQ_F16>(dense_out, residual, y, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
+  }
+}

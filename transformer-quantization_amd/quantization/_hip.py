@@ -43,6 +43,7 @@ SIGNATURES = {
     'tq_last_error': (C.c_char_p, []),
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
     'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
+    'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
     'tq_fake_quant_bwd_workspace_bytes': (_sz, [_u64]),
     'tq_fake_quant_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _int, _QP, _vp, _sz, _vp]),
     'tq_minmax_workspace_bytes': (_sz, [_u64, _u64, _u64]),
@@ -179,6 +180,22 @@ class HipBackend:
                                                _ptr(b.detach().float().contiguous()), _ptr(y), x.numel(),
                                                x.shape[-1], _dtype_code(x, 'affine_fake_quant'),
                                                C.byref(q), _stream())
+        _check(rc, self.lib)
+        return y
+
+    def residual_layernorm_quant(self, dense_out, residual, q_dense, q_sum, ln_weight, ln_bias, ln_eps, q_out):
+        """y = Q_out(LN(Q_sum(Q_dense(dense_out) + residual))); each q_* is None or the 7-tuple
+        (delta, zero_float, signed, n_bits, symmetric, log_domain, eps) of a per-tensor quantizer."""
+        _need_device(dense_out, 'residual_layernorm_quant')
+        a, r = dense_out.contiguous(), residual.contiguous().to(dense_out.dtype)
+        y = torch.empty_like(a)
+        d = a.shape[-1]
+        descs = [None if q is None else self._qdesc(*q, 1, 1) for q in (q_dense, q_sum, q_out)]
+        refs = [None if dsc is None else C.byref(dsc) for dsc in descs]
+        rc = self.lib.tq_residual_layernorm_quant_fwd(
+            _ptr(a), _ptr(r), _ptr(y), a.numel() // d, d, _dtype_code(a, 'residual_layernorm_quant'),
+            refs[0], refs[1], _ptr(ln_weight.detach().float().contiguous()),
+            _ptr(ln_bias.detach().float().contiguous()), float(ln_eps), refs[2], _stream())
         _check(rc, self.lib)
         return y
 

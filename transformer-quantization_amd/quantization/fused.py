@@ -1,0 +1,51 @@
+"""Fused fixed-range layer tails -- new, no counterpart module upstream.
+
+``residual_layernorm_quant`` runs the tail of BertSelfOutput / BertOutput
+(reference models/quantized_bert.py:238-248, 264-280)
+
+    Q_ln( LayerNorm( Q_res( Q_dense(dense_out) + residual ) ) )
+
+as ONE kernel (``tq_residual_layernorm_quant_fwd``: 2 reads + 1 write of [B*T, d]) when every
+quantizer involved has a fixed per-tensor range; otherwise it falls back to the layered modules, so
+calibration / QAT / per-embedding configurations keep their exact semantics.
+"""
+import torch
+
+from quantization import _hip
+from quantization.base_quantized_classes import FP32Acts
+from quantization.quantization_manager import QuantizationManager, Qstates
+
+
+def _fixed_per_tensor(enabled, mgr):
+    """-> ('off' | 'no' | 7-tuple): disabled quantizer, not fusable, or kernel arguments."""
+    if not enabled or isinstance(mgr, FP32Acts):
+        return 'off'
+    if not isinstance(mgr, QuantizationManager) or mgr.state != Qstates.fix_ranges:
+        return 'no'
+    q = mgr.quantizer
+    if not q.is_initialized or q._delta.numel() != 1:
+        return 'no'
+    return (q._delta, q._zero_float, getattr(q, '_signed', None), q.n_bits, q.symmetric,
+            q.scale_domain == 'log', q.eps)
+
+
+def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
+    """dense: QuantLinear, res_quantizer: QuantizedActivation, layer_norm: QuantLayerNorm.
+    Equivalent to ``layer_norm(res_quantizer(dense(x) + residual))``."""
+    q1 = _fixed_per_tensor(dense._quant_a and dense.activation_function is None, dense.activation_quantizer)
+    q2 = _fixed_per_tensor(res_quantizer._quant_a, res_quantizer.activation_quantizer)
+    q3 = _fixed_per_tensor(layer_norm._quant_a and layer_norm.activation_function is None,
+                           layer_norm.activation_quantizer)
+    fusable = ('no' not in (q1, q2, q3) and dense.activation_function is None
+               and layer_norm.activation_function is None and x.is_cuda
+               and not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad))
+               and len(layer_norm.normalized_shape) == 1
+               and dense.activation_save_target is None and layer_norm.activation_save_target is None)
+    if not fusable:
+        return layer_norm(res_quantizer(dense(x) + residual))
+    w, b = dense.get_params()
+    gemm = dense.run_forward(x, w, b)                       # hipBLASLt through torch (the real GEMM)
+    ln_w, ln_b = layer_norm.get_params()                    # fake-quantized (cached in eval) affine
+    arg = lambda q: None if q == 'off' else q
+    return _hip.backend().residual_layernorm_quant(gemm, residual, arg(q1), arg(q2), ln_w, ln_b,
+                                                   layer_norm.eps, arg(q3))

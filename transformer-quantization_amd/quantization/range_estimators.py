@@ -135,11 +135,12 @@ class CurrentMinMaxEstimator(RangeEstimatorBase):
 
 
 def _percentile_rows(rows, q):
-    """np.percentile(rows, q, axis=-1) (linear interpolation) evaluated on the device.
+    """np.percentile(rows, q, axis=-1) (method 'linear') with the sort on the device.
 
-    The reference moves the whole tensor to the host and calls numpy (:121-140).  Here the sort
-    stays on the GPU and only the two neighbours of each virtual index are combined, with numpy's
-    lerp formula."""
+    The reference moves the whole tensor to the host and calls numpy (:121-140).  Here only the two
+    order statistics around each virtual index are combined, with numpy's own arithmetic: the
+    difference b - a in the data dtype (fp32), the interpolation in float64, the result narrowed to
+    fp32 by ``torch.Tensor(...)`` -- bit-identical to numpy on the same values."""
     srt, _ = torch.sort(rows.detach().float(), dim=-1)
     n = srt.shape[-1]
     out = []
@@ -149,9 +150,9 @@ def _percentile_rows(rows, q):
         hi_i = min(lo_i + 1, n - 1)
         t = vidx - lo_i
         a, b = srt[:, lo_i], srt[:, hi_i]
-        diff = b - a
-        val = a + diff * t if t < 0.5 else b - diff * (1 - t)
-        out.append(val)
+        diff = (b - a).double()
+        val = a.double() + diff * t if t < 0.5 else b.double() - diff * (1 - t)
+        out.append(val.float())
     return out[0], out[1]
 
 
