@@ -327,7 +327,7 @@ static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t 
 #undef TQ_LAUNCH_TENSOR
     return check_launch("fq_tensor");
   }
-  if (vec_ok && q.n_params > 1 && q.inner == 1 && q.n_params % V == 0 && q.n_params <= 16384) {
+  if (vec_ok && q.n_params > 1 && q.inner == 1 && q.n_params % V == 0 && q.n_params <= 8192) {   // 2 x d floats of LDS <= 64 KiB
     const size_t lds = q.n_params * 2 * sizeof(float);
 #define TQ_LAUNCH_AXIS(NTV, UV)                                                                            \
     {                                                                                                      \
@@ -563,7 +563,7 @@ extern "C" int tq_affine_fake_quant_fwd(const void* x, const float* w, const flo
   if (int e = check_quantizer(q, n, "tq_affine_fake_quant_fwd")) return e;
   TQ_REQUIRE(q->n_params == 1, "tq_affine_fake_quant_fwd: per-tensor output quantizer only");
   const uint64_t V = dtype == TQ_F32 ? 4 : 8;
-  TQ_REQUIRE(d >= V && d % V == 0 && d <= 16384 && n % d == 0, "tq_affine_fake_quant_fwd: d=%llu unsupported", (unsigned long long)d);
+  TQ_REQUIRE(d >= V && d % V == 0 && d <= 8192 && n % d == 0, "tq_affine_fake_quant_fwd: d=%llu unsupported", (unsigned long long)d);
   TQ_REQUIRE(aligned16(x) && aligned16(y), "tq_affine_fake_quant_fwd: x / y must be 16-byte aligned");
   TQ_REQUIRE(n / V / (kBlock) < (1ull << 31), "tq_affine_fake_quant_fwd: tensor too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
