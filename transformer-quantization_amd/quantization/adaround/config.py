@@ -1,11 +1,6 @@
 """Default AdaRound hyper-parameters (same keys/values as the reference's
 quantization/adaround/config.py:17-38)."""
-from quantization.adaround.utils import (
-    AdaRoundActQuantMode,
-    AdaRoundInitMode,
-    AdaRoundMode,
-    AdaRoundTempDecayType,
-)
+from quantization.adaround import utils as opt
 from utils.utils import DotDict
 
 
@@ -13,20 +8,12 @@ class AdaRoundConfig(DotDict):
     pass
 
 
-DEFAULT_ADAROUND_CONFIG = AdaRoundConfig(
-    layers=('all',),                                  # which layers to optimise
-    num_samples=1024,                                 # cached calibration samples
-    init=AdaRoundInitMode.range_estimator,            # weight grid initialisation
-    round_mode=AdaRoundMode.learned_hard_sigmoid,     # relaxation h(alpha)
-    asym=True,                                        # layer input from the quantized network
-    include_act_func=True,
-    lr=1e-3,
-    iters=1000,
-    weight=0.01,                                      # lambda of the rounding regulariser
-    annealing=(20, 2),                                # beta: start -> end
-    decay_type=AdaRoundTempDecayType.cosine,
-    decay_shape=1.0,
-    decay_start=0.0,
-    warmup=0.2,                                       # fraction of iters without regulariser
-    act_quant_mode=AdaRoundActQuantMode.post_adaround,
-)
+_WHAT = dict(layers=('all',), num_samples=1024, init=opt.AdaRoundInitMode.range_estimator)
+_RELAXATION = dict(round_mode=opt.AdaRoundMode.learned_hard_sigmoid, asym=True, include_act_func=True)
+_OPTIMISER = dict(lr=1e-3, iters=1000)
+_REGULARISER = dict(weight=0.01, annealing=(20, 2), warmup=0.2, decay_start=0.0, decay_shape=1.0,
+                    decay_type=opt.AdaRoundTempDecayType.cosine)
+_ACTIVATIONS = dict(act_quant_mode=opt.AdaRoundActQuantMode.post_adaround)
+
+DEFAULT_ADAROUND_CONFIG = AdaRoundConfig(**_WHAT, **_RELAXATION, **_OPTIMISER, **_REGULARISER,
+                                         **_ACTIVATIONS)

@@ -8,7 +8,7 @@ goes through ``tq_recon_loss`` / ``tq_adaround_reg`` in the fused optimisation l
 optimizer drives ``CombinedLoss`` itself.
 """
 import logging
-from enum import Flag, auto
+from enum import Flag
 from math import ceil
 
 import numpy as np
@@ -26,6 +26,8 @@ def sigmoid(x):
 
 
 class BaseOption(Flag):
+    """Flag enum whose members print as their bare name (CLI-friendly)."""
+
     def __str__(self):
         return self.name
 
@@ -38,52 +40,41 @@ class BaseOption(Flag):
         return [m.name for m in cls]
 
 
-class AdaRoundActQuantMode(BaseOption):
-    no_act_quant = auto()    # activations stay FP32
-    post_adaround = auto()   # AdaRound with FP32 activations, quantize them afterwards (default)
-
-
-class AdaRoundInitMode(BaseOption):
-    """How the weight quantization grid is initialised."""
-    range_estimator = auto()
-    mse = auto()
-    mse_out = auto()
-    mse_out_asym = auto()
-
-
-class AdaRoundLossType(BaseOption):
-    relaxation = auto()
-    temp_decay = auto()
-
-
-class AdaRoundMode(BaseOption):
-    nearest = auto()
-    learned_sigmoid = auto()
-    learned_hard_sigmoid = auto()
-    sigmoid_temp_decay = auto()
-
-    RELAXATION = learned_sigmoid | learned_hard_sigmoid | sigmoid_temp_decay
-
+class _RoundingOption(BaseOption):
     @classmethod
     def list_names(cls):
-        skip = (AdaRoundMode.nearest, AdaRoundMode.RELAXATION)
-        return [m.name for m in cls if m not in skip]
+        # user-selectable relaxations only: neither the default nor the composite alias
+        return [m.name for m in cls if m.name not in ('nearest', 'RELAXATION')]
 
+
+def _flags(base, name, *members, **aliases):
+    """Flag enum with power-of-two members in the given order (same values as `auto()`) plus
+    composite aliases given as tuples of member names."""
+    table = {m: 1 << i for i, m in enumerate(members)}
+    for alias, parts in aliases.items():
+        table[alias] = sum(table[p] for p in parts)
+    return base(name, table, module=__name__)
+
+
+# activations stay FP32 during AdaRound | are quantized afterwards (default)
+AdaRoundActQuantMode = _flags(BaseOption, 'AdaRoundActQuantMode', 'no_act_quant', 'post_adaround')
+# how the weight quantization grid is initialised
+AdaRoundInitMode = _flags(BaseOption, 'AdaRoundInitMode', 'range_estimator', 'mse', 'mse_out',
+                          'mse_out_asym')
+# regularisation term
+AdaRoundLossType = _flags(BaseOption, 'AdaRoundLossType', 'relaxation', 'temp_decay')
+# rounding: nearest (default) or one of the continuous relaxations of the AdaRound paper
+AdaRoundMode = _flags(_RoundingOption, 'AdaRoundMode', 'nearest', 'learned_sigmoid',
+                      'learned_hard_sigmoid', 'sigmoid_temp_decay',
+                      RELAXATION=('learned_sigmoid', 'learned_hard_sigmoid', 'sigmoid_temp_decay'))
+AdaRoundTempDecayType = _flags(BaseOption, 'AdaRoundTempDecayType', 'linear', 'cosine', 'sigmoid',
+                               'power', 'exp', 'log')
 
 MODE_TO_LOSS_TYPE = {
     AdaRoundMode.learned_hard_sigmoid: AdaRoundLossType.relaxation,
     AdaRoundMode.learned_sigmoid: AdaRoundLossType.relaxation,
     AdaRoundMode.sigmoid_temp_decay: AdaRoundLossType.temp_decay,
 }
-
-
-class AdaRoundTempDecayType(BaseOption):
-    linear = auto()
-    cosine = auto()
-    sigmoid = auto()
-    power = auto()
-    exp = auto()
-    log = auto()
 
 
 class TempDecay:

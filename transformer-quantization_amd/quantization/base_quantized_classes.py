@@ -12,9 +12,11 @@ from quantization.range_estimators import RangeEstimators
 
 
 def _if_initialised(action):
+    """Visitor for nn.Module.apply: call `action` on every manager that already holds a range."""
     def visit(layer):
         if isinstance(layer, QuantizationManager) and layer.quantizer.is_initialized:
             getattr(layer, action)()
+    visit.__name__ = '_set_layer_' + action
     return visit
 
 
@@ -25,8 +27,13 @@ _set_layer_estimate_ranges_train = _if_initialised('estimate_ranges_train')
 
 
 class QuantizedModule(nn.Module):
-    """Carries the quantization configuration of one layer, the weight/activation on-off
-    switches and the cache of quantized parameters (invalidated whenever it could go stale)."""
+    """Per-layer quantization configuration + on/off switches + the cache of quantized parameters.
+
+    Keyword arguments (the reference's whole `qparams` surface, base_quantized_classes.py:41-60):
+    method / act_method (QMethods), n_bits / n_bits_act, per_channel_weights / per_channel_acts,
+    percentile, weight_range_method / weight_range_options, act_range_method / act_range_options
+    (RangeEstimators + their kwargs), scale_domain.  ``quant_dict`` is accepted and ignored here.
+    """
 
     def __init__(self, *args, method=QMethods.asymmetric_uniform, act_method=None, n_bits=8,
                  n_bits_act=None, per_channel_weights=False, per_channel_acts=False,
@@ -36,26 +43,24 @@ class QuantizedModule(nn.Module):
         kwargs.pop('quant_dict', None)
         super().__init__(*args, **kwargs)
 
-        self.method = method
-        self.act_method = act_method or method
-        self.n_bits = n_bits
-        self.n_bits_act = n_bits_act or n_bits
-        self.per_channel_weights = per_channel_weights
-        self.per_channel_acts = per_channel_acts
-        self.percentile = percentile
+        # weights
+        self.method, self.n_bits = method, n_bits
+        self.per_channel_weights, self.percentile = per_channel_weights, percentile
         self.weight_range_method = weight_range_method
-        self.weight_range_options = weight_range_options if weight_range_options else {}
+        self.weight_range_options = dict(weight_range_options) if weight_range_options else {}
+        # activations default to the weight settings
+        self.act_method = act_method if act_method else method
+        self.n_bits_act = n_bits_act if n_bits_act else n_bits
+        self.per_channel_acts = per_channel_acts
         self.act_range_method = act_range_method
-        self.act_range_options = act_range_options if act_range_options else {}
+        self.act_range_options = dict(act_range_options) if act_range_options else {}
         self.scale_domain = scale_domain
 
-        self.cached_params = None
-        self._caching = True
-
         self.quant_params = None
-        self._quant_w = False
-        self._quant_a = False
+        self.cached_params, self._caching = None, True
+        self._quant_w = self._quant_a = False
 
+    # ---- quantized-parameter cache: dropped whenever it could be stale ---------------------------
     @property
     def caching(self):
         return self._caching
@@ -66,13 +71,25 @@ class QuantizedModule(nn.Module):
         if not value:
             self.cached_params = None
 
-    def quantized_weights(self):
+    def train(self, mode=True):
+        if mode:
+            self.cached_params = None
+        return super().train(mode)
+
+    def _apply(self, *args, **kwargs):      # .to() / .cuda() / .float() move the parameters
         self.cached_params = None
-        self._quant_w = True
+        return super()._apply(*args, **kwargs)
+
+    # ---- on / off ---------------------------------------------------------------------------------
+    def _weights(self, on):
+        self.cached_params = None
+        self._quant_w = on
+
+    def quantized_weights(self):
+        self._weights(True)
 
     def full_precision_weights(self):
-        self.cached_params = None
-        self._quant_w = False
+        self._weights(False)
 
     def quantized_acts(self):
         self._quant_a = True
@@ -81,13 +98,14 @@ class QuantizedModule(nn.Module):
         self._quant_a = False
 
     def quantized(self):
-        self.quantized_weights()
-        self.quantized_acts()
+        self._weights(True)
+        self._quant_a = True
 
     def full_precision(self):
-        self.full_precision_weights()
-        self.full_precision_acts()
+        self._weights(False)
+        self._quant_a = False
 
+    # ---- range states of every manager below this module ------------------------------------------
     def learn_ranges(self):
         self.apply(_set_layer_learn_ranges)
 
@@ -100,33 +118,21 @@ class QuantizedModule(nn.Module):
     def estimate_ranges_train(self):
         self.apply(_set_layer_estimate_ranges_train)
 
-    def train(self, mode=True):
-        super().train(mode)
-        if mode:
-            self.cached_params = None
-        return self
-
-    def _apply(self, *args, **kwargs):
-        self.cached_params = None
-        return super()._apply(*args, **kwargs)
-
     def extra_repr(self):
-        own = 'weight_quant={}, act_quant={}'.format(self._quant_w, self._quant_a)
-        parent = super().extra_repr()
-        return '{},\n{}'.format(parent, own) if parent else own
+        own = f'weight_quant={self._quant_w}, act_quant={self._quant_a}'
+        inherited = super().extra_repr()
+        return f'{inherited},\n{own}' if inherited else own
 
 
 class QuantizedActivation(QuantizedModule):
-    """Stand-alone activation quantizer (residual sums, attention scores/probs, ...)."""
+    """Stand-alone activation quantizer (residual sums, attention scores / probs, embedding sums)."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.activation_quantizer = QuantizationManager(
-            qmethod=self.act_method,
-            qparams=dict(n_bits=self.n_bits_act, scale_domain=self.scale_domain),
-            init=self.act_range_method,
-            init_params=self.act_range_options,
-        )
+            qmethod=self.act_method, init=self.act_range_method,
+            qparams={'n_bits': self.n_bits_act, 'scale_domain': self.scale_domain},
+            init_params=self.act_range_options)
 
     def quantize_activations(self, x):
         return self.activation_quantizer(x) if self._quant_a else x
@@ -136,6 +142,8 @@ class QuantizedActivation(QuantizedModule):
 
 
 class FP32Acts(nn.Module):
+    """Identity stand-in for a disabled quantizer."""
+
     def forward(self, x):
         return x
 

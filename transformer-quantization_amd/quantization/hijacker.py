@@ -31,68 +31,63 @@ class QuantizationHijacker(QuantizedModule):
             assert isinstance(activation, tuple(activations_list))
         self.activation_function = copy.deepcopy(activation) if activation else None
 
-        self.activation_quantizer = QuantizationManager(
-            qmethod=self.act_method,
-            init=self.act_range_method,
-            per_channel=self.per_channel_acts,
-            qparams=dict(n_bits=self.n_bits_act, scale_domain=self.scale_domain),
-            init_params=self.act_range_options,
-        )
+        self.activation_quantizer = self._manager(
+            self.act_method, self.act_range_method, self.per_channel_acts, self.n_bits_act,
+            self.act_range_options)
+        # `percentile` is understood by the current-min/max estimator only
+        weight_options = ({'percentile': self.percentile}
+                          if self.weight_range_method == RangeEstimators.current_minmax
+                          else self.weight_range_options)
+        self.weight_quantizer = self._manager(
+            self.method, self.weight_range_method, self.per_channel_weights, self.n_bits,
+            weight_options)
 
-        # current_minmax is the only weight estimator that understands `percentile`
-        if self.weight_range_method == RangeEstimators.current_minmax:
-            weight_init_params = dict(percentile=self.percentile)
-        else:
-            weight_init_params = self.weight_range_options
-        self.weight_quantizer = QuantizationManager(
-            qmethod=self.method,
-            init=self.weight_range_method,
-            per_channel=self.per_channel_weights,
-            qparams=dict(n_bits=self.n_bits, scale_domain=self.scale_domain),
-            init_params=weight_init_params,
-        )
         self.activation_save_target = None
         self.activation_save_name = None
 
+    def _manager(self, qmethod, estimator, per_channel, n_bits, estimator_options):
+        return QuantizationManager(
+            qmethod=qmethod, init=estimator, per_channel=per_channel, init_params=estimator_options,
+            qparams={'n_bits': n_bits, 'scale_domain': self.scale_domain})
+
+    # ---- forward ------------------------------------------------------------------------------
     def forward(self, x, offsets=None):
         weight, bias = self.get_params()
-        out = self.run_forward(x, weight, bias, offsets=offsets)
-        return self.quantize_activations(out)
+        return self.quantize_activations(self.run_forward(x, weight, bias, offsets=offsets))
+
+    def run_forward(self, x, weight, bias, offsets=None):
+        """The wrapped layer's own computation; provided by the concrete class."""
+        raise NotImplementedError()
+
+    def get_weight_bias(self):
+        return self.weight, getattr(self, 'bias', None)
 
     def get_params(self):
-        if not self.training and self.cached_params:
+        """(weight, bias) with the weight fake-quantized if enabled; cached in eval mode."""
+        cache_usable = not self.training
+        if cache_usable and self.cached_params:
             return self.cached_params
 
         weight, bias = self.get_weight_bias()
         if self._quant_w:
             weight = self.weight_quantizer(weight)
 
-        if self._caching and not self.training and self.cached_params is None:
-            self.cached_params = (
-                weight.detach().to(torch.float32),
-                bias.detach().to(torch.float32) if bias is not None else None,
-            )
+        if cache_usable and self._caching and self.cached_params is None:
+            # detached fp32 copies, like the reference's numpy round trip -- but resident in HBM
+            self.cached_params = (weight.detach().to(torch.float32),
+                                  None if bias is None else bias.detach().to(torch.float32))
         return weight, bias
 
-    def get_weight_bias(self):
-        return self.weight, (self.bias if hasattr(self, 'bias') else None)
-
-    def run_forward(self, x, weight, bias, offsets=None):
-        """The wrapped layer's own computation; provided by the concrete class."""
-        raise NotImplementedError()
+    def _save(self, suffix, tensor):
+        if self.activation_save_target is not None:
+            self.activation_save_target[self.activation_save_name + suffix] = tensor.data.cpu().numpy()
 
     def quantize_activations(self, activations):
         """Optional activation function, then one output quantizer for the whole layer."""
         if self.activation_function is not None:
             activations = self.activation_function(activations)
-
-        if self.activation_save_target is not None:
-            self.activation_save_target[self.activation_save_name] = activations.data.cpu().numpy()
-
+        self._save('', activations)
         if self._quant_a:
             activations = self.activation_quantizer(activations)
-            if self.activation_save_target is not None:
-                self.activation_save_target[self.activation_save_name + '_Q'] = \
-                    activations.data.cpu().numpy()
-
+            self._save('_Q', activations)
         return activations
