@@ -226,6 +226,9 @@ def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, bat
     n_total = data_tensor.size(0)
     q = layer.weight_quantizer.quantizer
     be = _hip.backend()
+    # plain Linear layers without a folded activation function: closed-form gradient, no autograd
+    from quantization.autoquant_utils import QuantLinear
+    manual_linear = fused and type(layer) is QuantLinear and layer.activation_function is None
 
     for i in range(iters):
         idx = (torch.as_tensor(batch_indices[i]) if batch_indices is not None
@@ -252,9 +255,26 @@ def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, bat
         b, reg_on = loss_fn.schedule(it)
         w = layer.weight
         w_q = be.adaround_fwd(w, q.alpha.detach(), q.kernel_args(w), q.mode_code(), True,
-                              q.temperature).requires_grad_(True)
+                              q.temperature)
+        if not manual_linear:
+            w_q.requires_grad_(True)
         bias = layer.bias if hasattr(layer, 'bias') else None
-        if cur_inp.size(0) > 0:
+        if cur_inp.size(0) == 0:
+            rec = torch.zeros((), device=device)
+            grad_wq = torch.zeros_like(w_q)
+        elif manual_linear:
+            # no autograd: out = x W_q^T + b ; dL/dout = 2 (out - tgt) * share / (#means) ;
+            # dL/dW_q = dL/dout^T x   (two hipBLASLt GEMMs + one element-wise kernel)
+            with torch.no_grad():
+                out = layer.run_forward(cur_inp, w_q.detach(), bias)
+                share = cur_inp.size(0) / n_global
+                n_means = out.numel() // out.size(1) if out.dim() > 1 else 1
+                diff = out - cur_out
+                grad_out = diff * (2.0 * share / n_means)
+                grad_wq = grad_out.reshape(-1, grad_out.shape[-1]).t().mm(
+                    cur_inp.reshape(-1, cur_inp.shape[-1]))
+                rec = None      # evaluated only when it is logged
+        else:
             out = layer.run_forward(cur_inp, w_q, bias)
             if layer.activation_function is not None:
                 out = layer.activation_function(out)
@@ -263,9 +283,6 @@ def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, bat
                 cur_inp.size(0) / n_global)
             rec.backward()
             grad_wq = w_q.grad
-        else:
-            rec = torch.zeros((), device=device)
-            grad_wq = torch.zeros_like(w_q)
         grad_wq = tq_dist.sync_sum(grad_wq)
         optimizer.step(w, grad_wq, loss_fn.weight if reg_on else 0.0, b)
         if loss_fn.loss_type == AdaRoundLossType.temp_decay and it >= loss_fn.loss_start:
@@ -276,6 +293,8 @@ def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, bat
         if it == 1 or it % 100 == 0:
             round_loss = float(be.adaround_reg(q.alpha, q.mode_code(), q.temperature, b,
                                                loss_fn.weight)) if reg_on else 0.0
-            rec_v = float(tq_dist.sync_sum(rec.detach().clone()))
+            if rec is None:
+                rec = be.recon_loss(out, cur_out) * (cur_inp.size(0) / n_global)
+            rec_v = float(tq_dist.sync_sum(rec.detach().clone().double()))
             logger.info(f'Total loss:\t{rec_v + round_loss:.4f} (rec:{rec_v:.4f}, '
                         f'round:{round_loss:.3f})\tb={b:.2f}\titer={it}')
