@@ -43,7 +43,7 @@ extern "C" {
 enum { TQ_F32 = 0, TQ_BF16 = 1, TQ_F16 = 2 };
 /* storage dtype of the optional integer-index output */
 enum { TQ_IDX_NONE = 0, TQ_IDX_F32 = 1, TQ_IDX_I8 = 2, TQ_IDX_U8 = 3, TQ_IDX_I16 = 4,
-       TQ_IDX_I32 = 5 };
+       TQ_IDX_I32 = 5, TQ_IDX_I8_M128 = 6 /* int8(index - 128): operand of tq_linear_i8_fwd */ };
 /* error codes */
 enum { TQ_OK = 0, TQ_EINVAL = -1, TQ_ELAUNCH = -2, TQ_EWORKSPACE = -3, TQ_EUNSUPPORTED = -4 };
 /* range-estimator update rules for tq_range_update */
@@ -100,6 +100,28 @@ int tq_residual_layernorm_quant_fwd(const void* dense_out, const void* residual,
                                     const tq_quantizer* q_dense, const tq_quantizer* q_sum,
                                     const float* ln_weight, const float* ln_bias, float ln_eps,
                                     const tq_quantizer* q_out, tq_stream_t stream);
+
+/* (f3) Fused integer Linear + bias + activation + output quantizer on the i8 matrix cores.
+ * Replaces QuantizationHijacker.forward for a Linear with fixed ranges (quantization/hijacker.py:
+ * 66-116 + autoquant_utils.py:16-21):  y = Q_out( act( F.linear(Q_x(x), Q_w(W), b) ) ), evaluated
+ * exactly on the integer grids:
+ *     y_pre[m,n] = s_x s_w[n] ( sum_k x_idx[m,k] w_idx[n,k] + (128 - z_x) w_rowsum[n] ) + b[n]
+ *   x_idx   int8 [M, K]  activation indices minus 128 (tq_fake_quant_fwd with TQ_IDX_I8_M128);
+ *                         the input quantizer is asymmetric per-tensor, <= 8 bits (x_delta,
+ *                         x_zero_float: its raw device buffers)
+ *   w_idx   int8 [N, K]  weight indices of a symmetric quantizer (TQ_IDX_I8), w_rowsum int32 [N]
+ *                         their row sums (tq_rowsum_i8, once per weight), w_delta [1] or [N]
+ *   activation 0 none, 1 ReLU, 2 GELU (erf), 3 Tanh;  q_out NULL or a per-tensor quantizer
+ *   y       [M, N] fp32 or bf16.   M, N multiples of 32; K multiple of 64, <= 16384.
+ * The accumulation is exact (i32); it differs from the reference's fp32 simulation by that
+ * simulation's own accumulation round-off (~1e-6 relative).                                       */
+enum { TQ_ACT_NONE = 0, TQ_ACT_RELU = 1, TQ_ACT_GELU = 2, TQ_ACT_TANH = 3 };
+int tq_rowsum_i8(const int8_t* w_idx, int32_t* rowsum, uint64_t N, uint64_t K, tq_stream_t stream);
+int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum,
+                     const float* bias, void* y, int y_dtype, uint64_t M, uint64_t N, uint64_t K,
+                     const float* x_delta, const float* x_zero_float, int x_n_bits, float x_eps,
+                     const float* w_delta, uint64_t w_n_params, float w_eps, int activation,
+                     const tq_quantizer* q_out, tq_stream_t stream);
 
 /* STE backward of the same op (autograd through quantizers.py:12-19,
  * 184-185, 209): dx = ((g * scale) * mask) / scale with mask = [int_min <= round(x/s)+zp <=

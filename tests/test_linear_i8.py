@@ -1,0 +1,109 @@
+"""(f3) fused integer Linear + bias + activation + fake-quant on the i8 matrix cores.
+
+The integer contraction is exact; the reference's fp32 simulation `F.linear(Q(x), Q(W), b)` is an
+fp32-rounded evaluation of the same number.  Bars: pre-quantizer output within 1e-5 (relative to the
+row scale) of the CPU fp32 simulation and within fp32 epsilon of the float64 value; after the output
+quantizer >= 99.9 % of elements identical to the oracle chain, the rest one grid step away."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(M, N, K, n_bits_w, n_bits_a, per_channel, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(N, K, generator=g) * 0.05
+    x = torch.randn(M, K, generator=g) * 1.5 + 0.3
+    b = torch.randn(N, generator=g) * 0.1
+    if per_channel:
+        wd, ws = O.sym_params_from_range(w.amin(1), w.amax(1), n_bits_w)
+    else:
+        wd, ws = O.sym_params_from_range(w.min(), w.max(), n_bits_w)
+    assert bool(ws)
+    xd, xz = O.asym_params_from_range(x.min(), x.max(), n_bits_a)
+    w_idx, w_q = O.fake_quant(w, wd, None, n_bits_w, True, True, per_channel=per_channel)
+    x_idx, x_q = O.fake_quant(x, xd, xz, n_bits_a, False)
+    return dict(w=w, x=x, b=b, wd=wd, xd=xd, xz=xz, w_idx=w_idx, w_q=w_q, x_idx=x_idx, x_q=x_q)
+
+
+@pytest.mark.parametrize('shape', [(1024, 768, 768), (1024, 3072, 768), (1024, 768, 3072), (64, 128, 512),
+                                   (1024, 512, 384), (32, 32, 64)])
+@pytest.mark.parametrize('cfg', [(8, 8, False), (4, 4, False), (8, 8, True), (4, 8, True)])
+def test_linear_i8_vs_fp32_simulation(shape, cfg):
+    from quantization import _hip
+    be = _hip.backend()
+    M, N, K = shape
+    n_bits_w, n_bits_a, per_channel = cfg
+    p = _problem(M, N, K, n_bits_w, n_bits_a, per_channel, seed=M + N + K)
+    dev = lambda t: t.cuda()
+    x_i8 = be.quantize_to_int8(dev(p['x_q']), dev(p['xd']), dev(p['xz']), None, n_bits_a, False, False, 1e-8,
+                               1, 1, minus_128=True)
+    assert torch.equal(x_i8.cpu().int() + 128, p['x_idx'].int())          # re-quantisation is exact
+    n_par = N if per_channel else 1
+    w_i8 = be.quantize_to_int8(dev(p['w_q']), dev(p['wd']), None, dev(torch.tensor(True)), n_bits_w, True, False,
+                               1e-8, n_par, K if per_channel else 1, minus_128=False)
+    assert torch.equal(w_i8.cpu().int(), p['w_idx'].int())
+    rs = be.rowsum_i8(w_i8)
+    assert torch.equal(rs.cpu().long(), p['w_idx'].long().sum(1))
+    sim32 = torch.nn.functional.linear(p['x_q'], p['w_q'], p['b'])                      # the reference's path
+    sim64 = torch.nn.functional.linear(p['x_q'].double(), p['w_q'].double(), p['b'].double())
+    xq = (dev(p['xd']), dev(p['xz']), n_bits_a, 1e-8)
+    y = be.linear_i8(x_i8, w_i8, rs, dev(p['b']), xq, dev(p['wd']).reshape(-1), 1e-8, _hip.ACT_NONE, None,
+                     torch.float32).cpu()
+    scale = sim64.abs().max().item()
+    assert (y.double() - sim64).abs().max().item() <= 4e-7 * scale + 1e-7     # fp32 epsilon of the exact value
+    assert (y - sim32).abs().max().item() <= 1e-5 * scale                      # north-star tolerance
+    # with activation + output quantizer
+    for act, fn in ((_hip.ACT_GELU, torch.nn.GELU()), (_hip.ACT_RELU, torch.relu), (_hip.ACT_TANH, torch.tanh),
+                    (_hip.ACT_NONE, lambda v: v)):
+        pre = fn(sim64).float()
+        od, oz = O.asym_params_from_range(pre.min(), pre.max(), 8)
+        _, ref = O.fake_quant(pre, od, oz, 8, False)
+        q_out = (dev(od), dev(oz), None, 8, False, False, 1e-8)
+        yq = be.linear_i8(x_i8, w_i8, rs, dev(p['b']), xq, dev(p['wd']).reshape(-1), 1e-8, act, q_out,
+                          torch.float32).cpu()
+        diff = (yq - ref).abs()
+        assert (diff == 0).float().mean().item() >= 0.999, (act, (diff == 0).float().mean().item())
+        assert diff.max().item() <= float(od) * 1.001
+    yb = be.linear_i8(x_i8, w_i8, rs, dev(p['b']), xq, dev(p['wd']).reshape(-1), 1e-8, _hip.ACT_NONE, None,
+                      torch.bfloat16).cpu()
+    assert torch.equal(yb, y.to(torch.bfloat16))
+
+
+def test_bert_forward_with_integer_linears():
+    """Whole BERT-base fixed-range forward with every eligible Linear on the i8 matrix cores (and the
+    fused layer tails): logits stay within the same envelope as CPU-vs-GPU GEMM round-off."""
+    from quantization import autoquant_utils
+    from tests.test_bert_e2e import _build, _fixture, _calibrate_and_run
+    from tests.harness_bert import QResidualBlock
+    z = _fixture()
+    model, _ = _build('cuda')
+    ids = torch.from_numpy(z['input_ids']).cuda()
+    layered = _calibrate_and_run(model, ids)
+    calls = {'n': 0}
+    from quantization import _hip
+    be = _hip.backend()
+    orig = be.linear_i8
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return orig(*a, **k)
+    be.linear_i8 = counting
+    autoquant_utils.INT8_LINEAR = True
+    try:
+        with torch.no_grad():
+            y_int = model(ids)
+            n_plain = calls['n']
+            QResidualBlock.fuse = True
+            y_int_fused = model(ids)
+    finally:
+        autoquant_utils.INT8_LINEAR = False
+        QResidualBlock.fuse = False
+        be.linear_i8 = orig
+    assert n_plain == 12 * 6                      # q, k, v, attention-out, intermediate, output per layer
+    span = float(layered.max() - layered.min())
+    for y in (y_int, y_int_fused):
+        assert float((y - layered).abs().max()) <= 0.10 * span

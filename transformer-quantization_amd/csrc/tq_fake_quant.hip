@@ -32,6 +32,10 @@ __device__ __forceinline__ void store_idx(void* idx, int idx_dtype, uint64_t off
 #pragma unroll
       for (int j = 0; j < V; ++j) o.e[j] = (int8_t)(int)xi[j];
       *reinterpret_cast<PackN<V, int8_t>*>(static_cast<int8_t*>(idx) + off) = o; break; }
+    case TQ_IDX_I8_M128: { PackN<V, int8_t> o;       // index - 128: the signed operand of the i8 GEMM
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.e[j] = (int8_t)((int)xi[j] - 128);
+      *reinterpret_cast<PackN<V, int8_t>*>(static_cast<int8_t*>(idx) + off) = o; break; }
     case TQ_IDX_U8: { PackN<V, uint8_t> o;
 #pragma unroll
       for (int j = 0; j < V; ++j) o.e[j] = (uint8_t)(int)xi[j];
@@ -51,6 +55,7 @@ __device__ __forceinline__ void store_idx1(void* idx, int idx_dtype, uint64_t of
   switch (idx_dtype) {
     case TQ_IDX_F32: static_cast<float*>(idx)[off] = xi; break;
     case TQ_IDX_I8: static_cast<int8_t*>(idx)[off] = (int8_t)(int)xi; break;
+    case TQ_IDX_I8_M128: static_cast<int8_t*>(idx)[off] = (int8_t)((int)xi - 128); break;
     case TQ_IDX_U8: static_cast<uint8_t*>(idx)[off] = (uint8_t)(int)xi; break;
     case TQ_IDX_I16: static_cast<int16_t*>(idx)[off] = (int16_t)(int)xi; break;
     default: static_cast<int32_t*>(idx)[off] = (int32_t)xi; break;
@@ -306,7 +311,7 @@ template <int DT, bool HAS_IDX>
 static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t n, const tq_quantizer& q,
                      hipStream_t st) {
   constexpr int V = Store<DT>::kVec;
-  const size_t idx_es = idx_dtype == TQ_IDX_F32 || idx_dtype == TQ_IDX_I32 ? 4 : (idx_dtype == TQ_IDX_I16 ? 2 : 1);
+  const size_t idx_es = idx_dtype == TQ_IDX_F32 || idx_dtype == TQ_IDX_I32 ? 4 : (idx_dtype == TQ_IDX_I16 ? 2 : 1);   // I8 / U8 / I8_M128: 1
   const bool vec_ok = aligned16(x) && (y == nullptr || aligned16(y)) &&
                       (!HAS_IDX || (reinterpret_cast<uintptr_t>(idx) % (V * idx_es)) == 0);
   static const int nt_min_mb = tuning("TQ_NT_MIN_MB", 64);   // streaming hint above this footprint
@@ -526,7 +531,7 @@ extern "C" int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtyp
   TQ_REQUIRE(x != nullptr, "tq_fake_quant_fwd: x is NULL");
   TQ_REQUIRE(y != nullptr || (idx != nullptr && idx_dtype != TQ_IDX_NONE), "tq_fake_quant_fwd: no output requested");
   TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_fake_quant_fwd: bad dtype %d", dtype);
-  TQ_REQUIRE(idx_dtype >= TQ_IDX_NONE && idx_dtype <= TQ_IDX_I32, "tq_fake_quant_fwd: bad idx_dtype %d", idx_dtype);
+  TQ_REQUIRE(idx_dtype >= TQ_IDX_NONE && idx_dtype <= TQ_IDX_I8_M128, "tq_fake_quant_fwd: bad idx_dtype %d", idx_dtype);
   if (int e = check_quantizer(q, n, "tq_fake_quant_fwd")) return e;
   if (n == 0) return TQ_OK;
   const bool has_idx = idx != nullptr && idx_dtype != TQ_IDX_NONE;

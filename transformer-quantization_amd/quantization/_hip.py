@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libtq_hip.so')
 
 TQ_F32, TQ_BF16, TQ_F16 = 0, 1, 2
-IDX_NONE, IDX_F32, IDX_I8, IDX_U8, IDX_I16, IDX_I32 = range(6)
+IDX_NONE, IDX_F32, IDX_I8, IDX_U8, IDX_I16, IDX_I32, IDX_I8_M128 = range(7)
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = range(4)
 EST_CURRENT, EST_ALL, EST_RUNNING = 0, 1, 2
 ADA_SIGMOID, ADA_HARD_SIGMOID, ADA_SIGMOID_TEMP = 0, 1, 2
 
@@ -44,6 +45,9 @@ SIGNATURES = {
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
     'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
     'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
+    'tq_rowsum_i8': (_int, [_vp, _vp, _u64, _u64, _vp]),
+    'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
+                                _int, _QP, _vp]),
     'tq_fake_quant_bwd_workspace_bytes': (_sz, [_u64]),
     'tq_fake_quant_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _int, _QP, _vp, _sz, _vp]),
     'tq_minmax_workspace_bytes': (_sz, [_u64, _u64, _u64]),
@@ -196,6 +200,39 @@ class HipBackend:
             _ptr(a), _ptr(r), _ptr(y), a.numel() // d, d, _dtype_code(a, 'residual_layernorm_quant'),
             refs[0], refs[1], _ptr(ln_weight.detach().float().contiguous()),
             _ptr(ln_bias.detach().float().contiguous()), float(ln_eps), refs[2], _stream())
+        _check(rc, self.lib)
+        return y
+
+    def quantize_to_int8(self, x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params,
+                         inner, minus_128):
+        """int8 grid indices of x (minus 128 for unsigned activation grids)."""
+        _need_device(x, 'quantize_to_int8')
+        x = x.contiguous()
+        idx = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+        q = self._qdesc(delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner)
+        rc = self.lib.tq_fake_quant_fwd(_ptr(x), None, _ptr(idx), IDX_I8_M128 if minus_128 else IDX_I8,
+                                        x.numel(), _dtype_code(x, 'quantize_to_int8'), C.byref(q), _stream())
+        _check(rc, self.lib)
+        return idx
+
+    def rowsum_i8(self, w_idx):
+        out = torch.empty(w_idx.shape[0], dtype=torch.int32, device=w_idx.device)
+        rc = self.lib.tq_rowsum_i8(_ptr(w_idx), _ptr(out), w_idx.shape[0], w_idx.shape[1], _stream())
+        _check(rc, self.lib)
+        return out
+
+    def linear_i8(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta, w_eps, activation, q_out, out_dtype):
+        """x_idx int8 [..., K]; x_q = (delta, zero_float, n_bits, eps) of the input quantizer;
+        q_out None or the 7-tuple of a per-tensor quantizer.  -> y [..., N]."""
+        K = x_idx.shape[-1]
+        M = x_idx.numel() // K
+        N = w_idx.shape[0]
+        y = torch.empty(x_idx.shape[:-1] + (N,), dtype=out_dtype, device=x_idx.device)
+        qd = None if q_out is None else self._qdesc(*q_out, 1, 1)
+        rc = self.lib.tq_linear_i8_fwd(
+            _ptr(x_idx), _ptr(w_idx), _ptr(w_rowsum), _ptr(bias), _ptr(y), _DTYPES[out_dtype], M, N, K,
+            _ptr(x_q[0]), _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(w_delta), w_delta.numel(),
+            float(w_eps), int(activation), None if qd is None else C.byref(qd), _stream())
         _check(rc, self.lib)
         return y
 

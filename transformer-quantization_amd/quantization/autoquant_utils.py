@@ -18,12 +18,98 @@ from quantization.hijacker import QuantizationHijacker, activations_list
 from quantization.quantization_manager import QuantizationManager
 
 
+# Opt-in: run eval-mode quantized Linears with fixed ranges as an exact integer
+# GEMM on the i8 matrix cores with bias / activation / output quantizer fused into the epilogue
+# (tq_linear_i8_fwd).  Off by default: the default path reproduces the reference's fp32 simulation
+# bit-for-bit up to GEMM round-off, the integer path evaluates the same numbers exactly (it differs
+# from the simulation by the simulation's own fp32 accumulation error, ~1e-6 relative, which can move
+# an output sitting on a rounding boundary by one grid step).
+INT8_LINEAR = False
+
+_ACT_CODES = {type(None): _hip.ACT_NONE, nn.ReLU: _hip.ACT_RELU, nn.GELU: _hip.ACT_GELU, nn.Tanh: _hip.ACT_TANH}
+
+
+def _fixed_per_tensor_manager(mgr):
+    from quantization.quantization_manager import Qstates
+    return (isinstance(mgr, QuantizationManager) and mgr.state == Qstates.fix_ranges
+            and mgr.quantizer.is_initialized and mgr.quantizer._delta.numel() == 1)
+
+
 class QuantLinear(QuantizationHijacker, nn.Linear):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        self._int8_cache = None
 
     def run_forward(self, x, weight, bias, offsets=None):
         return F.linear(x.contiguous(), weight.contiguous(), bias=bias)
+
+    def forward(self, x, offsets=None):
+        if INT8_LINEAR:
+            y = self._int8_forward(x)
+            if y is not None:
+                return y
+        return super().forward(x, offsets)
+
+    # ---- integer path ---------------------------------------------------------------------------
+    def _int8_weights(self):
+        """(int8 indices [N, K], int32 row sums [N]) of the fake-quantized weight, cached per
+        (weight version, range buffers)."""
+        wq = self.weight_quantizer.quantizer
+        key = (self.weight.data_ptr(), self.weight._version, wq._delta.data_ptr(), wq._delta._version)
+        if self._int8_cache is None or self._int8_cache[0] != key:
+            be = _hip.backend()
+            n_par = wq._delta.numel()
+            w_idx = be.quantize_to_int8(self.weight.detach(), wq._delta, None, wq._signed, wq.n_bits, True,
+                                        False, wq.eps, n_par, self.in_features if n_par > 1 else 1,
+                                        minus_128=False)
+            # `signed` is read once here (host sync) so that the per-forward path stays sync-free and
+            # hipGraph-capturable
+            self._int8_cache = (key, w_idx, be.rowsum_i8(w_idx), bool(wq.signed))
+        return self._int8_cache[1:]
+
+    def _int8_forward(self, x, with_output_quantizer=True):
+        """Integer-GEMM evaluation of this layer, or None when the configuration does not allow it.
+        with_output_quantizer=False returns the pre-quantizer output (for fused layer tails)."""
+        src = getattr(x, '_tq_quantizer', None)          # the quantizer that produced x (fixed range)
+        wmgr = self.weight_quantizer
+        act_code = _ACT_CODES.get(type(self.activation_function))
+        if (src is None or self.training or not self._quant_w or act_code is None
+                or (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))
+                or not x.is_cuda or x.dtype != torch.float32
+                or self.activation_save_target is not None
+                or not isinstance(wmgr, QuantizationManager) or not wmgr.quantizer.is_initialized
+                or not wmgr.quantizer.symmetric or wmgr.quantizer.n_bits > 8
+                or wmgr.quantizer.scale_domain != 'linear'
+                or wmgr.quantizer._delta.numel() not in (1, self.out_features)
+                or src.symmetric or src.n_bits > 8 or src._delta is None or src._delta.numel() != 1
+                or src.scale_domain != 'linear'):
+            return None
+        from quantization.quantization_manager import Qstates
+        if wmgr.state != Qstates.fix_ranges:
+            return None
+        M = x.numel() // self.in_features
+        if self.in_features % 64 or self.out_features % 32 or M % 32 or self.in_features > 16384:
+            return None
+        q_out = None
+        amgr = self.activation_quantizer
+        if with_output_quantizer and self._quant_a and not isinstance(amgr, FP32Acts):
+            if not _fixed_per_tensor_manager(amgr):
+                return None
+            oq = amgr.quantizer
+            q_out = (oq._delta, oq._zero_float, getattr(oq, '_signed', None), oq.n_bits, oq.symmetric,
+                     oq.scale_domain == 'log', oq.eps)
+        be = _hip.backend()
+        w_idx, rowsum, w_signed = self._int8_weights()
+        if not w_signed:
+            return None                      # all-positive weights use an unsigned grid: not handled here
+        x_idx = be.quantize_to_int8(x, src._delta, src._zero_float, None, src.n_bits, False, False, src.eps,
+                                    1, 1, minus_128=True)
+        wq = wmgr.quantizer
+        y = be.linear_i8(x_idx, w_idx, rowsum, self.bias, (src._delta, src._zero_float, src.n_bits, src.eps),
+                         wq._delta.reshape(-1), wq.eps, act_code, q_out, torch.float32)
+        if q_out is not None:
+            y._tq_quantizer = amgr.quantizer
+        return y
 
 
 class QuantLayerNorm(QuantizationHijacker, nn.LayerNorm):

@@ -43,9 +43,17 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
                and dense.activation_save_target is None and layer_norm.activation_save_target is None)
     if not fusable:
         return layer_norm(res_quantizer(dense(x) + residual))
-    w, b = dense.get_params()
-    gemm = dense.run_forward(x, w, b)                       # hipBLASLt through torch (the real GEMM)
+    gemm = None
+    from quantization import autoquant_utils
+    if autoquant_utils.INT8_LINEAR and hasattr(dense, '_int8_forward'):
+        gemm = dense._int8_forward(x, with_output_quantizer=False)     # exact integer GEMM (MFMA i8)
+    if gemm is None:
+        w, b = dense.get_params()
+        gemm = dense.run_forward(x, w, b)                   # hipBLASLt through torch (fp32 simulation)
     ln_w, ln_b = layer_norm.get_params()                    # fake-quantized (cached in eval) affine
     arg = lambda q: None if q == 'off' else q
-    return _hip.backend().residual_layernorm_quant(gemm, residual, arg(q1), arg(q2), ln_w, ln_b,
-                                                   layer_norm.eps, arg(q3))
+    y = _hip.backend().residual_layernorm_quant(gemm, residual, arg(q1), arg(q2), ln_w, ln_b,
+                                                layer_norm.eps, arg(q3))
+    if q3 != 'off':
+        y._tq_quantizer = layer_norm.activation_quantizer.quantizer
+    return y

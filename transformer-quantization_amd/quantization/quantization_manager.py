@@ -175,7 +175,12 @@ class QuantizationManager(nn.Module):
                 return y
             cur_xmin, cur_xmax = est(x)
             self.set_quant_range(cur_xmin, cur_xmax)
-        return self.quantizer(x)
+        y = self.quantizer(x)
+        if self.state == Qstates.fix_ranges and not y.requires_grad:
+            # provenance tag: lets a consumer (the fused integer Linear) recover the exact grid
+            # indices of this tensor from the quantizer that produced it
+            y._tq_quantizer = self.quantizer
+        return y
 
     def set_quant_range(self, x_min, x_max):
         self.quantizer.set_quant_range(x_min, x_max)
