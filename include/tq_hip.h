@@ -96,6 +96,7 @@ int tq_affine_fake_quant_fwd(const void* x, const float* w, const float* b, void
  * biased centred variance) are fp32 two-pass over the row held in registers.  Supported row lengths:
  * d / (16-byte vector width) in {16,32,64,96,128,192,256,384,512,768}.                              */
 int tq_residual_layernorm_quant_fwd(const void* dense_out, const void* residual, void* y,
+                                    int8_t* y_idx /* optional int8(index - 128) of y, or NULL */,
                                     uint64_t rows, uint64_t d, int dtype,
                                     const tq_quantizer* q_dense, const tq_quantizer* q_sum,
                                     const float* ln_weight, const float* ln_bias, float ln_eps,
@@ -118,7 +119,9 @@ int tq_residual_layernorm_quant_fwd(const void* dense_out, const void* residual,
 enum { TQ_ACT_NONE = 0, TQ_ACT_RELU = 1, TQ_ACT_GELU = 2, TQ_ACT_TANH = 3 };
 int tq_rowsum_i8(const int8_t* w_idx, int32_t* rowsum, uint64_t N, uint64_t K, tq_stream_t stream);
 int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum,
-                     const float* bias, void* y, int y_dtype, uint64_t M, uint64_t N, uint64_t K,
+                     const float* bias, void* y,
+                     int8_t* y_idx /* optional int8(index - 128) of y for a following integer Linear */,
+                     int y_dtype, uint64_t M, uint64_t N, uint64_t K,
                      const float* x_delta, const float* x_zero_float, int x_n_bits, float x_eps,
                      const float* w_delta, uint64_t w_n_params, float w_eps, int activation,
                      const tq_quantizer* q_out, tq_stream_t stream);

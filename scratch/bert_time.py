@@ -45,8 +45,8 @@ with torch.no_grad():
     with torch.cuda.graph(g2):
         out2=model(ids)
     print('fixed-range forward ms (hipGraph, fused tails)', t(lambda: g2.replay(), n=30))
-from quantization import autoquant_utils
-autoquant_utils.INT8_LINEAR=True
+from quantization import options
+options.INT8_LINEAR=True
 with torch.no_grad():
     print('fixed-range forward ms (eager, int8 linears + fused tails)', t(lambda: model(ids)))
     g3=torch.cuda.CUDAGraph()

@@ -1,11 +1,11 @@
 import sys
 sys.path.insert(0,'/root/repo/transformer-quantization_amd'); sys.path.insert(0,'/root/repo')
 import torch
-from quantization import autoquant_utils
+from quantization import options
 from tests.test_bert_e2e import _build, _fixture, _calibrate_and_run
 z=_fixture(); model,_=_build('cuda'); ids=torch.from_numpy(z['input_ids']).cuda()
 layered=_calibrate_and_run(model, ids)
-autoquant_utils.INT8_LINEAR=True
+options.INT8_LINEAR=True
 q=model.layers[0].attention_self.query
 with torch.no_grad():
     h=model.embeddings(ids)

@@ -46,7 +46,8 @@ class OracleBackend:
         _, y = self._quant(r, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, 1, 1)
         return y.to(x.dtype)
 
-    def residual_layernorm_quant(self, dense_out, residual, q_dense, q_sum, ln_weight, ln_bias, ln_eps, q_out):
+    def residual_layernorm_quant(self, dense_out, residual, q_dense, q_sum, ln_weight, ln_bias, ln_eps, q_out,
+                                 want_idx=False):
         def q(v, a):
             return v if a is None else self._quant(v, *a, 1, 1)[1]
         u = q(q(dense_out.float(), q_dense) + residual.float(), q_sum)

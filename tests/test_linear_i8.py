@@ -68,6 +68,12 @@ def test_linear_i8_vs_fp32_simulation(shape, cfg):
         diff = (yq - ref).abs()
         assert (diff == 0).float().mean().item() >= 0.999, (act, (diff == 0).float().mean().item())
         assert diff.max().item() <= float(od) * 1.001
+        # the optional int8 index output is consistent with the dequantised output it accompanies
+        y2, yi = be.linear_i8(x_i8, w_i8, rs, dev(p['b']), xq, dev(p['wd']).reshape(-1), 1e-8, act, q_out,
+                              torch.float32, want_idx=True)
+        assert torch.equal(y2.cpu(), yq)
+        zp = O.effective_zero_point(oz, 8)
+        assert torch.equal((yi.cpu().float() + 128 - zp) * od, yq)
     yb = be.linear_i8(x_i8, w_i8, rs, dev(p['b']), xq, dev(p['wd']).reshape(-1), 1e-8, _hip.ACT_NONE, None,
                       torch.bfloat16).cpu()
     assert torch.equal(yb, y.to(torch.bfloat16))
@@ -76,7 +82,7 @@ def test_linear_i8_vs_fp32_simulation(shape, cfg):
 def test_bert_forward_with_integer_linears():
     """Whole BERT-base fixed-range forward with every eligible Linear on the i8 matrix cores (and the
     fused layer tails): logits stay within the same envelope as CPU-vs-GPU GEMM round-off."""
-    from quantization import autoquant_utils
+    from quantization import options
     from tests.test_bert_e2e import _build, _fixture, _calibrate_and_run
     from tests.harness_bert import QResidualBlock
     z = _fixture()
@@ -92,7 +98,7 @@ def test_bert_forward_with_integer_linears():
         calls['n'] += 1
         return orig(*a, **k)
     be.linear_i8 = counting
-    autoquant_utils.INT8_LINEAR = True
+    options.INT8_LINEAR = True
     try:
         with torch.no_grad():
             y_int = model(ids)
@@ -100,7 +106,7 @@ def test_bert_forward_with_integer_linears():
             QResidualBlock.fuse = True
             y_int_fused = model(ids)
     finally:
-        autoquant_utils.INT8_LINEAR = False
+        options.INT8_LINEAR = False
         QResidualBlock.fuse = False
         be.linear_i8 = orig
     assert n_plain == 12 * 6                      # q, k, v, attention-out, intermediate, output per layer

@@ -39,7 +39,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // NV = 16-byte vectors per lane per row (d == LPR * NV * V)
 template <int DT, int LPR, int NV>
 __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
-                                                         u32x4* __restrict__ y, uint64_t rows,
+                                                         u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          float ln_eps, tq_quantizer q1, tq_quantizer q2, tq_quantizer q3,
                                                          int on1, int on2, int on3) {
@@ -91,15 +91,26 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float o[V];
+      struct alignas(V) { int8_t e[V]; } oi;
 #pragma unroll
-      for (int j = 0; j < V; ++j) o[j] = apply_q((u[v][j] - mean) * rstd * w[v][j] + b[v][j], f3);
+      for (int j = 0; j < V; ++j) {
+        const float t = (u[v][j] - mean) * rstd * w[v][j] + b[v][j];
+        if (f3.on) {
+          const float xi = q_index(t, f3.p);
+          oi.e[j] = (int8_t)((int)xi - 128);
+          o[j] = q_dequant(xi, f3.p);
+        } else {
+          o[j] = t;
+        }
+      }
       st_stream(y + base + v * LPR + lane, Store<DT>::pack(o));
+      if (y_idx != nullptr) *reinterpret_cast<decltype(oi)*>(y_idx + (base + v * LPR + lane) * V) = oi;
     }
   }
 }
 
 template <int DT>
-static int launch_res_ln(const void* a, const void* r, void* y, uint64_t rows, uint64_t d, const float* w, const float* b,
+static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, uint64_t rows, uint64_t d, const float* w, const float* b,
                          float eps, const tq_quantizer* q1, const tq_quantizer* q2, const tq_quantizer* q3, hipStream_t st) {
   constexpr int V = Store<DT>::kVec;
   const tq_quantizer none{};
@@ -112,7 +123,7 @@ static int launch_res_ln(const void* a, const void* r, void* y, uint64_t rows, u
   if (vpr == (uint64_t)(LPR) * (NV)) {                                                                          \
     const unsigned rpb = kBlock / (LPR);                                                                        \
     const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(rows, rpb), 1), 1u << 20);   \
-    hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, rows, w, b, eps, \
+    hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, eps, \
                        c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr);                                \
     return check_launch("res_ln_quant_k");                                                                      \
   }
@@ -127,7 +138,7 @@ static int launch_res_ln(const void* a, const void* r, void* y, uint64_t rows, u
 
 using namespace tq;
 
-extern "C" int tq_residual_layernorm_quant_fwd(const void* dense_out, const void* residual, void* y, uint64_t rows,
+extern "C" int tq_residual_layernorm_quant_fwd(const void* dense_out, const void* residual, void* y, int8_t* y_idx, uint64_t rows,
                                                uint64_t d, int dtype, const tq_quantizer* q_dense,
                                                const tq_quantizer* q_sum, const float* ln_weight, const float* ln_bias,
                                                float ln_eps, const tq_quantizer* q_out, tq_stream_t stream) {
@@ -135,6 +146,8 @@ extern "C" int tq_residual_layernorm_quant_fwd(const void* dense_out, const void
   TQ_REQUIRE(dense_out && residual && y && ln_weight && ln_bias, "tq_residual_layernorm_quant_fwd: NULL pointer");
   TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_residual_layernorm_quant_fwd: bad dtype %d", dtype);
   TQ_REQUIRE(aligned16(dense_out) && aligned16(residual) && aligned16(y), "tq_residual_layernorm_quant_fwd: 16-byte alignment required");
+  TQ_REQUIRE(y_idx == nullptr || (q_out != nullptr && !q_out->symmetric && q_out->n_bits <= 8 && (reinterpret_cast<uintptr_t>(y_idx) & 7u) == 0),
+             "tq_residual_layernorm_quant_fwd: y_idx needs an asymmetric <= 8-bit output quantizer and 8-byte alignment");
   for (const tq_quantizer* q : {q_dense, q_sum, q_out})
     if (q != nullptr) {
       if (int e = check_quantizer(q, rows * d, "tq_residual_layernorm_quant_fwd")) return e;
@@ -142,8 +155,8 @@ extern "C" int tq_residual_layernorm_quant_fwd(const void* dense_out, const void
     }
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case TQ_F32: return launch_res_ln<TQ_F32>(dense_out, residual, y, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
-    case TQ_BF16: return launch_res_ln<TQ_BF16>(dense_out, residual, y, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
-    default: return launch_res_ln<TQ_F16>(dense_out, residual, y, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
+    case TQ_F32: return launch_res_ln<TQ_F32>(dense_out, residual, y, y_idx, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
+    case TQ_BF16: return launch_res_ln<TQ_BF16>(dense_out, residual, y, y_idx, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
+    default: return launch_res_ln<TQ_F16>(dense_out, residual, y, y_idx, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
   }
 }

@@ -43,6 +43,7 @@ struct LinArgs {
   const int32_t* w_rowsum;
   const float* bias;      // [N] or null
   void* y;                // [M, N]
+  int8_t* y_idx;          // optional [M, N] int8(index - 128) of y (needs q_out), or null
   uint32_t M, N, K;
   const float* x_delta;   // per-tensor input quantizer
   const float* x_zero_float;
@@ -82,13 +83,20 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI]
     for (int j = 0; j < MI; ++j) {
       const uint32_t m = m0 + j * 16 + r16;
       float o[4];
+      struct alignas(4) { int8_t e[4]; } oi4 = {{0, 0, 0, 0}};
+      int8_t (&oi)[4] = oi4.e;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = (float)(acc[i][j][r] + rs[r]) * sw[r] + bs[r];
         v = apply_act(v, p.act);
-        if (p.has_q) v = q_dequant(q_index(v, qo), qo);
+        if (p.has_q) {
+          const float xi = q_index(v, qo);
+          oi[r] = (int8_t)((int)xi - 128);
+          v = q_dequant(xi, qo);
+        }
         o[r] = v;
       }
+      if (p.y_idx != nullptr) *reinterpret_cast<uint32_t*>(p.y_idx + (size_t)m * p.N + n) = __builtin_bit_cast(uint32_t, oi4);
       if (YDT == TQ_F32) {
         *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + (size_t)m * p.N + n) = f32x4{o[0], o[1], o[2], o[3]};
       } else {
@@ -273,7 +281,7 @@ extern "C" int tq_rowsum_i8(const int8_t* w_idx, int32_t* rowsum, uint64_t N, ui
 }
 
 extern "C" int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum, const float* bias,
-                                void* y, int y_dtype, uint64_t M, uint64_t N, uint64_t K, const float* x_delta,
+                                void* y, int8_t* y_idx, int y_dtype, uint64_t M, uint64_t N, uint64_t K, const float* x_delta,
                                 const float* x_zero_float, int x_n_bits, float x_eps, const float* w_delta,
                                 uint64_t w_n_params, float w_eps, int activation, const tq_quantizer* q_out,
                                 tq_stream_t stream) {
@@ -288,11 +296,13 @@ extern "C" int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const 
   TQ_REQUIRE(activation >= ACT_NONE && activation <= ACT_TANH, "tq_linear_i8_fwd: unknown activation %d", activation);
   TQ_REQUIRE(aligned16(x_idx) && aligned16(w_idx) && aligned16(y), "tq_linear_i8_fwd: 16-byte alignment required");
   LinArgs a{};
-  a.x = x_idx; a.w = w_idx; a.w_rowsum = w_rowsum; a.bias = bias; a.y = y;
+  a.x = x_idx; a.w = w_idx; a.w_rowsum = w_rowsum; a.bias = bias; a.y = y; a.y_idx = y_idx;
   a.M = (uint32_t)M; a.N = (uint32_t)N; a.K = (uint32_t)K;
   a.x_delta = x_delta; a.x_zero_float = x_zero_float; a.x_eps = x_eps; a.x_n_bits = x_n_bits;
   a.w_delta = w_delta; a.w_n_params = (uint32_t)w_n_params; a.w_eps = w_eps; a.act = activation;
   a.has_q = q_out != nullptr;
+  TQ_REQUIRE(y_idx == nullptr || (q_out != nullptr && !q_out->symmetric && q_out->n_bits <= 8),
+             "tq_linear_i8_fwd: y_idx needs an asymmetric <= 8-bit output quantizer");
   if (q_out) {
     if (int e = check_quantizer(q_out, M * N, "tq_linear_i8_fwd")) return e;
     TQ_REQUIRE(q_out->n_params == 1, "tq_linear_i8_fwd: per-tensor output quantizer only");

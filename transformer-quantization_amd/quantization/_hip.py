@@ -44,9 +44,9 @@ SIGNATURES = {
     'tq_last_error': (C.c_char_p, []),
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
     'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
-    'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
+    'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
     'tq_rowsum_i8': (_int, [_vp, _vp, _u64, _u64, _vp]),
-    'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
+    'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
                                 _int, _QP, _vp]),
     'tq_fake_quant_bwd_workspace_bytes': (_sz, [_u64]),
     'tq_fake_quant_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _int, _QP, _vp, _sz, _vp]),
@@ -187,21 +187,35 @@ class HipBackend:
         _check(rc, self.lib)
         return y
 
-    def residual_layernorm_quant(self, dense_out, residual, q_dense, q_sum, ln_weight, ln_bias, ln_eps, q_out):
+    def residual_layernorm_quant(self, dense_out, residual, q_dense, q_sum, ln_weight, ln_bias, ln_eps, q_out,
+                                 want_idx=False):
         """y = Q_out(LN(Q_sum(Q_dense(dense_out) + residual))); each q_* is None or the 7-tuple
         (delta, zero_float, signed, n_bits, symmetric, log_domain, eps) of a per-tensor quantizer."""
         _need_device(dense_out, 'residual_layernorm_quant')
         a, r = dense_out.contiguous(), residual.contiguous().to(dense_out.dtype)
         y = torch.empty_like(a)
+        idx = torch.empty(a.shape, dtype=torch.int8, device=a.device) if want_idx else None
         d = a.shape[-1]
         descs = [None if q is None else self._qdesc(*q, 1, 1) for q in (q_dense, q_sum, q_out)]
         refs = [None if dsc is None else C.byref(dsc) for dsc in descs]
         rc = self.lib.tq_residual_layernorm_quant_fwd(
-            _ptr(a), _ptr(r), _ptr(y), a.numel() // d, d, _dtype_code(a, 'residual_layernorm_quant'),
+            _ptr(a), _ptr(r), _ptr(y), _ptr(idx), a.numel() // d, d, _dtype_code(a, 'residual_layernorm_quant'),
             refs[0], refs[1], _ptr(ln_weight.detach().float().contiguous()),
             _ptr(ln_bias.detach().float().contiguous()), float(ln_eps), refs[2], _stream())
         _check(rc, self.lib)
-        return y
+        return (y, idx) if want_idx else y
+
+    def fake_quant_int8(self, x, delta, zero_float, n_bits, eps):
+        """Per-tensor asymmetric fake-quant that also emits int8(index - 128): one read, two writes."""
+        _need_device(x, 'fake_quant_int8')
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        idx = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+        q = self._qdesc(delta, zero_float, None, n_bits, False, False, eps, 1, 1)
+        rc = self.lib.tq_fake_quant_fwd(_ptr(x), _ptr(y), _ptr(idx), IDX_I8_M128, x.numel(),
+                                        _dtype_code(x, 'fake_quant_int8'), C.byref(q), _stream())
+        _check(rc, self.lib)
+        return y, idx
 
     def quantize_to_int8(self, x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params,
                          inner, minus_128):
@@ -221,20 +235,22 @@ class HipBackend:
         _check(rc, self.lib)
         return out
 
-    def linear_i8(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta, w_eps, activation, q_out, out_dtype):
+    def linear_i8(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta, w_eps, activation, q_out, out_dtype,
+                  want_idx=False):
         """x_idx int8 [..., K]; x_q = (delta, zero_float, n_bits, eps) of the input quantizer;
         q_out None or the 7-tuple of a per-tensor quantizer.  -> y [..., N]."""
         K = x_idx.shape[-1]
         M = x_idx.numel() // K
         N = w_idx.shape[0]
         y = torch.empty(x_idx.shape[:-1] + (N,), dtype=out_dtype, device=x_idx.device)
+        y_idx = torch.empty(y.shape, dtype=torch.int8, device=y.device) if want_idx else None
         qd = None if q_out is None else self._qdesc(*q_out, 1, 1)
         rc = self.lib.tq_linear_i8_fwd(
-            _ptr(x_idx), _ptr(w_idx), _ptr(w_rowsum), _ptr(bias), _ptr(y), _DTYPES[out_dtype], M, N, K,
+            _ptr(x_idx), _ptr(w_idx), _ptr(w_rowsum), _ptr(bias), _ptr(y), _ptr(y_idx), _DTYPES[out_dtype], M, N, K,
             _ptr(x_q[0]), _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(w_delta), w_delta.numel(),
             float(w_eps), int(activation), None if qd is None else C.byref(qd), _stream())
         _check(rc, self.lib)
-        return y
+        return (y, y_idx) if want_idx else y
 
     def fake_quant_bwd(self, x, grad_y, delta, zero_float, signed, n_bits, symmetric, log_domain, eps,
                        n_params, inner, param_grads=False):

@@ -13,19 +13,13 @@ from torch.nn import functional as F
 from torch.nn.modules.pooling import _AdaptiveAvgPoolNd, _AvgPoolNd
 
 from quantization import _hip
+from quantization import options
 from quantization.base_quantized_classes import FP32Acts, QuantizedActivation, QuantizedModule
 from quantization.hijacker import QuantizationHijacker, activations_list
 from quantization.quantization_manager import QuantizationManager
 
 
-# Opt-in: run eval-mode quantized Linears with fixed ranges as an exact integer
-# GEMM on the i8 matrix cores with bias / activation / output quantizer fused into the epilogue
-# (tq_linear_i8_fwd).  Off by default: the default path reproduces the reference's fp32 simulation
-# bit-for-bit up to GEMM round-off, the integer path evaluates the same numbers exactly (it differs
-# from the simulation by the simulation's own fp32 accumulation error, ~1e-6 relative, which can move
-# an output sitting on a rounding boundary by one grid step).
-INT8_LINEAR = False
-
+# The integer path is switched on with quantization.options.INT8_LINEAR (see there).
 _ACT_CODES = {type(None): _hip.ACT_NONE, nn.ReLU: _hip.ACT_RELU, nn.GELU: _hip.ACT_GELU, nn.Tanh: _hip.ACT_TANH}
 
 
@@ -44,7 +38,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         return F.linear(x.contiguous(), weight.contiguous(), bias=bias)
 
     def forward(self, x, offsets=None):
-        if INT8_LINEAR:
+        if options.INT8_LINEAR:
             y = self._int8_forward(x)
             if y is not None:
                 return y
@@ -102,13 +96,19 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         w_idx, rowsum, w_signed = self._int8_weights()
         if not w_signed:
             return None                      # all-positive weights use an unsigned grid: not handled here
-        x_idx = be.quantize_to_int8(x, src._delta, src._zero_float, None, src.n_bits, False, False, src.eps,
-                                    1, 1, minus_128=True)
+        x_idx = getattr(x, '_tq_idx', None)        # emitted by the producing quantizer in the same launch
+        if x_idx is None or x_idx.shape != x.shape:
+            x_idx = be.quantize_to_int8(x, src._delta, src._zero_float, None, src.n_bits, False, False,
+                                        src.eps, 1, 1, minus_128=True)
         wq = wmgr.quantizer
-        y = be.linear_i8(x_idx, w_idx, rowsum, self.bias, (src._delta, src._zero_float, src.n_bits, src.eps),
-                         wq._delta.reshape(-1), wq.eps, act_code, q_out, torch.float32)
+        want_idx = q_out is not None and not amgr.quantizer.symmetric and amgr.quantizer.n_bits <= 8
+        out = be.linear_i8(x_idx, w_idx, rowsum, self.bias, (src._delta, src._zero_float, src.n_bits, src.eps),
+                           wq._delta.reshape(-1), wq.eps, act_code, q_out, torch.float32, want_idx=want_idx)
+        y = out[0] if want_idx else out
         if q_out is not None:
             y._tq_quantizer = amgr.quantizer
+            if want_idx:
+                y._tq_idx = out[1]          # the next integer Linear consumes these directly
         return y
 
 

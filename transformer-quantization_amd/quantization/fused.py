@@ -44,16 +44,22 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
     if not fusable:
         return layer_norm(res_quantizer(dense(x) + residual))
     gemm = None
-    from quantization import autoquant_utils
-    if autoquant_utils.INT8_LINEAR and hasattr(dense, '_int8_forward'):
+    from quantization import options
+    if options.INT8_LINEAR and hasattr(dense, '_int8_forward'):
         gemm = dense._int8_forward(x, with_output_quantizer=False)     # exact integer GEMM (MFMA i8)
     if gemm is None:
         w, b = dense.get_params()
         gemm = dense.run_forward(x, w, b)                   # hipBLASLt through torch (fp32 simulation)
     ln_w, ln_b = layer_norm.get_params()                    # fake-quantized (cached in eval) affine
     arg = lambda q: None if q == 'off' else q
-    y = _hip.backend().residual_layernorm_quant(gemm, residual, arg(q1), arg(q2), ln_w, ln_b,
-                                                layer_norm.eps, arg(q3))
-    if q3 != 'off':
-        y._tq_quantizer = layer_norm.activation_quantizer.quantizer
+    oq = layer_norm.activation_quantizer.quantizer if q3 != 'off' else None
+    want_idx = (options.INT8_LINEAR and oq is not None and not oq.symmetric and oq.n_bits <= 8
+                and gemm.dtype == torch.float32)
+    out = _hip.backend().residual_layernorm_quant(gemm, residual, arg(q1), arg(q2), ln_w, ln_b,
+                                                  layer_norm.eps, arg(q3), want_idx=want_idx)
+    y = out[0] if want_idx else out
+    if oq is not None:
+        y._tq_quantizer = oq
+        if want_idx:
+            y._tq_idx = out[1]
     return y

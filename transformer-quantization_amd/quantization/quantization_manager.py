@@ -17,6 +17,7 @@ from torch import nn
 
 from quantization import _hip
 from quantization import distributed as tq_dist
+from quantization import options
 from quantization.quantizers import (
     AsymmetricUniformQuantizer,
     QMethods,
@@ -175,11 +176,30 @@ class QuantizationManager(nn.Module):
                 return y
             cur_xmin, cur_xmax = est(x)
             self.set_quant_range(cur_xmin, cur_xmax)
-        y = self.quantizer(x)
-        if self.state == Qstates.fix_ranges and not y.requires_grad:
-            # provenance tag: lets a consumer (the fused integer Linear) recover the exact grid
-            # indices of this tensor from the quantizer that produced it
-            y._tq_quantizer = self.quantizer
+        if self.state == Qstates.fix_ranges:
+            y = self._fixed_forward_with_indices(x) if options.INT8_LINEAR else None
+            if y is None:
+                y = self.quantizer(x)
+            if not y.requires_grad:
+                # provenance tag: lets a consumer (the fused integer Linear) recover the exact grid
+                # indices of this tensor from the quantizer that produced it
+                y._tq_quantizer = self.quantizer
+            return y
+        return self.quantizer(x)
+
+    def _fixed_forward_with_indices(self, x):
+        """Fixed per-tensor asymmetric <= 8-bit quantizer feeding integer Linears: one launch writes
+        the dequantised tensor AND its int8 indices (minus 128), saving the consumer's re-quantisation."""
+        q = self.quantizer
+        if (type(q) is not AsymmetricUniformQuantizer or q.n_bits > 8 or q._delta.numel() != 1
+                or q.scale_domain != 'linear' or not x.is_cuda or x.dtype != torch.float32
+                or (torch.is_grad_enabled() and x.requires_grad)):
+            return None
+        be = _hip.backend()
+        if not hasattr(be, 'fake_quant_int8'):
+            return None
+        y, idx = be.fake_quant_int8(x, q._delta, q._zero_float, q.n_bits, q.eps)
+        y._tq_idx = idx
         return y
 
     def set_quant_range(self, x_min, x_max):
