@@ -5,7 +5,7 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
-#include "../transformer-quantization_amd/csrc/tq_device.h"
+#include "../../transformer-quantization_amd/csrc/tq_device.h"
 using namespace tq;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
