@@ -126,6 +126,16 @@ int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_
                      const float* w_delta, uint64_t w_n_params, float w_eps, int activation,
                      const tq_quantizer* q_out, tq_stream_t stream);
 
+/* Fused attention probabilities with fixed ranges (reference models/quantized_bert.py:153-198):
+ *     probs = Q_probs( softmax( Q_scores(scores) / denom + mask, dim=-1 ) )
+ * scores / probs fp32 [rows, cols] (rows = B*H*T_query, cols = T_key in {32,64,128,256,512,1024}); mask
+ * fp32 [rows / rows_per_mask, cols] additive (BERT: [B, T], rows_per_mask = H * T_query) or NULL;
+ * each quantizer per-tensor or NULL.  1 read + 1 write instead of 5 sweeps.                       */
+int tq_scores_softmax_quant_fwd(const float* scores, float* probs, uint64_t rows, uint64_t cols,
+                                const float* mask, uint64_t rows_per_mask, float denom,
+                                const tq_quantizer* q_scores, const tq_quantizer* q_probs,
+                                tq_stream_t stream);
+
 /* STE backward of the same op (autograd through quantizers.py:12-19,
  * 184-185, 209): dx = ((g * scale) * mask) / scale with mask = [int_min <= round(x/s)+zp <=
  * int_max]: 3 streams, 6 B/elem bf16.  For a per-tensor quantizer, non-NULL grad_delta /

@@ -68,6 +68,31 @@ with torch.no_grad():
         o = model(ids)
     c['fixed_range_forward_hipgraph_ms'] = wall(lambda: g.replay(), n=30)
     c['graph_equals_eager'] = bool(torch.equal(o, model(ids)))
+
+    def graphed(key):
+        gg = torch.cuda.CUDAGraph()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                model(ids)
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(gg):
+            oo = model(ids)
+        c[key + '_hipgraph_ms'] = wall(lambda: gg.replay(), n=30)
+        c[key + '_max_logit_dev_vs_layered'] = float((oo - o).abs().max())
+
+    # opt-in fast paths of the fixed-range forward (each parity-tested against the layered path)
+    from tests.harness_bert import QResidualBlock, QSelfAttention
+    from quantization import options
+    QResidualBlock.fuse = True
+    graphed('fixed_range_forward_fused_tails')
+    options.INT8_LINEAR = True
+    graphed('fixed_range_forward_fused_tails_int8_linear')
+    QSelfAttention.fuse = True
+    graphed('fixed_range_forward_fused_tails_int8_linear_fused_attention')
+    QResidualBlock.fuse = QSelfAttention.fuse = False
+    options.INT8_LINEAR = False
+    c['logit_span'] = float(o.max() - o.min())
 c['activation_elems_per_forward'] = 172234768
 c['reference_cpu_8thr_ms'] = {'fp32': 239, 'fixed_range': 368, 'calibrating': 5100,
                               'source': 'BASELINE.md section 2 (survey container, 8 vCPU)'}

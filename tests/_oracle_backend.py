@@ -54,6 +54,14 @@ class OracleBackend:
         v = torch.nn.functional.layer_norm(u, (u.shape[-1],), ln_weight.float(), ln_bias.float(), ln_eps)
         return q(v, q_out).to(dense_out.dtype)
 
+    def scores_softmax_quant(self, scores, mask, rows_per_mask, denom, q_scores, q_probs):
+        def q(v, a):
+            return v if a is None else self._quant(v, *a, 1, 1)[1]
+        s = q(scores.float(), q_scores) / denom
+        if mask is not None:
+            s = s + mask.reshape(mask.shape[0], 1, 1, mask.shape[-1])
+        return q(torch.softmax(s, dim=-1), q_probs)
+
     def fake_quant_bwd(self, x, grad_y, delta, zero_float, signed, n_bits, symmetric, log_domain,
                        eps, n_params, inner, param_grads=False):
         sgn = bool(signed.item()) if signed is not None else False

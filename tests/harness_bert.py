@@ -58,13 +58,21 @@ class QSelfAttention(QuantizedModel):
         B, T, _ = x.shape
         return x.view(B, T, self.heads, self.head_dim).permute(0, 2, 1, 3)
 
+    fuse = False   # set True: scores-quant -> scale -> mask -> softmax -> probs-quant as one kernel
+
     def forward(self, h, mask):
         q, k, v = self._split(self.query(h)), self._split(self.key(h)), self._split(self.value(h))
-        scores = self.attn_scores_act_quantizer(torch.matmul(q, k.transpose(-1, -2)))
-        scores = scores / math.sqrt(self.head_dim)
-        if mask is not None:
-            scores = scores + mask
-        probs = self.attn_probs_act_quantizer(torch.softmax(scores, dim=-1))
+        raw = torch.matmul(q, k.transpose(-1, -2))
+        if self.fuse:
+            from quantization.fused import scores_softmax_quant
+            probs = scores_softmax_quant(self.attn_scores_act_quantizer, self.attn_probs_act_quantizer, raw,
+                                         mask, math.sqrt(self.head_dim))
+        else:
+            scores = self.attn_scores_act_quantizer(raw)
+            scores = scores / math.sqrt(self.head_dim)
+            if mask is not None:
+                scores = scores + mask
+            probs = self.attn_probs_act_quantizer(torch.softmax(scores, dim=-1))
         ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).contiguous()
         return self.context_act_quantizer(ctx.view(ctx.shape[0], ctx.shape[1], -1))
 

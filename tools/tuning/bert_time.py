@@ -58,3 +58,16 @@ with torch.no_grad():
         out3=model(ids)
     print('fixed-range forward ms (hipGraph, int8 linears + fused tails)', t(lambda: g3.replay(), n=30))
     print('max |logit diff| vs fp32-simulated GEMMs', float((out3-out).abs().max()))
+from tests.harness_bert import QSelfAttention
+QSelfAttention.fuse=True
+with torch.no_grad():
+    print('fixed-range forward ms (eager, int8 + fused tails + fused attention probs)', t(lambda: model(ids)))
+    g4=torch.cuda.CUDAGraph()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3): model(ids)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g4):
+        out4=model(ids)
+    print('fixed-range forward ms (hipGraph, int8 + fused tails + fused attention probs)', t(lambda: g4.replay(), n=30))
+    print('max |logit diff| vs fp32-simulated GEMMs', float((out4-out).abs().max()))

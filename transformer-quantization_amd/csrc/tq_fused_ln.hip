@@ -134,6 +134,55 @@ static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, u
                    (unsigned long long)d);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Attention probabilities with fixed ranges (reference models/quantized_bert.py:153-198):
+//     p = Q_probs( softmax( Q_scores(scores) / denom + mask , dim=-1 ) )
+// = quantizer, division, mask add, softmax, quantizer: five sweeps of [B, H, T, T] in the reference,
+// here 1 read + 1 write.  LPR lanes own one row of T = LPR * NV * 4 fp32 values.
+template <int LPR, int NV>
+__global__ __launch_bounds__(kBlock) void softmax_quant_k(const f32x4* __restrict__ s, f32x4* __restrict__ y, uint64_t rows,
+                                                          const float* __restrict__ mask, uint64_t rows_per_mask,
+                                                          float denom, tq_quantizer q1, tq_quantizer q2, int on1, int on2) {
+  constexpr int RPB = kBlock / LPR;
+  constexpr uint32_t T4 = LPR * NV;              // float4 vectors per row
+  const FusedQ f1 = {on1 ? make_qp(q1, 0) : QP{1.f, 0.f, 0.f, 0.f}, on1};
+  const FusedQ f2 = {on2 ? make_qp(q2, 0) : QP{1.f, 0.f, 0.f, 0.f}, on2};
+  const int lane = threadIdx.x % LPR, sub = threadIdx.x / LPR;
+  for (uint64_t row = (uint64_t)blockIdx.x * RPB + sub; row < rows; row += (uint64_t)gridDim.x * RPB) {
+    const f32x4* mrow = mask ? reinterpret_cast<const f32x4*>(mask + (row / rows_per_mask) * (uint64_t)T4 * 4) : nullptr;
+    float v[NV][4];
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const f32x4 in = s[row * T4 + k * LPR + lane];
+      f32x4 mk = {0.f, 0.f, 0.f, 0.f};
+      if (mrow) mk = mrow[k * LPR + lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = apply_q(in[j], f1) / denom;
+        if (mrow) t = t + mk[j];
+        v[k][j] = t;
+        mx = fmaxf(mx, t);
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, LPR));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[k][j] = expf(v[k][j] - mx); sum += v[k][j]; }
+    sum = group_sum<LPR>(sum);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = apply_q(v[k][j] / sum, f2);
+      y[row * T4 + k * LPR + lane] = o;
+    }
+  }
+}
+
 }  // namespace tq
 
 using namespace tq;
@@ -159,4 +208,37 @@ extern "C" int tq_residual_layernorm_quant_fwd(const void* dense_out, const void
     case TQ_BF16: return launch_res_ln<TQ_BF16>(dense_out, residual, y, y_idx, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
     default: return launch_res_ln<TQ_F16>(dense_out, residual, y, y_idx, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
   }
+}
+
+extern "C" int tq_scores_softmax_quant_fwd(const float* scores, float* probs, uint64_t rows, uint64_t cols,
+                                           const float* mask, uint64_t rows_per_mask, float denom,
+                                           const tq_quantizer* q_scores, const tq_quantizer* q_probs, tq_stream_t stream) {
+  if (rows == 0) return TQ_OK;
+  TQ_REQUIRE(scores && probs, "tq_scores_softmax_quant_fwd: NULL pointer");
+  TQ_REQUIRE(aligned16(scores) && aligned16(probs) && (mask == nullptr || aligned16(mask)),
+             "tq_scores_softmax_quant_fwd: 16-byte alignment required");
+  TQ_REQUIRE(mask == nullptr || (rows_per_mask >= 1 && rows % rows_per_mask == 0), "tq_scores_softmax_quant_fwd: bad mask layout");
+  TQ_REQUIRE(denom != 0.0f, "tq_scores_softmax_quant_fwd: denom == 0");
+  for (const tq_quantizer* q : {q_scores, q_probs})
+    if (q != nullptr) {
+      if (int e = check_quantizer(q, rows * cols, "tq_scores_softmax_quant_fwd")) return e;
+      TQ_REQUIRE(q->n_params == 1, "tq_scores_softmax_quant_fwd: per-tensor quantizers only");
+    }
+  const tq_quantizer none{};
+  const tq_quantizer &c1 = q_scores ? *q_scores : none, &c2 = q_probs ? *q_probs : none;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const auto sv = reinterpret_cast<const f32x4*>(scores);
+  auto yv = reinterpret_cast<f32x4*>(probs);
+#define TQ_SM(LPR, NV)                                                                                          \
+  if (cols == (uint64_t)(LPR) * (NV) * 4) {                                                                     \
+    const unsigned rpb = kBlock / (LPR);                                                                        \
+    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(rows, rpb), 1), 1u << 20);   \
+    hipLaunchKernelGGL((softmax_quant_k<LPR, NV>), dim3(grid), dim3(kBlock), 0, st, sv, yv, rows, mask, rows_per_mask, \
+                       denom, c1, c2, q_scores != nullptr, q_probs != nullptr);                                 \
+    return check_launch("softmax_quant_k");                                                                     \
+  }
+  TQ_SM(8, 1) TQ_SM(16, 1) TQ_SM(32, 1) TQ_SM(64, 1) TQ_SM(64, 2) TQ_SM(64, 4)
+#undef TQ_SM
+  return set_error(TQ_EUNSUPPORTED, "tq_scores_softmax_quant_fwd: row length %llu unsupported (32..1024, power of two)",
+                   (unsigned long long)cols);
 }

@@ -45,6 +45,7 @@ SIGNATURES = {
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
     'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
     'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
+    'tq_scores_softmax_quant_fwd': (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _f, _QP, _QP, _vp]),
     'tq_rowsum_i8': (_int, [_vp, _vp, _u64, _u64, _vp]),
     'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
                                 _int, _QP, _vp]),
@@ -204,6 +205,19 @@ class HipBackend:
             _ptr(ln_bias.detach().float().contiguous()), float(ln_eps), refs[2], _stream())
         _check(rc, self.lib)
         return (y, idx) if want_idx else y
+
+    def scores_softmax_quant(self, scores, mask, rows_per_mask, denom, q_scores, q_probs):
+        """probs = Q_probs(softmax(Q_scores(scores) / denom + mask)); q_* None or per-tensor 7-tuples."""
+        _need_device(scores, 'scores_softmax_quant')
+        s = scores.contiguous()
+        y = torch.empty_like(s)
+        cols = s.shape[-1]
+        descs = [None if q is None else self._qdesc(*q, 1, 1) for q in (q_scores, q_probs)]
+        refs = [None if dsc is None else C.byref(dsc) for dsc in descs]
+        rc = self.lib.tq_scores_softmax_quant_fwd(_ptr(s), _ptr(y), s.numel() // cols, cols, _ptr(mask),
+                                                  int(rows_per_mask), float(denom), refs[0], refs[1], _stream())
+        _check(rc, self.lib)
+        return y
 
     def fake_quant_int8(self, x, delta, zero_float, n_bits, eps):
         """Per-tensor asymmetric fake-quant that also emits int8(index - 128): one read, two writes."""

@@ -6,12 +6,15 @@
     Q_ln( LayerNorm( Q_res( Q_dense(dense_out) + residual ) ) )
 
 as ONE kernel (``tq_residual_layernorm_quant_fwd``: 2 reads + 1 write of [B*T, d]) when every
-quantizer involved has a fixed per-tensor range; otherwise it falls back to the layered modules, so
-calibration / QAT / per-embedding configurations keep their exact semantics.
+quantizer involved has a fixed per-tensor range; otherwise it runs the layered modules (the same HIP
+kernels, one launch per stage), so calibration / QAT / per-embedding configurations keep their exact
+semantics.  ``scores_softmax_quant`` does the same for the attention probabilities
+(``tq_scores_softmax_quant_fwd``: quantizer -> 1/sqrt(d) -> mask -> softmax -> quantizer, 1 read + 1 write).
 """
 import torch
 
 from quantization import _hip
+from quantization import options
 from quantization.base_quantized_classes import FP32Acts
 from quantization.quantization_manager import QuantizationManager, Qstates
 
@@ -44,7 +47,6 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
     if not fusable:
         return layer_norm(res_quantizer(dense(x) + residual))
     gemm = None
-    from quantization import options
     if options.INT8_LINEAR and hasattr(dense, '_int8_forward'):
         gemm = dense._int8_forward(x, with_output_quantizer=False)     # exact integer GEMM (MFMA i8)
     if gemm is None:
@@ -63,3 +65,25 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
         if want_idx:
             y._tq_idx = out[1]
     return y
+
+
+def scores_softmax_quant(scores_quantizer, probs_quantizer, scores, mask, denom):
+    """Equivalent to ``probs_quantizer(softmax(scores_quantizer(scores) / denom + mask, dim=-1))``
+    (reference models/quantized_bert.py:153-198) as one kernel when both quantizers are fixed and
+    per-tensor.  scores: fp32 [B, H, Tq, Tk]; mask: additive, broadcastable [B, 1, 1, Tk] or None."""
+    q1 = _fixed_per_tensor(scores_quantizer._quant_a, scores_quantizer.activation_quantizer)
+    q2 = _fixed_per_tensor(probs_quantizer._quant_a, probs_quantizer.activation_quantizer)
+    Tk = scores.shape[-1]
+    ok_mask = mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1
+                               and mask.shape[0] == scores.shape[0] and mask.shape[3] == Tk)
+    if ('no' in (q1, q2) or not scores.is_cuda or scores.dtype != torch.float32 or scores.dim() != 4
+            or not ok_mask or Tk not in (32, 64, 128, 256, 512, 1024)
+            or (torch.is_grad_enabled() and scores.requires_grad)):
+        s = scores_quantizer(scores) / denom
+        if mask is not None:
+            s = s + mask
+        return probs_quantizer(torch.softmax(s, dim=-1))
+    arg = lambda q: None if q == 'off' else q
+    m = None if mask is None else mask.reshape(mask.shape[0], Tk).float().contiguous()
+    return _hip.backend().scores_softmax_quant(scores, m, scores.shape[1] * scores.shape[2], denom,
+                                               arg(q1), arg(q2))
