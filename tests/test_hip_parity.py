@@ -124,6 +124,93 @@ def test_fake_quant_unaligned_and_index_dtypes(q):
     assert torch.equal(idx.cpu().float(), ref_idx)
 
 
+def _tie_adjacent(scale, ks, spread=3):
+    """fp32 inputs whose quotient by `scale` sits on / next to the rounding ties k + 1/2: the cases where
+    the kernels' reciprocal fast path must hand over to the true division (csrc/tq_device.h)."""
+    import numpy as np
+    base = ((ks.astype(np.float64) + 0.5) * np.float64(scale)).astype(np.float32)
+    out = [base]
+    lo, hi = base.copy(), base.copy()
+    for _ in range(spread):
+        lo = np.nextafter(lo, np.float32(-np.inf)); hi = np.nextafter(hi, np.float32(np.inf))
+        out += [lo.copy(), hi.copy()]
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize('n_bits', [4, 8, 16])
+def test_rounding_ties_are_bit_exact(q, n_bits):
+    """rne(x / scale) through the guarded-reciprocal path == true division, on tie-adjacent inputs,
+    for awkward scales (per-tensor, per-embedding and inside the MSE candidate kernel)."""
+    import numpy as np
+    from quantization import _hip
+    be = _hip.backend()
+    rs = np.random.RandomState(n_bits)
+    top = 2 ** n_bits - 1
+    ks = np.arange(-8, top + 8)
+    if ks.size > 4096:
+        ks = np.concatenate([ks[:600], rs.choice(ks, 3000, replace=False), ks[-600:]])
+    scales = np.concatenate([[1.0, 0.1, 1.0 / 3.0, 0.7, 1e-8, 3.0000002, 0.049999997, 123.456],
+                             np.exp(rs.uniform(-12, 6, 24))]).astype(np.float32)
+    # per tensor, asymmetric + symmetric
+    for sc in scales:
+        x = torch.from_numpy(_tie_adjacent(sc, ks))
+        x = torch.cat([x, -x])
+        x = x[:x.numel() // 8 * 8]
+        delta = torch.tensor(float(sc))
+        zf = torch.tensor(float(rs.uniform(0, top)))
+        ref_idx, ref_y = O.fake_quant(x, delta, zf, n_bits, False)
+        y, idx = be.fake_quant(x.to(DEV), delta.to(DEV), zf.to(DEV), None, n_bits, False, False, 1e-8, 1, 1,
+                               idx_dtype=torch.int32)
+        assert torch.equal(idx.cpu().float(), ref_idx), float(sc)
+        assert torch.equal(y.cpu(), ref_y), float(sc)
+        sg = torch.tensor(True)
+        ref_idx, ref_y = O.fake_quant(x, delta, None, n_bits, True, True)
+        y, idx = be.fake_quant(x.to(DEV), delta.to(DEV), None, sg.to(DEV), n_bits, True, False, 1e-8, 1, 1,
+                               idx_dtype=torch.int32)
+        assert torch.equal(idx.cpu().float(), ref_idx) and torch.equal(y.cpu(), ref_y), float(sc)
+    # per embedding: column c has its own scale; rows = tie-adjacent values of that column
+    d = 32
+    sc = scales[:d]
+    kk = ks[:: max(1, ks.size // 200)]
+    cols = [_tie_adjacent(s_, kk) for s_ in sc]
+    x = torch.from_numpy(np.stack(cols, axis=1).copy())             # [rows, d]
+    delta = torch.from_numpy(sc.copy())
+    zf = torch.from_numpy(rs.uniform(0, top, d).astype(np.float32))
+    ref_idx, ref_y = O.fake_quant(x, delta, zf, n_bits, False, axis=1)
+    y, idx = be.fake_quant(x.to(DEV), delta.to(DEV), zf.to(DEV), None, n_bits, False, False, 1e-8, d, 1,
+                           idx_dtype=torch.int32)
+    assert torch.equal(idx.cpu().float(), ref_idx) and torch.equal(y.cpu(), ref_y)
+    xb = x.to(torch.bfloat16)
+    ref_idx, ref_y = O.fake_quant_lowp(xb, delta, zf, n_bits, False, axis=1)
+    y, idx = be.fake_quant(xb.to(DEV), delta.to(DEV), zf.to(DEV), None, n_bits, False, False, 1e-8, d, 1,
+                           idx_dtype=torch.int32)
+    assert torch.equal(idx.cpu().float(), ref_idx) and torch.equal(y.cpu(), ref_y)
+
+
+def test_mse_candidate_losses_on_tie_adjacent_inputs(q):
+    """Candidate kernel: a single mis-rounded element changes a loss by ~scale^2; compare against fp64
+    sums of the oracle's per-element errors."""
+    import numpy as np
+    from quantization import _hip
+    be = _hip.backend()
+    rs = np.random.RandomState(3)
+    scales = np.exp(rs.uniform(-6, 1, 48)).astype(np.float32)
+    ks = np.arange(0, 256)
+    x = torch.from_numpy(np.concatenate([_tie_adjacent(s_, ks, spread=1) for s_ in scales[:8]]))
+    x = x[:x.numel() // 1024 * 1024].contiguous()
+    tab = np.stack([scales, rs.randint(0, 255, scales.size).astype(np.float32),
+                    np.zeros_like(scales), np.full_like(scales, 255.0)], axis=1).astype(np.float32)
+    ref = []
+    for sc_, zp_, lo_, hi_ in tab:
+        xi = torch.clamp(torch.round(x / float(sc_)) + float(zp_), float(lo_), float(hi_))
+        err = x - float(sc_) * (xi - float(zp_))
+        ref.append(float((err.double() ** 2).sum()))
+    loss = be.zeros_f64((1, scales.size), DEV)
+    be.mse_candidates(x.to(DEV), 1, torch.from_numpy(tab).to(DEV), loss)
+    got = loss.cpu().numpy()[0]
+    assert np.allclose(got, np.array(ref), rtol=2e-6, atol=0), np.abs(got / np.array(ref) - 1).max()
+
+
 def test_special_values_nan_inf(q):
     from quantization import _hip
     x = torch.tensor([float('nan'), float('inf'), -float('inf'), 0.0, -0.0, 1e-30, 0.5, 1.5, 2.5,

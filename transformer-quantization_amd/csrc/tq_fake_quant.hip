@@ -64,12 +64,14 @@ __device__ __forceinline__ void store_idx1(void* idx, int idx_dtype, uint64_t of
 
 // one 16-byte vector: widen, quantize, (store indices), dequantize, narrow
 template <int DT, bool HAS_IDX>
-__device__ __forceinline__ u32x4 fq_vec(const u32x4& in, const QP& p, void* idx, int idx_dtype, uint64_t elem_off) {
+__device__ __forceinline__ u32x4 fq_vec(const u32x4& in, const QP& p, float rcp, void* idx, int idx_dtype,
+                                        uint64_t elem_off) {
   constexpr int V = Store<DT>::kVec;
-  float f[V];
-  Store<DT>::unpack(in, f);
+  float g[V], f[V];
+  Store<DT>::unpack(in, g);
+  rne_quot<V>(g, p.scale, rcp, f);
 #pragma unroll
-  for (int j = 0; j < V; ++j) f[j] = q_index(f[j], p);
+  for (int j = 0; j < V; ++j) f[j] = clamp_nanprop(f[j] + p.zp, p.lo, p.hi);
   if (HAS_IDX) store_idx<V>(idx, idx_dtype, elem_off, f);
 #pragma unroll
   for (int j = 0; j < V; ++j) f[j] = q_dequant(f[j], p);
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x,
   constexpr int V = Store<DT>::kVec;
   constexpr uint64_t TILE = (uint64_t)kBlock * U;
   const QP p = make_qp(q, 0);
+  const float rcp = guarded_rcp(p.scale);
   const uint64_t n_vec = n / V;
 
   for (uint64_t t0 = (uint64_t)blockIdx.x * TILE; t0 < n_vec; t0 += (uint64_t)gridDim.x * TILE) {
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x,
       for (int u = 0; u < U; ++u) v[u] = NT ? ld_stream(x + i + u * kBlock) : x[i + u * kBlock];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const u32x4 o = fq_vec<DT, HAS_IDX>(v[u], p, idx, idx_dtype, (i + u * kBlock) * V);
+        const u32x4 o = fq_vec<DT, HAS_IDX>(v[u], p, rcp, idx, idx_dtype, (i + u * kBlock) * V);
         if (y) { if (NT) st_stream(y + i + u * kBlock, o); else y[i + u * kBlock] = o; }
       }
     } else {
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x,
       for (int u = 0; u < U; ++u) {
         const uint64_t k = i + u * kBlock;
         if (k < n_vec) {
-          const u32x4 o = fq_vec<DT, HAS_IDX>(x[k], p, idx, idx_dtype, k * V);
+          const u32x4 o = fq_vec<DT, HAS_IDX>(x[k], p, rcp, idx, idx_dtype, k * V);
           if (y) y[k] = o;
         }
       }
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u
   const uint32_t d = (uint32_t)q.n_params;
   float* s_scale = s_par;
   float* s_zp = s_par + d;
+  float* s_rcp = s_par + 2 * d;                     // guarded reciprocals (tq_device.h)
   const uint64_t n_vec = n / V;
   const uint32_t vpr = d / V;                       // vectors per row (<= 2048)
 
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u
     const QP p = make_qp(q, c);
     s_scale[c] = p.scale;
     s_zp[c] = p.zp;
+    s_rcp[c] = guarded_rcp(p.scale);
   }
   const QP p0 = make_qp(q, 0);   // int_min / int_max do not depend on the column
   const float lo = p0.lo, hi = p0.hi;
@@ -190,8 +195,15 @@ __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint64_t k = i0 + (uint64_t)u * kBlock;
-        float f[V], sc[V], zp[V];
-        Store<DT>::unpack(v[u], f);
+        float g[V], f[V], sc[V], zp[V];
+        Store<DT>::unpack(v[u], g);
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+          const f32x4 r4 = *reinterpret_cast<const f32x4*>(s_rcp + cv * V + j);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) f[j + m] = rne_quot_try(g[j + m], r4[m], ok);
+        }
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
           const f32x4 s4 = *reinterpret_cast<const f32x4*>(s_scale + cv * V + j);
@@ -199,11 +211,12 @@ __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u
 #pragma unroll
           for (int m = 0; m < 4; ++m) { sc[j + m] = s4[m]; zp[j + m] = z4[m]; }
         }
+        if (!ok) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const QP p = {sc[j], zp[j], lo, hi};
-          f[j] = q_index(f[j], p);
+          for (int j = 0; j < V; ++j) f[j] = rintf(g[j] / sc[j]);
         }
+#pragma unroll
+        for (int j = 0; j < V; ++j) f[j] = clamp_nanprop(f[j] + zp[j], lo, hi);
         if (full || k < n_vec) {
           if (HAS_IDX) store_idx<V>(idx, idx_dtype, k * V, f);
           if (y) {
@@ -217,6 +230,94 @@ __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u
         if (cv >= vpr) cv -= vpr;
       }
     }
+  }
+}
+
+// Register-resident variant: the block size is chosen as a multiple of the vectors per row, so a lane
+// owns ONE vector column for its whole life and keeps that column's (scale, zp) in registers: no LDS,
+// no barrier, no column arithmetic in the loop.  Tile = blockDim.x * U consecutive vectors.
+template <int DT, bool HAS_IDX, bool NT, int U, int MAXB>
+__global__ __launch_bounds__(MAXB) void fq_axis_reg(const u32x4* __restrict__ x, u32x4* __restrict__ y,
+                                                    void* __restrict__ idx, int idx_dtype, uint64_t n, tq_quantizer q) {
+  constexpr int V = Store<DT>::kVec;
+  const uint32_t bs = blockDim.x;
+  const uint64_t tile_vecs = (uint64_t)bs * U;
+  const uint64_t n_vec = n / V;
+  const uint32_t vpr = (uint32_t)q.n_params / V;
+  const uint64_t n_tiles = (n_vec + tile_vecs - 1) / tile_vecs;
+  uint64_t tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+
+  u32x4 v[U];
+  auto load_tile = [&](uint64_t t) {
+    const uint64_t i0 = t * tile_vecs + threadIdx.x;
+    if ((t + 1) * tile_vecs <= n_vec) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = NT ? ld_stream(x + i0 + (uint64_t)u * bs) : x[i0 + (uint64_t)u * bs];
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t k = i0 + (uint64_t)u * bs;
+        v[u] = u32x4{0, 0, 0, 0};
+        if (k < n_vec) v[u] = x[k];
+      }
+    }
+  };
+  load_tile(tile);                                  // data loads in flight while the parameters arrive
+
+  // parameters of this lane's V columns: straight 16-byte loads first, arithmetic afterwards (make_qp per
+  // column would serialise 2 V dependent scalar loads behind its wave-uniform branches)
+  const uint32_t c0 = (threadIdx.x % vpr) * V;
+  float sc[V], zp[V];
+  {
+    f32x4 dv[V / 4], zv[V / 4];
+#pragma unroll
+    for (int j = 0; j < V / 4; ++j) {
+      dv[j] = *reinterpret_cast<const f32x4*>(q.delta + c0 + 4 * j);
+      zv[j] = q.symmetric ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(q.zero_float + c0 + 4 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sc[j] = dv[j / 4][j % 4]; zp[j] = zv[j / 4][j % 4]; }
+  }
+  const QP p0 = make_qp(q, 0);                        // int_min / int_max do not depend on the column
+  const float lo = p0.lo, hi = p0.hi;
+  float rc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    sc[j] = q.log_domain ? expf(sc[j]) : (sc[j] < q.eps ? q.eps : sc[j]);              // quantizers.py:142-147
+    zp[j] = q.symmetric ? 0.0f : clamp_nanprop(rintf(zp[j]), lo, hi);                  // :149-153, :330-332
+    rc[j] = guarded_rcp(sc[j]);
+  }
+  for (;;) {
+    const uint64_t i0 = tile * tile_vecs + threadIdx.x;
+    const bool full = (tile + 1) * tile_vecs <= n_vec;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t k = i0 + (uint64_t)u * bs;
+      float g[V], f[V];
+      Store<DT>::unpack(v[u], g);
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < V; ++j) f[j] = rne_quot_try(g[j], rc[j], ok);
+      if (!ok) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) f[j] = rintf(g[j] / sc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) f[j] = clamp_nanprop(f[j] + zp[j], lo, hi);
+      if (full || k < n_vec) {
+        if (HAS_IDX) store_idx<V>(idx, idx_dtype, k * V, f);
+        if (y) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) f[j] = sc[j] * (f[j] - zp[j]);
+          const u32x4 o = Store<DT>::pack(f);
+          if (NT) st_stream(y + k, o); else y[k] = o;
+        }
+      }
+    }
+    tile += gridDim.x;
+    if (tile >= n_tiles) break;
+    load_tile(tile);
   }
 }
 
@@ -283,10 +384,11 @@ __global__ __launch_bounds__(kBlock) void fq_rows(const u32x4* __restrict__ x, u
   const uint64_t vec_per_row = q.inner / V;
   for (uint64_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
     const QP p = make_qp(q, row % q.n_params);
+    const float rcp = guarded_rcp(p.scale);
     const uint64_t base = row * vec_per_row;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < vec_per_row;
          i += (uint64_t)gridDim.x * kBlock) {
-      const u32x4 o = fq_vec<DT, HAS_IDX>(x[base + i], p, idx, idx_dtype, (base + i) * V);
+      const u32x4 o = fq_vec<DT, HAS_IDX>(x[base + i], p, rcp, idx, idx_dtype, (base + i) * V);
       if (y) y[base + i] = o;
     }
   }
@@ -332,12 +434,38 @@ static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t 
 #undef TQ_LAUNCH_TENSOR
     return check_launch("fq_tensor");
   }
-  if (vec_ok && q.n_params > 1 && q.inner == 1 && q.n_params % V == 0 && q.n_params <= 8192) {   // 2 x d floats of LDS <= 64 KiB
-    const size_t lds = q.n_params * 2 * sizeof(float);
+  // per-embedding parameters, row of vpr = d / V vectors: block size = a multiple of vpr (<= 1024)
+  // (measured: the register variant wins for fp32 rows of <= 256 vectors, the LDS-table variant for bf16)
+  static const int axis_reg = tuning("TQ_AXIS_REG", 2);   // 0: LDS table first, 1: registers first, 2: by dtype
+  const bool lds_ok = vec_ok && q.n_params > 1 && q.inner == 1 && q.n_params % V == 0 && q.n_params <= 5440;
+  const bool reg_ok = vec_ok && q.n_params > 1 && q.inner == 1 && q.n_params % V == 0 && q.n_params / V <= 1024 &&
+                      aligned16(q.delta) && (q.symmetric || aligned16(q.zero_float));
+  const bool prefer_reg = axis_reg == 1 || (axis_reg == 2 && DT == TQ_F32 && q.n_params / V <= 256);
+  if (reg_ok && (prefer_reg || !lds_ok)) {
+    const uint32_t vpr = (uint32_t)(q.n_params / V);
+    const uint32_t bs = vpr <= kBlock ? vpr * (kBlock / vpr) : vpr;
+#define TQ_LAUNCH_AXIS_REG(NTV, UV, MB)                                                                    \
+    hipLaunchKernelGGL((fq_axis_reg<DT, HAS_IDX, NTV, UV, MB>),                                             \
+                       dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n_vec_all, (uint64_t)bs * UV), 1), kMaxTiles)), \
+                       dim3(bs), 0, st, xv, yv, idx, idx_dtype, n, q)
+    if (bs <= kBlock) {
+      if (big) { if (nt) TQ_LAUNCH_AXIS_REG(true, 4, kBlock); else TQ_LAUNCH_AXIS_REG(false, 4, kBlock); }
+      else     { if (nt) TQ_LAUNCH_AXIS_REG(true, 1, kBlock); else TQ_LAUNCH_AXIS_REG(false, 1, kBlock); }
+    } else {
+      if (big) { if (nt) TQ_LAUNCH_AXIS_REG(true, 2, 1024); else TQ_LAUNCH_AXIS_REG(false, 2, 1024); }
+      else     { if (nt) TQ_LAUNCH_AXIS_REG(true, 1, 1024); else TQ_LAUNCH_AXIS_REG(false, 1, 1024); }
+    }
+#undef TQ_LAUNCH_AXIS_REG
+    return check_launch("fq_axis_reg");
+  }
+  if (lds_ok) {   // 3 x d floats of LDS <= 64 KiB
+    const size_t lds = q.n_params * 3 * sizeof(float);
+    static const int tpb_env = tuning("TQ_AXIS_TPB", 0);
 #define TQ_LAUNCH_AXIS(NTV, UV)                                                                            \
     {                                                                                                      \
       const uint64_t n_tiles = std::max<uint64_t>(ceil_div(n_vec_all, kBlock * UV), 1);                    \
-      const uint32_t tpb = n_tiles >= 32768 ? 2 : 1;                                                       \
+      const uint32_t want = q.n_params > 2048 ? 8 : (q.n_params > 1024 ? 4 : 2);  /* amortise the table fill */ \
+      const uint32_t tpb = tpb_env > 0 ? (uint32_t)tpb_env : (n_tiles >= 16384ull * want ? want : 1);          \
       hipLaunchKernelGGL((fq_axis<DT, HAS_IDX, NTV, UV>),                                                   \
                          dim3((unsigned)std::min<uint64_t>(ceil_div(n_tiles, tpb), kMaxTiles)),            \
                          dim3(kBlock), lds, st, xv, yv, idx, idx_dtype, n, q, tpb);                         \

@@ -35,12 +35,17 @@ __global__ __launch_bounds__(kBlock) void mse_cand_k(const void* __restrict__ x,
   constexpr int NV = E / V;   // 16-byte vectors per lane per tile
   typedef typename Store<DT>::elem_t T;
   __shared__ float4 s_c[kCandTile];
+  __shared__ float s_r[kCandTile];                 // guarded reciprocal of each candidate's scale
   __shared__ double s_acc[kBlock / kWave][kCandTile];
 
   const uint32_t c0 = blockIdx.y * cand_tile;
   const uint32_t nc = min(cand_tile, n_cand - c0);
   for (uint32_t c = threadIdx.x; c < kCandTile; c += kBlock) {
-    if (c < nc) s_c[c] = cand[c0 + c];
+    if (c < nc) {
+      const float4 pc = cand[c0 + c];
+      s_c[c] = pc;
+      s_r[c] = guarded_rcp(pc.x);
+    }
 #pragma unroll
     for (int w = 0; w < kBlock / kWave; ++w) s_acc[w][c] = 0.0;
   }
@@ -97,10 +102,12 @@ __global__ __launch_bounds__(kBlock) void mse_cand_k(const void* __restrict__ x,
     for (uint32_t c = 0; c < nc; ++c) {
       const float4 pc = s_c[c];
       const QP p = {pc.x, pc.y, pc.z, pc.w};
+      float h[E];
+      rne_quot<E>(f, p.scale, s_r[c], h);          // == rintf(f[j] / p.scale), see tq_device.h
       float acc = 0.0f;
 #pragma unroll
       for (int j = 0; j < E; ++j) {
-        const float d = f[j] - q_dequant(q_index(f[j], p), p);
+        const float d = f[j] - q_dequant(clamp_nanprop(h[j] + p.zp, p.lo, p.hi), p);
         acc += d * d;
       }
       const double tot = wave_sum((double)acc);
