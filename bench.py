@@ -121,7 +121,7 @@ def _cpu_model():
     return platform.processor()
 
 
-def timed_region(fn, steps, world):
+def timed_region(fn, steps, use_dist):
     """barrier + sync, K back-to-back steps bracketed by ONE HIP event pair on torch's current
     stream (the stream the kernels are launched on), sync + barrier.
     -> (wall seconds for the K steps, device milliseconds per step = event span / K).
@@ -130,7 +130,7 @@ def timed_region(fn, steps, world):
     per-kernel average to < 1 %."""
     start = torch.cuda.Event(enable_timing=True)
     end = torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -139,7 +139,7 @@ def timed_region(fn, steps, world):
         fn()
     end.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     wall = time.perf_counter() - t0
     return wall, start.elapsed_time(end) / steps
@@ -168,7 +168,10 @@ def main():
     backend = os.environ.get('TQ_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    # TQ_BENCH_FORCE_DIST=1: initialise the process group (RCCL) even for a 1-rank torchrun launch, so the
+    # collective path (barriers, fused MAX all-reduce in calibration) can be exercised on a 1-GPU box.
+    use_dist = world > 1 or (os.environ.get('TQ_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ)
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
@@ -180,8 +183,8 @@ def main():
     from quantization.range_estimators import RangeEstimators
     from quantization.base_quantized_classes import QuantizedActivation
     assert _hip.backend().name == 'hip'
-    if world > 1:
-        tq_dist.enable()
+    if use_dist:
+        tq_dist.enable(force=(world == 1))
 
     B, S = args.batch, args.seq
     x = make_hidden(B, S, device, seed=1000 + rank)
@@ -196,7 +199,7 @@ def main():
     calib_batches = [x, make_hidden(B, S, device, seed=2000 + rank)]
     for xb in calib_batches:
         qa(xb)
-    cal_wall, cal_ms = timed_region(lambda: qa(x), max(4, min(args.steps, 20)), world)
+    cal_wall, cal_ms = timed_region(lambda: qa(x), max(4, min(args.steps, 20)), use_dist)
     cal_steps = max(4, min(args.steps, 20))
     qa.activation_quantizer.fix_ranges()
     del calib_batches
@@ -212,9 +215,9 @@ def main():
             torch.cuda.synchronize()
         for _ in range(args.warmup):
             qa(x)
-        wall, ev_ms = timed_region(lambda: qa(x), args.steps, world)
+        wall, ev_ms = timed_region(lambda: qa(x), args.steps, use_dist)
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([wall, cal_wall], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, cal_wall = float(tmax[0]), float(tmax[1])
@@ -287,7 +290,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

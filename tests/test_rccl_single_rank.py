@@ -1,0 +1,88 @@
+"""The collective path on real RCCL, as far as a 1-GPU box allows: a 1-rank `nccl` process group (the GPU
+boxes the tests run on have one device, and RCCL refuses two ranks on one device).  Checks that the
+fused MAX / SUM all-reduces of quantization.distributed accept the device tensors the estimators hand
+them (fp32 [-min;max] pairs, fp64 candidate-loss vectors), that sharded calibration is a no-op at world
+size 1, and that bench.py runs its N>1 control flow (barriers, all-reduced timing) over RCCL.
+World-size-2 semantics are covered on CPU with gloo (tests/test_dist_gloo.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.path.join(ROOT, 'transformer-quantization_amd')); sys.path.insert(0, ROOT)
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+from quantization import distributed as tq_dist
+from quantization.quantization_manager import QuantizationManager
+from quantization.quantizers import QMethods
+from quantization.range_estimators import RangeEstimators
+from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+g = torch.Generator(device='cuda').manual_seed(7)
+x = torch.randn(16, 64, 768, device='cuda', generator=g); x[..., 308] *= 20
+def run(init, axis=None, n_groups=None, params=None):
+    m = QuantizationManager(qmethod=QMethods.asymmetric_uniform, init=RangeEstimators[init],
+                            qparams=dict(n_bits=8), init_params=params or {})
+    if axis is not None:
+        set_act_quant_axis_and_groups(m, axis=axis, n_groups=n_groups)
+    y = m(tq_dist.shard_batch(x))
+    return y, m.quantizer._delta.clone(), m.quantizer._zero_float.clone()
+cases = [('running_minmax', None, None, None), ('current_minmax', 2, None, None), ('current_minmax', 2, 6, None),
+         ('MSE', None, None, dict(num_candidates=50))]
+local = [run(*c) for c in cases]
+tq_dist.enable(force=True)
+assert tq_dist.is_enabled()
+shared = [run(*c) for c in cases]
+for a, b in zip(local, shared):
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+mn, mx = tq_dist.sync_minmax(torch.tensor([-1.0, 2.0], device='cuda'), torch.tensor([3.0, 4.0], device='cuda'))
+assert mn.tolist() == [-1.0, 2.0] and mx.tolist() == [3.0, 4.0]
+s = tq_dist.sync_sum(torch.arange(5, dtype=torch.float64, device='cuda'))
+assert s.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+st = tq_dist.stats()
+assert st['minmax_calls'] >= len(cases) + 1 and st['sum_calls'] >= 2, st
+tq_dist.disable()
+dist.destroy_process_group()
+print('RCCL_SINGLE_RANK_OK', st)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(args, extra_env=None, timeout=300):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(extra_env or {}))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_estimators_over_rccl_world1(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text('ROOT = %r\n' % ROOT + WORKER)
+    r = _torchrun([str(script)])
+    assert r.returncode == 0 and 'RCCL_SINGLE_RANK_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_distributed_control_flow_over_rccl():
+    r = _torchrun(['bench.py', '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu', '--batch', '64', '--seq', '128'],
+                  extra_env={'TQ_BENCH_FORCE_DIST': '1'})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 1 and out['value'] > 0 and out['roofline']['achieved'] > 0

@@ -22,24 +22,26 @@ import torch.distributed as dist
 
 _group = None
 _enabled = False
+_force = False     # run the collectives even in a 1-rank group (RCCL smoke tests on a 1-GPU box)
 _stats = {'minmax_calls': 0, 'sum_calls': 0, 'bytes': 0}
 
 
-def enable(group=None):
-    """Turn on statistic all-reduce (requires an initialised default process group)."""
-    global _group, _enabled
+def enable(group=None, force=False):
+    """Turn on statistic all-reduce (requires an initialised default process group).  A 1-rank group
+    skips the collectives unless `force` is set."""
+    global _group, _enabled, _force
     if not dist.is_available() or not dist.is_initialized():
         raise RuntimeError('torch.distributed is not initialised')
-    _group, _enabled = group, True
+    _group, _enabled, _force = group, True, bool(force)
 
 
 def disable():
-    global _group, _enabled
-    _group, _enabled = None, False
+    global _group, _enabled, _force
+    _group, _enabled, _force = None, False, False
 
 
 def is_enabled():
-    return _enabled and dist.is_initialized() and dist.get_world_size(_group) > 1
+    return _enabled and dist.is_initialized() and (_force or dist.get_world_size(_group) > 1)
 
 
 def stats():
