@@ -1,148 +1,4 @@
-"""Synthetic-data BERT harness built on the drop-in quantization package.
-
-The reference's models/quantized_bert.py is out of scope as code (it depends on transformers-4.1
-container internals), but its tensor edges define the workload: 161 activation quantizers and 102
-weight quantizers for BERT-base.  This module places quantizers at the same
-edges, in the same order, around a plain re-statement of the BERT forward, using only the public API
-of `quantization/` -- it is the consumer the parity test (tests/test_bert_e2e.py) and the whole-model
-calibration benchmark drive.  Weights come from a HuggingFace `BertForSequenceClassification`
-(random-init; no checkpoints are available offline).
-
-Quantizer sites per encoder layer, in call order (reference models/quantized_bert.py:135-146, 154,
-198, 213, 239-245, 265-277, 291): q, k, v | scores | probs | context | self-output dense | residual
-sum | LayerNorm | intermediate(+GELU) | output dense | residual sum | LayerNorm.
-"""
-import math
-
-import torch
-from torch import nn
-
-from quantization.autoquant_utils import quantize_model
-from quantization.base_quantized_classes import QuantizedActivation
-from quantization.base_quantized_model import QuantizedModel
-
-
-class QEmbeddings(QuantizedModel):
-    def __init__(self, hf, **qp):
-        super().__init__()
-        self.word_embeddings = quantize_model(hf.word_embeddings, **qp)
-        self.position_embeddings = quantize_model(hf.position_embeddings, **qp)
-        self.token_type_embeddings = quantize_model(hf.token_type_embeddings, **qp)
-        self.sum_input_token_type_embd_act_quantizer = QuantizedActivation(**qp)
-        self.sum_pos_embd_act_quantizer = QuantizedActivation(**qp)
-        self.LayerNorm = quantize_model(hf.LayerNorm, **qp)
-
-    def forward(self, input_ids):
-        B, T = input_ids.shape
-        pos = torch.arange(T, device=input_ids.device).unsqueeze(0)
-        tok = torch.zeros_like(input_ids)
-        x = self.word_embeddings(input_ids) + self.token_type_embeddings(tok)
-        x = self.sum_input_token_type_embd_act_quantizer(x)
-        x = x + self.position_embeddings(pos)
-        x = self.sum_pos_embd_act_quantizer(x)
-        return self.LayerNorm(x)
-
-
-class QSelfAttention(QuantizedModel):
-    def __init__(self, hf, **qp):
-        super().__init__()
-        self.heads, self.head_dim = hf.num_attention_heads, hf.attention_head_size
-        self.query = quantize_model(hf.query, **qp)
-        self.key = quantize_model(hf.key, **qp)
-        self.value = quantize_model(hf.value, **qp)
-        self.attn_scores_act_quantizer = QuantizedActivation(**qp)
-        self.attn_probs_act_quantizer = QuantizedActivation(**qp)
-        self.context_act_quantizer = QuantizedActivation(**qp)
-
-    def _split(self, x):
-        B, T, _ = x.shape
-        return x.view(B, T, self.heads, self.head_dim).permute(0, 2, 1, 3)
-
-    fuse = False   # set True: scores-quant -> scale -> mask -> softmax -> probs-quant as one kernel
-
-    def forward(self, h, mask):
-        q, k, v = self._split(self.query(h)), self._split(self.key(h)), self._split(self.value(h))
-        raw = torch.matmul(q, k.transpose(-1, -2))
-        if self.fuse:
-            from quantization.fused import scores_softmax_quant
-            probs = scores_softmax_quant(self.attn_scores_act_quantizer, self.attn_probs_act_quantizer, raw,
-                                         mask, math.sqrt(self.head_dim))
-        else:
-            scores = self.attn_scores_act_quantizer(raw)
-            scores = scores / math.sqrt(self.head_dim)
-            if mask is not None:
-                scores = scores + mask
-            probs = self.attn_probs_act_quantizer(torch.softmax(scores, dim=-1))
-        ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).contiguous()
-        return self.context_act_quantizer(ctx.view(ctx.shape[0], ctx.shape[1], -1))
-
-
-class QResidualBlock(QuantizedModel):
-    """dense -> (+ residual) -> quantize -> LayerNorm (BertSelfOutput / BertOutput)."""
-
-    def __init__(self, hf, **qp):
-        super().__init__()
-        self.dense = quantize_model(hf.dense, **qp)
-        self.res_act_quantizer = QuantizedActivation(**qp)
-        self.LayerNorm = quantize_model(hf.LayerNorm, **qp)
-
-    fuse = False   # set True to run the fixed-range tail as one kernel (quantization/fused.py)
-
-    def forward(self, h, residual):
-        if self.fuse:
-            from quantization.fused import residual_layernorm_quant
-            return residual_layernorm_quant(self.dense, self.res_act_quantizer, self.LayerNorm, h, residual)
-        return self.LayerNorm(self.res_act_quantizer(self.dense(h) + residual))
-
-
-class QLayer(QuantizedModel):
-    def __init__(self, hf, **qp):
-        super().__init__()
-        self.attention_self = QSelfAttention(hf.attention.self, **qp)
-        self.attention_output = QResidualBlock(hf.attention.output, **qp)
-        self.intermediate = quantize_model(nn.Sequential(hf.intermediate.dense, nn.GELU()), **qp)
-        self.output = QResidualBlock(hf.output, **qp)
-
-    def forward(self, h, mask):
-        a = self.attention_output(self.attention_self(h, mask), h)
-        return self.output(self.intermediate(a), a)
-
-
-class QBertForSequenceClassification(QuantizedModel):
-    def __init__(self, hf, **qp):
-        super().__init__()
-        self.embeddings = QEmbeddings(hf.bert.embeddings, **qp)
-        self.layers = nn.ModuleList([QLayer(l, **qp) for l in hf.bert.encoder.layer])
-        self.pooler = quantize_model(nn.Sequential(hf.bert.pooler.dense, nn.Tanh()), **qp)
-        self.classifier = quantize_model(hf.classifier, **qp)
-
-    def forward(self, input_ids, attention_mask=None):
-        mask = None
-        if attention_mask is not None:
-            mask = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
-        else:
-            mask = torch.zeros(input_ids.shape[0], 1, 1, input_ids.shape[1], device=input_ids.device)
-        h = self.embeddings(input_ids)
-        for layer in self.layers:
-            h = layer(h, mask)
-        return self.classifier(self.pooler(h[:, 0]))
-
-
-def build_bert_base(seed=1000, num_labels=2, num_layers=None, **qp):
-    """Random-init HF BERT-base (seeded on the CPU generator) wrapped with quantizers."""
-    from transformers import BertConfig, BertForSequenceClassification
-    torch.manual_seed(seed)
-    cfg = BertConfig(num_labels=num_labels)
-    if num_layers is not None:
-        cfg.num_hidden_layers = num_layers
-    hf = BertForSequenceClassification(cfg).eval()
-    return QBertForSequenceClassification(hf, **qp), hf
-
-
-def quantizer_census(model):
-    from quantization.quantization_manager import QuantizationManager
-    act = [(n, m) for n, m in model.named_modules()
-           if isinstance(m, QuantizationManager) and n.endswith('activation_quantizer')]
-    wts = [(n, m) for n, m in model.named_modules()
-           if isinstance(m, QuantizationManager) and n.endswith('weight_quantizer')]
-    return act, wts
+"""The BERT harness lives in the package (transformer-quantization_amd/harness/bert.py) since the
+validate_quantized CLI uses it too; tests keep importing it from here."""
+from harness.bert import *          # noqa: F401,F403
+from harness.bert import QBertForSequenceClassification, QResidualBlock, QSelfAttention, build_bert_base, quantizer_census  # noqa: F401

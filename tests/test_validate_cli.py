@@ -1,0 +1,94 @@
+"""(f4) validate_quantized: flag surface of the reference's quantization options + end-to-end runs on a
+2-layer random-init BERT with synthetic tokens."""
+import json
+import os
+
+import pytest
+import torch
+
+import validate_quantized as V
+
+
+def _cfg(*flags):
+    return V.make_config(V.build_parser().parse_args(list(flags)))
+
+
+def test_flag_surface_and_defaults():
+    c = _cfg('--qmethod', 'symmetric_uniform')
+    assert c.quant.qmethod_act == 'symmetric_uniform' and c.quant.n_bits == 8 and c.quant.n_bits_act is None
+    assert c.quant.act_quant and c.quant.weight_quant and c.quant.quant_setup == 'all'
+    assert c.act_quant.quant_method == 'running_minmax' and c.act_quant.num_batches == 1 and c.act_quant.options == {}
+    assert c.adaround.layers is None and c.adaround.iters == 10000 or c.adaround.iters > 0
+    qp = V.make_qparams(c)
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    assert qp['method'] is QMethods.symmetric_uniform and qp['act_range_method'] is RangeEstimators.running_minmax
+    assert qp['weight_range_options'] == {} and qp['per_channel_weights'] is False
+
+    c = _cfg('--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--no-act-quant', '--per-channel',
+             '--weight-quant-method', 'MSE', '--weight-opt-method', 'golden_section', '--num-candidates', '50',
+             '--act-quant-method', 'MSE', '--act-num-candidates', '64', '--act-opt-method', 'golden_section',
+             '--percentile', '99.9', '--quant-dict', "{'y': 'ngp6', 'h': 16}", '--per-token',
+             '--adaround', 'layers.0.output.dense, classifier', '--adaround-annealing', '20', '2',
+             '--adaround-no-act-func', '--no-adaround-asym')
+    assert not c.quant.act_quant and c.quant.per_channel and c.quant.dynamic            # per-token implies dynamic
+    assert c.quant.quant_dict == {'y': 'ngp6', 'h': 16}
+    assert c.adaround.layers == ('layers.0.output.dense', 'classifier') and c.adaround.annealing == (20.0, 2.0)
+    assert c.adaround.include_act_func is False and c.adaround.asym is False
+    qp = V.make_qparams(c)
+    from quantization.range_estimators import OptMethod
+    assert qp['weight_range_options'] == {'opt_method': OptMethod.golden_section, 'num_candidates': 50}
+    assert qp['act_range_options'] == {'num_candidates': 64, 'opt_method': OptMethod.golden_section, 'percentile': 99.9}
+
+
+def test_flag_cross_checks_match_the_reference():
+    with pytest.raises(ValueError, match='num_candidates'):
+        _cfg('--qmethod', 'symmetric_uniform', '--act-num-candidates', '10')            # only valid with MSE
+    with pytest.raises(ValueError, match='momentum'):
+        _cfg('--qmethod', 'symmetric_uniform', '--act-quant-method', 'MSE', '--act-momentum', '0.1')
+    with pytest.raises(ValueError, match='double'):
+        _cfg('--qmethod', 'symmetric_uniform', '--double')
+    with pytest.raises(SystemExit):
+        V.build_parser().parse_args([])                                                 # --qmethod is required
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('flags', [
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--num-est-batches', '2'],
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--per-groups', '6', '--per-groups-permute',
+     '--quant-setup', 'FP_logits', '--act-quant-method', 'current_minmax'],
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--per-embd', '--n-bits-act', '6',
+     '--quant-dict', "{'h': 16, 'Et': 4, 's': 'fp32'}", '--quant-setup', 'MSE_logits'],
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--n-bits', '4', '--n-bits-act', '8',
+     '--weight-quant-method', 'MSE', '--adaround', 'layers.0.output.dense', '--adaround-iters', '60',
+     '--adaround-num-samples', '16'],
+], ids=['w8a8', 'peg6-permute-fp-logits', 'per-embd-mixed-precision', 'w4a8-adaround'])
+def test_end_to_end_on_two_layers(flags, tmp_path, capsys):
+    rep = V.main(flags + ['--num-layers', '2', '--num-eval-batches', '2', '--output-dir', str(tmp_path)])
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])['quantizers'] == rep['quantizers']
+    f = rep['fidelity_vs_fp32']
+    # sanity only: random-init logits are tiny, so the low-bit configurations (W4, 6-bit activations) sit near 0 dB
+    assert f['samples'] == 16 and f['logit_sqnr_db'] > (3.0 if not ({'--quant-dict', '--adaround'} & set(flags)) else -10.0), f
+    sd = torch.load(os.path.join(tmp_path, 'state_dict.pth'))
+    assert any(k.endswith('activation_quantizer.quantizer._delta') for k in sd)
+    assert any(k.endswith('weight_quantizer.range_estimator.quantizer._delta') for k in sd)
+    if '--adaround' in flags:
+        sda = torch.load(os.path.join(tmp_path, 'state_dict_adaround.pth'))
+        assert any(k.endswith('.alpha') for k in sda), 'AdaRound state (alpha) must be in the checkpoint'
+        assert 'adaround' in rep['timings_s']
+
+
+@pytest.mark.gpu
+def test_state_dict_round_trip_and_fast_inference(tmp_path, capsys):
+    base = ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--num-layers', '2',
+            '--num-eval-batches', '2', '--num-est-batches', '2']
+    a = V.main(base + ['--output-dir', str(tmp_path)])
+    b = V.main(base + ['--load-state-dict', os.path.join(tmp_path, 'state_dict.pth')])
+    assert b['load_state_dict']['unexpected'] == []
+    assert abs(a['fidelity_vs_fp32']['logit_sqnr_db'] - b['fidelity_vs_fp32']['logit_sqnr_db']) < 1e-6
+    c = V.main(base + ['--load-state-dict', os.path.join(tmp_path, 'state_dict.pth'), '--fast-inference'])
+    assert abs(a['fidelity_vs_fp32']['logit_sqnr_db'] - c['fidelity_vs_fp32']['logit_sqnr_db']) < 3.0
+    from harness.bert import QResidualBlock, QSelfAttention
+    from quantization import options
+    QResidualBlock.fuse = QSelfAttention.fuse = False
+    options.INT8_LINEAR = False

@@ -1,0 +1,307 @@
+#!/usr/bin/env python
+"""validate-quantized on synthetic data.
+
+The reference's entry point (`main.py validate-quantized`, main.py:905-918) fine-tunes / loads a GLUE
+checkpoint, wraps it into the quantized model, estimates ranges, optionally runs AdaRound and evaluates
+on the GLUE dev set.  Checkpoints and datasets are not available offline and are out of scope; this
+harness keeps the QUANTIZATION flags -- same names, defaults and validation rules as
+utils/quant_click_options.py:49-353 and utils/transformer_click_options.py:403-452 -- and runs the same
+sequence on a random-init BERT with synthetic token batches:
+
+    build FP32 model -> wrap -> per-embedding / quant-dict overrides -> (permutation ranges) ->
+    range estimation over --num-est-batches -> fix ranges -> (AdaRound) -> evaluate
+
+"Evaluation" without labels is fidelity to the FP32 model on held-out synthetic batches (logit SQNR,
+arg-max agreement) plus timings.  One JSON document is printed; --output-dir additionally stores
+`state_dict.pth` (and `state_dict_adaround.pth` after AdaRound, main.py:588) whose keys follow the
+reference's naming, and --load-state-dict restores one instead of calibrating.
+
+Example:
+    python transformer-quantization_amd/validate_quantized.py --qmethod symmetric_uniform \\
+        --qmethod-act asymmetric_uniform --n-bits 8 --act-quant-method running_minmax \\
+        --num-est-batches 4 --per-groups 6 --per-groups-permute
+"""
+import argparse
+import ast
+import json
+import os
+import sys
+import time
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+import torch  # noqa: E402
+
+from quantization.adaround.config import DEFAULT_ADAROUND_CONFIG as C  # noqa: E402
+from quantization.adaround.utils import (  # noqa: E402
+    AdaRoundActQuantMode, AdaRoundInitMode, AdaRoundMode, AdaRoundTempDecayType)
+from quantization.quantizers import QMethods  # noqa: E402
+from quantization.range_estimators import OptMethod, RangeEstimators  # noqa: E402
+from utils.utils import DotDict  # noqa: E402
+
+
+def _names(enum):
+    return [m.name for m in enum]
+
+
+def _on_off(parser, name, default, help_on, off_name=None):
+    dest = name.replace('-', '_')
+    parser.add_argument('--' + name, dest=dest, action='store_true', default=default, help=help_on)
+    parser.add_argument('--' + (off_name or 'no-' + name), dest=dest, action='store_false')
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(description=__doc__.split('\n\n')[0], formatter_class=argparse.RawTextHelpFormatter)
+    g = ap.add_argument_group('quantization (utils/quant_click_options.py:49-130)')
+    g.add_argument('--qmethod', choices=_names(QMethods), required=True, help='Quantization scheme to use.')
+    g.add_argument('--qmethod-act', choices=_names(QMethods), default=None,
+                   help='Scheme for activations; defaults to --qmethod.')
+    g.add_argument('--weight-quant-method', choices=_names(RangeEstimators), default=RangeEstimators.current_minmax.name)
+    g.add_argument('--weight-opt-method', choices=_names(OptMethod), default=OptMethod.grid.name)
+    g.add_argument('--num-candidates', type=int, default=None, help='Grid points of the weight MSE search.')
+    g.add_argument('--n-bits', type=int, default=8)
+    g.add_argument('--n-bits-act', type=int, default=None)
+    g.add_argument('--per-channel', action='store_true', help='One weight range per output channel.')
+    g.add_argument('--percentile', type=float, default=None, help='Percentile clipping (weights and activations).')
+    _on_off(g, 'act-quant', True, 'Quantize activations (default).')
+    _on_off(g, 'weight-quant', True, 'Quantize weights (default).')
+    g.add_argument('--quant-setup', choices=['all', 'FP_logits', 'MSE_logits'], default='all')
+
+    g = ap.add_argument_group('activation ranges (utils/quant_click_options.py:133-196)')
+    g.add_argument('--act-quant-method', choices=_names(RangeEstimators), default=RangeEstimators.running_minmax.name)
+    g.add_argument('--act-opt-method', choices=_names(OptMethod), default=OptMethod.grid.name)
+    g.add_argument('--act-num-candidates', type=int, default=None)
+    g.add_argument('--act-momentum', type=float, default=None)
+    g.add_argument('--cross-entropy-layer', type=str, default=None)
+    g.add_argument('--num-est-batches', type=int, default=1)
+
+    g = ap.add_argument_group('transformer quantization (utils/transformer_click_options.py:403-452)')
+    g.add_argument('--est-ranges-batch-size', type=int, default=None)
+    g.add_argument('--quant-dict', type=str, default=None, help="e.g. \"{'y': 'ngp6', 'h': 16, 'Et': 4}\"")
+    g.add_argument('--per-token', action='store_true')
+    g.add_argument('--per-embd', action='store_true')
+    g.add_argument('--per-groups', type=int, default=None)
+    g.add_argument('--per-groups-permute', action='store_true')
+    g.add_argument('--per-groups-permute-shared-h', action='store_true')
+    g.add_argument('--double', action='store_true', help='Unsupported on this path (fp64 tensors are refused).')
+    g.add_argument('--dynamic', action='store_true', help='Ranges follow every batch (no fix_ranges).')
+
+    g = ap.add_argument_group('AdaRound (utils/quant_click_options.py:229-353)')
+    g.add_argument('--adaround', type=lambda s: tuple(p.strip() for p in s.split(',') if p.strip()), default=None,
+                   help="'all' or comma-separated layer names.")
+    g.add_argument('--adaround-num-samples', type=int, default=C.num_samples)
+    g.add_argument('--adaround-init', choices=AdaRoundInitMode.list_names(), default=C.init.name)
+    g.add_argument('--adaround-mode', choices=AdaRoundMode.list_names(), default=C.round_mode.name)
+    _on_off(g, 'adaround-asym', C.asym, 'Asymmetric reconstruction (quantized-input, FP32-output targets).')
+    _on_off(g, 'adaround-include-act-func', C.include_act_func, 'Reconstruct after the activation function.',
+            off_name='adaround-no-act-func')
+    g.add_argument('--adaround-lr', type=float, default=C.lr)
+    g.add_argument('--adaround-iters', type=int, default=C.iters)
+    g.add_argument('--adaround-weight', type=float, default=C.weight)
+    g.add_argument('--adaround-annealing', type=float, nargs=2, default=tuple(C.annealing))
+    g.add_argument('--adaround-decay-type', choices=AdaRoundTempDecayType.list_names(), default=C.decay_type.name)
+    g.add_argument('--adaround-decay-shape', type=float, default=C.decay_shape)
+    g.add_argument('--adaround-decay-start', type=float, default=C.decay_start)
+    g.add_argument('--adaround-warmup', type=float, default=C.warmup)
+    g.add_argument('--adaround-act-quant', choices=AdaRoundActQuantMode.list_names(), default=C.act_quant_mode.name)
+
+    g = ap.add_argument_group('synthetic workload / run control (this harness only)')
+    g.add_argument('--num-layers', type=int, default=12, help='Encoder layers of the random-init BERT-base.')
+    g.add_argument('--batch-size', type=int, default=8)
+    g.add_argument('--max-seq-length', type=int, default=128)
+    g.add_argument('--num-eval-batches', type=int, default=4)
+    g.add_argument('--seed', type=int, default=1000)
+    g.add_argument('--device', default='cuda')
+    g.add_argument('--fast-inference', action='store_true',
+                   help='Evaluate with the opt-in fused fixed-range paths (fused LN tails / attention, int8 MFMA Linears).')
+    g.add_argument('--output-dir', default=None)
+    g.add_argument('--load-state-dict', default=None, help='Skip range estimation; load ranges from this state_dict.')
+    return ap
+
+
+def make_config(args):
+    """argparse namespace -> the reference's config layout (config.quant / .act_quant / .adaround), with
+    the reference's cross-checks (quant_click_options.py:96-118, 171-193)."""
+    a = vars(args)
+    config = DotDict()
+    config.quant = DotDict({k: a[k] for k in (
+        'qmethod', 'qmethod_act', 'weight_quant_method', 'weight_opt_method', 'num_candidates', 'n_bits',
+        'n_bits_act', 'per_channel', 'percentile', 'act_quant', 'weight_quant', 'quant_setup', 'quant_dict',
+        'per_token', 'per_embd', 'per_groups', 'per_groups_permute', 'per_groups_permute_shared_h', 'dynamic')})
+    config.quant.qmethod_act = config.quant.qmethod_act or config.quant.qmethod
+    config.quant.est_ranges_batch_size = args.est_ranges_batch_size or args.batch_size
+    if config.quant.per_token:
+        config.quant.dynamic = True
+    if config.quant.quant_dict is not None:
+        config.quant.quant_dict = ast.literal_eval(config.quant.quant_dict)   # the reference uses eval()
+        if not isinstance(config.quant.quant_dict, dict):
+            raise ValueError('--quant-dict must be a python dict literal')
+    config.double = args.double
+    if args.double:
+        raise ValueError('--double is not supported: the MI355X kernels compute in fp32 (DESIGN.md section 7)')
+
+    config.act_quant = DotDict(quant_method=args.act_quant_method, cross_entropy_layer=args.cross_entropy_layer,
+                               num_batches=args.num_est_batches, options={})
+    if args.act_num_candidates is not None:
+        if args.act_quant_method != 'MSE':
+            raise ValueError('Wrong option num_candidates passed')
+        config.act_quant.options['num_candidates'] = args.act_num_candidates
+    if args.act_momentum is not None:
+        if args.act_quant_method != 'running_minmax':
+            raise ValueError('Wrong option momentum passed')
+        config.act_quant.options['momentum'] = args.act_momentum
+    if args.act_opt_method != 'grid':
+        config.act_quant.options['opt_method'] = OptMethod[args.act_opt_method]
+
+    ada = DotDict(dict(C))
+    ada.layers = args.adaround
+    ada.num_samples = args.adaround_num_samples
+    ada.init = AdaRoundInitMode[args.adaround_init]
+    ada.round_mode = AdaRoundMode[args.adaround_mode]
+    ada.asym = args.adaround_asym
+    ada.include_act_func = args.adaround_include_act_func
+    ada.lr, ada.iters, ada.weight = args.adaround_lr, args.adaround_iters, args.adaround_weight
+    ada.annealing = tuple(args.adaround_annealing)
+    ada.decay_type = AdaRoundTempDecayType[args.adaround_decay_type]
+    ada.decay_shape, ada.decay_start, ada.warmup = args.adaround_decay_shape, args.adaround_decay_start, args.adaround_warmup
+    ada.act_quant_mode = AdaRoundActQuantMode[args.adaround_act_quant]
+    config.adaround = ada
+    return config
+
+
+def make_qparams(config):
+    """config -> keyword arguments of the Quant* wrappers (counterpart of quant_click_options.py:356-380)."""
+    w_opts = {}
+    if config.quant.weight_quant_method in ('MSE', 'cross_entropy'):
+        w_opts['opt_method'] = OptMethod[config.quant.weight_opt_method]
+    if config.quant.num_candidates is not None:
+        w_opts['num_candidates'] = config.quant.num_candidates
+    a_opts = config.act_quant.options
+    if config.quant.percentile is not None:
+        a_opts['percentile'] = config.quant.percentile
+    return dict(method=QMethods[config.quant.qmethod], act_method=QMethods[config.quant.qmethod_act],
+                n_bits=config.quant.n_bits, n_bits_act=config.quant.n_bits_act,
+                per_channel_weights=config.quant.per_channel, percentile=config.quant.percentile,
+                quant_setup=config.quant.quant_setup,
+                weight_range_method=RangeEstimators[config.quant.weight_quant_method], weight_range_options=w_opts,
+                act_range_method=RangeEstimators[config.act_quant.quant_method], act_range_options=a_opts)
+
+
+def synthetic_batches(n, batch_size, seq_len, vocab, seed, with_labels=False):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        ids = torch.randint(1000, vocab, (batch_size, seq_len), generator=g)
+        ids[:, 0], ids[:, -1] = 101, 102                      # [CLS] ... [SEP]
+        out.append((ids, torch.randint(0, 2, (batch_size,), generator=g)) if with_labels else (ids,))
+    return out
+
+
+def _timed(fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize()
+    return r, time.perf_counter() - t0
+
+
+def run(config, args):
+    from harness.bert import (QResidualBlock, QSelfAttention, apply_activation_granularity, apply_quant_dict,
+                              build_bert_base, estimate_permutation_ranges, quantizer_census)
+    from quantization import _hip, options
+    from utils.utils import pass_data_for_range_estimation, seed_all
+    if not str(args.device).startswith('cuda') or not torch.cuda.is_available():
+        raise SystemExit('validate_quantized needs a ROCm GPU: the quantization kernels have no CPU fallback')
+    assert _hip.backend().name == 'hip'
+    seed_all(args.seed)
+    dev = torch.device(args.device)
+    report = {'config': {'quant': dict(config.quant), 'act_quant': {k: str(v) for k, v in config.act_quant.items()}},
+              'workload': f'random-init BERT-base ({args.num_layers} layers), synthetic tokens '
+                          f'[{args.batch_size},{args.max_seq_length}]', 'timings_s': {}}
+
+    qp = make_qparams(config)
+    model, hf = build_bert_base(seed=args.seed, num_layers=args.num_layers, **qp)
+    model, hf = model.to(dev).eval(), hf.to(dev).eval()
+    vocab = hf.config.vocab_size
+    est = synthetic_batches(max(config.act_quant.num_batches, 1), config.quant.est_ranges_batch_size,
+                            args.max_seq_length, vocab, args.seed + 1, with_labels=True)
+    evalb = synthetic_batches(args.num_eval_batches, args.batch_size, args.max_seq_length, vocab, args.seed + 2)
+
+    n_sites = apply_activation_granularity(model, config.quant.per_token, config.quant.per_embd, config.quant.per_groups,
+                                           config.quant.per_groups_permute or config.quant.per_groups_permute_shared_h)
+    apply_quant_dict(model, config.quant.quant_dict)
+    acts, wts = quantizer_census(model)
+    report['quantizers'] = {'activation': len(acts), 'weight': len(wts), 'per_embedding_sites': n_sites}
+
+    with torch.no_grad():
+        if args.load_state_dict:
+            # ranges come from the checkpoint: initialise the buffers' shapes with one batch, then load
+            pass_data_for_range_estimation(est[:1], model, config.quant.act_quant, config.quant.weight_quant, 1)
+            missing = model.load_state_dict(torch.load(args.load_state_dict, map_location=dev), strict=False)
+            report['load_state_dict'] = {'missing': list(missing.missing_keys), 'unexpected': list(missing.unexpected_keys)}
+        else:
+            if config.quant.per_groups_permute or config.quant.per_groups_permute_shared_h:
+                _, t = _timed(lambda: estimate_permutation_ranges(model, est, config.quant.per_groups_permute_shared_h))
+                report['timings_s']['permutation_ranges'] = t
+            _, t = _timed(lambda: pass_data_for_range_estimation(
+                est, model, config.quant.act_quant, config.quant.weight_quant, config.act_quant.num_batches,
+                cross_entropy_layer=config.act_quant.cross_entropy_layer))
+            report['timings_s']['range_estimation'] = t
+        model.set_quant_state(config.quant.weight_quant, config.quant.act_quant)
+        if not config.quant.dynamic:
+            model.fix_ranges()
+
+    if config.quant.weight_quant and config.adaround.layers is not None:
+        from utils.adaround_utils import apply_adaround_to_model
+        cfg = DotDict(adaround=config.adaround, quant=config.quant, act_quant=config.act_quant)
+        ada_data = synthetic_batches(max(1, config.adaround.num_samples // args.batch_size), args.batch_size,
+                                     args.max_seq_length, vocab, args.seed + 3, with_labels=True)
+        _, t = _timed(lambda: apply_adaround_to_model(cfg, model, data_loader=ada_data, range_est_data_loader=est,
+                                                      batch_size=args.batch_size))
+        report['timings_s']['adaround'] = t
+        if args.output_dir:
+            os.makedirs(args.output_dir, exist_ok=True)
+            torch.save(model.state_dict(), os.path.join(args.output_dir, 'state_dict_adaround.pth'))
+
+    if args.fast_inference:
+        QResidualBlock.fuse = QSelfAttention.fuse = True
+        options.INT8_LINEAR = True
+    sig = noise = 0.0
+    agree = total = 0
+    with torch.no_grad():
+        model.eval()
+
+        def evaluate():
+            nonlocal sig, noise, agree, total
+            for (ids,) in evalb:
+                ids = ids.to(dev)
+                ref = hf(input_ids=ids).logits.float()
+                out = model(ids).float()
+                sig += float((ref.double() ** 2).sum())
+                noise += float(((ref - out).double() ** 2).sum())
+                agree += int((ref.argmax(-1) == out.argmax(-1)).sum())
+                total += ids.shape[0]
+        _, t = _timed(evaluate)
+    report['timings_s']['evaluation_incl_fp32_reference'] = t
+    import math
+    report['fidelity_vs_fp32'] = {'logit_sqnr_db': (10 * math.log10(sig / noise)) if noise > 0 else float('inf'),
+                                  'argmax_agreement': agree / max(total, 1), 'samples': total}
+    if args.output_dir:
+        os.makedirs(args.output_dir, exist_ok=True)
+        torch.save(model.state_dict(), os.path.join(args.output_dir, 'state_dict.pth'))
+        report['state_dict'] = os.path.join(args.output_dir, 'state_dict.pth')
+    return report
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    config = make_config(args)
+    report = run(config, args)
+    print(json.dumps(report, default=str))
+    return report
+
+
+if __name__ == '__main__':
+    main()
