@@ -1,0 +1,122 @@
+"""(f3) tq_attention_i8_fwd: the attention core on int8 grid indices.  Reference = the layered chain on
+the dequantised tensors evaluated in float64 for the two GEMMs (i.e. the exact values the reference's
+fp32 GEMMs approximate) with the oracle's quantizers and torch's fp32 softmax in between.  exp() / row
+sums differ in the last ulp between implementations, so a probability (or a context value) within
+round-off of a rounding boundary may land one grid step away: bars are >= 99.5 % of the context outputs
+bit-identical, none further than 2 steps (a flipped probability index moves a context value by at most
+s_p |v|, which can cross one more boundary)."""
+import math
+
+import pytest
+import torch
+
+from oracle import tq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(lo, hi):
+    d, z = O.asym_params_from_range(lo, hi, 8)
+    return d, z
+
+
+def _dq(idx8, p):
+    d, z = p
+    zp = torch.clamp(torch.round(z), 0, 255)
+    return (d * ((idx8.double() + 128) - zp.double()))
+
+
+def _reference(qi, ki, vi, H, mask, pq, pk, pv, ps, pp, pc):
+    B, T, D = qi.shape
+    dh = D // H
+    split = lambda x: x.view(B, T, H, dh).permute(0, 2, 1, 3)
+    Q, K, V = split(_dq(qi, pq)), split(_dq(ki, pk)), split(_dq(vi, pv))
+    S = torch.matmul(Q, K.transpose(-1, -2)).float()
+    if ps is not None:
+        S = O.fake_quant(S, ps[0], ps[1], 8, False)[1]
+    S = S / math.sqrt(dh)
+    if mask is not None:
+        S = S + mask.view(B, 1, 1, T)
+    P = O.fake_quant(torch.softmax(S, dim=-1), pp[0], pp[1], 8, False)[1]
+    C = torch.matmul(P.double(), V).float().permute(0, 2, 1, 3).reshape(B, T, D)
+    if pc is not None:
+        return O.fake_quant(C, pc[0], pc[1], 8, False)
+    return None, C
+
+
+@pytest.mark.parametrize('T', [64, 128, 256])
+def test_attention_i8_vs_float64_reference(T):
+    from quantization import _hip
+    be = _hip.backend()
+    B, H = 2, 3
+    D = H * 64
+    g = torch.Generator().manual_seed(T)
+    qi, ki, vi = (torch.randint(-128, 128, (B, T, D), generator=g, dtype=torch.int8) for _ in range(3))
+    keep = (torch.rand(B, T, generator=g) > 0.25).float()
+    keep[:, 0] = 1
+    mask = (1 - keep) * -10000.0
+    pq, pk, pv = _params(-3.0, 2.5), _params(-2.0, 3.0), _params(-1.5, 1.0)
+    ps, pp, pc = _params(-60.0, 70.0), _params(0.0, 0.6), _params(-1.2, 0.9)
+    dev = lambda t: None if t is None else t.cuda()
+    k7 = lambda p: None if p is None else (dev(p[0]), dev(p[1]), None, 8, False, False, 1e-8)
+    for use_s, use_c, use_m in ((1, 1, 1), (0, 1, 1), (1, 1, 0), (1, 0, 1)):
+        ref_idx, ref = _reference(qi, ki, vi, H, mask if use_m else None, pq, pk, pv,
+                                  ps if use_s else None, pp, pc if use_c else None)
+        out = be.attention_i8(dev(qi), dev(ki), dev(vi), H, dev(mask) if use_m else None, 8.0, k7(pq), k7(pk), k7(pv),
+                              k7(ps) if use_s else None, k7(pp), k7(pc) if use_c else None, want_idx=bool(use_c))
+        ctx = (out[0] if use_c else out).cpu()
+        diff = (ctx - ref).abs()
+        if use_c:
+            step = float(pc[0])
+            assert float((diff == 0).float().mean()) >= 0.995, (T, use_s, use_m, float((diff == 0).float().mean()))
+            assert float(diff.max()) <= 2.01 * step
+            idx = out[1].cpu().float() + 128
+            assert torch.equal(idx * 0 + ctx, ctx) and float((idx - ref_idx).abs().max()) <= 2
+            # the emitted indices are the indices of the emitted values
+            zp = torch.clamp(torch.round(pc[1]), 0, 255)
+            assert torch.equal(pc[0] * (idx - zp), ctx)
+        else:
+            # un-quantized context: a flipped probability index shifts a value by <= s_p * max|v|
+            tol = float(pp[0]) * float(_dq(vi, pv).abs().max()) * 2
+            assert float(diff.max()) <= tol, (float(diff.max()), tol)
+            assert float((diff <= 1e-5 * ref.abs() + 1e-6).float().mean()) >= 0.9
+
+
+def test_attention_i8_rejects_unsupported():
+    from quantization import _hip
+    be = _hip.backend()
+    z = lambda *s: torch.zeros(*s, dtype=torch.int8, device='cuda')
+    p = lambda: (torch.tensor(0.1).cuda(), torch.tensor(3.0).cuda(), None, 8, False, False, 1e-8)
+    with pytest.raises(_hip.TQError):       # T = 96
+        be.attention_i8(z(1, 96, 128), z(1, 96, 128), z(1, 96, 128), 2, None, 8.0, p(), p(), p(), None, p(), None)
+    with pytest.raises(_hip.TQError):       # head_dim = 32
+        be.attention_i8(z(1, 64, 128), z(1, 64, 128), z(1, 64, 128), 4, None, 8.0, p(), p(), p(), None, p(), None)
+    sym = (torch.tensor(0.1).cuda(), None, torch.tensor(True).cuda(), 8, True, False, 1e-8)
+    with pytest.raises(_hip.TQError):       # symmetric probabilities grid
+        be.attention_i8(z(1, 64, 128), z(1, 64, 128), z(1, 64, 128), 2, None, 8.0, p(), p(), p(), None, sym, None)
+
+
+def test_bert_forward_with_integer_attention_matches_layered():
+    from tests.test_bert_e2e import _build, _fixture, _calibrate_and_run
+    from tests.harness_bert import QResidualBlock, QSelfAttention
+    from quantization import options
+    z = _fixture()
+    model, _ = _build('cuda')
+    ids = torch.from_numpy(z['input_ids']).cuda()
+    layered = _calibrate_and_run(model, ids)
+    QResidualBlock.fuse = QSelfAttention.fuse = True
+    options.INT8_LINEAR = True
+    try:
+        from quantization import _hip
+        calls = []
+        orig = _hip.HipBackend.attention_i8
+        _hip.HipBackend.attention_i8 = lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1]
+        with torch.no_grad():
+            fused = model(ids)
+        _hip.HipBackend.attention_i8 = orig
+    finally:
+        QResidualBlock.fuse = QSelfAttention.fuse = False
+        options.INT8_LINEAR = False
+    assert len(calls) == 12, 'the integer attention kernel must serve all 12 layers'
+    span = float(layered.max() - layered.min())
+    assert float((fused - layered).abs().max()) <= 0.10 * span

@@ -71,3 +71,4 @@ with torch.no_grad():
         out4=model(ids)
     print('fixed-range forward ms (hipGraph, int8 + fused tails + fused attention probs)', t(lambda: g4.replay(), n=30))
     print('max |logit diff| vs fp32-simulated GEMMs', float((out4-out).abs().max()))
+print('(the last configuration above already routes the attention core through tq_attention_i8_fwd when the tags are present)')

@@ -62,7 +62,14 @@ class QSelfAttention(QuantizedModel):
     fuse = False   # set True: scores-quant -> scale -> mask -> softmax -> probs-quant as one kernel
 
     def forward(self, h, mask):
-        q, k, v = self._split(self.query(h)), self._split(self.key(h)), self._split(self.value(h))
+        qo, ko, vo = self.query(h), self.key(h), self.value(h)
+        if self.fuse:
+            from quantization.fused import quantized_attention
+            ctx = quantized_attention(qo, ko, vo, mask, self.heads, self.attn_scores_act_quantizer,
+                                      self.attn_probs_act_quantizer, self.context_act_quantizer)
+            if ctx is not None:                  # whole attention core as one integer kernel
+                return ctx
+        q, k, v = self._split(qo), self._split(ko), self._split(vo)
         raw = torch.matmul(q, k.transpose(-1, -2))
         if self.fuse:
             from quantization.fused import scores_softmax_quant

@@ -45,6 +45,7 @@ SIGNATURES = {
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
     'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
     'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
+    'tq_attention_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u64, _vp, _f, _QP, _QP, _QP, _QP, _QP, _QP, _vp]),
     'tq_scores_softmax_quant_fwd': (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _f, _QP, _QP, _vp]),
     'tq_rowsum_i8': (_int, [_vp, _vp, _u64, _u64, _vp]),
     'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
@@ -205,6 +206,22 @@ class HipBackend:
             _ptr(ln_bias.detach().float().contiguous()), float(ln_eps), refs[2], _stream())
         _check(rc, self.lib)
         return (y, idx) if want_idx else y
+
+    def attention_i8(self, q_idx, k_idx, v_idx, num_heads, mask, denom, q_q, q_k, q_v, q_scores, q_probs, q_ctx,
+                     want_idx=False):
+        """Quantized attention core on int8 indices [B, T, H * 64]; every q_* is a per-tensor 7-tuple
+        (q_scores / q_ctx may be None).  -> ctx fp32 [B, T, H * 64] (, int8 indices of ctx)."""
+        _need_device(q_idx, 'attention_i8')
+        B, T, D = q_idx.shape
+        ctx = torch.empty(q_idx.shape, dtype=torch.float32, device=q_idx.device)
+        ctx_idx = torch.empty(q_idx.shape, dtype=torch.int8, device=q_idx.device) if want_idx else None
+        descs = [None if q is None else self._qdesc(*q, 1, 1) for q in (q_q, q_k, q_v, q_scores, q_probs, q_ctx)]
+        refs = [None if dsc is None else C.byref(dsc) for dsc in descs]
+        rc = self.lib.tq_attention_i8_fwd(_ptr(q_idx.contiguous()), _ptr(k_idx.contiguous()), _ptr(v_idx.contiguous()),
+                                          _ptr(ctx), _ptr(ctx_idx), B, T, num_heads, D // num_heads, _ptr(mask),
+                                          float(denom), *refs, _stream())
+        _check(rc, self.lib)
+        return (ctx, ctx_idx) if want_idx else ctx
 
     def scores_softmax_quant(self, scores, mask, rows_per_mask, denom, q_scores, q_probs):
         """probs = Q_probs(softmax(Q_scores(scores) / denom + mask)); q_* None or per-tensor 7-tuples."""

@@ -87,3 +87,58 @@ def scores_softmax_quant(scores_quantizer, probs_quantizer, scores, mask, denom)
     m = None if mask is None else mask.reshape(mask.shape[0], Tk).float().contiguous()
     return _hip.backend().scores_softmax_quant(scores, m, scores.shape[1] * scores.shape[2], denom,
                                                arg(q1), arg(q2))
+
+
+def _int8_source(t):
+    """(int8 indices, 7-tuple) of a tensor produced by a fixed per-tensor asymmetric <= 8-bit quantizer
+    that emitted its indices (provenance tags set by QuantizationManager / the integer Linear)."""
+    q, idx = getattr(t, '_tq_quantizer', None), getattr(t, '_tq_idx', None)
+    if (q is None or idx is None or idx.shape != t.shape or q.symmetric or q.n_bits > 8
+            or q.scale_domain != 'linear' or q._delta.numel() != 1):
+        return None
+    return idx, (q._delta, q._zero_float, None, q.n_bits, False, False, q.eps)
+
+
+def quantized_attention(query, key, value, mask, num_heads, scores_quantizer, probs_quantizer,
+                        context_quantizer):
+    """Attention core of a quantized BERT layer (reference models/quantized_bert.py:135-213) on the
+    OUTPUTS of the quantized query / key / value Linears, each [B, T, H * d]:
+
+        ctx = context_quantizer(merge_heads(probs_quantizer(softmax(
+                  scores_quantizer(Q K^T) / sqrt(d) + mask)) V))
+
+    Runs as one integer kernel (tq_attention_i8_fwd) when options.INT8_LINEAR is on, the three inputs
+    carry their int8 grid indices, every quantizer involved is fixed, per-tensor (asymmetric <= 8 bit
+    for Q, K, V and the probabilities), T in {64, 128, 256} and d == 64.  Returns None otherwise: the
+    caller then runs the layered modules."""
+    if not options.INT8_LINEAR or query.dim() != 3 or not query.is_cuda:
+        return None
+    if torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad):
+        return None
+    B, T, D = query.shape
+    if D % num_heads or D // num_heads != 64 or T not in (64, 128, 256):
+        return None
+    srcs = [_int8_source(t) for t in (query, key, value)]
+    qs = _fixed_per_tensor(scores_quantizer._quant_a, scores_quantizer.activation_quantizer)
+    qp = _fixed_per_tensor(probs_quantizer._quant_a, probs_quantizer.activation_quantizer)
+    qc = _fixed_per_tensor(context_quantizer._quant_a, context_quantizer.activation_quantizer)
+    if None in srcs or 'no' in (qs, qp, qc) or qp == 'off':
+        return None
+    if qp[4] or qp[5] or qp[3] > 8:                       # probabilities: asymmetric, linear, <= 8 bit
+        return None
+    if mask is not None:
+        if not (mask.dim() == 4 and mask.shape[0] == B and mask.shape[1] == 1 and mask.shape[2] == 1
+                and mask.shape[3] == T):
+            return None
+        mask = mask.reshape(B, T).float().contiguous()
+    arg = lambda q: None if q == 'off' else q
+    cq = context_quantizer.activation_quantizer.quantizer if qc != 'off' else None
+    want_idx = cq is not None and not cq.symmetric and cq.n_bits <= 8
+    out = _hip.backend().attention_i8(srcs[0][0], srcs[1][0], srcs[2][0], num_heads, mask, float(D // num_heads) ** 0.5,
+                                      srcs[0][1], srcs[1][1], srcs[2][1], arg(qs), qp, arg(qc), want_idx=want_idx)
+    ctx = out[0] if want_idx else out
+    if cq is not None:
+        ctx._tq_quantizer = cq
+        if want_idx:
+            ctx._tq_idx = out[1]
+    return ctx
