@@ -65,17 +65,24 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
   const size_t base = (size_t)b * T * row_stride + (size_t)h * kHeadDim;
 
   // ---- V^T -> LDS with the key permutation of the accumulator layout -------------------------------
-  for (uint32_t c = tid; c < (uint32_t)T * 4; c += kAttnThreads) {
-    const uint32_t key = c >> 2, part = c & 3;
-    const v4i raw = *reinterpret_cast<const v4i*>(p.v + base + (size_t)key * row_stride + part * 16);
-    const uint32_t slot = key_slot(key);
+  // One work item = 4 consecutive keys x 16 head dims: four 16-byte loads, 4x4 byte transposes in
+  // registers, sixteen 32-bit LDS stores (keys 4m .. 4m+3 are adjacent slots of one V^T row).
+  for (uint32_t c = tid; c < (uint32_t)T; c += kAttnThreads) {
+    const uint32_t key4 = (c >> 2) * 4, part = c & 3;
+    v4i raw[4];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const uint32_t word = (uint32_t)raw[w];
+    for (int kk = 0; kk < 4; ++kk)
+      raw[kk] = *reinterpret_cast<const v4i*>(p.v + base + (size_t)(key4 + kk) * row_stride + part * 16);
+    const uint32_t slot = key_slot(key4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        s_vt[(part * 16 + w * 4 + e) * PITCH + slot] = (int8_t)((word >> (8 * e)) & 0xff);
-    }
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) word |= (((uint32_t)raw[kk][w] >> (8 * e)) & 0xffu) << (8 * kk);
+        *reinterpret_cast<uint32_t*>(s_vt + (part * 16 + w * 4 + e) * PITCH + slot) = word;
+      }
   }
 
   // ---- S^T = K Q^T for this wave's 16 queries --------------------------------------------------------
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
   QP ps = {1.f, 0.f, 0.f, 0.f}, pc = {1.f, 0.f, 0.f, 0.f};
   if (p.has_scores) ps = make_qp(p.q_scores, 0);
   if (p.has_ctx) pc = make_qp(p.q_ctx, 0);
+  const float rcp_s = guarded_rcp(ps.scale), rcp_p = guarded_rcp(pp.scale);   // rne(x / scale), tq_device.h
 
   const int rsq = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fq, zero4, 0, 0, 0)[0];   // sum_d a'_q of column r16
   const int q_const = ck * rsq + kHeadDim * cq * ck;
@@ -106,7 +114,12 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v = (float)(acc[r] + cq * rsk[r] + q_const) * s_qk;
-      if (p.has_scores) v = q_dequant(q_index(v, ps), ps);
+      if (p.has_scores) {
+        bool ok = true;
+        float hq = rne_quot_try(v, rcp_s, ok);
+        if (!ok) hq = rintf(v / ps.scale);
+        v = q_dequant(clamp_nanprop(hq + ps.zp, ps.lo, ps.hi), ps);
+      }
       v = v / p.denom;
       if (p.mask) v = v + mk[r];
       sc[t][r] = v;
@@ -133,7 +146,11 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
       uint32_t word = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int a = (int)q_index(sc[s * 4 + tt][r] / sum, pp) - 128;
+        const float pr = sc[s * 4 + tt][r] / sum;
+        bool ok = true;
+        float hq = rne_quot_try(pr, rcp_p, ok);
+        if (!ok) hq = rintf(pr / pp.scale);
+        const int a = (int)clamp_nanprop(hq + pp.zp, pp.lo, pp.hi) - 128;
         word |= ((uint32_t)a & 0xffu) << (8 * r);
       }
       fp[s][tt] = (int)word;
