@@ -204,6 +204,17 @@ int tq_calibrate_minmax(const void* x, uint64_t n, int dtype, uint64_t n_params,
                         float* zero_float, uint8_t* signed_flag, void* y, void* workspace,
                         size_t workspace_bytes, tq_stream_t stream);
 
+/* The same step for ONE range (per-tensor quantizer), as 2 launches instead of 4: the statistics kernel's
+ * last-finishing block (ticket in *counter) also applies the estimator rule and writes cur_min / cur_max
+ * / delta / zero_float | signed_flag (each [1]); then the quantizer runs if y != NULL.  *counter
+ * (device, 4 bytes) must be 0 on entry and is 0 again when the kernel has finished; workspace as
+ * tq_calibrate_workspace_bytes(n, 1, 1).  The result does not depend on which block finishes last.  */
+int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mode, const float* prev_min,
+                        const float* prev_max, float* cur_min, float* cur_max, double momentum,
+                        int n_bits, int symmetric, float eps, int log_domain, float* delta,
+                        float* zero_float, uint8_t* signed_flag, void* y, void* workspace,
+                        size_t workspace_bytes, uint32_t* counter, tq_stream_t stream);
+
 /* PEG phase 1 (range_estimators.py:68-80): ranges = max - min per embedding dim; on later
  * batches the reference stores 0.1*r + 0.9*r of the NEW ranges (quirk q4).                    */
 int tq_axis_ranges(const float* new_min, const float* new_max, float* ranges, uint64_t n,

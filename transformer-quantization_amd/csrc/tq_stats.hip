@@ -432,6 +432,108 @@ __global__ __launch_bounds__(1024) void calib_update_k(int mode, const float* __
   }
 }
 
+// ------------------------------------------------------------------------------ per-tensor calibration, one launch
+// Statistics + estimator update + range -> parameters for ONE range (per-tensor quantizers: 161 of the
+// 161 activation sites of the BERT W8A8 config).  Every block reduces its contiguous chunk to a partial
+// (as mm_rows does) and takes a ticket; the block that draws the last ticket reduces the partials
+// (min / max are order-independent, so the result does not depend on which block that is), applies the
+// estimator rule and writes state and quantizer parameters.  2 dependent launches per calibrating
+// call (this + the quantizer) instead of 4.  `counter` must be 0 on entry and is 0 again on exit.
+template <int DT, bool VEC>
+__global__ __launch_bounds__(kBlock) void calib_tensor_k(const void* __restrict__ x, uint64_t n, float* ws,
+                                                         uint32_t* counter, int mode, const float* prev_min,
+                                                         const float* prev_max, float* cur_min, float* cur_max,
+                                                         double momentum_d, int n_bits, int symmetric, float eps,
+                                                         int log_domain, float* delta, float* zero_float,
+                                                         uint8_t* signed_flag) {
+  constexpr int V = Store<DT>::kVec;
+  typedef typename Store<DT>::elem_t E;
+  __shared__ float s_red[2][kBlock / kWave];
+  __shared__ uint32_t s_ticket;
+  MinMax acc;
+  if (VEC) {
+    const u32x4* xv = static_cast<const u32x4*>(x);
+    const uint64_t n_all = n / V;
+    const uint64_t chunk = (n_all + gridDim.x - 1) / gridDim.x;
+    const uint64_t n_vec = min(n_all, ((uint64_t)blockIdx.x + 1) * chunk);
+    constexpr int U = 4;
+    uint64_t i = (uint64_t)blockIdx.x * chunk + threadIdx.x;
+    for (; i + (U - 1) * (uint64_t)kBlock < n_vec; i += U * (uint64_t)kBlock) {
+      u32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = ld_stream(xv + i + u * (uint64_t)kBlock);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f[V];
+        Store<DT>::unpack(v[u], f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc.add(f[j]);
+      }
+    }
+    for (; i < n_vec; i += kBlock) {
+      float f[V];
+      Store<DT>::unpack(xv[i], f);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc.add(f[j]);
+    }
+    if (blockIdx.x == 0 && n_all * V + threadIdx.x < n)                      // ragged tail (< V elements)
+      acc.add(Store<DT>::load1(static_cast<const E*>(x) + n_all * V + threadIdx.x));
+  } else {
+    const E* xs = static_cast<const E*>(x);
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+      acc.add(Store<DT>::load1(xs + i));
+  }
+  const int w = threadIdx.x / kWave;
+  float mn = wave_min(acc.lo()), mx = wave_max(acc.hi());
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_red[0][w] = mn; s_red[1][w] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kBlock / kWave; ++k) { mn = min_nanprop(mn, s_red[0][k]); mx = max_nanprop(mx, s_red[1][k]); }
+    __hip_atomic_store(ws + 2 * blockIdx.x, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ws + 2 * blockIdx.x + 1, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_ticket = atomicAdd(counter, 1u);
+  }
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return;
+
+  // ---- last block: partials -> statistic -> estimator state -> quantizer parameters -------------------------
+  __threadfence();
+  mn = kInf; mx = -kInf;
+  for (uint32_t b = threadIdx.x; b < gridDim.x; b += kBlock) {
+    mn = min_nanprop(mn, __hip_atomic_load(ws + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    mx = max_nanprop(mx, __hip_atomic_load(ws + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  mn = wave_min(mn); mx = wave_max(mx);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_red[0][w] = mn; s_red[1][w] = mx; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int k = 1; k < kBlock / kWave; ++k) { mn = min_nanprop(mn, s_red[0][k]); mx = max_nanprop(mx, s_red[1][k]); }
+  float a = mn, b = mx;
+  if (!(mode == TQ_EST_CURRENT || prev_min == nullptr)) {
+    const float pa = prev_min[0], pb = prev_max[0];
+    const float om = (float)(1.0 - momentum_d), mom = (float)momentum_d;
+    if (mode == TQ_EST_ALL) { a = min_nanprop(pa, a); b = max_nanprop(pb, b); }     // range_estimators.py:162-167
+    else { a = om * a + mom * pa; b = om * b + mom * pb; }                          // :209-214
+  }
+  cur_min[0] = a;
+  cur_max[0] = b;
+  const float lo = min_nanprop(a, 0.0f), hi = max_nanprop(b, eps);                  // quantizers.py:258-259
+  if (symmetric) {
+    const bool sgn = lo < 0.0f;
+    signed_flag[0] = sgn ? 1 : 0;
+    const float d = max_nanprop(fabsf(lo), hi) / grid_top(n_bits - (sgn ? 1 : 0));  // :334-344
+    delta[0] = log_domain ? logf(d) : d;
+  } else {
+    const float d = (hi - lo) / grid_top(n_bits);                                   // :276-277
+    zero_float[0] = (-lo) / d;
+    delta[0] = log_domain ? logf(d) : d;
+  }
+  __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
 }  // namespace tq
 
 using namespace tq;
@@ -537,6 +639,45 @@ extern "C" int tq_calibrate_minmax(const void* x, uint64_t n, int dtype, uint64_
   if (int e = check_launch("calib_update_k")) return e;
   if (y != nullptr) {
     tq_quantizer q{delta, zero_float, signed_flag, n_bits, symmetric, log_domain, eps, n_params, inner};
+    return tq_fake_quant_fwd(x, y, nullptr, TQ_IDX_NONE, n, dtype, &q, stream);
+  }
+  return TQ_OK;
+}
+
+extern "C" int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mode, const float* prev_min,
+                                   const float* prev_max, float* cur_min, float* cur_max, double momentum, int n_bits,
+                                   int symmetric, float eps, int log_domain, float* delta, float* zero_float,
+                                   uint8_t* signed_flag, void* y, void* workspace, size_t workspace_bytes,
+                                   uint32_t* counter, tq_stream_t stream) {
+  TQ_REQUIRE(x && n > 0, "tq_calibrate_tensor: empty tensor has no min/max");
+  TQ_REQUIRE(cur_min && cur_max && delta && counter, "tq_calibrate_tensor: NULL output");
+  TQ_REQUIRE((prev_min == nullptr) == (prev_max == nullptr), "tq_calibrate_tensor: prev_min / prev_max mismatch");
+  TQ_REQUIRE(symmetric ? signed_flag != nullptr : zero_float != nullptr, "tq_calibrate_tensor: missing parameter output");
+  TQ_REQUIRE(mode >= TQ_EST_CURRENT && mode <= TQ_EST_RUNNING, "tq_calibrate_tensor: bad mode %d", mode);
+  TQ_REQUIRE(n_bits >= 1 && n_bits <= 24, "tq_calibrate_tensor: n_bits=%d", n_bits);
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_calibrate_tensor: bad dtype %d", dtype);
+  const int V = dtype == TQ_F32 ? 4 : 8;
+  const MMPlan pl = plan_minmax(n, 1, 1, V, aligned16(x));
+  TQ_REQUIRE(workspace && workspace_bytes >= (size_t)pl.gx * 2 * sizeof(float), "tq_calibrate_tensor: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* ws = static_cast<float*>(workspace);
+  const bool vec = aligned16(x);
+#define TQ_CALIB(DTV)                                                                                              \
+  if (vec) hipLaunchKernelGGL((calib_tensor_k<DTV, true>), dim3(pl.gx), dim3(kBlock), 0, st, x, n, ws, counter, mode, prev_min, \
+                              prev_max, cur_min, cur_max, momentum, n_bits, symmetric, eps, log_domain, delta, zero_float,     \
+                              signed_flag);                                                                          \
+  else hipLaunchKernelGGL((calib_tensor_k<DTV, false>), dim3(pl.gx), dim3(kBlock), 0, st, x, n, ws, counter, mode, prev_min,   \
+                          prev_max, cur_min, cur_max, momentum, n_bits, symmetric, eps, log_domain, delta, zero_float,         \
+                          signed_flag)
+  switch (dtype) {
+    case TQ_F32: TQ_CALIB(TQ_F32); break;
+    case TQ_BF16: TQ_CALIB(TQ_BF16); break;
+    default: TQ_CALIB(TQ_F16); break;
+  }
+#undef TQ_CALIB
+  if (int e = check_launch("calib_tensor_k")) return e;
+  if (y != nullptr) {
+    tq_quantizer q{delta, zero_float, signed_flag, n_bits, symmetric, log_domain, eps, 1, 1};
     return tq_fake_quant_fwd(x, y, nullptr, TQ_IDX_NONE, n, dtype, &q, stream);
   }
   return TQ_OK;

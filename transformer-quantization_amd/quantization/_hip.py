@@ -57,6 +57,8 @@ SIGNATURES = {
     'tq_calibrate_workspace_bytes': (_sz, [_u64, _u64, _u64]),
     'tq_calibrate_minmax': (_int, [_vp, _u64, _int, _u64, _u64, _int, _vp, _vp, _vp, _vp, _d, _u64, _vp, _int,
                                    _int, _f, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'tq_calibrate_tensor': (_int, [_vp, _u64, _int, _int, _vp, _vp, _vp, _vp, _d, _int, _int, _f, _int, _vp, _vp, _vp,
+                                   _vp, _vp, _sz, _vp, _vp]),
     'tq_range_update': (_int, [_int, _vp, _vp, _vp, _vp, _u64, _int, _d, _u64, _vp, _vp]),
     'tq_axis_ranges': (_int, [_vp, _vp, _vp, _u64, _int, _vp]),
     'tq_set_range_asym': (_int, [_vp, _vp, _u64, _int, _f, _int, _vp, _vp, _vp]),
@@ -110,7 +112,14 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (the raw getter is ~10x cheaper than
+    building a torch.cuda.Stream object per call; launch-bound calibration makes 161 such calls per batch)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -135,6 +144,7 @@ class HipBackend:
     def __init__(self):
         self.lib = load_library()
         self._ws = {}
+        self._counters = {}      # zeroed ticket words of tq_calibrate_tensor, one per (device, stream)
 
     # -- helpers -------------------------------------------------------------------------
     def _workspace(self, device, nbytes):
@@ -327,6 +337,25 @@ class HipBackend:
         _need_device(x, 'calibrate_minmax')
         x = x.contiguous()
         dev = x.device
+        if n_params == 1 and not n_groups:
+            # one range: statistics + update + parameters in one launch (tq_calibrate_tensor)
+            st = _stream()
+            key = (dev.index, st)
+            counter = self._counters.get(key)
+            if counter is None:
+                counter = self._counters[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+            out = torch.empty(4, dtype=torch.float32, device=dev)        # cur_min, cur_max, delta, zero_float
+            signed = torch.empty((), dtype=torch.bool, device=dev) if symmetric else None
+            y = torch.empty_like(x) if want_y else None
+            ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), 1, 1))
+            base = out.data_ptr()
+            rc = self.lib.tq_calibrate_tensor(
+                x.data_ptr(), x.numel(), _dtype_code(x, 'calibrate_minmax'), mode, _ptr(prev_min), _ptr(prev_max),
+                base, base + 4, float(momentum), int(n_bits), int(bool(symmetric)), float(eps), int(bool(log_domain)),
+                base + 8, None if symmetric else base + 12, _ptr(signed), _ptr(y), ws.data_ptr(), ws.numel(),
+                counter.data_ptr(), st)
+            _check(rc, self.lib)
+            return (out[0], out[1], out[2], None if symmetric else out[3], signed, y)
         cur = torch.empty(2, n_params, dtype=torch.float32, device=dev)
         par = torch.empty(1 if symmetric else 2, n_params, dtype=torch.float32, device=dev)
         signed = torch.empty((), dtype=torch.bool, device=dev) if symmetric else None

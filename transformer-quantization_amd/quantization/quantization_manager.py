@@ -122,7 +122,7 @@ class QuantizationManager(nn.Module):
         be = _hip.backend()
         if (mode is None or type(q) not in _FUSED_QUANTIZERS or not FUSED_CALIBRATION
                 or not hasattr(be, 'calibrate_minmax') or not x.is_cuda or tq_dist.is_enabled()
-                or getattr(est, 'percentile', None)
+                or getattr(est, 'percentile', None) or '_delta' not in q._buffers     # trainable ranges
                 or (torch.is_grad_enabled() and x.requires_grad)):
             return None
         axis = None if mode == _hip.EST_ALL else est.axis
@@ -150,12 +150,14 @@ class QuantizationManager(nn.Module):
         cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_minmax(
             x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0), n_groups, order,
             q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log')
-        est.current_xmin, est.current_xmax = cur_min, cur_max
-        q._delta = delta
+        # registered buffers: rebinding through the dict skips nn.Module.__setattr__'s type dispatch
+        # (4 rebinds per call x 161 quantizers per calibration batch)
+        est._buffers['current_xmin'], est._buffers['current_xmax'] = cur_min, cur_max
+        q._buffers['_delta'] = delta
         if q.symmetric:
-            q._signed = signed
+            q._buffers['_signed'] = signed
         else:
-            q._zero_float = zero_float
+            q._buffers['_zero_float'] = zero_float
         # same buffer shapes as quantizer.forward leaves behind ([1,1,d] / [C,1,..] views)
         if q.axis is not None:
             q._adjust_params_per_axis(x)
