@@ -72,3 +72,20 @@ with torch.no_grad():
     print('fixed-range forward ms (hipGraph, int8 + fused tails + fused attention probs)', t(lambda: g4.replay(), n=30))
     print('max |logit diff| vs fp32-simulated GEMMs', float((out4-out).abs().max()))
 print('(the last configuration above already routes the attention core through tq_attention_i8_fwd when the tags are present)')
+# ---- calibration as a hipGraph (options.INPLACE_CALIBRATION_STATE) ----
+QResidualBlock.fuse = QSelfAttention.fuse = False
+options.INT8_LINEAR = False
+options.INPLACE_CALIBRATION_STATE = True
+model2, _ = _build('cuda')
+with torch.no_grad():
+    model2.set_quant_state(True, True)
+    model2(ids)
+    print('calibrating forward ms (eager, in-place state)', t(lambda: model2(ids)))
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2): model2(ids)
+    torch.cuda.current_stream().wait_stream(s)
+    gc_ = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gc_):
+        oc = model2(ids)
+    print('calibrating forward ms (hipGraph replay)', t(lambda: gc_.replay(), n=30))

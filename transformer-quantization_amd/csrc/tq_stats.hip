@@ -358,10 +358,11 @@ __global__ void set_range_sym_k(const float* __restrict__ x_min, const float* __
 // (range_update_k followed by set_range_*_k); n <= kCalibMaxN so the new state fits in LDS.
 constexpr uint32_t kCalibMaxN = 4096;
 
+// prev_* may alias cur_* (in-place state): every thread reads prev[dim] before it writes cur[dim].
 __global__ __launch_bounds__(1024) void calib_update_k(int mode, const float* __restrict__ new_min,
-                                                       const float* __restrict__ new_max, const float* __restrict__ prev_min,
-                                                       const float* __restrict__ prev_max, float* __restrict__ cur_min,
-                                                       float* __restrict__ cur_max, uint32_t n, double momentum_d,
+                                                       const float* __restrict__ new_max, const float* prev_min,
+                                                       const float* prev_max, float* cur_min,
+                                                       float* cur_max, uint32_t n, double momentum_d,
                                                        uint32_t n_groups, const int64_t* __restrict__ order, int n_bits,
                                                        int symmetric, float eps, int log_domain, float* __restrict__ delta,
                                                        float* __restrict__ zero_float, uint8_t* __restrict__ signed_flag) {

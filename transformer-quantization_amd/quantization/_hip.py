@@ -331,9 +331,11 @@ class HipBackend:
     CALIB_MAX_PARAMS = 4096
 
     def calibrate_minmax(self, x, n_params, inner, mode, prev_min, prev_max, momentum, n_groups, order,
-                         n_bits, symmetric, eps, log_domain, want_y=True):
+                         n_bits, symmetric, eps, log_domain, want_y=True, out=None):
         """Fused estimating step (statistics -> estimator update -> quantizer parameters -> y).
-        -> (cur_min, cur_max, delta, zero_float | None, signed | None, y | None); 0-D for n_params == 1."""
+        -> (cur_min, cur_max, delta, zero_float | None, signed | None, y | None); 0-D for n_params == 1.
+        out = (cur_min, cur_max, delta, zero_float | None, signed | None): existing fp32 / bool device
+        tensors to update in place (cur_* may be the same tensors as prev_*); fresh tensors otherwise."""
         _need_device(x, 'calibrate_minmax')
         x = x.contiguous()
         dev = x.device
@@ -344,22 +346,32 @@ class HipBackend:
             counter = self._counters.get(key)
             if counter is None:
                 counter = self._counters[key] = torch.zeros(1, dtype=torch.int32, device=dev)
-            out = torch.empty(4, dtype=torch.float32, device=dev)        # cur_min, cur_max, delta, zero_float
-            signed = torch.empty((), dtype=torch.bool, device=dev) if symmetric else None
+            if out is None:
+                buf = torch.empty(4, dtype=torch.float32, device=dev)    # cur_min, cur_max, delta, zero_float
+                out = (buf[0], buf[1], buf[2], None if symmetric else buf[3],
+                       torch.empty((), dtype=torch.bool, device=dev) if symmetric else None)
             y = torch.empty_like(x) if want_y else None
             ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), 1, 1))
-            base = out.data_ptr()
             rc = self.lib.tq_calibrate_tensor(
                 x.data_ptr(), x.numel(), _dtype_code(x, 'calibrate_minmax'), mode, _ptr(prev_min), _ptr(prev_max),
-                base, base + 4, float(momentum), int(n_bits), int(bool(symmetric)), float(eps), int(bool(log_domain)),
-                base + 8, None if symmetric else base + 12, _ptr(signed), _ptr(y), ws.data_ptr(), ws.numel(),
+                _ptr(out[0]), _ptr(out[1]), float(momentum), int(n_bits), int(bool(symmetric)), float(eps),
+                int(bool(log_domain)), _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _ptr(y), ws.data_ptr(), ws.numel(),
                 counter.data_ptr(), st)
             _check(rc, self.lib)
-            return (out[0], out[1], out[2], None if symmetric else out[3], signed, y)
+            return (*out, y)
+        y = torch.empty_like(x) if want_y else None
+        if out is not None:
+            ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), n_params, inner))
+            rc = self.lib.tq_calibrate_minmax(
+                _ptr(x), x.numel(), _dtype_code(x, 'calibrate_minmax'), n_params, inner, mode,
+                _ptr(prev_min), _ptr(prev_max), _ptr(out[0]), _ptr(out[1]), float(momentum), int(n_groups or 0),
+                _ptr(order), int(n_bits), int(bool(symmetric)), float(eps), int(bool(log_domain)),
+                _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _ptr(y), _ptr(ws), ws.numel(), _stream())
+            _check(rc, self.lib)
+            return (*out, y)
         cur = torch.empty(2, n_params, dtype=torch.float32, device=dev)
         par = torch.empty(1 if symmetric else 2, n_params, dtype=torch.float32, device=dev)
         signed = torch.empty((), dtype=torch.bool, device=dev) if symmetric else None
-        y = torch.empty_like(x) if want_y else None
         ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), n_params, inner))
         rc = self.lib.tq_calibrate_minmax(
             _ptr(x), x.numel(), _dtype_code(x, 'calibrate_minmax'), n_params, inner, mode,

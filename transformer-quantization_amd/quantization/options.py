@@ -8,3 +8,12 @@
 # simulation by the simulation's own fp32 accumulation error (~1e-6 relative), which can move an
 # output that sits on a rounding boundary by one grid step.
 INT8_LINEAR = False
+
+# Estimator state (current_xmin / current_xmax) and quantizer parameters (_delta / _zero_float / _signed)
+# are rebound to FRESH tensors on every calibrating forward, like the reference does.  With this switch
+# the fused calibration step updates the existing buffers IN PLACE once they exist (same values, same
+# shapes), which makes a calibrating forward replayable as a hipGraph: capture one forward after the
+# first (eager) batch, then copy each new batch into the static input and replay -- no Python, no
+# allocation, no host synchronisation between the 161 + 102 quantizers of a BERT-base.  Off by
+# default because code that keeps references to earlier state tensors would see them change.
+INPLACE_CALIBRATION_STATE = False

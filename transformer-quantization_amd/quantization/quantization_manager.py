@@ -147,9 +147,12 @@ class QuantizationManager(nn.Module):
             order = be.argsort(est.ranges)
         prev_min = est.current_xmin if mode != _hip.EST_CURRENT else None
         prev_max = est.current_xmax if mode != _hip.EST_CURRENT else None
+        out = None
+        if options.INPLACE_CALIBRATION_STATE:
+            out = self._inplace_state(est, q, n_params, x.device)
         cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_minmax(
             x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0), n_groups, order,
-            q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log')
+            q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log', out=out)
         # registered buffers: rebinding through the dict skips nn.Module.__setattr__'s type dispatch
         # (4 rebinds per call x 161 quantizers per calibration batch)
         est._buffers['current_xmin'], est._buffers['current_xmax'] = cur_min, cur_max
@@ -164,6 +167,22 @@ class QuantizationManager(nn.Module):
         if q.per_channel:
             q._adjust_params_per_channel(x)
         return y
+
+    @staticmethod
+    def _inplace_state(est, q, n_params, device):
+        """Existing (state, parameter) buffers to overwrite, or None while any of them is missing or has
+        another size (first batch, changed layout): the step then allocates fresh ones."""
+        bufs = [est.current_xmin, est.current_xmax, q._delta,
+                None if q.symmetric else q._zero_float, q._signed if q.symmetric else None]
+        need = [True, True, True, not q.symmetric, q.symmetric]
+        for t, wanted in zip(bufs, need):
+            if not wanted:
+                continue
+            if (t is None or t.device != device or not t.is_contiguous()
+                    or t.numel() != (1 if t.dtype == torch.bool else n_params)
+                    or t.dtype not in (torch.float32, torch.bool)):
+                return None
+        return tuple(bufs)
 
     def forward(self, x):
         est = self.range_estimator
