@@ -18,7 +18,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-constexpr int PITCH = 144;   // 128 B of K + 16 B pad: conflict-free ds_read_b128 over 16 rows
+constexpr int PITCH = 160;   // 128 B of K + 32 B pad: conflict-free ds_read_b128 under the real 4 x 16 lane grouping (144 is 2-way)
 
 // WT = wave tile edge (32 or 64); block = 2 x 2 waves -> block tile BT = 2 * WT; BK = 128 bytes
 // gm x gn = 8: XCD x (= blockIdx % 8, the hardware's round-robin) owns the tile rectangle (x / gn, x % gn) of a

@@ -53,7 +53,7 @@ __device__ __forceinline__ uint32_t key_slot(uint32_t key) {
 template <int NT>   // NT = T / 16 key tiles
 __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
   constexpr int T = NT * 16, KS = NT / 4;          // KS = 64-key MFMA steps of the second GEMM
-  constexpr int PITCH = T + 16;                    // conflict-free ds_read_b128 over 16 rows
+  constexpr int PITCH = T + 32;                    // 32 * odd bytes: conflict-free ds_read_b128 (4 x 16 lane groups, 64 banks)
   __shared__ __attribute__((aligned(16))) int8_t s_vt[kHeadDim * PITCH];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

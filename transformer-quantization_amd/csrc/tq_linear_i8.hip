@@ -165,11 +165,11 @@ __global__ __launch_bounds__(kBlock) void linear_i8_k(LinArgs p) {
 // retires ~1 line per 4 clocks (14.6 B/clk/CU; 7.6 us for 1024x768x768, 76 us for 8192x3072x768).
 // Here a block of 2 x 2 waves owns a BT x BT tile (BT = 2 * WT); per 128-byte K slab the 256 threads
 // load both operand slabs with fully coalesced accesses (8 lanes = one 128-byte line of one row),
-// park them in LDS (row pitch 144 B: conflict-free ds_read_b128 over 16 rows) and every wave reads its
+// park them in LDS (row pitch 160 B: conflict-free ds_read_b128, see kLdsPitch) and every wave reads its
 // MFMA fragments from there.  Double-buffered: the next slab's global loads are in flight while the
 // current slab's 2 * NI * MI MFMAs run; one barrier per slab.  4.7 us / 9.5 us / 42.6 us for the three
 // shapes above (hipBLASLt bf16: 6.8 / 11.2 / 47.1 us, fp32: 14.4 / 48 / 280 us).  M, N % BT == 0, K % 128 == 0.
-constexpr int kLdsPitch = 144;
+constexpr int kLdsPitch = 160;   // 32 * odd: conflict-free under ds_read_b128's 4 x 16 lane grouping (144 is 2-way)
 
 template <int WT, int YDT>
 __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
