@@ -172,9 +172,13 @@ __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u
 
   for (uint32_t c = threadIdx.x; c < d; c += kBlock) {
     const QP p = make_qp(q, c);
-    s_scale[c] = p.scale;
-    s_zp[c] = p.zp;
-    s_rcp[c] = guarded_rcp(p.scale);
+    // "plane" layout: floats j = 4m .. 4m+3 of every vector column sit in plane m, so a ds_read_b128 has a
+    // lane stride of 16 B (conflict-free: 16 lanes x 16 B = all 64 banks); with the natural layout a bf16
+    // lane's 8 parameters are 32 B apart from its neighbour's and every read is 2-way conflicted
+    const uint32_t slot = ((c % V) / 4 * vpr + c / V) * 4 + (c & 3);
+    s_scale[slot] = p.scale;
+    s_zp[slot] = p.zp;
+    s_rcp[slot] = guarded_rcp(p.scale);
   }
   const QP p0 = make_qp(q, 0);   // int_min / int_max do not depend on the column
   const float lo = p0.lo, hi = p0.hi;
@@ -200,14 +204,14 @@ __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
-          const f32x4 r4 = *reinterpret_cast<const f32x4*>(s_rcp + cv * V + j);
+          const f32x4 r4 = *reinterpret_cast<const f32x4*>(s_rcp + ((j / 4) * vpr + cv) * 4);
 #pragma unroll
           for (int m = 0; m < 4; ++m) f[j + m] = rne_quot_try(g[j + m], r4[m], ok);
         }
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
-          const f32x4 s4 = *reinterpret_cast<const f32x4*>(s_scale + cv * V + j);
-          const f32x4 z4 = *reinterpret_cast<const f32x4*>(s_zp + cv * V + j);
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(s_scale + ((j / 4) * vpr + cv) * 4);
+          const f32x4 z4 = *reinterpret_cast<const f32x4*>(s_zp + ((j / 4) * vpr + cv) * 4);
 #pragma unroll
           for (int m = 0; m < 4; ++m) { sc[j + m] = s4[m]; zp[j + m] = z4[m]; }
         }
@@ -347,7 +351,11 @@ __global__ __launch_bounds__(kBlock) void fq_affine(const u32x4* __restrict__ x,
     v[u] = u32x4{0, 0, 0, 0};
     if (full || k < n_vec) v[u] = NT ? ld_stream(x + k) : x[k];
   }
-  for (uint32_t c = threadIdx.x; c < d; c += kBlock) { s_w[c] = w[c]; s_b[c] = b[c]; }
+  for (uint32_t c = threadIdx.x; c < d; c += kBlock) {      // plane layout, as in fq_axis (conflict-free b128 reads)
+    const uint32_t slot = ((c % V) / 4 * vpr + c / V) * 4 + (c & 3);
+    s_w[slot] = w[c];
+    s_b[slot] = b[c];
+  }
   const QP p = make_qp(q, 0);
   __syncthreads();
   uint32_t cv = ((uint32_t)(tile % vpr) * (TILE % vpr)) % vpr + threadIdx.x % vpr;
@@ -360,8 +368,8 @@ __global__ __launch_bounds__(kBlock) void fq_affine(const u32x4* __restrict__ x,
     Store<DT>::unpack(v[u], f);
 #pragma unroll
     for (int j = 0; j < V; j += 4) {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_w + cv * V + j);
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_b + cv * V + j);
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_w + ((j / 4) * vpr + cv) * 4);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_b + ((j / 4) * vpr + cv) * 4);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const float r = f[j + m] * w4[m] + b4[m];          // mul, then add (no fma: -ffp-contract=off)
@@ -465,7 +473,7 @@ static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t 
     {                                                                                                      \
       const uint64_t n_tiles = std::max<uint64_t>(ceil_div(n_vec_all, kBlock * UV), 1);                    \
       const uint32_t want = q.n_params > 2048 ? 8 : (q.n_params > 1024 ? 4 : 2);  /* amortise the table fill */ \
-      const uint32_t tpb = tpb_env > 0 ? (uint32_t)tpb_env : (n_tiles >= 16384ull * want ? want : 1);          \
+      const uint32_t tpb = tpb_env > 0 ? (uint32_t)tpb_env : (n_tiles >= 2048ull * want ? want : (n_tiles >= 4096 ? 2 : 1));          \
       hipLaunchKernelGGL((fq_axis<DT, HAS_IDX, NTV, UV>),                                                   \
                          dim3((unsigned)std::min<uint64_t>(ceil_div(n_tiles, tpb), kMaxTiles)),            \
                          dim3(kBlock), lds, st, xv, yv, idx, idx_dtype, n, q, tpb);                         \
