@@ -126,6 +126,18 @@ int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_
                      const float* w_delta, uint64_t w_n_params, float w_eps, int activation,
                      const tq_quantizer* q_out, tq_stream_t stream);
 
+/* Several quantized Linears that share their input, as ONE launch: the weights (and row sums, biases,
+ * per-row weight scales w_delta[N]) of n_groups <= 3 layers are stacked along N; group g owns output
+ * columns [g N / n_groups, (g+1) N / n_groups) and has its own per-tensor output quantizer q_out[g]
+ * (BERT: query | key | value, models/quantized_bert.py:135-146).  y may be NULL (index-only output:
+ * the attention core reads int8 indices).  M % 64 == 0, K % 128 == 0, N / n_groups % 64 == 0.        */
+int tq_linear_i8_grouped_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum,
+                             const float* bias, void* y, int8_t* y_idx, int y_dtype, uint64_t M,
+                             uint64_t N, uint64_t K, const float* x_delta, const float* x_zero_float,
+                             int x_n_bits, float x_eps, const float* w_delta, float w_eps,
+                             int activation, uint64_t n_groups, const tq_quantizer* const* q_out,
+                             tq_stream_t stream);
+
 /* Fixed-range quantized self-attention core on the i8 matrix cores (reference
  * models/quantized_bert.py:135-213: head split, Q K^T, score quantizer, 1/sqrt(d), mask, softmax,
  * probability quantizer, P V, head merge, context quantizer -- 2 batched fp32 GEMMs, 4 permute copies
@@ -137,6 +149,8 @@ int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_
  * exact integer contractions with zero-point corrections; scores and probabilities never reach HBM. */
 int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, const int8_t* v_idx, float* ctx,
                         int8_t* ctx_idx, uint64_t B, uint64_t T, uint64_t H, uint64_t head_dim,
+                        uint64_t qkv_row_stride /* elements between tokens of q/k/v; 0 = H*head_dim;
+                                                   3*H*head_dim inside a stacked Q|K|V buffer */,
                         const float* mask, float denom, const tq_quantizer* q_q,
                         const tq_quantizer* q_k, const tq_quantizer* q_v, const tq_quantizer* q_scores,
                         const tq_quantizer* q_probs, const tq_quantizer* q_ctx, tq_stream_t stream);

@@ -108,15 +108,44 @@ def test_bert_forward_with_integer_attention_matches_layered():
     options.INT8_LINEAR = True
     try:
         from quantization import _hip
-        calls = []
-        orig = _hip.HipBackend.attention_i8
+        calls, gcalls = [], []
+        orig, gorig = _hip.HipBackend.attention_i8, _hip.HipBackend.linear_i8_grouped
         _hip.HipBackend.attention_i8 = lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1]
+        _hip.HipBackend.linear_i8_grouped = lambda self, *a, **k: (gcalls.append(1), gorig(self, *a, **k))[1]
         with torch.no_grad():
             fused = model(ids)
-        _hip.HipBackend.attention_i8 = orig
+        _hip.HipBackend.attention_i8, _hip.HipBackend.linear_i8_grouped = orig, gorig
     finally:
         QResidualBlock.fuse = QSelfAttention.fuse = False
         options.INT8_LINEAR = False
     assert len(calls) == 12, 'the integer attention kernel must serve all 12 layers'
+    assert len(gcalls) == 12, 'query / key / value must run as one grouped GEMM per layer'
     span = float(layered.max() - layered.min())
     assert float((fused - layered).abs().max()) <= 0.10 * span
+
+
+def test_stacked_qkv_projection_equals_three_linears():
+    """quantized_self_attention (grouped QKV GEMM, index-only output, strided attention reads) must be
+    bit-identical to three separate integer Linears followed by quantized_attention."""
+    from tests.test_bert_e2e import _build, _fixture, _calibrate_and_run
+    from quantization import options
+    from quantization.fused import quantized_attention, quantized_self_attention
+    z = _fixture()
+    model, _ = _build('cuda')
+    ids = torch.from_numpy(z['input_ids']).cuda()
+    _calibrate_and_run(model, ids)
+    options.INT8_LINEAR = True
+    try:
+        with torch.no_grad():
+            h = model.embeddings(ids)                      # tagged with its quantizer + int8 indices
+            assert getattr(h, '_tq_idx', None) is not None
+            A = model.layers[0].attention_self
+            mask = torch.zeros(ids.shape[0], 1, 1, ids.shape[1], device='cuda')
+            mask[1, ..., 100:] = -10000.0
+            args = (mask, A.heads, A.attn_scores_act_quantizer, A.attn_probs_act_quantizer, A.context_act_quantizer)
+            one = quantized_self_attention(h, A.query, A.key, A.value, *args)
+            sep = quantized_attention(A.query(h), A.key(h), A.value(h), *args)
+    finally:
+        options.INT8_LINEAR = False
+    assert one is not None and sep is not None
+    assert torch.equal(one, sep) and torch.equal(one._tq_idx, sep._tq_idx)

@@ -39,6 +39,7 @@ struct AttnArgs {
   int8_t* ctx_idx;            // optional int8(index - 128) of ctx (needs q_ctx)
   const float* mask;          // additive [B, T] or null
   uint32_t B, T, H;
+  uint32_t in_stride;         // elements between consecutive tokens of q / k / v (H * 64, or 3 * H * 64 inside a stacked QKV buffer)
   float denom;
   tq_quantizer qq, qk, qv;    // per-tensor asymmetric, n_bits <= 8
   tq_quantizer q_scores, q_probs, q_ctx;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
   const uint32_t qblocks = T / (16 * kAttnWaves);
   const uint32_t bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
   const uint32_t b = bh / p.H, h = bh % p.H;
-  const size_t row_stride = (size_t)p.H * kHeadDim;
+  const size_t row_stride = p.in_stride;
   const size_t base = (size_t)b * T * row_stride + (size_t)h * kHeadDim;
 
   // ---- V^T -> LDS with the key permutation of the accumulator layout -------------------------------
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
 #pragma unroll
   for (int s = 0; s < KS; ++s) rsp4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fp[s], rsp4, 0, 0, 0);
   const int p_const = cv * rsp4[0] + T * cp * cv;    // sum_k a'_p of column r16
-  const size_t out_row = ((size_t)b * T + qrow) * row_stride + (size_t)h * kHeadDim;
+  const size_t out_row = ((size_t)b * T + qrow) * ((size_t)p.H * kHeadDim) + (size_t)h * kHeadDim;
 #pragma unroll
   for (int j = 0; j < kHeadDim / 16; ++j) {
     v4i acc = zero4, csv = zero4;
@@ -204,7 +205,7 @@ static int check_i8_grid(const tq_quantizer* q, const char* what) {
 
 extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, const int8_t* v_idx, float* ctx,
                                    int8_t* ctx_idx, uint64_t B, uint64_t T, uint64_t H, uint64_t head_dim,
-                                   const float* mask, float denom, const tq_quantizer* q_q,
+                                   uint64_t qkv_row_stride, const float* mask, float denom, const tq_quantizer* q_q,
                                    const tq_quantizer* q_k, const tq_quantizer* q_v, const tq_quantizer* q_scores,
                                    const tq_quantizer* q_probs, const tq_quantizer* q_ctx, tq_stream_t stream) {
   if (B == 0 || T == 0 || H == 0) return TQ_OK;
@@ -216,6 +217,9 @@ extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, con
              (mask == nullptr || aligned16(mask)) && (ctx_idx == nullptr || (reinterpret_cast<uintptr_t>(ctx_idx) % 4) == 0),
              "tq_attention_i8_fwd: 16-byte alignment required");
   TQ_REQUIRE(denom != 0.0f, "tq_attention_i8_fwd: denom == 0");
+  if (qkv_row_stride == 0) qkv_row_stride = H * head_dim;
+  TQ_REQUIRE(qkv_row_stride >= H * head_dim && qkv_row_stride % 16 == 0 && qkv_row_stride < (1ull << 31),
+             "tq_attention_i8_fwd: bad qkv_row_stride %llu", (unsigned long long)qkv_row_stride);
   TQ_REQUIRE(B * H * (T / (16 * kAttnWaves)) < (1ull << 31), "tq_attention_i8_fwd: too many tiles");
   if (int e = check_i8_grid(q_q, "query")) return e;
   if (int e = check_i8_grid(q_k, "key")) return e;
@@ -235,7 +239,7 @@ extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, con
   }
   AttnArgs a{};
   a.q = q_idx; a.k = k_idx; a.v = v_idx; a.ctx = ctx; a.ctx_idx = ctx_idx; a.mask = mask;
-  a.B = (uint32_t)B; a.T = (uint32_t)T; a.H = (uint32_t)H; a.denom = denom;
+  a.B = (uint32_t)B; a.T = (uint32_t)T; a.H = (uint32_t)H; a.in_stride = (uint32_t)qkv_row_stride; a.denom = denom;
   a.qq = *q_q; a.qk = *q_k; a.qv = *q_v; a.q_probs = *q_probs;
   a.has_scores = q_scores != nullptr; a.has_ctx = q_ctx != nullptr;
   if (q_scores) a.q_scores = *q_scores;

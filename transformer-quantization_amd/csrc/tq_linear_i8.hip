@@ -54,7 +54,9 @@ struct LinArgs {
   float w_eps;
   int act;
   int has_q;
-  tq_quantizer q_out;
+  tq_quantizer q_out;     // group 0
+  tq_quantizer q_out1, q_out2;   // groups 1, 2 of a grouped launch (Q | K | V stacked along N)
+  uint32_t group_cols;    // output columns per group (N for a plain launch); multiple of 64
 };
 
 // ---- epilogue: zero-point correction, scales, bias, activation, output quantizer ----------------------
@@ -66,7 +68,10 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI]
   const int zx = (int)clamp_nanprop(rintf(p.x_zero_float[0]), 0.0f, grid_top(p.x_n_bits));
   const int shift = 128 - zx;
   QP qo = {1.f, 0.f, 0.f, 0.f};
-  if (p.has_q) qo = make_qp(p.q_out, 0);
+  if (p.has_q) {
+    const uint32_t grp = n0 / p.group_cols;             // a block tile never straddles two groups
+    qo = make_qp(grp == 0 ? p.q_out : (grp == 1 ? p.q_out1 : p.q_out2), 0);
+  }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const uint32_t n = n0 + i * 16 + kg * 4;            // this lane's 4 consecutive output features
@@ -97,6 +102,7 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI]
         o[r] = v;
       }
       if (p.y_idx != nullptr) *reinterpret_cast<uint32_t*>(p.y_idx + (size_t)m * p.N + n) = __builtin_bit_cast(uint32_t, oi4);
+      if (p.y == nullptr) continue;                       // index-only output (grouped QKV projection)
       if (YDT == TQ_F32) {
         *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + (size_t)m * p.N + n) = f32x4{o[0], o[1], o[2], o[3]};
       } else {
@@ -280,6 +286,43 @@ extern "C" int tq_rowsum_i8(const int8_t* w_idx, int32_t* rowsum, uint64_t N, ui
   return check_launch("rowsum_i8_k");
 }
 
+extern "C" int tq_linear_i8_grouped_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum,
+                                        const float* bias, void* y, int8_t* y_idx, int y_dtype, uint64_t M, uint64_t N,
+                                        uint64_t K, const float* x_delta, const float* x_zero_float, int x_n_bits,
+                                        float x_eps, const float* w_delta, float w_eps, int activation,
+                                        uint64_t n_groups, const tq_quantizer* const* q_out, tq_stream_t stream) {
+  if (M == 0 || N == 0) return TQ_OK;
+  TQ_REQUIRE(x_idx && w_idx && w_rowsum && x_delta && x_zero_float && w_delta && q_out, "tq_linear_i8_grouped_fwd: NULL pointer");
+  TQ_REQUIRE(y != nullptr || y_idx != nullptr, "tq_linear_i8_grouped_fwd: no output requested");
+  TQ_REQUIRE(y_dtype == TQ_F32 || y_dtype == TQ_BF16, "tq_linear_i8_grouped_fwd: y dtype must be fp32 or bf16");
+  TQ_REQUIRE(n_groups >= 1 && n_groups <= 3 && N % n_groups == 0 && (N / n_groups) % 64 == 0,
+             "tq_linear_i8_grouped_fwd: 1..3 groups of a multiple of 64 output features");
+  TQ_REQUIRE(M % 64 == 0 && K % 128 == 0 && K <= 16384 && M < (1u << 31) && N < (1u << 31),
+             "tq_linear_i8_grouped_fwd: unsupported shape M=%llu N=%llu K=%llu (M %% 64, K %% 128)", (unsigned long long)M,
+             (unsigned long long)N, (unsigned long long)K);
+  TQ_REQUIRE(x_n_bits >= 1 && x_n_bits <= 8, "tq_linear_i8_grouped_fwd: input quantizer must have <= 8 bits");
+  TQ_REQUIRE(activation >= ACT_NONE && activation <= ACT_TANH, "tq_linear_i8_grouped_fwd: unknown activation %d", activation);
+  TQ_REQUIRE(aligned16(x_idx) && aligned16(w_idx) && (y == nullptr || aligned16(y)), "tq_linear_i8_grouped_fwd: 16-byte alignment required");
+  LinArgs a{};
+  a.x = x_idx; a.w = w_idx; a.w_rowsum = w_rowsum; a.bias = bias; a.y = y; a.y_idx = y_idx;
+  a.M = (uint32_t)M; a.N = (uint32_t)N; a.K = (uint32_t)K;
+  a.x_delta = x_delta; a.x_zero_float = x_zero_float; a.x_eps = x_eps; a.x_n_bits = x_n_bits;
+  a.w_delta = w_delta; a.w_n_params = (uint32_t)N; a.w_eps = w_eps; a.act = activation;
+  a.has_q = 1;
+  a.group_cols = (uint32_t)(N / n_groups);
+  tq_quantizer* slots[3] = {&a.q_out, &a.q_out1, &a.q_out2};
+  for (uint64_t g = 0; g < n_groups; ++g) {
+    TQ_REQUIRE(q_out[g] != nullptr, "tq_linear_i8_grouped_fwd: every group needs an output quantizer");
+    if (int e = check_quantizer(q_out[g], M * N, "tq_linear_i8_grouped_fwd")) return e;
+    TQ_REQUIRE(q_out[g]->n_params == 1, "tq_linear_i8_grouped_fwd: per-tensor output quantizers only");
+    TQ_REQUIRE(y_idx == nullptr || (!q_out[g]->symmetric && q_out[g]->n_bits <= 8),
+               "tq_linear_i8_grouped_fwd: y_idx needs asymmetric <= 8-bit output quantizers");
+    *slots[g] = *q_out[g];
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return y_dtype == TQ_F32 ? launch_linear<TQ_F32>(a, st) : launch_linear<TQ_BF16>(a, st);
+}
+
 extern "C" int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum, const float* bias,
                                 void* y, int8_t* y_idx, int y_dtype, uint64_t M, uint64_t N, uint64_t K, const float* x_delta,
                                 const float* x_zero_float, int x_n_bits, float x_eps, const float* w_delta,
@@ -301,6 +344,7 @@ extern "C" int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const 
   a.x_delta = x_delta; a.x_zero_float = x_zero_float; a.x_eps = x_eps; a.x_n_bits = x_n_bits;
   a.w_delta = w_delta; a.w_n_params = (uint32_t)w_n_params; a.w_eps = w_eps; a.act = activation;
   a.has_q = q_out != nullptr;
+  a.group_cols = (uint32_t)N;
   TQ_REQUIRE(y_idx == nullptr || (q_out != nullptr && !q_out->symmetric && q_out->n_bits <= 8),
              "tq_linear_i8_fwd: y_idx needs an asymmetric <= 8-bit output quantizer");
   if (q_out) {

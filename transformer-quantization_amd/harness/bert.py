@@ -62,6 +62,13 @@ class QSelfAttention(QuantizedModel):
     fuse = False   # set True: scores-quant -> scale -> mask -> softmax -> probs-quant as one kernel
 
     def forward(self, h, mask):
+        if self.fuse:
+            from quantization.fused import quantized_self_attention
+            ctx = quantized_self_attention(h, self.query, self.key, self.value, mask, self.heads,
+                                           self.attn_scores_act_quantizer, self.attn_probs_act_quantizer,
+                                           self.context_act_quantizer)
+            if ctx is not None:                  # stacked QKV projection + attention core: 2 integer kernels
+                return ctx
         qo, ko, vo = self.query(h), self.key(h), self.value(h)
         if self.fuse:
             from quantization.fused import quantized_attention

@@ -45,7 +45,9 @@ SIGNATURES = {
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
     'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
     'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
-    'tq_attention_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u64, _vp, _f, _QP, _QP, _QP, _QP, _QP, _QP, _vp]),
+    'tq_attention_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u64, _u64, _vp, _f, _QP, _QP, _QP, _QP, _QP, _QP, _vp]),
+    'tq_linear_i8_grouped_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _f, _int,
+                                        _u64, C.POINTER(_QP), _vp]),
     'tq_scores_softmax_quant_fwd': (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _f, _QP, _QP, _vp]),
     'tq_rowsum_i8': (_int, [_vp, _vp, _u64, _u64, _vp]),
     'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
@@ -219,19 +221,42 @@ class HipBackend:
 
     def attention_i8(self, q_idx, k_idx, v_idx, num_heads, mask, denom, q_q, q_k, q_v, q_scores, q_probs, q_ctx,
                      want_idx=False):
-        """Quantized attention core on int8 indices [B, T, H * 64]; every q_* is a per-tensor 7-tuple
-        (q_scores / q_ctx may be None).  -> ctx fp32 [B, T, H * 64] (, int8 indices of ctx)."""
+        """Quantized attention core on int8 indices [B, T, H * 64] (contiguous tensors, or the three column
+        blocks of one stacked [B, T, 3 * H * 64] buffer); every q_* is a per-tensor 7-tuple (q_scores /
+        q_ctx may be None).  -> ctx fp32 [B, T, H * 64] (, int8 indices of ctx)."""
         _need_device(q_idx, 'attention_i8')
         B, T, D = q_idx.shape
-        ctx = torch.empty(q_idx.shape, dtype=torch.float32, device=q_idx.device)
-        ctx_idx = torch.empty(q_idx.shape, dtype=torch.int8, device=q_idx.device) if want_idx else None
+        stride = q_idx.stride(1)
+        if not (q_idx.stride(2) == 1 and q_idx.stride(0) == T * stride and k_idx.stride() == q_idx.stride()
+                and v_idx.stride() == q_idx.stride()):
+            q_idx, k_idx, v_idx = q_idx.contiguous(), k_idx.contiguous(), v_idx.contiguous()
+            stride = D
+        ctx = torch.empty((B, T, D), dtype=torch.float32, device=q_idx.device)
+        ctx_idx = torch.empty((B, T, D), dtype=torch.int8, device=q_idx.device) if want_idx else None
         descs = [None if q is None else self._qdesc(*q, 1, 1) for q in (q_q, q_k, q_v, q_scores, q_probs, q_ctx)]
         refs = [None if dsc is None else C.byref(dsc) for dsc in descs]
-        rc = self.lib.tq_attention_i8_fwd(_ptr(q_idx.contiguous()), _ptr(k_idx.contiguous()), _ptr(v_idx.contiguous()),
-                                          _ptr(ctx), _ptr(ctx_idx), B, T, num_heads, D // num_heads, _ptr(mask),
-                                          float(denom), *refs, _stream())
+        rc = self.lib.tq_attention_i8_fwd(_ptr(q_idx), _ptr(k_idx), _ptr(v_idx), _ptr(ctx), _ptr(ctx_idx), B, T,
+                                          num_heads, D // num_heads, stride, _ptr(mask), float(denom), *refs, _stream())
         _check(rc, self.lib)
         return (ctx, ctx_idx) if want_idx else ctx
+
+    def linear_i8_grouped(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta_rows, w_eps, activation, q_outs,
+                          want_y=False, want_idx=True, out_dtype=torch.float32):
+        """len(q_outs) Linears sharing x_idx as one launch: w_idx / w_rowsum / bias / w_delta_rows stacked along
+        N, q_outs[g] the per-tensor 7-tuple of group g's output quantizer.  -> (y | None, y_idx | None)."""
+        K = x_idx.shape[-1]
+        M = x_idx.numel() // K
+        N = w_idx.shape[0]
+        y = torch.empty(x_idx.shape[:-1] + (N,), dtype=out_dtype, device=x_idx.device) if want_y else None
+        y_idx = torch.empty(x_idx.shape[:-1] + (N,), dtype=torch.int8, device=x_idx.device) if want_idx else None
+        descs = [self._qdesc(*q, 1, 1) for q in q_outs]
+        arr = (C.POINTER(tq_quantizer) * len(descs))(*[C.pointer(d) for d in descs])
+        rc = self.lib.tq_linear_i8_grouped_fwd(
+            _ptr(x_idx), _ptr(w_idx), _ptr(w_rowsum), _ptr(bias), _ptr(y), _ptr(y_idx), _DTYPES[out_dtype], M, N, K,
+            _ptr(x_q[0]), _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(w_delta_rows), float(w_eps), int(activation),
+            len(descs), C.cast(arr, C.POINTER(_QP)), _stream())
+        _check(rc, self.lib)
+        return y, y_idx
 
     def scores_softmax_quant(self, scores, mask, rows_per_mask, denom, q_scores, q_probs):
         """probs = Q_probs(softmax(Q_scores(scores) / denom + mask)); q_* None or per-tensor 7-tuples."""

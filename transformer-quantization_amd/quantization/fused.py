@@ -142,3 +142,94 @@ def quantized_attention(query, key, value, mask, num_heads, scores_quantizer, pr
         if want_idx:
             ctx._tq_idx = out[1]
     return ctx
+
+
+def _stacked_qkv(layers):
+    """int8 weights / row sums / biases / per-row weight scales of several QuantLinears stacked along the
+    output dimension, cached on the first layer until any weight or weight range changes."""
+    key = tuple((l.weight.data_ptr(), l.weight._version, l.weight_quantizer.quantizer._delta.data_ptr(),
+                 l.weight_quantizer.quantizer._delta._version) for l in layers)
+    cache = getattr(layers[0], '_stacked_i8_cache', None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    parts = [l._int8_weights() for l in layers]              # (w_idx, rowsum, signed) per layer
+    if not all(p[2] for p in parts):
+        return None
+    dev = layers[0].weight.device
+    w_idx = torch.cat([p[0] for p in parts], dim=0).contiguous()
+    rowsum = torch.cat([p[1] for p in parts], dim=0).contiguous()
+    if all(l.bias is None for l in layers):
+        bias = None
+    else:
+        bias = torch.cat([l.bias.detach().float() if l.bias is not None else
+                          torch.zeros(l.out_features, device=dev) for l in layers]).contiguous()
+    scales = torch.cat([l.weight_quantizer.quantizer._delta.detach().reshape(-1).float().expand(l.out_features)
+                        if l.weight_quantizer.quantizer._delta.numel() == 1
+                        else l.weight_quantizer.quantizer._delta.detach().reshape(-1).float() for l in layers]).contiguous()
+    packed = (w_idx, rowsum, bias, scales)
+    layers[0]._stacked_i8_cache = (key, packed)
+    return packed
+
+
+def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quantizer, probs_quantizer,
+                             context_quantizer):
+    """Self-attention of a quantized BERT layer from the layer input: the query / key / value Linears run as
+    ONE grouped integer GEMM that only emits int8 indices (tq_linear_i8_grouped_fwd), which the integer
+    attention core consumes in place (column blocks of the stacked buffer).  Same preconditions as
+    `quantized_attention` plus: the three Linears are plain eval-mode QuantLinears without activation
+    function whose weight and output quantizers are fixed, and x carries its int8 indices.  Returns None
+    when any of that does not hold (run the layered modules then)."""
+    from quantization.autoquant_utils import QuantLinear, _fixed_per_tensor_manager
+    layers = (query, key, value)
+    if not options.INT8_LINEAR or x.dim() != 3 or not x.is_cuda or x.dtype != torch.float32:
+        return None
+    if torch.is_grad_enabled() and (x.requires_grad or any(l.weight.requires_grad for l in layers)):
+        return None
+    src = _int8_source(x)
+    B, T, K = x.shape
+    D = query.out_features
+    if (src is None or D % num_heads or D // num_heads != 64 or T not in (64, 128, 256) or (B * T) % 64 or K % 128
+            or K > 16384):
+        return None
+    outs = []
+    for l in layers:
+        if (type(l) is not QuantLinear or l.training or not l._quant_w or not l._quant_a
+                or l.activation_function is not None or l.activation_save_target is not None
+                or l.in_features != K or l.out_features != D
+                or not _fixed_per_tensor_manager(l.activation_quantizer)
+                or l.weight_quantizer.state != Qstates.fix_ranges):
+            return None
+        wq, oq = l.weight_quantizer.quantizer, l.activation_quantizer.quantizer
+        if (not wq.symmetric or wq.n_bits > 8 or wq.scale_domain != 'linear' or wq._delta.numel() not in (1, D)
+                or oq.symmetric or oq.n_bits > 8 or oq.scale_domain != 'linear'):
+            return None
+        outs.append((oq._delta, oq._zero_float, None, oq.n_bits, False, False, oq.eps))
+    qs = _fixed_per_tensor(scores_quantizer._quant_a, scores_quantizer.activation_quantizer)
+    qp = _fixed_per_tensor(probs_quantizer._quant_a, probs_quantizer.activation_quantizer)
+    qc = _fixed_per_tensor(context_quantizer._quant_a, context_quantizer.activation_quantizer)
+    if 'no' in (qs, qp, qc) or qp == 'off' or qp[4] or qp[5] or qp[3] > 8:
+        return None
+    if mask is not None:
+        if not (mask.dim() == 4 and mask.shape[0] == B and mask.shape[1] == 1 and mask.shape[2] == 1
+                and mask.shape[3] == T):
+            return None
+        mask = mask.reshape(B, T).float().contiguous()
+    packed = _stacked_qkv(layers)
+    if packed is None:
+        return None
+    w_idx, rowsum, bias, scales = packed
+    be = _hip.backend()
+    x_idx, xq = src
+    _, qkv = be.linear_i8_grouped(x_idx, w_idx, rowsum, bias, (xq[0], xq[1], xq[3], xq[6]), scales,
+                                  query.weight_quantizer.quantizer.eps, 0, outs, want_y=False, want_idx=True)
+    arg = lambda q: None if q == 'off' else q
+    cq = context_quantizer.activation_quantizer.quantizer if qc != 'off' else None
+    want_idx = cq is not None and not cq.symmetric and cq.n_bits <= 8
+    out = be.attention_i8(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], num_heads, mask, float(D // num_heads) ** 0.5,
+                          outs[0], outs[1], outs[2], arg(qs), qp, arg(qc), want_idx=want_idx)
+    ctx = out[0] if want_idx else out
+    if cq is not None:
+        ctx._tq_quantizer = cq
+        if want_idx:
+            ctx._tq_idx = out[1]
+    return ctx
