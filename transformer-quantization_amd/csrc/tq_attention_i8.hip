@@ -100,6 +100,11 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
   if (p.has_ctx) pc = make_qp(p.q_ctx, 0);
   const float rcp_s = guarded_rcp(ps.scale), rcp_p = guarded_rcp(pp.scale);   // rne(x / scale), tq_device.h
 
+  // denom = 2^k (normal range): the division is an exact scaling
+  const uint32_t dbits = f32_to_bits(p.denom);
+  const bool denom_pow2 = (dbits & 0x007fffffu) == 0 && (dbits >> 23) >= 32 && (dbits >> 23) <= 222;
+  const float inv_denom = 1.0f / p.denom;
+
   const int rsq = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fq, zero4, 0, 0, 0)[0];   // sum_d a'_q of column r16
   const int q_const = ck * rsq + kHeadDim * cq * ck;
 
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
         if (!ok) hq = rintf(v / ps.scale);
         v = q_dequant(clamp_nanprop(hq + ps.zp, ps.lo, ps.hi), ps);
       }
-      v = v / p.denom;
+      v = denom_pow2 ? v * inv_denom : v / p.denom;      // x / 2^k == x * 2^-k exactly (sqrt(64) = 8)
       if (p.mask) v = v + mk[r];
       sc[t][r] = v;
       mx = fmaxf(mx, v);
@@ -137,6 +142,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
     for (int r = 0; r < 4; ++r) { sc[t][r] = expf(sc[t][r] - mx); sum += sc[t][r]; }
   sum += __shfl_xor(sum, 16);
   sum += __shfl_xor(sum, 32);
+  const float inv_sum = (sum >= 7.888609052210118e-31f && sum <= 1.2676506002282294e30f) ? 1.0f / sum : __builtin_nanf("");
 
   // ---- probability indices -> B operand of the second GEMM (byte tt * 4 + r of step s = key 64s + 16tt + 4g + r)
   v4i fp[KS];
@@ -147,10 +153,12 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
       uint32_t word = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pr = sc[s * 4 + tt][r] / sum;
+        // rne((e / sum) / scale): e * (1/sum) * (1/scale) carries <= 4 roundings (2^-22 relative) against the
+        // 2 of the exact chain, inside the 2^-21 tie guard of rne_quot_try; doubtful lanes redo it exactly
+        const float e = sc[s * 4 + tt][r];
         bool ok = true;
-        float hq = rne_quot_try(pr, rcp_p, ok);
-        if (!ok) hq = rintf(pr / pp.scale);
+        float hq = rne_quot_try(e * inv_sum, rcp_p, ok);
+        if (!ok) hq = rintf((e / sum) / pp.scale);
         const int a = (int)clamp_nanprop(hq + pp.zp, pp.lo, pp.hi) - 128;
         word |= ((uint32_t)a & 0xffu) << (8 * r);
       }
