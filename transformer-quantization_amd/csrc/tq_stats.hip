@@ -501,9 +501,19 @@ __global__ __launch_bounds__(kBlock) void calib_tensor_k(const void* __restrict_
   // ---- last block: partials -> statistic -> estimator state -> quantizer parameters -------------------------
   __threadfence();
   mn = kInf; mx = -kInf;
-  for (uint32_t b = threadIdx.x; b < gridDim.x; b += kBlock) {
-    mn = min_nanprop(mn, __hip_atomic_load(ws + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    mx = max_nanprop(mx, __hip_atomic_load(ws + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  {
+    // the fence invalidated this CU's L1 (buffer_inv sc1), so plain loads see every block's partial; 4 independent
+    // loads in flight per lane (atomic / volatile loads are issued one at a time, ~1.5 us each)
+    const float* wsv = ws;
+    uint32_t b = threadIdx.x;
+    for (; b + 3 * kBlock < gridDim.x; b += 4 * kBlock) {
+      float lo4[4], hi4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { lo4[u] = wsv[2 * (b + u * kBlock)]; hi4[u] = wsv[2 * (b + u * kBlock) + 1]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { mn = min_nanprop(mn, lo4[u]); mx = max_nanprop(mx, hi4[u]); }
+    }
+    for (; b < gridDim.x; b += kBlock) { mn = min_nanprop(mn, wsv[2 * b]); mx = max_nanprop(mx, wsv[2 * b + 1]); }
   }
   mn = wave_min(mn); mx = wave_max(mx);
   __syncthreads();
@@ -645,6 +655,8 @@ extern "C" int tq_calibrate_minmax(const void* x, uint64_t n, int dtype, uint64_
   return TQ_OK;
 }
 
+constexpr unsigned kTicketMaxBlocks = 512;
+
 extern "C" int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mode, const float* prev_min,
                                    const float* prev_max, float* cur_min, float* cur_max, double momentum, int n_bits,
                                    int symmetric, float eps, int log_domain, float* delta, float* zero_float,
@@ -659,6 +671,13 @@ extern "C" int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mod
   TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_calibrate_tensor: bad dtype %d", dtype);
   const int V = dtype == TQ_F32 ? 4 : 8;
   const MMPlan pl = plan_minmax(n, 1, 1, V, aligned16(x));
+  // Every block pays a device-scope release (buffer_wbl2 + buffer_inv: the 8 XCD L2s are not coherent with each
+  // other) before it takes its ticket: ~3.5 us x blocks / resident blocks.  Worth it while launches dominate
+  // (small tensors); a [1024,512,768] tensor has 16384 blocks and ran 930 us against 125 us for the separate
+  // statistics + finalize + update launches, so large tensors take that path.
+  if (pl.gx > kTicketMaxBlocks)
+    return tq_calibrate_minmax(x, n, dtype, 1, 1, mode, prev_min, prev_max, cur_min, cur_max, momentum, 0, nullptr, n_bits,
+                               symmetric, eps, log_domain, delta, zero_float, signed_flag, y, workspace, workspace_bytes, stream);
   TQ_REQUIRE(workspace && workspace_bytes >= (size_t)pl.gx * 2 * sizeof(float), "tq_calibrate_tensor: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);

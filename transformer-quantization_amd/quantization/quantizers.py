@@ -269,8 +269,11 @@ class AsymmetricUniformQuantizer(QuantizerBase):
 
     def _adjust_params_per_axis(self, x_float):
         # reference :213-217 (a symmetric quantizer has no _zero_float and fails here, as upstream)
+        d = self._delta
+        if d.dim() == x_float.dim() and d.numel() == d.shape[self.axis] and self._zero_float.shape == d.shape:
+            return                       # already in broadcast layout: skip two views + two buffer rebinds per call
         shape = [1] * self.axis + [-1] + [1] * (x_float.dim() - self.axis - 1)
-        self._delta = self._delta.view(shape)
+        self._delta = d.view(shape)
         self._zero_float = self._zero_float.view(shape)
 
     def _adjust_params_per_channel(self, x):
