@@ -121,10 +121,7 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
     for (int r = 0; r < 4; ++r) {
       float v = (float)(acc[r] + cq * rsk[r] + q_const) * s_qk;
       if (p.has_scores) {
-        bool ok = true;
-        float hq = rne_quot_try(v, rcp_s, ok);
-        if (!ok) hq = rintf(v / ps.scale);
-        v = q_dequant(clamp_nanprop(hq + ps.zp, ps.lo, ps.hi), ps);
+        v = q_dequant(clamp_nanprop(rne_quot1(v, ps.scale, rcp_s) + ps.zp, ps.lo, ps.hi), ps);
       }
       v = denom_pow2 ? v * inv_denom : v / p.denom;      // x / 2^k == x * 2^-k exactly (sqrt(64) = 8)
       if (p.mask) v = v + mk[r];
@@ -153,12 +150,13 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
       uint32_t word = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        // rne((e / sum) / scale): e * (1/sum) * (1/scale) carries <= 4 roundings (2^-22 relative) against the
-        // 2 of the exact chain, inside the 2^-21 tie guard of rne_quot_try; doubtful lanes redo it exactly
+        // rne((e / sum) / scale): e * (1/sum) * (1/scale) carries 4 roundings against the 2 of the exact chain
+        // (<= 6 u apart); a band of 8 u (|h| + 1) around the ties decides which elements redo it exactly
         const float e = sc[s * 4 + tt][r];
-        bool ok = true;
-        float hq = rne_quot_try(e * inv_sum, rcp_p, ok);
-        if (!ok) hq = rintf((e / sum) / pp.scale);
+        const float q0 = (e * inv_sum) * rcp_p;
+        float hq = rintf(q0);
+        if (!(fabsf(q0 - hq) < __builtin_fmaf(fabsf(hq), -2.0f * kTieTol, 0.5f - 2.0f * kTieTol)))   // 4 roundings: 8 u band
+          hq = rintf((e / sum) / pp.scale);
         const int a = (int)clamp_nanprop(hq + pp.zp, pp.lo, pp.hi) - 128;
         word |= ((uint32_t)a & 0xffu) << (8 * r);
       }

@@ -61,37 +61,35 @@ __device__ __forceinline__ QP make_qp(const tq_quantizer& q, uint64_t p) {
 // The IEEE fp32 division is 10 of the ~19 VALU instructions of a fake-quant element and makes the bf16
 // per-embedding and the candidate-search kernels VALU-bound.  Only rne(x / scale) is needed, so:
 //     r  = RN(1 / scale)                      once per parameter (true division)
-//     q0 = RN(x * r),  h = rne(q0)            |q0 - RN(x / scale)| <= 3 * 2^-24 |x / scale|  (< 2^-22.4 rel.)
+//     q0 = RN(x * r),  h = rne(q0)            |q0 - RN(x / scale)| <= 3 u |x / scale|,  u = 2^-24
 // h can differ from rne(RN(x / scale)) only if a rounding tie m + 1/2 lies within that distance of q0.
-// The guard accepts h when q0 is farther than 2^-21 (|h| + 1) from every tie (q0 - h is exact) and
-// otherwise -- about 1e-4 of the elements of an 8-bit grid, NaN / Inf, |h| >= 2^20, or a scale outside
-// [2^-100, 2^100] (r = NaN) -- the caller recomputes with the true division.  The result is therefore
+// The guard accepts h when q0 is farther than 4 u (|h| + 1) from every tie (q0 - h is exact); otherwise --
+// a few 1e-5 of the elements of an 8-bit grid (the band grows with |h|), NaN / Inf, |h| >= 2^21, or a scale
+// outside [2^-100, 2^100] (r = NaN) -- THAT element is recomputed with the true division.  The result is
 // bit-identical to the division path for every input (tests/test_hip_parity.py: tie-adjacent inputs).
-constexpr float kTieTol = 4.76837158203125e-07f;    // 2^-21
+// Not used by the per-tensor kernels: they are HBM-bound with the division in place, and a data-dependent
+// slow path can only cost there (measured: -20 % on a tensor whose indices span the whole 8-bit grid when
+// a doubtful element made its whole 8-element vector take the division).
+constexpr float kTieTol = 2.384185791015625e-07f;    // 4 u = 2^-22
 
 __device__ __forceinline__ float guarded_rcp(float scale) {
   return (scale >= 7.888609052210118e-31f && scale <= 1.2676506002282294e30f) ? 1.0f / scale : __builtin_nanf("");
 }
 
-// h = rne(x * r); ok &= "h is provably rne(x / scale)"
-__device__ __forceinline__ float rne_quot_try(float x, float r, bool& ok) {
+// rne(x / scale) given r = guarded_rcp(scale)
+__device__ __forceinline__ float rne_quot1(float x, float scale, float r) {
   const float q0 = x * r;
-  const float h = rintf(q0);
+  float h = rintf(q0);
   const float thr = __builtin_fmaf(fabsf(h), -kTieTol, 0.5f - kTieTol);
-  ok = ok && (fabsf(q0 - h) < thr);
+  if (!(fabsf(q0 - h) < thr)) h = rintf(x / scale);
   return h;
 }
 
-// V quotients sharing one scale: fast path for all, true division for all if any of them is doubtful
+// V quotients sharing one scale
 template <int V>
 __device__ __forceinline__ void rne_quot(const float (&x)[V], float scale, float r, float (&h)[V]) {
-  bool ok = true;
 #pragma unroll
-  for (int j = 0; j < V; ++j) h[j] = rne_quot_try(x[j], r, ok);
-  if (!ok) {
-#pragma unroll
-    for (int j = 0; j < V; ++j) h[j] = rintf(x[j] / scale);
-  }
+  for (int j = 0; j < V; ++j) h[j] = rne_quot1(x[j], scale, r);
 }
 
 // x_int = clamp(round(x / scale) + zp, lo, hi)   (quantizers.py:184-185)

@@ -64,14 +64,12 @@ __device__ __forceinline__ void store_idx1(void* idx, int idx_dtype, uint64_t of
 
 // one 16-byte vector: widen, quantize, (store indices), dequantize, narrow
 template <int DT, bool HAS_IDX>
-__device__ __forceinline__ u32x4 fq_vec(const u32x4& in, const QP& p, float rcp, void* idx, int idx_dtype,
-                                        uint64_t elem_off) {
+__device__ __forceinline__ u32x4 fq_vec(const u32x4& in, const QP& p, void* idx, int idx_dtype, uint64_t elem_off) {
   constexpr int V = Store<DT>::kVec;
-  float g[V], f[V];
-  Store<DT>::unpack(in, g);
-  rne_quot<V>(g, p.scale, rcp, f);
+  float f[V];
+  Store<DT>::unpack(in, f);
 #pragma unroll
-  for (int j = 0; j < V; ++j) f[j] = clamp_nanprop(f[j] + p.zp, p.lo, p.hi);
+  for (int j = 0; j < V; ++j) f[j] = q_index(f[j], p);     // true division: HBM-bound anyway, data-independent speed
   if (HAS_IDX) store_idx<V>(idx, idx_dtype, elem_off, f);
 #pragma unroll
   for (int j = 0; j < V; ++j) f[j] = q_dequant(f[j], p);
@@ -94,7 +92,6 @@ __global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x,
   constexpr int V = Store<DT>::kVec;
   constexpr uint64_t TILE = (uint64_t)kBlock * U;
   const QP p = make_qp(q, 0);
-  const float rcp = guarded_rcp(p.scale);
   const uint64_t n_vec = n / V;
 
   for (uint64_t t0 = (uint64_t)blockIdx.x * TILE; t0 < n_vec; t0 += (uint64_t)gridDim.x * TILE) {
@@ -105,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x,
       for (int u = 0; u < U; ++u) v[u] = NT ? ld_stream(x + i + u * kBlock) : x[i + u * kBlock];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const u32x4 o = fq_vec<DT, HAS_IDX>(v[u], p, rcp, idx, idx_dtype, (i + u * kBlock) * V);
+        const u32x4 o = fq_vec<DT, HAS_IDX>(v[u], p, idx, idx_dtype, (i + u * kBlock) * V);
         if (y) { if (NT) st_stream(y + i + u * kBlock, o); else y[i + u * kBlock] = o; }
       }
     } else {
@@ -113,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x,
       for (int u = 0; u < U; ++u) {
         const uint64_t k = i + u * kBlock;
         if (k < n_vec) {
-          const u32x4 o = fq_vec<DT, HAS_IDX>(x[k], p, rcp, idx, idx_dtype, k * V);
+          const u32x4 o = fq_vec<DT, HAS_IDX>(x[k], p, idx, idx_dtype, k * V);
           if (y) y[k] = o;
         }
       }
@@ -201,26 +198,18 @@ __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u
         const uint64_t k = i0 + (uint64_t)u * kBlock;
         float g[V], f[V], sc[V], zp[V];
         Store<DT>::unpack(v[u], g);
-        bool ok = true;
 #pragma unroll
         for (int j = 0; j < V; j += 4) {
           const f32x4 r4 = *reinterpret_cast<const f32x4*>(s_rcp + ((j / 4) * vpr + cv) * 4);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) f[j + m] = rne_quot_try(g[j + m], r4[m], ok);
-        }
-#pragma unroll
-        for (int j = 0; j < V; j += 4) {
           const f32x4 s4 = *reinterpret_cast<const f32x4*>(s_scale + ((j / 4) * vpr + cv) * 4);
           const f32x4 z4 = *reinterpret_cast<const f32x4*>(s_zp + ((j / 4) * vpr + cv) * 4);
 #pragma unroll
-          for (int m = 0; m < 4; ++m) { sc[j + m] = s4[m]; zp[j + m] = z4[m]; }
+          for (int m = 0; m < 4; ++m) {
+            sc[j + m] = s4[m];
+            zp[j + m] = z4[m];
+            f[j + m] = clamp_nanprop(rne_quot1(g[j + m], s4[m], r4[m]) + z4[m], lo, hi);
+          }
         }
-        if (!ok) {
-#pragma unroll
-          for (int j = 0; j < V; ++j) f[j] = rintf(g[j] / sc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < V; ++j) f[j] = clamp_nanprop(f[j] + zp[j], lo, hi);
         if (full || k < n_vec) {
           if (HAS_IDX) store_idx<V>(idx, idx_dtype, k * V, f);
           if (y) {
@@ -300,15 +289,8 @@ __global__ __launch_bounds__(MAXB) void fq_axis_reg(const u32x4* __restrict__ x,
       const uint64_t k = i0 + (uint64_t)u * bs;
       float g[V], f[V];
       Store<DT>::unpack(v[u], g);
-      bool ok = true;
 #pragma unroll
-      for (int j = 0; j < V; ++j) f[j] = rne_quot_try(g[j], rc[j], ok);
-      if (!ok) {
-#pragma unroll
-        for (int j = 0; j < V; ++j) f[j] = rintf(g[j] / sc[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < V; ++j) f[j] = clamp_nanprop(f[j] + zp[j], lo, hi);
+      for (int j = 0; j < V; ++j) f[j] = clamp_nanprop(rne_quot1(g[j], sc[j], rc[j]) + zp[j], lo, hi);
       if (full || k < n_vec) {
         if (HAS_IDX) store_idx<V>(idx, idx_dtype, k * V, f);
         if (y) {
@@ -392,11 +374,10 @@ __global__ __launch_bounds__(kBlock) void fq_rows(const u32x4* __restrict__ x, u
   const uint64_t vec_per_row = q.inner / V;
   for (uint64_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
     const QP p = make_qp(q, row % q.n_params);
-    const float rcp = guarded_rcp(p.scale);
     const uint64_t base = row * vec_per_row;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < vec_per_row;
          i += (uint64_t)gridDim.x * kBlock) {
-      const u32x4 o = fq_vec<DT, HAS_IDX>(x[base + i], p, rcp, idx, idx_dtype, (base + i) * V);
+      const u32x4 o = fq_vec<DT, HAS_IDX>(x[base + i], p, idx, idx_dtype, (base + i) * V);
       if (y) y[base + i] = o;
     }
   }
