@@ -145,7 +145,7 @@ int tq_linear_i8_grouped_fwd(const int8_t* x_idx, const int8_t* w_idx, const int
  * emitted by the producing Linears (TQ_IDX_I8_M128 / y_idx), with their per-tensor asymmetric <= 8-bit
  * quantizers q_q / q_k / q_v; q_probs likewise (required); q_scores / q_ctx per-tensor or NULL.
  * mask: additive fp32 [B, T] or NULL.  ctx fp32 [B, T, H * 64]; ctx_idx optional int8(index - 128)
- * of ctx (needs an asymmetric <= 8-bit q_ctx).  T in {64, 128, 256}, head_dim == 64.  Both GEMMs are
+ * of ctx (needs an asymmetric <= 8-bit q_ctx).  T a multiple of 64, <= 512; head_dim == 64.  Both GEMMs are
  * exact integer contractions with zero-point corrections; scores and probabilities never reach HBM. */
 int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, const int8_t* v_idx, float* ctx,
                         int8_t* ctx_idx, uint64_t B, uint64_t T, uint64_t H, uint64_t head_dim,

@@ -44,7 +44,7 @@ def _reference(qi, ki, vi, H, mask, pq, pk, pv, ps, pp, pc):
     return None, C
 
 
-@pytest.mark.parametrize('T', [64, 128, 256])
+@pytest.mark.parametrize('T', [64, 128, 192, 256, 384, 512])
 def test_attention_i8_vs_float64_reference(T):
     from quantization import _hip
     be = _hip.backend()
@@ -77,7 +77,8 @@ def test_attention_i8_vs_float64_reference(T):
             assert torch.equal(pc[0] * (idx - zp), ctx)
         else:
             # un-quantized context: a flipped probability index shifts a value by <= s_p * max|v|
-            tol = float(pp[0]) * float(_dq(vi, pv).abs().max()) * 2
+            # (a few probability indices per row may flip by one step; the more keys, the more candidates)
+            tol = float(pp[0]) * float(_dq(vi, pv).abs().max()) * 4
             assert float(diff.max()) <= tol, (float(diff.max()), tol)
             assert float((diff <= 1e-5 * ref.abs() + 1e-6).float().mean()) >= 0.9
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t key_slot(uint32_t key) {
 }
 
 template <int NT>   // NT = T / 16 key tiles
-__global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {
+__global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {   // up to 512 VGPRs per lane at 2 waves
   constexpr int T = NT * 16, KS = NT / 4;          // KS = 64-key MFMA steps of the second GEMM
   constexpr int PITCH = T + 32;                    // 32 * odd bytes: conflict-free ds_read_b128 (4 x 16 lane groups, 64 banks)
   __shared__ __attribute__((aligned(16))) int8_t s_vt[kHeadDim * PITCH];
@@ -217,7 +217,7 @@ extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, con
   if (B == 0 || T == 0 || H == 0) return TQ_OK;
   TQ_REQUIRE(q_idx && k_idx && v_idx && ctx, "tq_attention_i8_fwd: NULL pointer");
   TQ_REQUIRE(head_dim == kHeadDim, "tq_attention_i8_fwd: head_dim %llu unsupported (64)", (unsigned long long)head_dim);
-  TQ_REQUIRE(T == 64 || T == 128 || T == 256, "tq_attention_i8_fwd: sequence length %llu unsupported (64, 128, 256)",
+  TQ_REQUIRE(T % 64 == 0 && T <= 512, "tq_attention_i8_fwd: sequence length %llu unsupported (multiples of 64 up to 512)",
              (unsigned long long)T);
   TQ_REQUIRE(aligned16(q_idx) && aligned16(k_idx) && aligned16(v_idx) && aligned16(ctx) &&
              (mask == nullptr || aligned16(mask)) && (ctx_idx == nullptr || (reinterpret_cast<uintptr_t>(ctx_idx) % 4) == 0),
@@ -252,10 +252,11 @@ extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, con
   if (q_ctx) a.q_ctx = *q_ctx;
   const unsigned grid = (unsigned)(B * H * (T / (16 * kAttnWaves)));
   hipStream_t st = static_cast<hipStream_t>(stream);
+#define TQ_ATTN(NTV) case NTV * 16: hipLaunchKernelGGL((attention_i8_k<NTV>), dim3(grid), dim3(kAttnThreads), 0, st, a); break
   switch (T) {
-    case 64: hipLaunchKernelGGL((attention_i8_k<4>), dim3(grid), dim3(kAttnThreads), 0, st, a); break;
-    case 128: hipLaunchKernelGGL((attention_i8_k<8>), dim3(grid), dim3(kAttnThreads), 0, st, a); break;
-    default: hipLaunchKernelGGL((attention_i8_k<16>), dim3(grid), dim3(kAttnThreads), 0, st, a); break;
+    TQ_ATTN(4); TQ_ATTN(8); TQ_ATTN(12); TQ_ATTN(16); TQ_ATTN(20); TQ_ATTN(24); TQ_ATTN(28); TQ_ATTN(32);
+    default: return set_error(TQ_EUNSUPPORTED, "tq_attention_i8_fwd: sequence length %llu", (unsigned long long)T);
   }
+#undef TQ_ATTN
   return check_launch("attention_i8_k");
 }
