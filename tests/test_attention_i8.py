@@ -150,3 +150,35 @@ def test_stacked_qkv_projection_equals_three_linears():
         options.INT8_LINEAR = False
     assert one is not None and sep is not None
     assert torch.equal(one, sep) and torch.equal(one._tq_idx, sep._tq_idx)
+
+
+@pytest.mark.parametrize('n_bits', [4, 6])
+def test_attention_i8_low_bit_grids(n_bits):
+    """W4A4-style configurations: Q / K / V / probabilities / context on 4- and 6-bit grids (indices are
+    still carried as int8(index - 128))."""
+    from quantization import _hip
+    be = _hip.backend()
+    B, H, T = 2, 2, 128
+    D = H * 64
+    top = 2 ** n_bits - 1
+    g = torch.Generator().manual_seed(n_bits)
+    qi, ki, vi = ((torch.randint(0, top + 1, (B, T, D), generator=g) - 128).to(torch.int8) for _ in range(3))
+    P = lambda lo, hi: O.asym_params_from_range(lo, hi, n_bits)
+    pq, pk, pv, ps, pp, pc = P(-3.0, 2.5), P(-2.0, 3.0), P(-1.5, 1.0), P(-40.0, 50.0), P(0.0, 0.3), P(-0.6, 0.5)
+
+    def dq(idx8, p):
+        zp = torch.clamp(torch.round(p[1]), 0, top)
+        return p[0] * ((idx8.double() + 128) - zp.double())
+    split = lambda x: x.view(B, T, H, 64).permute(0, 2, 1, 3)
+    S = torch.matmul(split(dq(qi, pq)), split(dq(ki, pk)).transpose(-1, -2)).float()
+    S = O.fake_quant(S, ps[0], ps[1], n_bits, False)[1] / 8.0
+    Pm = O.fake_quant(torch.softmax(S, dim=-1), pp[0], pp[1], n_bits, False)[1]
+    C = torch.matmul(Pm.double(), split(dq(vi, pv))).float().permute(0, 2, 1, 3).reshape(B, T, D)
+    ref_idx, ref = O.fake_quant(C, pc[0], pc[1], n_bits, False)
+    k7 = lambda p: (p[0].cuda(), p[1].cuda(), None, n_bits, False, False, 1e-8)
+    ctx, idx = be.attention_i8(qi.cuda(), ki.cuda(), vi.cuda(), H, None, 8.0, k7(pq), k7(pk), k7(pv), k7(ps), k7(pp), k7(pc),
+                               want_idx=True)
+    diff = (ctx.cpu() - ref).abs()
+    assert float((diff == 0).float().mean()) >= 0.99
+    assert float(diff.max()) <= 2.01 * float(pc[0])
+    assert float((idx.cpu().float() + 128 - ref_idx).abs().max()) <= 2
