@@ -277,7 +277,7 @@ def main():
             with torch.no_grad():
                 for _ in range(5):
                     qa(xs)
-                _, ms = timed_region(lambda: qa(xs), 30, 1)
+                _, ms = timed_region(lambda: qa(xs), 30, False)
             sweep.append({'shape': [b, s, 768], 'kernel_ms': round(ms, 4),
                           'M_elems_s': round(xs.numel() / ms / 1e3, 1),
                           'GBps': round(xs.numel() * BYTES_PER_ELEM / ms / 1e6, 1)})
