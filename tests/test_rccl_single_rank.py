@@ -86,3 +86,17 @@ def test_bench_distributed_control_flow_over_rccl():
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 1 and out['value'] > 0 and out['roofline']['achieved'] > 0
+
+
+def test_bench_single_process_with_sweep():
+    """The plain `python bench.py` path (no process group) incl. --sweep: one JSON line with the contract's keys."""
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '3', '--warmup', '1', '--no-cpu', '--sweep', '--batch', '64',
+                        '--seq', '128'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in out, k
+    assert out['steps'] == 3 and out['warmup'] == 1 and out['config']['workload']
+    assert set(out['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+    assert len(out['sweep']) >= 3
