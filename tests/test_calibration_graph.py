@@ -86,3 +86,36 @@ def test_inplace_state_matches_rebinding_eagerly():
         assert torch.equal(x, y)
     for (k, v), (k2, v2) in zip(a.state_dict().items(), b_.state_dict().items()):
         assert k == k2 and torch.equal(v.reshape(-1), v2.reshape(-1)), k
+
+
+def test_graphed_forward_helper_calibrating_and_fixed():
+    """quantization.graphs.GraphedForward: capture + state restore + replay == eager, for a calibrating forward
+    (in-place state) and then for the fixed-range forward of the same model."""
+    from quantization import options
+    from quantization.graphs import GraphedForward
+    batches = _batches(4)
+    with torch.no_grad():
+        ref = _model(2)
+        for b in batches:
+            ref(b)
+        ref.fix_ranges()
+        ref_fixed = ref(batches[0])
+        options.INPLACE_CALIBRATION_STATE = True
+        try:
+            m = _model(2)
+            m(batches[0])
+            g = GraphedForward(m, batches[1])
+            for b in batches[1:]:
+                g(b)
+        finally:
+            options.INPLACE_CALIBRATION_STATE = False
+        m.fix_ranges()
+        gf = GraphedForward(m, batches[0])
+        out = gf(batches[0]).clone()
+        out2 = gf(batches[2]).clone()
+        eager2 = m(batches[2])
+    for (k, v), (k2, v2) in zip(m.state_dict().items(), ref.state_dict().items()):
+        assert k == k2 and torch.equal(v.reshape(-1), v2.reshape(-1)), k
+    assert torch.equal(out, ref_fixed) and torch.equal(out2, eager2)
+    with pytest.raises(ValueError):
+        gf(batches[0][:4])

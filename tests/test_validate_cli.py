@@ -86,6 +86,8 @@ def test_state_dict_round_trip_and_fast_inference(tmp_path, capsys):
     b = V.main(base + ['--load-state-dict', os.path.join(tmp_path, 'state_dict.pth')])
     assert b['load_state_dict']['unexpected'] == []
     assert abs(a['fidelity_vs_fp32']['logit_sqnr_db'] - b['fidelity_vs_fp32']['logit_sqnr_db']) < 1e-6
+    d = V.main(base + ['--hip-graph'])                       # graph-replayed calibration + evaluation: same numbers
+    assert abs(a['fidelity_vs_fp32']['logit_sqnr_db'] - d['fidelity_vs_fp32']['logit_sqnr_db']) < 1e-6
     c = V.main(base + ['--load-state-dict', os.path.join(tmp_path, 'state_dict.pth'), '--fast-inference'])
     assert abs(a['fidelity_vs_fp32']['logit_sqnr_db'] - c['fidelity_vs_fp32']['logit_sqnr_db']) < 3.0
     from harness.bert import QResidualBlock, QSelfAttention

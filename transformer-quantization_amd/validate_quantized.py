@@ -116,6 +116,8 @@ def build_parser():
     g.add_argument('--device', default='cuda')
     g.add_argument('--fast-inference', action='store_true',
                    help='Evaluate with the opt-in fused fixed-range paths (fused LN tails / attention, int8 MFMA Linears).')
+    g.add_argument('--hip-graph', action='store_true',
+                   help='Replay calibration batches 2..N and the evaluation forward as hipGraphs (quantization/graphs.py).')
     g.add_argument('--output-dir', default=None)
     g.add_argument('--load-state-dict', default=None, help='Skip range estimation; load ranges from this state_dict.')
     return ap
@@ -245,9 +247,26 @@ def run(config, args):
             if config.quant.per_groups_permute or config.quant.per_groups_permute_shared_h:
                 _, t = _timed(lambda: estimate_permutation_ranges(model, est, config.quant.per_groups_permute_shared_h))
                 report['timings_s']['permutation_ranges'] = t
-            _, t = _timed(lambda: pass_data_for_range_estimation(
-                est, model, config.quant.act_quant, config.quant.weight_quant, config.act_quant.num_batches,
-                cross_entropy_layer=config.act_quant.cross_entropy_layer))
+            n_est = config.act_quant.num_batches if config.quant.act_quant else 1
+            if args.hip_graph and n_est > 1:
+                from quantization.graphs import GraphedForward
+                options.INPLACE_CALIBRATION_STATE = True
+
+                def calibrate():
+                    # batch 1 eager (creates every state buffer), batches 2..N as replays of one captured forward
+                    pass_data_for_range_estimation(est[:1], model, config.quant.act_quant, config.quant.weight_quant, 1,
+                                                   cross_entropy_layer=config.act_quant.cross_entropy_layer)
+                    g = GraphedForward(model, est[1][0].to(dev))
+                    for batch in est[1:n_est]:
+                        g(batch[0].to(dev))
+                try:
+                    _, t = _timed(calibrate)
+                finally:
+                    options.INPLACE_CALIBRATION_STATE = False
+            else:
+                _, t = _timed(lambda: pass_data_for_range_estimation(
+                    est, model, config.quant.act_quant, config.quant.weight_quant, config.act_quant.num_batches,
+                    cross_entropy_layer=config.act_quant.cross_entropy_layer))
             report['timings_s']['range_estimation'] = t
         model.set_quant_state(config.quant.weight_quant, config.quant.act_quant)
         if not config.quant.dynamic:
@@ -273,12 +292,17 @@ def run(config, args):
     with torch.no_grad():
         model.eval()
 
+        fwd = model
+        if args.hip_graph and not config.quant.dynamic:
+            from quantization.graphs import GraphedForward
+            fwd = GraphedForward(model, evalb[0][0].to(dev))
+
         def evaluate():
             nonlocal sig, noise, agree, total
             for (ids,) in evalb:
                 ids = ids.to(dev)
                 ref = hf(input_ids=ids).logits.float()
-                out = model(ids).float()
+                out = fwd(ids).float()
                 sig += float((ref.double() ** 2).sum())
                 noise += float(((ref - out).double() ** 2).sum())
                 agree += int((ref.argmax(-1) == out.argmax(-1)).sum())
