@@ -393,3 +393,41 @@ def test_percentile_ranges_match_numpy():
         lo, hi = est(w)
         r = np.percentile(w.numpy(), (p, 100))
         assert lo.shape == (1,) and float(lo) == np.float32(r[0]) and float(hi) == np.float32(r[1])
+
+
+def test_adaround_samples_from_the_cached_rows():
+    """Layers whose input does not carry the batch dimension (BERT's position embeddings see one [1, T]
+    index tensor per forward) cache one row per BATCH, not per sample; the optimisation loop must draw its
+    indices from the cached rows like the reference (adaround/adaround.py:236) -- drawing from the number
+    of samples indexes past the cache (a GPU memory fault on the device path)."""
+    from quantization.adaround import apply_adaround_to_layer
+    from quantization.adaround.config import DEFAULT_ADAROUND_CONFIG
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.quantizers import QMethods
+
+    class Net(QuantizedModel):
+        def __init__(self):
+            super().__init__()
+            self.tok = quantize_model(nn.Embedding(50, 16), method=QMethods.symmetric_uniform, n_bits=4)
+            self.pos = quantize_model(nn.Embedding(8, 16), method=QMethods.symmetric_uniform, n_bits=4)
+            self.fc = quantize_model(nn.Linear(16, 4), method=QMethods.symmetric_uniform, n_bits=4)
+
+        def forward(self, ids):
+            pos = torch.arange(ids.shape[1]).unsqueeze(0)
+            return self.fc(self.tok(ids) + self.pos(pos))
+
+    torch.manual_seed(0)
+    net = Net().eval()
+    data = torch.randint(0, 50, (24, 8))
+    net.set_quant_state(True, False)
+    with torch.no_grad():
+        net(data[:4])
+    cfg = copy.deepcopy(DEFAULT_ADAROUND_CONFIG)
+    cfg.iters = 12
+    for name in ('pos', 'tok', 'fc'):
+        net.full_precision()
+        getattr(net, name).quantized_weights()
+        res = apply_adaround_to_layer(net, getattr(net, name), data, batch_size=4, act_quant=False,
+                                      adaround_config=copy.deepcopy(cfg))
+        assert np.isfinite(res.loss_hard_after)

@@ -62,9 +62,12 @@ def test_flag_cross_checks_match_the_reference():
     ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--n-bits', '4', '--n-bits-act', '8',
      '--weight-quant-method', 'MSE', '--adaround', 'layers.0.output.dense', '--adaround-iters', '60',
      '--adaround-num-samples', '16'],
-], ids=['w8a8', 'peg6-permute-fp-logits', 'per-embd-mixed-precision', 'w4a8-adaround'])
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--n-bits', '4', '--n-bits-act', '8',
+     '--adaround', 'all', '--adaround-iters', '12', '--adaround-num-samples', '16'],
+], ids=['w8a8', 'peg6-permute-fp-logits', 'per-embd-mixed-precision', 'w4a8-adaround', 'w4a8-adaround-all-layers'])
 def test_end_to_end_on_two_layers(flags, tmp_path, capsys):
-    rep = V.main(flags + ['--num-layers', '2', '--num-eval-batches', '2', '--output-dir', str(tmp_path)])
+    layers = '1' if 'all' in flags else '2'      # 'all' also walks embeddings (incl. the [1, T] position ids) and LayerNorms
+    rep = V.main(flags + ['--num-layers', layers, '--num-eval-batches', '2', '--output-dir', str(tmp_path)])
     assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])['quantizers'] == rep['quantizers']
     f = rep['fidelity_vs_fp32']
     # sanity only: random-init logits are tiny, so the low-bit configurations (W4, 6-bit activations) sit near 0 dB

@@ -221,9 +221,18 @@ def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, bat
         logger.info('Caching data for local loss optimization')
         cached_inps, cached_outs, device, ws, rk = _cache_layer_io(
             get_inp_out, data_tensor, batch_size, keep_gpu)
+        # The sampling population is the set of CACHED rows, as upstream (:236): for most layers one row per
+        # sample, but e.g. BERT's position embeddings see one [1, T] input per forward, i.e. one row per
+        # cached batch.  Sharded: row i lives on rank i % ws; ranks may differ by one row, so use the minimum.
+        rows = cached_inps.size(0)
+        if ws > 1:
+            r = torch.tensor([rows], device=device, dtype=torch.int64)
+            torch.distributed.all_reduce(r, op=torch.distributed.ReduceOp.MIN)
+            rows = int(r)
+        n_total = rows * ws
     else:
         ws, rk, device = 1, 0, layer.weight.device
-    n_total = data_tensor.size(0)
+        n_total = data_tensor.size(0)
     q = layer.weight_quantizer.quantizer
     be = _hip.backend()
     # plain Linear layers without a folded activation function: closed-form gradient, no autograd
@@ -237,6 +246,8 @@ def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, bat
         if use_cached_data:
             if ws > 1:
                 idx = idx[idx % ws == rk] // ws      # samples of this rank, local positions
+            if idx.numel() and int(idx.max()) >= cached_inps.size(0):
+                raise IndexError(f'sample index {int(idx.max())} outside the {cached_inps.size(0)} cached rows')
             cur_inp = cached_inps[idx].to(device)
             cur_out = cached_outs[idx].to(device)
         else:
