@@ -102,6 +102,15 @@ int tq_residual_layernorm_quant_fwd(const void* dense_out, const void* residual,
                                     const float* ln_weight, const float* ln_bias, float ln_eps,
                                     const tq_quantizer* q_out, tq_stream_t stream);
 
+/* The same tail with MobileBERT's NoNorm (element-wise affine, no statistics) in place of LayerNorm
+ * (reference models/quantized_mobilebert.py:58-72 with :287-304, :330-352):
+ *     y = Q_out( Q_sum( Q_dense(dense_out) + residual ) * weight + bias )
+ * weight / bias: fp32 [d], already fake-quantized; mul and add are separate fp32 operations.       */
+int tq_residual_nonorm_quant_fwd(const void* dense_out, const void* residual, void* y, int8_t* y_idx,
+                                 uint64_t rows, uint64_t d, int dtype, const tq_quantizer* q_dense,
+                                 const tq_quantizer* q_sum, const float* weight, const float* bias,
+                                 const tq_quantizer* q_out, tq_stream_t stream);
+
 /* (f3) Fused integer Linear + bias + activation + output quantizer on the i8 matrix cores.
  * Replaces QuantizationHijacker.forward for a Linear with fixed ranges (quantization/hijacker.py:
  * 66-116 + autoquant_utils.py:16-21):  y = Q_out( act( F.linear(Q_x(x), Q_w(W), b) ) ), evaluated

@@ -51,7 +51,10 @@ class OracleBackend:
         def q(v, a):
             return v if a is None else self._quant(v, *a, 1, 1)[1]
         u = q(q(dense_out.float(), q_dense) + residual.float(), q_sum)
-        v = torch.nn.functional.layer_norm(u, (u.shape[-1],), ln_weight.float(), ln_bias.float(), ln_eps)
+        if ln_eps is None:
+            v = u * ln_weight.float() + ln_bias.float()
+        else:
+            v = torch.nn.functional.layer_norm(u, (u.shape[-1],), ln_weight.float(), ln_bias.float(), ln_eps)
         return q(v, q_out).to(dense_out.dtype)
 
     def scores_softmax_quant(self, scores, mask, rows_per_mask, denom, q_scores, q_probs):

@@ -77,3 +77,66 @@ def test_fused_block_in_bert_harness_matches_layered():
     span = float(layered.max() - layered.min())
     assert float((fused - layered).abs().max()) <= 0.10 * span
     assert float(((fused - layered).abs() == 0).float().mean()) >= 0.5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('d', [512, 128])
+def test_nonorm_tail_is_bit_exact(dtype, d):
+    """MobileBERT tail (NoNorm has no statistics, so nothing depends on a summation order): the fused kernel
+    must equal the oracle chain bit for bit, indices included."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(d + 1)
+    rows = 2048
+    a = (torch.randn(rows, d, generator=g) * 2).to(dtype)
+    r = (torch.randn(rows, d, generator=g) * 1.5).to(dtype)
+    w = 1 + 0.3 * torch.randn(d, generator=g)
+    b = 0.2 * torch.randn(d, generator=g)
+    p1, p2, p3 = (O.asym_params_from_range(lo, hi, 8) for lo, hi in ((-7.0, 7.5), (-9.0, 11.0), (-12.0, 14.0)))
+    k = lambda q: None if q is None else (q[0].cuda(), q[1].cuda(), None, 8, False, False, 1e-8)
+
+    def q(v, p):
+        return v if p is None else O.fake_quant(v, p[0], p[1], 8, False)[1]
+    for use in ((1, 1, 1), (0, 1, 1), (1, 0, 0)):
+        q1, q2, q3 = (p if u else None for p, u in zip((p1, p2, p3), use))
+        u_ = q(q(a.float(), q1) + r.float(), q2)
+        v_ = u_ * w + b
+        ref = q(v_, q3).to(dtype)
+        out = be.residual_layernorm_quant(a.cuda(), r.cuda(), k(q1), k(q2), w.cuda(), b.cuda(), None, k(q3),
+                                          want_idx=q3 is not None)
+        y = (out[0] if q3 is not None else out).cpu()
+        assert y.dtype == dtype and torch.equal(y, ref), use
+        if q3 is not None:
+            ref_idx = O.fake_quant(v_, q3[0], q3[1], 8, False)[0]
+            assert torch.equal(out[1].cpu().float() + 128, ref_idx)
+
+
+def test_nonorm_block_module_level():
+    """quantization.fused.residual_layernorm_quant with a QuantNoNorm == the layered MobileBERT modules."""
+    from torch import nn
+    from quantization.autoquant_utils import QuantNoNorm, quantize_model
+    from quantization.base_quantized_classes import QuantizedActivation
+    from quantization.fused import residual_layernorm_quant
+    from quantization.quantizers import QMethods
+    torch.manual_seed(0)
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8)
+
+    class NoNorm(nn.Module):
+        def __init__(self, d):
+            super().__init__()
+            self.weight = nn.Parameter(1 + 0.2 * torch.randn(d))
+            self.bias = nn.Parameter(0.1 * torch.randn(d))
+    dense = quantize_model(nn.Linear(128, 512), **qp).cuda().eval()
+    resq = QuantizedActivation(**qp).cuda().eval()
+    nn_ = QuantNoNorm(NoNorm(512), **qp).cuda().eval()
+    x = torch.randn(4, 64, 128, device='cuda')
+    res = torch.randn(4, 64, 512, device='cuda')
+    with torch.no_grad():
+        for m in (dense, resq, nn_):
+            m.quantized()
+        layered0 = nn_(resq(dense(x) + res))               # estimating: sets every range
+        for m in (dense, resq, nn_):
+            m.fix_ranges()
+        layered = nn_(resq(dense(x) + res))
+        fused = residual_layernorm_quant(dense, resq, nn_, x, res)
+    assert torch.equal(fused, layered)

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
                                                          u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          float ln_eps, tq_quantizer q1, tq_quantizer q2, tq_quantizer q3,
-                                                         int on1, int on2, int on3) {
+                                                         int on1, int on2, int on3, int affine_only) {
   constexpr int V = Store<DT>::kVec;
   constexpr int RPB = kBlock / LPR;                 // rows per block iteration
   constexpr uint32_t d = LPR * NV * V;
@@ -81,13 +81,18 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
         s += u[v][j];
       }
     }
-    const float mean = group_sum<LPR>(s) * inv_d;
-    float ss = 0.f;
+    // MobileBERT's NoNorm (models/quantized_mobilebert.py:58-72) is the affine part alone: u * w + b.  With
+    // mean = 0 and rstd = 1 the expression below evaluates exactly that ((u - 0) * 1 is exact).
+    float mean = 0.0f, rstd = 1.0f;
+    if (!affine_only) {
+      mean = group_sum<LPR>(s) * inv_d;
+      float ss = 0.f;
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
+      for (int v = 0; v < NV; ++v)
 #pragma unroll
-      for (int j = 0; j < V; ++j) { const float c = u[v][j] - mean; ss += c * c; }
-    const float rstd = 1.0f / sqrtf(group_sum<LPR>(ss) * inv_d + ln_eps);
+        for (int j = 0; j < V; ++j) { const float c = u[v][j] - mean; ss += c * c; }
+      rstd = 1.0f / sqrtf(group_sum<LPR>(ss) * inv_d + ln_eps);
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float o[V];
@@ -111,7 +116,8 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
 
 template <int DT>
 static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, uint64_t rows, uint64_t d, const float* w, const float* b,
-                         float eps, const tq_quantizer* q1, const tq_quantizer* q2, const tq_quantizer* q3, hipStream_t st) {
+                         float eps, const tq_quantizer* q1, const tq_quantizer* q2, const tq_quantizer* q3, int affine_only,
+                         hipStream_t st) {
   constexpr int V = Store<DT>::kVec;
   const tq_quantizer none{};
   const tq_quantizer &c1 = q1 ? *q1 : none, &c2 = q2 ? *q2 : none, &c3 = q3 ? *q3 : none;
@@ -124,7 +130,7 @@ static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, u
     const unsigned rpb = kBlock / (LPR);                                                                        \
     const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(rows, rpb), 1), 1u << 20);   \
     hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, eps, \
-                       c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr);                                \
+                       c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, affine_only);                   \
     return check_launch("res_ln_quant_k");                                                                      \
   }
   // d (bf16 | fp32): 768 -> 96 | 192 vectors, 3072 -> 384 | 768, 512 -> 64 | 128, 128 -> 16 | 32, 1024 -> 128 | 256
@@ -187,27 +193,42 @@ __global__ __launch_bounds__(kBlock) void softmax_quant_k(const f32x4* __restric
 
 using namespace tq;
 
+static int residual_tail(const char* who, const void* dense_out, const void* residual, void* y, int8_t* y_idx, uint64_t rows,
+                         uint64_t d, int dtype, const tq_quantizer* q_dense, const tq_quantizer* q_sum, const float* weight,
+                         const float* bias, float ln_eps, const tq_quantizer* q_out, int affine_only, tq_stream_t stream) {
+  if (rows == 0) return TQ_OK;
+  TQ_REQUIRE(dense_out && residual && y && weight && bias, "%s: NULL pointer", who);
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "%s: bad dtype %d", who, dtype);
+  TQ_REQUIRE(aligned16(dense_out) && aligned16(residual) && aligned16(y), "%s: 16-byte alignment required", who);
+  TQ_REQUIRE(y_idx == nullptr || (q_out != nullptr && !q_out->symmetric && q_out->n_bits <= 8 && (reinterpret_cast<uintptr_t>(y_idx) & 7u) == 0),
+             "%s: y_idx needs an asymmetric <= 8-bit output quantizer and 8-byte alignment", who);
+  for (const tq_quantizer* q : {q_dense, q_sum, q_out})
+    if (q != nullptr) {
+      if (int e = check_quantizer(q, rows * d, who)) return e;
+      TQ_REQUIRE(q->n_params == 1, "%s: per-tensor quantizers only", who);
+    }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case TQ_F32: return launch_res_ln<TQ_F32>(dense_out, residual, y, y_idx, rows, d, weight, bias, ln_eps, q_dense, q_sum, q_out, affine_only, st);
+    case TQ_BF16: return launch_res_ln<TQ_BF16>(dense_out, residual, y, y_idx, rows, d, weight, bias, ln_eps, q_dense, q_sum, q_out, affine_only, st);
+    default: return launch_res_ln<TQ_F16>(dense_out, residual, y, y_idx, rows, d, weight, bias, ln_eps, q_dense, q_sum, q_out, affine_only, st);
+  }
+}
+
 extern "C" int tq_residual_layernorm_quant_fwd(const void* dense_out, const void* residual, void* y, int8_t* y_idx, uint64_t rows,
                                                uint64_t d, int dtype, const tq_quantizer* q_dense,
                                                const tq_quantizer* q_sum, const float* ln_weight, const float* ln_bias,
                                                float ln_eps, const tq_quantizer* q_out, tq_stream_t stream) {
-  if (rows == 0) return TQ_OK;
-  TQ_REQUIRE(dense_out && residual && y && ln_weight && ln_bias, "tq_residual_layernorm_quant_fwd: NULL pointer");
-  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_residual_layernorm_quant_fwd: bad dtype %d", dtype);
-  TQ_REQUIRE(aligned16(dense_out) && aligned16(residual) && aligned16(y), "tq_residual_layernorm_quant_fwd: 16-byte alignment required");
-  TQ_REQUIRE(y_idx == nullptr || (q_out != nullptr && !q_out->symmetric && q_out->n_bits <= 8 && (reinterpret_cast<uintptr_t>(y_idx) & 7u) == 0),
-             "tq_residual_layernorm_quant_fwd: y_idx needs an asymmetric <= 8-bit output quantizer and 8-byte alignment");
-  for (const tq_quantizer* q : {q_dense, q_sum, q_out})
-    if (q != nullptr) {
-      if (int e = check_quantizer(q, rows * d, "tq_residual_layernorm_quant_fwd")) return e;
-      TQ_REQUIRE(q->n_params == 1, "tq_residual_layernorm_quant_fwd: per-tensor quantizers only");
-    }
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (dtype) {
-    case TQ_F32: return launch_res_ln<TQ_F32>(dense_out, residual, y, y_idx, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
-    case TQ_BF16: return launch_res_ln<TQ_BF16>(dense_out, residual, y, y_idx, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
-    default: return launch_res_ln<TQ_F16>(dense_out, residual, y, y_idx, rows, d, ln_weight, ln_bias, ln_eps, q_dense, q_sum, q_out, st);
-  }
+  return residual_tail("tq_residual_layernorm_quant_fwd", dense_out, residual, y, y_idx, rows, d, dtype, q_dense, q_sum, ln_weight,
+                       ln_bias, ln_eps, q_out, 0, stream);
+}
+
+extern "C" int tq_residual_nonorm_quant_fwd(const void* dense_out, const void* residual, void* y, int8_t* y_idx, uint64_t rows,
+                                            uint64_t d, int dtype, const tq_quantizer* q_dense, const tq_quantizer* q_sum,
+                                            const float* weight, const float* bias, const tq_quantizer* q_out,
+                                            tq_stream_t stream) {
+  return residual_tail("tq_residual_nonorm_quant_fwd", dense_out, residual, y, y_idx, rows, d, dtype, q_dense, q_sum, weight, bias,
+                       0.0f, q_out, 1, stream);
 }
 
 extern "C" int tq_scores_softmax_quant_fwd(const float* scores, float* probs, uint64_t rows, uint64_t cols,

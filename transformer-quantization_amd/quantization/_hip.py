@@ -45,6 +45,7 @@ SIGNATURES = {
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
     'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
     'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
+    'tq_residual_nonorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _QP, _vp]),
     'tq_attention_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u64, _u64, _vp, _f, _QP, _QP, _QP, _QP, _QP, _QP, _vp]),
     'tq_linear_i8_grouped_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _f, _int,
                                         _u64, C.POINTER(_QP), _vp]),
@@ -204,7 +205,8 @@ class HipBackend:
     def residual_layernorm_quant(self, dense_out, residual, q_dense, q_sum, ln_weight, ln_bias, ln_eps, q_out,
                                  want_idx=False):
         """y = Q_out(LN(Q_sum(Q_dense(dense_out) + residual))); each q_* is None or the 7-tuple
-        (delta, zero_float, signed, n_bits, symmetric, log_domain, eps) of a per-tensor quantizer."""
+        (delta, zero_float, signed, n_bits, symmetric, log_domain, eps) of a per-tensor quantizer.
+        ln_eps=None selects MobileBERT's NoNorm (u * w + b) instead of LayerNorm."""
         _need_device(dense_out, 'residual_layernorm_quant')
         a, r = dense_out.contiguous(), residual.contiguous().to(dense_out.dtype)
         y = torch.empty_like(a)
@@ -212,10 +214,15 @@ class HipBackend:
         d = a.shape[-1]
         descs = [None if q is None else self._qdesc(*q, 1, 1) for q in (q_dense, q_sum, q_out)]
         refs = [None if dsc is None else C.byref(dsc) for dsc in descs]
-        rc = self.lib.tq_residual_layernorm_quant_fwd(
-            _ptr(a), _ptr(r), _ptr(y), _ptr(idx), a.numel() // d, d, _dtype_code(a, 'residual_layernorm_quant'),
-            refs[0], refs[1], _ptr(ln_weight.detach().float().contiguous()),
-            _ptr(ln_bias.detach().float().contiguous()), float(ln_eps), refs[2], _stream())
+        w32, b32 = ln_weight.detach().float().contiguous(), ln_bias.detach().float().contiguous()
+        if ln_eps is None:          # NoNorm: element-wise affine, no statistics
+            rc = self.lib.tq_residual_nonorm_quant_fwd(
+                _ptr(a), _ptr(r), _ptr(y), _ptr(idx), a.numel() // d, d, _dtype_code(a, 'residual_layernorm_quant'),
+                refs[0], refs[1], _ptr(w32), _ptr(b32), refs[2], _stream())
+        else:
+            rc = self.lib.tq_residual_layernorm_quant_fwd(
+                _ptr(a), _ptr(r), _ptr(y), _ptr(idx), a.numel() // d, d, _dtype_code(a, 'residual_layernorm_quant'),
+                refs[0], refs[1], _ptr(w32), _ptr(b32), float(ln_eps), refs[2], _stream())
         _check(rc, self.lib)
         return (y, idx) if want_idx else y
 

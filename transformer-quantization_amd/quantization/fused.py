@@ -33,16 +33,18 @@ def _fixed_per_tensor(enabled, mgr):
 
 
 def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
-    """dense: QuantLinear, res_quantizer: QuantizedActivation, layer_norm: QuantLayerNorm.
-    Equivalent to ``layer_norm(res_quantizer(dense(x) + residual))``."""
+    """dense: QuantLinear, res_quantizer: QuantizedActivation, layer_norm: QuantLayerNorm or MobileBERT's
+    QuantNoNorm (tq_residual_nonorm_quant_fwd).  Equivalent to ``layer_norm(res_quantizer(dense(x) + residual))``."""
     q1 = _fixed_per_tensor(dense._quant_a and dense.activation_function is None, dense.activation_quantizer)
     q2 = _fixed_per_tensor(res_quantizer._quant_a, res_quantizer.activation_quantizer)
     q3 = _fixed_per_tensor(layer_norm._quant_a and layer_norm.activation_function is None,
                            layer_norm.activation_quantizer)
+    from quantization.autoquant_utils import QuantNoNorm
+    is_nonorm = isinstance(layer_norm, QuantNoNorm)
     fusable = ('no' not in (q1, q2, q3) and dense.activation_function is None
                and layer_norm.activation_function is None and x.is_cuda
                and not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad))
-               and len(layer_norm.normalized_shape) == 1
+               and (is_nonorm or len(layer_norm.normalized_shape) == 1)
                and dense.activation_save_target is None and layer_norm.activation_save_target is None)
     if not fusable:
         return layer_norm(res_quantizer(dense(x) + residual))
@@ -52,13 +54,20 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
     if gemm is None:
         w, b = dense.get_params()
         gemm = dense.run_forward(x, w, b)                   # hipBLASLt through torch (fp32 simulation)
-    ln_w, ln_b = layer_norm.get_params()                    # fake-quantized (cached in eval) affine
+    if is_nonorm:
+        # one weight quantizer serves weight and bias, in this order (upstream quirk, autoquant_utils.QuantNoNorm)
+        ln_w, ln_b = layer_norm.weight, layer_norm.bias
+        if layer_norm._quant_w:
+            ln_w = layer_norm.weight_quantizer(ln_w)
+            ln_b = layer_norm.weight_quantizer(ln_b)
+    else:
+        ln_w, ln_b = layer_norm.get_params()                # fake-quantized (cached in eval) affine
     arg = lambda q: None if q == 'off' else q
     oq = layer_norm.activation_quantizer.quantizer if q3 != 'off' else None
     want_idx = (options.INT8_LINEAR and oq is not None and not oq.symmetric and oq.n_bits <= 8
                 and gemm.dtype == torch.float32)
     out = _hip.backend().residual_layernorm_quant(gemm, residual, arg(q1), arg(q2), ln_w, ln_b,
-                                                  layer_norm.eps, arg(q3), want_idx=want_idx)
+                                                  None if is_nonorm else layer_norm.eps, arg(q3), want_idx=want_idx)
     y = out[0] if want_idx else out
     if oq is not None:
         y._tq_quantizer = oq
