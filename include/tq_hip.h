@@ -150,11 +150,11 @@ int tq_linear_i8_grouped_fwd(const int8_t* x_idx, const int8_t* w_idx, const int
 /* Fixed-range quantized self-attention core on the i8 matrix cores (reference
  * models/quantized_bert.py:135-213: head split, Q K^T, score quantizer, 1/sqrt(d), mask, softmax,
  * probability quantizer, P V, head merge, context quantizer -- 2 batched fp32 GEMMs, 4 permute copies
- * and 6 element-wise sweeps upstream).  q_idx / k_idx / v_idx: int8(index - 128) [B, T, H * 64] as
+ * and 6 element-wise sweeps upstream).  q_idx / k_idx / v_idx: int8(index - 128) [B, T, H * head_dim] as
  * emitted by the producing Linears (TQ_IDX_I8_M128 / y_idx), with their per-tensor asymmetric <= 8-bit
  * quantizers q_q / q_k / q_v; q_probs likewise (required); q_scores / q_ctx per-tensor or NULL.
- * mask: additive fp32 [B, T] or NULL.  ctx fp32 [B, T, H * 64]; ctx_idx optional int8(index - 128)
- * of ctx (needs an asymmetric <= 8-bit q_ctx).  T a multiple of 64, <= 512; head_dim == 64.  Both GEMMs are
+ * mask: additive fp32 [B, T] or NULL.  ctx fp32 [B, T, H * head_dim]; ctx_idx optional int8(index - 128)
+ * of ctx (needs an asymmetric <= 8-bit q_ctx).  T a multiple of 64, <= 512; head_dim 64 (BERT) or 32 (MobileBERT).  Both GEMMs are
  * exact integer contractions with zero-point corrections; scores and probabilities never reach HBM. */
 int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, const int8_t* v_idx, float* ctx,
                         int8_t* ctx_idx, uint64_t B, uint64_t T, uint64_t H, uint64_t head_dim,

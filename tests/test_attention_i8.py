@@ -90,8 +90,8 @@ def test_attention_i8_rejects_unsupported():
     p = lambda: (torch.tensor(0.1).cuda(), torch.tensor(3.0).cuda(), None, 8, False, False, 1e-8)
     with pytest.raises(_hip.TQError):       # T = 96
         be.attention_i8(z(1, 96, 128), z(1, 96, 128), z(1, 96, 128), 2, None, 8.0, p(), p(), p(), None, p(), None)
-    with pytest.raises(_hip.TQError):       # head_dim = 32
-        be.attention_i8(z(1, 64, 128), z(1, 64, 128), z(1, 64, 128), 4, None, 8.0, p(), p(), p(), None, p(), None)
+    with pytest.raises(_hip.TQError):       # head_dim = 16
+        be.attention_i8(z(1, 64, 128), z(1, 64, 128), z(1, 64, 128), 8, None, 4.0, p(), p(), p(), None, p(), None)
     sym = (torch.tensor(0.1).cuda(), None, torch.tensor(True).cuda(), 8, True, False, 1e-8)
     with pytest.raises(_hip.TQError):       # symmetric probabilities grid
         be.attention_i8(z(1, 64, 128), z(1, 64, 128), z(1, 64, 128), 2, None, 8.0, p(), p(), p(), None, sym, None)
@@ -180,5 +180,28 @@ def test_attention_i8_low_bit_grids(n_bits):
                                want_idx=True)
     diff = (ctx.cpu() - ref).abs()
     assert float((diff == 0).float().mean()) >= 0.99
+    assert float(diff.max()) <= 2.01 * float(pc[0])
+    assert float((idx.cpu().float() + 128 - ref_idx).abs().max()) <= 2
+
+
+@pytest.mark.parametrize('T', [128, 384])
+def test_attention_i8_head_dim_32(T):
+    """MobileBERT geometry: 4 heads of 32 dims (half of the MFMA K step is zero padding)."""
+    from quantization import _hip
+    be = _hip.backend()
+    B, H, dh = 2, 4, 32
+    D = H * dh
+    g = torch.Generator().manual_seed(T + 7)
+    qi, ki, vi = (torch.randint(-128, 128, (B, T, D), generator=g, dtype=torch.int8) for _ in range(3))
+    mask = ((torch.rand(B, T, generator=g) > 0.8).float()) * -10000.0
+    mask[:, 0] = 0
+    pq, pk, pv = _params(-3.0, 2.5), _params(-2.0, 3.0), _params(-1.5, 1.0)
+    ps, pp, pc = _params(-30.0, 35.0), _params(0.0, 0.6), _params(-1.2, 0.9)
+    ref_idx, ref = _reference(qi, ki, vi, H, mask, pq, pk, pv, ps, pp, pc)
+    k7 = lambda p: (p[0].cuda(), p[1].cuda(), None, 8, False, False, 1e-8)
+    ctx, idx = be.attention_i8(qi.cuda(), ki.cuda(), vi.cuda(), H, mask.cuda(), math.sqrt(dh), k7(pq), k7(pk), k7(pv), k7(ps),
+                               k7(pp), k7(pc), want_idx=True)
+    diff = (ctx.cpu() - ref).abs()
+    assert float((diff == 0).float().mean()) >= 0.995
     assert float(diff.max()) <= 2.01 * float(pc[0])
     assert float((idx.cpu().float() + 128 - ref_idx).abs().max()) <= 2

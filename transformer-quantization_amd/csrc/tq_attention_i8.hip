@@ -31,7 +31,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int kAttnWaves = 2;
 constexpr int kAttnThreads = kAttnWaves * kWave;
-constexpr int kHeadDim = 64;
 
 struct AttnArgs {
   const int8_t *q, *k, *v;    // [B, T, H * 64] int8(index - 128)
@@ -51,11 +50,11 @@ __device__ __forceinline__ uint32_t key_slot(uint32_t key) {
   return (key & ~63u) | (((key >> 2) & 3u) << 4) | (((key >> 4) & 3u) << 2) | (key & 3u);
 }
 
-template <int NT>   // NT = T / 16 key tiles
+template <int NT, int DH>   // NT = T / 16 key tiles, DH = head dim (32 or 64)
 __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {   // up to 512 VGPRs per lane at 2 waves
   constexpr int T = NT * 16, KS = NT / 4;          // KS = 64-key MFMA steps of the second GEMM
   constexpr int PITCH = T + 32;                    // 32 * odd bytes: conflict-free ds_read_b128 (4 x 16 lane groups, 64 banks)
-  __shared__ __attribute__((aligned(16))) int8_t s_vt[kHeadDim * PITCH];
+  __shared__ __attribute__((aligned(16))) int8_t s_vt[DH * PITCH];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
@@ -63,13 +62,14 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {   /
   const uint32_t bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
   const uint32_t b = bh / p.H, h = bh % p.H;
   const size_t row_stride = p.in_stride;
-  const size_t base = (size_t)b * T * row_stride + (size_t)h * kHeadDim;
+  const size_t base = (size_t)b * T * row_stride + (size_t)h * DH;
 
   // ---- V^T -> LDS with the key permutation of the accumulator layout -------------------------------
   // One work item = 4 consecutive keys x 16 head dims: four 16-byte loads, 4x4 byte transposes in
   // registers, sixteen 32-bit LDS stores (keys 4m .. 4m+3 are adjacent slots of one V^T row).
-  for (uint32_t c = tid; c < (uint32_t)T; c += kAttnThreads) {
-    const uint32_t key4 = (c >> 2) * 4, part = c & 3;
+  constexpr uint32_t PARTS = DH / 16;
+  for (uint32_t c = tid; c < (uint32_t)T / 4 * PARTS; c += kAttnThreads) {
+    const uint32_t key4 = (c / PARTS) * 4, part = c % PARTS;
     v4i raw[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
@@ -90,7 +90,9 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {   /
   const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
   const v4i zero4 = {0, 0, 0, 0};
   const uint32_t qrow = qb * 16 * kAttnWaves + wave * 16 + r16;
-  const v4i fq = *reinterpret_cast<const v4i*>(p.q + base + (size_t)qrow * row_stride + g * 16);
+  const bool kin = g * 16 < DH;                     // lane groups beyond the head dim supply zeros
+  v4i fq = zero4;
+  if (kin) fq = *reinterpret_cast<const v4i*>(p.q + base + (size_t)qrow * row_stride + g * 16);
 
   const QP pq = make_qp(p.qq, 0), pk = make_qp(p.qk, 0), pv = make_qp(p.qv, 0), pp = make_qp(p.q_probs, 0);
   const int cq = 128 - (int)pq.zp, ck = 128 - (int)pk.zp, cv = 128 - (int)pv.zp, cp = 128 - (int)pp.zp;
@@ -106,13 +108,14 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {   /
   const float inv_denom = 1.0f / p.denom;
 
   const int rsq = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fq, zero4, 0, 0, 0)[0];   // sum_d a'_q of column r16
-  const int q_const = ck * rsq + kHeadDim * cq * ck;
+  const int q_const = ck * rsq + DH * cq * ck;
 
   float sc[NT][4];
   float mx = -__builtin_huge_valf();
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const v4i fk = *reinterpret_cast<const v4i*>(p.k + base + (size_t)(t * 16 + r16) * row_stride + g * 16);
+    v4i fk = zero4;
+    if (kin) fk = *reinterpret_cast<const v4i*>(p.k + base + (size_t)(t * 16 + r16) * row_stride + g * 16);
     const v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq, zero4, 0, 0, 0);
     const v4i rsk = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, ones, zero4, 0, 0, 0);    // sum_d a'_k of rows 4g + r
     f32x4 mk = {0.f, 0.f, 0.f, 0.f};
@@ -170,9 +173,9 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {   /
 #pragma unroll
   for (int s = 0; s < KS; ++s) rsp4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fp[s], rsp4, 0, 0, 0);
   const int p_const = cv * rsp4[0] + T * cp * cv;    // sum_k a'_p of column r16
-  const size_t out_row = ((size_t)b * T + qrow) * ((size_t)p.H * kHeadDim) + (size_t)h * kHeadDim;
+  const size_t out_row = ((size_t)b * T + qrow) * ((size_t)p.H * DH) + (size_t)h * DH;
 #pragma unroll
-  for (int j = 0; j < kHeadDim / 16; ++j) {
+  for (int j = 0; j < DH / 16; ++j) {
     v4i acc = zero4, csv = zero4;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -216,7 +219,7 @@ extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, con
                                    const tq_quantizer* q_probs, const tq_quantizer* q_ctx, tq_stream_t stream) {
   if (B == 0 || T == 0 || H == 0) return TQ_OK;
   TQ_REQUIRE(q_idx && k_idx && v_idx && ctx, "tq_attention_i8_fwd: NULL pointer");
-  TQ_REQUIRE(head_dim == kHeadDim, "tq_attention_i8_fwd: head_dim %llu unsupported (64)", (unsigned long long)head_dim);
+  TQ_REQUIRE(head_dim == 64 || head_dim == 32, "tq_attention_i8_fwd: head_dim %llu unsupported (32, 64)", (unsigned long long)head_dim);
   TQ_REQUIRE(T % 64 == 0 && T <= 512, "tq_attention_i8_fwd: sequence length %llu unsupported (multiples of 64 up to 512)",
              (unsigned long long)T);
   TQ_REQUIRE(aligned16(q_idx) && aligned16(k_idx) && aligned16(v_idx) && aligned16(ctx) &&
@@ -252,7 +255,11 @@ extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, con
   if (q_ctx) a.q_ctx = *q_ctx;
   const unsigned grid = (unsigned)(B * H * (T / (16 * kAttnWaves)));
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define TQ_ATTN(NTV) case NTV * 16: hipLaunchKernelGGL((attention_i8_k<NTV>), dim3(grid), dim3(kAttnThreads), 0, st, a); break
+#define TQ_ATTN(NTV)                                                                                             \
+  case NTV * 16:                                                                                                 \
+    if (head_dim == 64) hipLaunchKernelGGL((attention_i8_k<NTV, 64>), dim3(grid), dim3(kAttnThreads), 0, st, a); \
+    else hipLaunchKernelGGL((attention_i8_k<NTV, 32>), dim3(grid), dim3(kAttnThreads), 0, st, a);                \
+    break
   switch (T) {
     TQ_ATTN(4); TQ_ATTN(8); TQ_ATTN(12); TQ_ATTN(16); TQ_ATTN(20); TQ_ATTN(24); TQ_ATTN(28); TQ_ATTN(32);
     default: return set_error(TQ_EUNSUPPORTED, "tq_attention_i8_fwd: sequence length %llu", (unsigned long long)T);

@@ -118,14 +118,14 @@ def quantized_attention(query, key, value, mask, num_heads, scores_quantizer, pr
 
     Runs as one integer kernel (tq_attention_i8_fwd) when options.INT8_LINEAR is on, the three inputs
     carry their int8 grid indices, every quantizer involved is fixed, per-tensor (asymmetric <= 8 bit
-    for Q, K, V and the probabilities), T a multiple of 64 up to 512 and d == 64.  Returns None otherwise: the
+    for Q, K, V and the probabilities), T a multiple of 64 up to 512 and d in (32, 64).  Returns None otherwise: the
     caller then runs the layered modules."""
     if not options.INT8_LINEAR or query.dim() != 3 or not query.is_cuda:
         return None
     if torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad):
         return None
     B, T, D = query.shape
-    if D % num_heads or D // num_heads != 64 or T % 64 or T > 512:
+    if D % num_heads or D // num_heads not in (32, 64) or T % 64 or T > 512:
         return None
     srcs = [_int8_source(t) for t in (query, key, value)]
     qs = _fixed_per_tensor(scores_quantizer._quant_a, scores_quantizer.activation_quantizer)
@@ -197,7 +197,7 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
     src = _int8_source(x)
     B, T, K = x.shape
     D = query.out_features
-    if (src is None or D % num_heads or D // num_heads != 64 or T % 64 or T > 512 or (B * T) % 64 or K % 128
+    if (src is None or D % num_heads or D // num_heads not in (32, 64) or T % 64 or T > 512 or (B * T) % 64 or K % 128
             or K > 16384):
         return None
     outs = []
