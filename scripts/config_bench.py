@@ -198,6 +198,22 @@ for rows, d in ((1024, 512), (1024, 128), (131072, 512)):
         zf = torch.tensor(7.0, device=dev)
         ms = wall(lambda: be.affine_fake_quant(x, w, b, delta, zf, None, 4, False, False, 1e-8), n=30)
         c[f'nonorm_quant_[{rows},{d}]_{str(dt)[6:]}'] = {'ms': ms, 'GBps': x.numel() * 2 * x.element_size() / ms / 1e6}
+# fused residual tail with NoNorm (dense-out quant + residual + quant + NoNorm + quant), 4-bit activations
+q4 = lambda d_, z_: (torch.tensor(d_, device=dev), torch.tensor(z_, device=dev), None, 4, False, False, 1e-8)
+for rows, d in ((1024, 512), (131072, 512)):
+    for dt in (torch.bfloat16, torch.float32):
+        a = torch.randn(rows, d, device=dev).to(dt)
+        r = torch.randn(rows, d, device=dev).to(dt)
+        w = torch.randn(d, device=dev)
+        b = torch.randn(d, device=dev)
+        ms = wall(lambda: be.residual_layernorm_quant(a, r, q4(0.5, 8.0), q4(0.7, 8.0), w, b, None, q4(0.9, 7.0)), n=30)
+        c[f'residual_nonorm_tail_[{rows},{d}]_{str(dt)[6:]}'] = {'ms': ms, 'GBps': a.numel() * 3 * a.element_size() / ms / 1e6}
+# integer attention core in MobileBERT geometry (4 heads x 32 dims), 4-bit Q / K / V / probabilities
+for B_, T_ in ((8, 128), (32, 384)):
+    qi, ki, vi = (torch.randint(-128, -112, (B_, T_, 128), dtype=torch.int8, device=dev) for _ in range(3))
+    P4 = [q4(0.3, 8.0), q4(0.3, 7.0), q4(0.2, 8.0), q4(2.0, 8.0), q4(0.06, 0.0), q4(0.2, 8.0)]
+    ms = wall(lambda: be.attention_i8(qi, ki, vi, 4, None, 32 ** 0.5, *P4, want_idx=True), n=30)
+    c[f'attention_i8_B{B_}_T{T_}_4x32'] = {'ms': ms}
 out['config5_mobilebert_w4a4_blocks'] = c
 
 print(json.dumps(out, indent=1))
