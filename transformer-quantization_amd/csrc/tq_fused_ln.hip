@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
                                                          u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          float ln_eps, tq_quantizer q1, tq_quantizer q2, tq_quantizer q3,
-                                                         int on1, int on2, int on3, int affine_only) {
+                                                         int on1, int on2, int on3, int affine_only, int nt) {
   constexpr int V = Store<DT>::kVec;
   constexpr int RPB = kBlock / LPR;                 // rows per block iteration
   constexpr uint32_t d = LPR * NV * V;
@@ -67,7 +67,12 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
     const uint64_t base = row * (d / V);
     u32x4 va[NV], vr[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) { va[v] = ld_stream(a + base + v * LPR + lane); vr[v] = ld_stream(r + base + v * LPR + lane); }
+    for (int v = 0; v < NV; ++v) {
+      // streaming hints only for tensors that cannot stay in L2 / MALL anyway: in a model forward the inputs were
+      // just written by the GEMM and the output is read by the next layer
+      va[v] = nt ? ld_stream(a + base + v * LPR + lane) : a[base + v * LPR + lane];
+      vr[v] = nt ? ld_stream(r + base + v * LPR + lane) : r[base + v * LPR + lane];
+    }
     float u[NV][V];
     float s = 0.f;
 #pragma unroll
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
           o[j] = t;
         }
       }
-      st_stream(y + base + v * LPR + lane, Store<DT>::pack(o));
+      if (nt) st_stream(y + base + v * LPR + lane, Store<DT>::pack(o)); else y[base + v * LPR + lane] = Store<DT>::pack(o);
       if (y_idx != nullptr) *reinterpret_cast<decltype(oi)*>(y_idx + (base + v * LPR + lane) * V) = oi;
     }
   }
@@ -125,12 +130,13 @@ static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, u
   const auto rv = static_cast<const u32x4*>(r);
   auto yv = static_cast<u32x4*>(y);
   const uint64_t vpr = d / V;
+  const int nt = rows * d * elem_size(DT) >= (64ull << 20);
 #define TQ_LN(LPR, NV)                                                                                          \
   if (vpr == (uint64_t)(LPR) * (NV)) {                                                                          \
     const unsigned rpb = kBlock / (LPR);                                                                        \
     const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(rows, rpb), 1), 1u << 20);   \
     hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, eps, \
-                       c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, affine_only);                   \
+                       c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, affine_only, nt);               \
     return check_launch("res_ln_quant_k");                                                                      \
   }
   // d (bf16 | fp32): 768 -> 96 | 192 vectors, 3072 -> 384 | 768, 512 -> 64 | 128, 128 -> 16 | 32, 1024 -> 128 | 256
