@@ -206,7 +206,8 @@ for rows, d in ((1024, 512), (131072, 512)):
         r = torch.randn(rows, d, device=dev).to(dt)
         w = torch.randn(d, device=dev)
         b = torch.randn(d, device=dev)
-        ms = wall(lambda: be.residual_layernorm_quant(a, r, q4(0.5, 8.0), q4(0.7, 8.0), w, b, None, q4(0.9, 7.0)), n=30)
+        qa_, qb_, qc_ = q4(0.5, 8.0), q4(0.7, 8.0), q4(0.9, 7.0)
+        ms = wall(lambda: be.residual_layernorm_quant(a, r, qa_, qb_, w, b, None, qc_), n=30)
         c[f'residual_nonorm_tail_[{rows},{d}]_{str(dt)[6:]}'] = {'ms': ms, 'GBps': a.numel() * 3 * a.element_size() / ms / 1e6}
 # integer attention core in MobileBERT geometry (4 heads x 32 dims), 4-bit Q / K / V / probabilities
 for B_, T_ in ((8, 128), (32, 384)):
@@ -214,6 +215,36 @@ for B_, T_ in ((8, 128), (32, 384)):
     P4 = [q4(0.3, 8.0), q4(0.3, 7.0), q4(0.2, 8.0), q4(2.0, 8.0), q4(0.06, 0.0), q4(0.2, 8.0)]
     ms = wall(lambda: be.attention_i8(qi, ki, vi, 4, None, 32 ** 0.5, *P4, want_idx=True), n=30)
     c[f'attention_i8_B{B_}_T{T_}_4x32'] = {'ms': ms}
+# quantized Linear forward at the MobileBERT shapes, W4 symmetric / A4 asymmetric, 1024 tokens:
+# layered (fake-quant weights cached, fp32 GEMM, output quantizer) vs the integer MFMA path with fused epilogue
+from quantization.base_quantized_classes import QuantizedActivation
+from quantization import options
+lin = {}
+for fin, fout in ((512, 128), (128, 128), (128, 512), (512, 512), (384, 512)):
+    torch.manual_seed(fin + fout)
+    qin = QuantizedActivation(act_method=QMethods.asymmetric_uniform, n_bits_act=4).to(dev).eval()
+    fc = quantize_model(torch.nn.Linear(fin, fout), method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform,
+                        n_bits=4, n_bits_act=4).to(dev).eval()
+    xin = torch.randn(8, 128, fin, device=dev)
+    with torch.no_grad():
+        qin.quantized_acts(); fc.quantized()
+        fc(qin(xin))
+        qin.fix_ranges(); fc.fix_ranges()
+        from quantization.graphs import GraphedForward
+        pair = torch.nn.Sequential(qin, fc)
+        g_lay = GraphedForward(pair, xin)
+        ms_layered = wall(lambda: g_lay(xin), n=50)
+        ref = fc(qin(xin))
+        options.INT8_LINEAR = True
+        g_int = GraphedForward(pair, xin)
+        ms_int = wall(lambda: g_int(xin), n=50)
+        got = fc(qin(xin))
+        options.INT8_LINEAR = False
+    step = float(fc.activation_quantizer.quantizer.delta)
+    lin[f'{fin}->{fout}'] = {'layered_hipgraph_us_incl_input_quantizer': ms_layered * 1e3, 'integer_mfma_hipgraph_us_incl_input_quantizer': ms_int * 1e3,
+                            'outputs_identical_frac': float((got == ref).float().mean()),
+                            'max_dev_in_steps': float((got - ref).abs().max()) / step}
+c['quant_linear_w4a4_1024_tokens'] = lin
 out['config5_mobilebert_w4a4_blocks'] = c
 
 print(json.dumps(out, indent=1))
