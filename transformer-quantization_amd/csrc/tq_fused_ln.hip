@@ -23,10 +23,22 @@ namespace tq {
 struct FusedQ {
   QP p;
   int on;
+  float rcp;     // guarded_rcp(p.scale): three quantizers per element make these kernels VALU-bound with the division
 };
 
+__device__ __forceinline__ FusedQ make_fq(const tq_quantizer& q, int on) {
+  FusedQ f = {QP{1.f, 0.f, 0.f, 0.f}, on, 1.f};
+  if (on) { f.p = make_qp(q, 0); f.rcp = guarded_rcp(f.p.scale); }
+  return f;
+}
+
+// x_int of v under q (bit-identical to q_index: rne_quot1 falls back to the division near ties)
+__device__ __forceinline__ float index_q(float v, const FusedQ& q) {
+  return clamp_nanprop(rne_quot1(v, q.p.scale, q.rcp) + q.p.zp, q.p.lo, q.p.hi);
+}
+
 __device__ __forceinline__ float apply_q(float v, const FusedQ& q) {
-  return q.on ? q_dequant(q_index(v, q.p), q.p) : v;
+  return q.on ? q_dequant(index_q(v, q), q.p) : v;
 }
 
 template <int LPR>
@@ -46,9 +58,7 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
   constexpr int V = Store<DT>::kVec;
   constexpr int RPB = kBlock / LPR;                 // rows per block iteration
   constexpr uint32_t d = LPR * NV * V;
-  const FusedQ f1 = {on1 ? make_qp(q1, 0) : QP{1.f, 0.f, 0.f, 0.f}, on1};
-  const FusedQ f2 = {on2 ? make_qp(q2, 0) : QP{1.f, 0.f, 0.f, 0.f}, on2};
-  const FusedQ f3 = {on3 ? make_qp(q3, 0) : QP{1.f, 0.f, 0.f, 0.f}, on3};
+  const FusedQ f1 = make_fq(q1, on1), f2 = make_fq(q2, on2), f3 = make_fq(q3, on3);
   const int lane = threadIdx.x % LPR;
   const int sub = threadIdx.x / LPR;
   const float inv_d = 1.0f / (float)d;
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
       for (int j = 0; j < V; ++j) {
         const float t = (u[v][j] - mean) * rstd * w[v][j] + b[v][j];
         if (f3.on) {
-          const float xi = q_index(t, f3.p);
+          const float xi = index_q(t, f3);
           oi.e[j] = (int8_t)((int)xi - 128);
           o[j] = q_dequant(xi, f3.p);
         } else {
@@ -157,8 +167,7 @@ __global__ __launch_bounds__(kBlock) void softmax_quant_k(const f32x4* __restric
                                                           float denom, tq_quantizer q1, tq_quantizer q2, int on1, int on2) {
   constexpr int RPB = kBlock / LPR;
   constexpr uint32_t T4 = LPR * NV;              // float4 vectors per row
-  const FusedQ f1 = {on1 ? make_qp(q1, 0) : QP{1.f, 0.f, 0.f, 0.f}, on1};
-  const FusedQ f2 = {on2 ? make_qp(q2, 0) : QP{1.f, 0.f, 0.f, 0.f}, on2};
+  const FusedQ f1 = make_fq(q1, on1), f2 = make_fq(q2, on2);
   const int lane = threadIdx.x % LPR, sub = threadIdx.x / LPR;
   for (uint64_t row = (uint64_t)blockIdx.x * RPB + sub; row < rows; row += (uint64_t)gridDim.x * RPB) {
     const f32x4* mrow = mask ? reinterpret_cast<const f32x4*>(mask + (row / rows_per_mask) * (uint64_t)T4 * 4) : nullptr;
