@@ -46,3 +46,24 @@ for key, counter in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         print(f'{n[:90]:90s} n={c} mean={v / max(c, 1):.1f}')
 
 json.dump(summary, open(os.path.join(out, f'summary_{tag}.json'), 'w'), indent=1)
+
+# bench.py reads profiles/pmc_traffic.json for `roofline.traffic`: bytes per launch of the dominant kernel
+# (tq::fq_tensor<bf16>, streaming variant) = 2 x FETCH_SIZE + WRITE_SIZE, counters in KiB (gfx950 counts 64 B per
+# 128-byte request on wide coalesced read streams -- MI355X_MICROARCH.md, HBM section).
+if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
+    pick = [n for n in summary['FETCH_SIZE'] if n.startswith('void tq::fq_tensor<1,') and n in summary['WRITE_SIZE']]
+    if pick:
+        name = max(pick, key=lambda n: summary['FETCH_SIZE'][n]['dispatches'])
+        fetch, write = summary['FETCH_SIZE'][name]['mean_value'], summary['WRITE_SIZE'][name]['mean_value']
+        traffic = {
+            'workload_elems': 1024 * 512 * 768, 'kernel': name,
+            'fetch_size_kib_mean': fetch, 'write_size_kib_mean': write,
+            'correction': 'gfx950: FETCH_SIZE counts 64 B per 128 B request for wide coalesced streams -> x2 '
+                          '(MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported; units KiB',
+            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over '
+                      f'`python bench.py --steps 20 --warmup 5 --no-cpu`, {tag} (scripts/profile_gpu.sh)',
+            'traffic_bytes_per_launch': int(round((2 * fetch + write) * 1024)),
+        }
+        json.dump(traffic, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1)
+        print('== traffic per launch:', traffic['traffic_bytes_per_launch'], 'bytes (algorithmic',
+              traffic['workload_elems'] * 4, ')')
