@@ -102,14 +102,31 @@ __global__ __launch_bounds__(kBlock) void mse_cand_k(const void* __restrict__ x,
     for (uint32_t c = 0; c < nc; ++c) {
       const float4 pc = s_c[c];
       const QP p = {pc.x, pc.y, pc.z, pc.w};
-      float h[E];
-      rne_quot<E>(f, p.scale, s_r[c], h);          // == rintf(f[j] / p.scale), see tq_device.h
-      float acc = 0.0f;
+      // Two elements per instruction where the ISA has packed fp32 forms (v_pk_mul / v_pk_add / v_pk_fma_f32):
+      // this kernel is VALU-bound (~14 fp32 ops per element and candidate), and rounding / compares / selects
+      // stay scalar.  Per-element semantics are those of rne_quot1 + clamp + dequant (tq_device.h).
+      const float rc = s_r[c];
+      const f32x2 r2 = {rc, rc}, s2 = {p.scale, p.scale}, z2 = {p.zp, p.zp};
+      const f32x2 tol2 = {-kTieTol, -kTieTol}, half2 = {0.5f - kTieTol, 0.5f - kTieTol};
+      f32x2 acc2 = {0.0f, 0.0f};
 #pragma unroll
-      for (int j = 0; j < E; ++j) {
-        const float d = f[j] - q_dequant(clamp_nanprop(h[j] + p.zp, p.lo, p.hi), p);
-        acc += d * d;
+      for (int j = 0; j < E; j += 2) {
+        const f32x2 x = {f[j], f[j + 1]};
+        const f32x2 q0 = x * r2;
+        f32x2 h = {rintf(q0.x), rintf(q0.y)};
+        const f32x2 thr = __builtin_elementwise_fma(__builtin_elementwise_abs(h), tol2, half2);
+        const f32x2 off = q0 - h;
+        if (!(fabsf(off.x) < thr.x)) h.x = rintf(x.x / p.scale);      // doubtful elements: true division
+        if (!(fabsf(off.y) < thr.y)) h.y = rintf(x.y / p.scale);
+        f32x2 xi = h + z2;
+        // v_med3_f32 (1 op) instead of the NaN-propagating clamp (4 ops): a NaN input still poisons this
+        // candidate's loss through x - dequant below, +-Inf clamps to the grid ends either way
+        xi.x = __builtin_amdgcn_fmed3f(xi.x, p.lo, p.hi);
+        xi.y = __builtin_amdgcn_fmed3f(xi.y, p.lo, p.hi);
+        const f32x2 d = x - s2 * (xi - z2);
+        acc2 = acc2 + d * d;
       }
+      const float acc = acc2.x + acc2.y;
       const double tot = wave_sum((double)acc);
       if (lane == 0) s_acc[wave][c] += tot;
     }
