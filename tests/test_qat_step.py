@@ -1,0 +1,74 @@
+"""QAT on the whole (2-layer) BERT harness: utils.qat_utils.prepare_model_for_quantization, then a few
+optimizer steps with (a) learnable ranges and (b) ranges estimated during training -- the STE backward
+kernel, the range gradients and the train-mode estimators working together end to end."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(learn_ranges, fix_act=False):
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from tests.harness_bert import build_bert_base
+    from utils.qat_utils import prepare_model_for_quantization
+    from utils.utils import DotDict
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    model, _ = build_bert_base(seed=1000, num_layers=2, **qp)
+    model = model.cuda()
+    g = torch.Generator().manual_seed(0)
+    batches = [(torch.randint(1000, 30000, (8, 64), generator=g).cuda(),) for _ in range(3)]
+    labels = torch.randint(0, 2, (8,), generator=g).cuda()
+    config = DotDict(quant=DotDict(act_quant=True, weight_quant=True),
+                     act_quant=DotDict(num_batches=2, cross_entropy_layer=None),
+                     qat=DotDict(learn_ranges=learn_ranges, fix_weight_ranges=False, fix_act_ranges=fix_act))
+    prepare_model_for_quantization(config, model, batches)
+    return model, batches, labels
+
+
+def _train(model, batches, labels, steps=4, lr=1e-3):
+    model.train()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=lr)
+    losses = []
+    for i in range(steps):
+        opt.zero_grad()
+        logits = model(batches[i % len(batches)][0])
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    return losses
+
+
+def test_qat_with_learnable_ranges():
+    model, batches, labels = _setup(learn_ranges=True)
+    ranges = {n: p for n, p in model.named_parameters() if n.endswith('_delta') or n.endswith('_zero_float')}
+    assert len(ranges) > 50, 'learn_ranges must turn the quantizer buffers into parameters'
+    before = {n: p.detach().clone() for n, p in ranges.items()}
+    losses = _train(model, batches, labels)
+    assert all(torch.isfinite(torch.tensor(losses))), losses
+    with_grad = [n for n, p in ranges.items() if p.grad is not None and torch.isfinite(p.grad).all()]
+    assert len(with_grad) >= 0.9 * len(ranges)
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in ranges.items())
+    assert moved > len(ranges) // 2, 'range parameters must receive STE gradients and be updated'
+
+
+@pytest.mark.parametrize('fix_act', [False, True])
+def test_qat_with_estimated_ranges(fix_act):
+    from quantization.quantization_manager import QuantizationManager, Qstates
+    model, batches, labels = _setup(learn_ranges=False, fix_act=fix_act)
+    acts = [m for n, m in model.named_modules() if isinstance(m, QuantizationManager) and n.endswith('activation_quantizer')]
+    want = Qstates.fix_ranges if fix_act else Qstates.estimate_ranges_train
+    assert all(m.state == want for m in acts)
+    snap = [m.quantizer._delta.detach().clone() for m in acts]
+    losses = _train(model, batches, labels)
+    assert all(torch.isfinite(torch.tensor(losses))), losses
+    changed = sum(int(not torch.equal(a, m.quantizer._delta.detach().reshape(a.shape))) for a, m in zip(snap, acts))
+    assert (changed == 0) if fix_act else (changed > len(acts) // 2)
+    model.eval()
+    with torch.no_grad():
+        out = model(batches[0][0])
+        d0 = [m.quantizer._delta.detach().clone() for m in acts]
+        model(batches[1][0])                       # eval mode: estimate_ranges_train must not move the ranges
+    assert all(torch.equal(a, m.quantizer._delta.detach()) for a, m in zip(d0, acts)) and torch.isfinite(out).all()
