@@ -1,0 +1,96 @@
+"""Error behaviour of the C ABI entry points of the fused paths: bad arguments come back as TQ_EINVAL /
+TQ_EUNSUPPORTED with a message in tq_last_error() (no exceptions, no launch), zero-size problems are no-ops."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    from quantization import _hip
+    be = _hip.backend()
+    d = torch.tensor(0.1, device='cuda')
+    z = torch.tensor(3.0, device='cuda')
+    q = _hip.tq_quantizer(d.data_ptr(), z.data_ptr(), None, 8, 0, 0, 1e-8, 1, 1)
+    return _hip, be, be.lib, q, (d, z)
+
+
+def _err(lib):
+    return lib.tq_last_error().decode()
+
+
+def test_attention_entry_point(env):
+    _hip, be, lib, q, keep = env
+    x = torch.zeros(2, 64, 128, dtype=torch.int8, device='cuda')
+    ctx = torch.empty(2, 64, 128, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    call = lambda **kw: lib.tq_attention_i8_fwd(
+        kw.get('q', x.data_ptr()), x.data_ptr(), x.data_ptr(), ctx.data_ptr(), None, kw.get('B', 2), kw.get('T', 64), 2,
+        kw.get('dh', 64), kw.get('stride', 0), None, kw.get('denom', 8.0), C.byref(q), C.byref(q), C.byref(q), None,
+        kw.get('qp', C.byref(q)), None, st)
+    assert call() == 0
+    assert call(B=0) == 0                                               # empty batch: no-op
+    assert call(q=None) == -1 and 'NULL' in _err(lib)
+    assert call(T=96) == -1 and 'sequence length' in _err(lib)
+    assert call(dh=48) == -1 and 'head_dim' in _err(lib)
+    assert call(denom=0.0) == -1 and 'denom' in _err(lib)
+    assert call(stride=100) == -1 and 'qkv_row_stride' in _err(lib)
+    assert call(qp=None) == -1 and 'probabilities' in _err(lib)
+    assert call(q=x.data_ptr() + 1) == -1 and 'alignment' in _err(lib)
+
+
+def test_linear_entry_points(env):
+    _hip, be, lib, q, (d, z) = env
+    M, N, K = 64, 128, 128
+    x = torch.zeros(M, K, dtype=torch.int8, device='cuda')
+    w = torch.zeros(N, K, dtype=torch.int8, device='cuda')
+    rs = torch.zeros(N, dtype=torch.int32, device='cuda')
+    wd = torch.full((N,), 0.01, device='cuda')
+    y = torch.empty(M, N, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    plain = lambda **kw: lib.tq_linear_i8_fwd(x.data_ptr(), w.data_ptr(), rs.data_ptr(), None, y.data_ptr(), None, 0,
+                                              kw.get('M', M), kw.get('N', N), kw.get('K', K), d.data_ptr(), z.data_ptr(),
+                                              kw.get('bits', 8), 1e-8, wd.data_ptr(), kw.get('wn', N), 1e-8, kw.get('act', 0),
+                                              None, st)
+    assert plain() == 0 and plain(M=0) == 0
+    assert plain(K=100) == -1 and 'unsupported shape' in _err(lib)
+    assert plain(bits=9) == -1 and '8 bits' in _err(lib)
+    assert plain(wn=7) == -1 and 'weight scales' in _err(lib)
+    assert plain(act=9) == -1 and 'activation' in _err(lib)
+    arr = (C.POINTER(_hip.tq_quantizer) * 2)(C.pointer(q), C.pointer(q))
+    grouped = lambda **kw: lib.tq_linear_i8_grouped_fwd(
+        x.data_ptr(), w.data_ptr(), rs.data_ptr(), None, kw.get('y', y.data_ptr()), kw.get('yi', None), 0, M, N, K, d.data_ptr(),
+        z.data_ptr(), 8, 1e-8, wd.data_ptr(), 1e-8, 0, kw.get('g', 2), C.cast(arr, C.POINTER(C.POINTER(_hip.tq_quantizer))), st)
+    assert grouped() == 0
+    assert grouped(g=4) == -1 and 'groups' in _err(lib)
+    assert grouped(y=None) == -1 and 'no output' in _err(lib)
+
+
+def test_tail_and_calibration_entry_points(env):
+    _hip, be, lib, q, keep = env
+    a = torch.zeros(8, 768, device='cuda')
+    w = torch.ones(768, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    tail = lambda **kw: lib.tq_residual_nonorm_quant_fwd(a.data_ptr(), a.data_ptr(), a.data_ptr(), None, kw.get('rows', 8),
+                                                         kw.get('d', 768), 0, C.byref(q), None, kw.get('w', w.data_ptr()),
+                                                         w.data_ptr(), None, st)
+    assert tail() == 0 and tail(rows=0) == 0
+    assert tail(w=None) == -1 and 'NULL' in _err(lib)
+    assert tail(d=772) == -4 and 'row length' in _err(lib)               # TQ_EUNSUPPORTED
+    out = torch.empty(4, device='cuda')
+    cnt = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ws = torch.empty(1 << 16, dtype=torch.uint8, device='cuda')
+    cal = lambda **kw: lib.tq_calibrate_tensor(a.data_ptr(), kw.get('n', a.numel()), 0, kw.get('mode', 0), None, None,
+                                               out.data_ptr(), out.data_ptr() + 4, 0.9, 8, 0, 1e-8, 0, out.data_ptr() + 8,
+                                               out.data_ptr() + 12, None, None, ws.data_ptr(), kw.get('wsb', ws.numel()),
+                                               kw.get('cnt', cnt.data_ptr()), st)
+    assert cal() == 0
+    torch.cuda.synchronize()
+    assert int(cnt) == 0, 'the ticket word must be back to 0 after the kernel'
+    assert cal(n=0) == -1 and 'empty' in _err(lib)
+    assert cal(mode=7) == -1 and 'mode' in _err(lib)
+    assert cal(cnt=None) == -1
+    assert cal(wsb=4) == -1 and 'workspace' in _err(lib)
