@@ -205,3 +205,40 @@ def test_attention_i8_head_dim_32(T):
     assert float((diff == 0).float().mean()) >= 0.995
     assert float(diff.max()) <= 2.01 * float(pc[0])
     assert float((idx.cpu().float() + 128 - ref_idx).abs().max()) <= 2
+
+
+def test_stacked_qkv_with_per_channel_weights():
+    """Grouped QKV GEMM with per-output-channel weight scales (the stacked per-row scale vector mixes the three
+    layers' scales) == three separate integer Linears, bit for bit."""
+    from torch import nn
+    from quantization import options
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_classes import QuantizedActivation
+    from quantization.fused import quantized_attention, quantized_self_attention
+    from quantization.quantizers import QMethods
+    torch.manual_seed(3)
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              per_channel_weights=True)
+    D, H, B, T = 256, 4, 4, 64
+    mods = [quantize_model(nn.Linear(D, D), **qp).cuda().eval() for _ in range(3)]
+    qin, qs, qpr, qc = (QuantizedActivation(**qp).cuda().eval() for _ in range(4))
+    x = torch.randn(B, T, D, device='cuda')
+    with torch.no_grad():
+        for m in mods + [qin, qs, qpr, qc]:
+            m.quantized()
+        h = qin(x)
+        q, k, v = (m(h) for m in mods)
+        sc = qs(torch.matmul(q.view(B, T, H, 64).permute(0, 2, 1, 3), k.view(B, T, H, 64).permute(0, 2, 3, 1)))
+        pr = qpr(torch.softmax(sc / 8.0, dim=-1))
+        qc(torch.matmul(pr, v.view(B, T, H, 64).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, T, D))
+        for m in mods + [qin, qs, qpr, qc]:
+            m.fix_ranges()
+        assert mods[0].weight_quantizer.quantizer._delta.numel() == D      # really per channel
+        options.INT8_LINEAR = True
+        try:
+            h = qin(x)
+            one = quantized_self_attention(h, *mods, None, H, qs, qpr, qc)
+            sep = quantized_attention(mods[0](h), mods[1](h), mods[2](h), None, H, qs, qpr, qc)
+        finally:
+            options.INT8_LINEAR = False
+    assert one is not None and sep is not None and torch.equal(one, sep)
