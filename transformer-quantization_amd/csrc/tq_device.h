@@ -154,6 +154,14 @@ template <> struct Store<TQ_BF16> {
   }
 };
 
+// fp32 -> fp16 narrowing must see the ROUNDED fp32 value: without the barrier LLVM folds the producing multiply
+// into v_fma_mixlo_f16, which rounds the exact product once and differs from RNE(fp32 result) at double-rounding
+// ties (found by tests/test_fuzz_parity.py: 46 of 442k elements of a per-embedding fp16 case).
+__device__ __forceinline__ _Float16 narrow_f16(float f) {
+  asm volatile("" : "+v"(f));
+  return (_Float16)f;
+}
+
 template <> struct Store<TQ_F16> {
   typedef uint16_t elem_t;
   static constexpr int kVec = 8;
@@ -170,7 +178,7 @@ template <> struct Store<TQ_F16> {
     u32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f16x2 h = {(_Float16)f[2 * i], (_Float16)f[2 * i + 1]};
+      f16x2 h = {narrow_f16(f[2 * i]), narrow_f16(f[2 * i + 1])};
       v[i] = __builtin_bit_cast(uint32_t, h);
     }
     return v;
@@ -179,7 +187,7 @@ template <> struct Store<TQ_F16> {
     return (float)__builtin_bit_cast(_Float16, *p);
   }
   static __device__ __forceinline__ void store1(elem_t* p, float f) {
-    *p = __builtin_bit_cast(uint16_t, (_Float16)f);
+    *p = __builtin_bit_cast(uint16_t, narrow_f16(f));
   }
 };
 
