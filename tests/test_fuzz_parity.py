@@ -94,3 +94,69 @@ def test_minmax_fuzz(seed):
         mn, mx = be.minmax(x.cuda(), n_params, inner)
         assert torch.equal(mn.cpu().reshape(-1), ref[0].reshape(-1)) and torch.equal(mx.cpu().reshape(-1), ref[1].reshape(-1)), \
             (layout, str(dtype), shape)
+
+
+@pytest.mark.parametrize('fused', [True, False], ids=['fused-calibration', 'layered-calibration'])
+@pytest.mark.parametrize('seed', range(3))
+def test_calibration_fuzz(seed, fused):
+    """Random estimator / layout / shape sequences through QuantizationManager (3 batches each): estimator state,
+    quantizer parameters and the quantized last batch against the oracle's functional restatement."""
+    from quantization import quantization_manager as qm
+    from quantization.quantization_manager import QuantizationManager
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+    rs = np.random.RandomState(3000 + seed)
+    g = torch.Generator().manual_seed(200 + seed)
+    prev = qm.FUSED_CALIBRATION
+    qm.FUSED_CALIBRATION = fused
+    try:
+        for _ in range(40):
+            est = str(rs.choice(['current_minmax', 'running_minmax', 'allminmax']))
+            layout = str(rs.choice(['tensor', 'embd', 'groups', 'channel']))
+            dtype = [torch.float32, torch.bfloat16][rs.randint(2)]
+            n_bits = int(rs.choice([4, 8]))
+            if layout == 'channel':
+                shape, axis, per_channel, ng = (int(rs.choice([3, 8, 30])), int(rs.choice([7, 8, 96]))), None, True, None
+            elif layout == 'tensor':
+                shape, axis, per_channel, ng = tuple(int(rs.choice([2, 5, 16, 64, 100])) for _ in range(rs.randint(1, 4))), None, False, None
+            else:
+                d = int(rs.choice([24, 96, 120, 768]))
+                shape, axis, per_channel = (int(rs.choice([1, 3, 8])), int(rs.choice([5, 16, 64])), d), 2, False
+                ng = int(rs.choice([2, 3, 6])) if layout == 'groups' else None
+            if est == 'allminmax' and layout in ('embd', 'groups'):
+                est = 'running_minmax'                       # AllMinMax ignores axis / groups upstream (quirk q5)
+            sym = per_channel and bool(rs.randint(2))
+            mgr = QuantizationManager(qmethod=QMethods.symmetric_uniform if sym else QMethods.asymmetric_uniform,
+                                      init=RangeEstimators[est], per_channel=per_channel, qparams=dict(n_bits=n_bits),
+                                      init_params=dict(momentum=0.7) if est == 'running_minmax' else {})
+            if axis is not None:
+                set_act_quant_axis_and_groups(mgr, axis=axis, n_groups=ng)
+            cur = (None, None)
+            for b in range(3):
+                x = (torch.randn(*shape, generator=g) * float(rs.choice([0.5, 4.0]))).to(dtype)
+                y = mgr(x.cuda())
+                new = O.batch_minmax(x.float(), axis=axis, n_groups=ng, per_channel=per_channel)
+                if est == 'current_minmax':
+                    cur = new
+                elif est == 'running_minmax':
+                    cur = O.running_update(cur[0], cur[1], new[0], new[1], 0.7)
+                else:
+                    cur = O.allminmax_update(cur[0], cur[1], new[0], new[1])
+            tag = (est, layout, str(dtype), shape, ng, sym, n_bits)
+            e, q = mgr.range_estimator, mgr.quantizer
+            assert torch.equal(e.current_xmin.cpu().reshape(-1), cur[0].reshape(-1)), tag
+            assert torch.equal(e.current_xmax.cpu().reshape(-1), cur[1].reshape(-1)), tag
+            if sym:
+                delta, signed = O.sym_params_from_range(cur[0], cur[1], n_bits)
+                zf, sgn = None, bool(signed)
+                assert bool(q._signed) == sgn, tag
+            else:
+                delta, zf = O.asym_params_from_range(cur[0], cur[1], n_bits)
+                sgn = False
+                assert torch.equal(q._zero_float.cpu().reshape(-1), zf.reshape(-1)), tag
+            assert torch.equal(q._delta.cpu().reshape(-1), delta.reshape(-1)), tag
+            _, ref_y = O.fake_quant_lowp(x, delta, zf, n_bits, sym, sgn, axis=axis, per_channel=per_channel)
+            assert torch.equal(y.cpu(), ref_y), tag
+    finally:
+        qm.FUSED_CALIBRATION = prev
