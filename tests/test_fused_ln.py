@@ -79,7 +79,7 @@ def test_fused_block_in_bert_harness_matches_layered():
     assert float(((fused - layered).abs() == 0).float().mean()) >= 0.5
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('d', [512, 128])
 def test_nonorm_tail_is_bit_exact(dtype, d):
     """MobileBERT tail (NoNorm has no statistics, so nothing depends on a summation order): the fused kernel

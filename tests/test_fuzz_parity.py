@@ -160,3 +160,46 @@ def test_calibration_fuzz(seed, fused):
             assert torch.equal(y.cpu(), ref_y), tag
     finally:
         qm.FUSED_CALIBRATION = prev
+
+
+@pytest.mark.parametrize('seed', range(3))
+def test_ste_backward_fuzz(seed):
+    """dx of the STE backward kernel (g inside the clip range, 0 outside) against autograd through the oracle,
+    bit-exact, over random shapes / dtypes / per-tensor and per-embedding parameters / (un)aligned pointers."""
+    from quantization import _hip
+    be = _hip.backend()
+    rs = np.random.RandomState(4000 + seed)
+    g = torch.Generator().manual_seed(300 + seed)
+    for _ in range(40):
+        dtype = [torch.float32, torch.bfloat16, torch.float16][rs.randint(3)]
+        per_embd = bool(rs.randint(2))
+        if per_embd:
+            d = int(rs.choice([8, 24, 96, 100, 768]))
+            shape = (int(rs.choice([1, 3, 17])), int(rs.choice([2, 16, 65])), d)
+        else:
+            shape = tuple(int(rs.choice([1, 3, 8, 33, 100, 257])) for _ in range(rs.randint(1, 4)))
+        n_bits = int(rs.choice([2, 4, 8]))
+        sym = (not per_embd) and bool(rs.randint(2))
+        x = (torch.randn(*shape, generator=g) * 3).to(dtype)
+        go = torch.randn(*shape, generator=g).to(dtype)
+        n_par = shape[-1] if per_embd else 1
+        lo = torch.as_tensor(-np.abs(rs.randn(n_par)).astype(np.float32) * 2 - 0.05)
+        hi = torch.as_tensor(np.abs(rs.randn(n_par)).astype(np.float32) * 2 + 0.05)
+        if n_par == 1:
+            lo, hi = lo[0], hi[0]
+        if sym:
+            delta, signed = O.sym_params_from_range(lo, hi, n_bits)
+            zf, sgn = None, bool(signed)
+        else:
+            delta, zf = O.asym_params_from_range(lo, hi, n_bits)
+            signed, sgn = None, False
+        _, ref_dx, _, _ = O.fake_quant_with_grads(x.float(), delta, zf, n_bits, sym, sgn, grad_out=go.float(),
+                                                  axis=(len(shape) - 1) if per_embd else None)
+        xd, gd = x.cuda(), go.cuda()
+        if rs.rand() < 0.3 and x.numel() > 1:
+            bx = torch.empty(x.numel() + 1, dtype=dtype, device='cuda')
+            xd = bx[1:].view(shape)
+            xd.copy_(x)
+        gx, _, _ = be.fake_quant_bwd(xd, gd, delta.reshape(-1).cuda(), None if zf is None else zf.reshape(-1).cuda(),
+                                     None if signed is None else signed.cuda(), n_bits, sym, False, 1e-8, n_par, 1)
+        assert torch.equal(gx.cpu(), ref_dx.to(dtype)), (str(dtype), shape, per_embd, sym, n_bits)
