@@ -203,3 +203,44 @@ def test_ste_backward_fuzz(seed):
         gx, _, _ = be.fake_quant_bwd(xd, gd, delta.reshape(-1).cuda(), None if zf is None else zf.reshape(-1).cuda(),
                                      None if signed is None else signed.cuda(), n_bits, sym, False, 1e-8, n_par, 1)
         assert torch.equal(gx.cpu(), ref_dx.to(dtype)), (str(dtype), shape, per_embd, sym, n_bits)
+
+
+@pytest.mark.parametrize('seed', range(2))
+def test_mse_candidates_fuzz(seed):
+    """Per-candidate squared-error sums (tq_mse_candidates: contiguous rows; tq_mse_candidates_grouped: column
+    groups of a [tokens, d] tensor) against float64 sums of the oracle's per-element errors; rows / groups,
+    ragged lengths, dtypes, candidate counts around the 128-candidate tile."""
+    from quantization import _hip
+    be = _hip.backend()
+    rs = np.random.RandomState(5000 + seed)
+    g = torch.Generator().manual_seed(400 + seed)
+    for _ in range(25):
+        dtype = [torch.float32, torch.bfloat16, torch.float16][rs.randint(3)]
+        C = int(rs.choice([1, 7, 100, 128, 129, 300]))
+        n_bits = int(rs.choice([4, 8]))
+        top = 2.0 ** n_bits - 1
+        scales = np.exp(rs.uniform(-5, 0, C)).astype(np.float32)
+        zps = np.round(rs.uniform(0, top, C)).astype(np.float32)
+        tab = np.stack([scales, zps, np.zeros(C, np.float32), np.full(C, top, np.float32)], 1)
+        grouped = bool(rs.randint(2))
+        if grouped:
+            ng = int(rs.choice([2, 3, 6]))
+            d = ng * int(rs.choice([4, 8, 20, 128]))
+            x = (torch.randn(int(rs.choice([1, 7, 64, 300])), d, generator=g) * 2).to(dtype)
+            rows_ref = [x.float().reshape(-1, ng, d // ng)[:, k, :].reshape(-1) for k in range(ng)]
+            loss = be.zeros_f64((ng, C), 'cuda')
+            be.mse_candidates_grouped(x.cuda(), ng, torch.from_numpy(tab).cuda(), loss)
+        else:
+            rows = int(rs.choice([1, 1, 3, 16]))
+            L = int(rs.choice([1, 5, 64, 1000, 4097, 20000]))
+            x = (torch.randn(rows, L, generator=g) * 2).to(dtype)
+            rows_ref = [x.float()[r] for r in range(rows)]
+            loss = be.zeros_f64((rows, C), 'cuda')
+            be.mse_candidates(x.cuda(), rows, torch.from_numpy(tab).cuda(), loss)
+        got = loss.cpu().numpy()
+        for r, xr in enumerate(rows_ref):
+            for c in range(0, C, max(1, C // 9)):
+                s_, z_ = float(scales[c]), float(zps[c])
+                xi = torch.clamp(torch.round(xr / s_) + z_, 0.0, top)
+                ref = float(((xr - s_ * (xi - z_)).double() ** 2).sum())
+                assert abs(got[r, c] - ref) <= 1e-5 * abs(ref) + 1e-12, (str(dtype), grouped, tuple(x.shape), C, r, c, got[r, c], ref)
