@@ -140,3 +140,34 @@ def test_nonorm_block_module_level():
         layered = nn_(resq(dense(x) + res))
         fused = residual_layernorm_quant(dense, resq, nn_, x, res)
     assert torch.equal(fused, layered)
+
+
+@pytest.mark.parametrize('dtype,d', [(torch.float32, d) for d in (64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072)] +
+                         [(torch.bfloat16, d) for d in (128, 256, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144)])
+def test_every_instantiated_row_length(dtype, d):
+    """One case per (lanes-per-row, vectors-per-lane) instantiation of the tail kernel, LayerNorm and NoNorm."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(d)
+    rows = 96
+    a = (torch.randn(rows, d, generator=g) * 2).to(dtype)
+    r = (torch.randn(rows, d, generator=g)).to(dtype)
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    b = 0.05 * torch.randn(d, generator=g)
+    p1, p2, p3 = (O.asym_params_from_range(lo, hi, 8) for lo, hi in ((-7.0, 7.5), (-9.0, 10.0), (-6.0, 8.0)))
+    k = lambda q: (q[0].cuda(), q[1].cuda(), None, 8, False, False, 1e-8)
+    for eps in (1e-12, None):
+        q1 = (p1[0], p1[1], 8, False, False)
+        q2 = (p2[0], p2[1], 8, False, False)
+        q3 = (p3[0], p3[1], 8, False, False)
+        if eps is None:
+            u = O.fake_quant(O.fake_quant(a.float(), p1[0], p1[1], 8, False)[1] + r.float(), p2[0], p2[1], 8, False)[1]
+            ref = O.fake_quant(u * w + b, p3[0], p3[1], 8, False)[1].to(dtype)
+        else:
+            ref = _oracle_chain(a, r, q1, q2, w, b, eps, q3)[0].to(dtype)
+        y = be.residual_layernorm_quant(a.cuda(), r.cuda(), k(p1), k(p2), w.cuda(), b.cuda(), eps, k(p3)).cpu()
+        diff = (y.float() - ref.float()).abs()
+        if eps is None:
+            assert torch.equal(y, ref), (str(dtype), d)
+        else:
+            assert float((diff == 0).float().mean()) >= 0.998 and float(diff.max()) <= float(p3[0]) * 1.01 + (0.1 if dtype != torch.float32 else 0)
