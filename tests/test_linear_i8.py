@@ -30,7 +30,11 @@ def _problem(M, N, K, n_bits_w, n_bits_a, per_channel, seed):
 
 
 @pytest.mark.parametrize('shape', [(1024, 768, 768), (1024, 3072, 768), (1024, 768, 3072), (64, 128, 512),
-                                   (1024, 512, 384), (32, 32, 64)])
+                                   (1024, 512, 384), (32, 32, 64),
+                                   (4096, 4096, 128),      # 128 x 128 block tiles (>= 1024 of them)
+                                   (96, 160, 192),         # M, N % 64 != 0: LDS-free kernel
+                                   (64, 64, 16384),        # longest supported K (i32 accumulator bound)
+                                   (128, 64, 64)])         # K % 128 != 0: LDS-free kernel
 @pytest.mark.parametrize('cfg', [(8, 8, False), (4, 4, False), (8, 8, True), (4, 8, True)])
 def test_linear_i8_vs_fp32_simulation(shape, cfg):
     from quantization import _hip
