@@ -242,3 +242,28 @@ def test_stacked_qkv_with_per_channel_weights():
         finally:
             options.INT8_LINEAR = False
     assert one is not None and sep is not None and torch.equal(one, sep)
+
+
+@pytest.mark.parametrize('fill', [float('-inf'), torch.finfo(torch.float32).min])
+def test_attention_i8_with_infinite_masks(fill):
+    """Newer HF versions mask with -inf / finfo.min instead of -10000: masked keys must get probability index z_p
+    exactly, un-masked rows must be unaffected."""
+    from quantization import _hip
+    be = _hip.backend()
+    B, H, T = 2, 2, 128
+    D = H * 64
+    g = torch.Generator().manual_seed(11)
+    qi, ki, vi = (torch.randint(-128, 128, (B, T, D), generator=g, dtype=torch.int8) for _ in range(3))
+    mask = torch.zeros(B, T)
+    mask[0, 40:] = fill
+    mask[1, ::3] = fill
+    mask[1, 0] = 0
+    pq, pk, pv = _params(-3.0, 2.5), _params(-2.0, 3.0), _params(-1.5, 1.0)
+    ps, pp, pc = _params(-60.0, 70.0), _params(0.0, 0.6), _params(-1.2, 0.9)
+    ref_idx, ref = _reference(qi, ki, vi, H, mask, pq, pk, pv, ps, pp, pc)
+    k7 = lambda p: (p[0].cuda(), p[1].cuda(), None, 8, False, False, 1e-8)
+    ctx, idx = be.attention_i8(qi.cuda(), ki.cuda(), vi.cuda(), H, mask.cuda(), 8.0, k7(pq), k7(pk), k7(pv), k7(ps), k7(pp),
+                               k7(pc), want_idx=True)
+    assert torch.isfinite(ctx).all()
+    diff = (ctx.cpu() - ref).abs()
+    assert float((diff == 0).float().mean()) >= 0.995 and float(diff.max()) <= 2.01 * float(pc[0])
