@@ -244,3 +244,54 @@ def test_mse_candidates_fuzz(seed):
                 xi = torch.clamp(torch.round(xr / s_) + z_, 0.0, top)
                 ref = float(((xr - s_ * (xi - z_)).double() ** 2).sum())
                 assert abs(got[r, c] - ref) <= 1e-5 * abs(ref) + 1e-12, (str(dtype), grouped, tuple(x.shape), C, r, c, got[r, c], ref)
+
+
+@pytest.mark.parametrize('seed', range(2))
+def test_adaround_kernels_fuzz(seed):
+    """K10 (soft / hard AdaRound forward) and the alpha initialisation against the oracle over random weight
+    shapes, per-tensor / per-channel symmetric and asymmetric grids and the three relaxations.  Hard rounding is
+    bit-exact; the soft forward involves sigmoid / log (device libm vs SLEEF): 2e-5 of a grid step."""
+    from quantization import _hip
+    be = _hip.backend()
+    rs = np.random.RandomState(6000 + seed)
+    g = torch.Generator().manual_seed(500 + seed)
+    modes = [('learned_sigmoid', _hip.ADA_SIGMOID), ('learned_hard_sigmoid', _hip.ADA_HARD_SIGMOID),
+             ('sigmoid_temp_decay', _hip.ADA_SIGMOID_TEMP)]
+    for _ in range(30):
+        shape = (int(rs.choice([1, 3, 16, 64, 257])), int(rs.choice([1, 7, 64, 768])))
+        per_channel = bool(rs.randint(2))
+        sym = bool(rs.randint(2))
+        n_bits = int(rs.choice([2, 4, 8]))
+        mode, code = modes[rs.randint(3)]
+        temp = float(rs.choice([2.0, 8.0, 20.0]))
+        w = torch.randn(*shape, generator=g) * 0.1
+        lo = w.amin(1) if per_channel else w.min()
+        hi = w.amax(1) if per_channel else w.max()
+        if sym:
+            delta, signed = O.sym_params_from_range(lo, hi, n_bits)
+            zf, sgn = None, bool(signed)
+        else:
+            delta, zf = O.asym_params_from_range(lo, hi, n_bits)
+            signed, sgn = None, False
+        n_par = shape[0] if per_channel else 1
+        inner = shape[1] if per_channel else 1
+        dev = lambda t: None if t is None else t.reshape(-1).cuda()
+        qargs = (dev(delta), dev(zf), None if signed is None else signed.cuda(), n_bits, sym, False, 1e-8, n_par, inner)
+        dB = delta.reshape(-1, 1) if per_channel else delta
+        zB = None if zf is None else (zf.reshape(-1, 1) if per_channel else zf)
+        scale = O.effective_scale(dB)
+        # alpha initialisation
+        a_ref = O.ada_alpha_init(w, scale, mode, temp)
+        a_dev = be.adaround_init_alpha(w.cuda(), qargs, code, temp).cpu()
+        fin = torch.isfinite(a_ref)
+        assert torch.allclose(a_dev[fin], a_ref[fin], rtol=2e-4, atol=2e-4), (shape, mode, sym, n_bits)
+        # forward with a shared alpha
+        alpha = (torch.randn(*shape, generator=g) * 3)
+        for soft in (True, False):
+            _, ref = O.ada_fake_quant(w, alpha, dB, zB, n_bits, sym, sgn, mode, soft, temperature=temp)
+            got = be.adaround_fwd(w.cuda(), alpha.cuda(), qargs, code, soft, temp).cpu()
+            if soft:
+                step = scale.expand_as(w) if torch.is_tensor(scale) else scale
+                assert float(((got - ref).abs() / step).max()) <= 2e-5, (shape, mode, sym, n_bits, per_channel)
+            else:
+                assert torch.equal(got, ref), (shape, mode, sym, n_bits, per_channel)
