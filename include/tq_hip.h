@@ -274,6 +274,25 @@ int tq_mse_candidates_grouped(const void* x, uint64_t n_tokens, uint64_t d, uint
                               int dtype, const float* cand, uint64_t n_cand, double* loss,
                               void* workspace, size_t workspace_bytes, tq_stream_t stream);
 
+/* The same losses in the REFERENCE'S OWN fp32 summation order.  MSE_Estimator.loss_fx
+ * (range_estimators.py:248-256) returns torch.sum(torch.sum(err.view(len(data), -1), dim=1)) as an fp32
+ * value produced by ATen's CPU cascade-sum kernel; scipy's bounded Brent search (golden section, :296-327,
+ * :422-470) and the numpy argmin of the grid searches (:370, :405) consume that value, so bit-equal
+ * thresholds need the same rounding sequence, not a more accurate sum.  This entry point reproduces it
+ * (32 accumulator columns x 4 cascade levels per row = one half-wave per row span, see
+ * csrc/tq_mse_ordered.hip; restated and pinned against torch.sum in oracle/aten_sum.py):
+ *   x          [rows, row_len] contiguous, rows = len(data) of the reference's view
+ *   reduce_rows 1: loss[c] / loss_f32[c] <- the second torch.sum over the row sums (per_channel_loss=False)
+ *              0: loss[r, c] / loss_f32[r, c] <- the row sums themselves (per_channel_loss=True)
+ *   loss       fp64, the fp32 result is ADDED to it (the reference accumulates batches in a float64 numpy
+ *              array, :366, :399); may be NULL
+ *   loss_f32   fp32, overwritten with the value itself (golden section); may be NULL
+ * Single-threaded ATen order (the reference's CPU run is thread-count dependent only for >= 32768 rows). */
+size_t tq_mse_ordered_workspace_bytes(uint64_t rows, uint64_t row_len, uint64_t n_cand);
+int tq_mse_candidates_ordered(const void* x, uint64_t rows, uint64_t row_len, int dtype,
+                              const float* cand, uint64_t n_cand, int reduce_rows, double* loss,
+                              float* loss_f32, void* workspace, size_t workspace_bytes,
+                              tq_stream_t stream);
 /* K9: CrossEntropyEstimator.loss_fx (range_estimators.py:498-502) for all candidates:
  * loss[c] += -sum softmax(x,dim=1) * log_softmax(Q_c(x),dim=1), x fp32 [rows, cols].          */
 int tq_xent_candidates(const float* x, uint64_t rows, uint64_t cols, const float* cand,

@@ -42,7 +42,7 @@ def fq_case(z, m):
 def est_inputs(z, m):
     name = m['inputs']
     src = {'batches': 'batches', 'wbatches': 'wbatches', 'logits': 'logits',
-           'pos_batches': 'batches'}[name]
+           'pos_batches': 'batches', 'wbig': 'wbig', 'abig': 'abig'}[name]
     xs = [t(b) for b in z[src]]
     if name == 'pos_batches':
         xs = [b.abs() for b in xs]

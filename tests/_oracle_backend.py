@@ -138,6 +138,24 @@ class OracleBackend:
                 loss[:, ci] += per_row.double()
         return loss
 
+    def mse_candidates_ordered(self, x, cand, loss=None, per_row=False, want_f32=False):
+        # literally the reference's two torch.sum calls (range_estimators.py:250-256)
+        xf = x.detach().float()
+        rows = xf.shape[0] if xf.dim() > 0 else 1
+        f32 = torch.zeros((rows if per_row else 1, cand.shape[0]), dtype=torch.float32) if want_f32 else None
+        if xf.numel() == 0:
+            return loss, f32
+        for ci in range(cand.shape[0]):
+            y = self._table_quant(xf, cand[ci])
+            v = torch.sum(((xf - y) ** 2).view(rows, -1), dim=1)
+            if not per_row:
+                v = torch.sum(v).reshape(1)
+            if loss is not None:
+                loss[:, ci] += v.double()
+            if f32 is not None:
+                f32[:, ci] = v
+        return loss, f32
+
     def mse_candidates_grouped(self, x, n_groups, cand, loss):
         # the [n_groups, -1] view the reference's per-channel estimator would see
         xf = x.detach().float()

@@ -141,6 +141,13 @@ def gen_estimators():
                 for i in range(3)]
     data['wbatches'] = np.stack([np32(b) for b in wbatches])
     pos_batches = [b.abs() for b in batches]
+    # larger inputs (round 2): a weight-shaped [64, 96] matrix (rows > 8: the second torch.sum of loss_fx runs
+    # ATen's vector path) and a [4, 40, 96] activation (3840-element rows: cascade levels of the row sums)
+    wbig = [torch.randn(64, 96, generator=torch.Generator().manual_seed(2300 + i)) * 0.05 * (1 + i)
+            for i in range(3)]
+    data['wbig'] = np.stack([np32(b) for b in wbig])
+    abig = [hidden_like((4, 40, 96), 2400 + i, outlier_dims=(7, 40)) for i in range(3)]
+    data['abig'] = np.stack([np32(b) for b in abig])
 
     def run(name, method, init, n_bits, layout, init_params, inputs='batches'):
         nonlocal k
@@ -152,7 +159,8 @@ def gen_estimators():
             set_act_quant_axis_and_groups(mgr, axis=2, n_groups=None)
         elif layout == 'peg4':
             set_act_quant_axis_and_groups(mgr, axis=2, n_groups=4)
-        xs = {'batches': batches, 'wbatches': wbatches, 'pos_batches': pos_batches}[inputs]
+        xs = {'batches': batches, 'wbatches': wbatches, 'pos_batches': pos_batches, 'wbig': wbig,
+              'abig': abig}[inputs]
         mins, maxs, deltas, zfs = [], [], [], []
         for x in xs:
             y = mgr(x)
@@ -225,6 +233,23 @@ def gen_estimators():
                          signed=(bool(mgr.quantizer.signed)
                                  if method == 'symmetric_uniform' else None)))
         k += 1
+
+    # round 2 (appended so that earlier trace numbers stay put): the full asymmetric 8-bit 2-D grid
+    # (100 x 64 x 2 candidates, range_estimators.py:378-420) and golden-section searches on larger inputs,
+    # incl. the README's weight recipe shape class (MSE / golden_section, symmetric, per-tensor; README.md:149-157)
+    run('mse2d-asym8-full', 'asymmetric_uniform', 'MSE', 8, 'per_tensor', dict(num_candidates=100))
+    run('golden-asym8', 'asymmetric_uniform', 'MSE', 8, 'per_tensor',
+        dict(opt_method=OptMethod.golden_section))
+    run('golden-sym8-weight', 'symmetric_uniform', 'MSE', 8, 'per_tensor',
+        dict(opt_method=OptMethod.golden_section), inputs='wbig')
+    run('golden-sym4-weight-channel', 'symmetric_uniform', 'MSE', 4, 'per_channel',
+        dict(opt_method=OptMethod.golden_section), inputs='wbig')
+    run('golden-asym8-act', 'asymmetric_uniform', 'MSE', 8, 'per_tensor',
+        dict(opt_method=OptMethod.golden_section), inputs='abig')
+    run('mse1d-sym8-weight-channel', 'symmetric_uniform', 'MSE', 8, 'per_channel',
+        dict(num_candidates=100), inputs='wbig')
+    run('mse2d-asym8-act', 'asymmetric_uniform', 'MSE', 8, 'per_tensor', dict(num_candidates=30),
+        inputs='abig')
 
     # permuted PEG: phase 1 (ranges) then group statistics
     mgr = QuantizationManager(qmethod=QMethods.asymmetric_uniform,

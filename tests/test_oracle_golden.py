@@ -192,3 +192,22 @@ def test_ste_grad_matches_analytic():
     mask = ((raw >= 0) & (raw <= 15)).float()
     assert torch.allclose(dx, mask, atol=1e-6)
     assert dd.shape == delta.shape and dz.shape == zf.shape
+
+
+def test_aten_sum_restatement():
+    """oracle/aten_sum.py (numpy restatement of ATen's cascade sum, the order the reference's loss_fx values
+    come out in) == the live torch.sum of this container, bit for bit, on the shapes the MSE estimator
+    produces: row sums of weights / activations followed by the sum of the row sums."""
+    from oracle import aten_sum as A
+    g = torch.Generator().manual_seed(11)
+    for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 31, 32, 33, 63, 100, 255, 257, 768, 769, 1000, 3072, 4097,
+              8192 + 17, 30522, 32767):
+        for _ in range(3):
+            x = (torch.randn(n, generator=g) * 3) ** 2
+            assert float(A.row_sum(x.numpy())) == torch.sum(x).item(), n
+    for shape in ((768, 768), (8, 98304), (64, 3072), (768, 1), (2, 768), (5, 7), (100, 5), (3, 131072 + 555)):
+        e = (torch.randn(*shape, generator=g) * 2) ** 2
+        ref_rows = torch.sum(e, dim=1)
+        assert np.array_equal(A.sum_rows(e.numpy()), ref_rows.numpy()), shape
+        assert float(A.loss_sum(e.numpy())) == torch.sum(ref_rows).item(), shape
+        assert np.array_equal(A.loss_sum(e.numpy(), per_channel_loss=True), ref_rows.numpy()), shape

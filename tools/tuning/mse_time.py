@@ -27,3 +27,17 @@ for shape in ((8, 128, 768), (256, 512, 768)):
         loss = be.zeros_f64((1, C), 'cuda')
         ms = wall(lambda: be.mse_candidates(xx, 1, tab, loss), n=5, w=1)
         print(f'raw kernel {shape} C={C}: {ms:.3f} ms  {xx.numel()*C/ms/1e9:.1f} T cand-elem/s')
+# ordered (reference summation order) kernel, same shapes
+import os
+for shape in ((8, 128, 768), (3072, 768), (256, 512, 768)):
+    xx = torch.randn(*shape, device='cuda')
+    for C in (1, 100, 12800):
+        if C == 12800 and shape[0] == 256:
+            continue
+        tab = torch.tensor(np.stack([np.linspace(0.01, 0.2, C), np.full(C, 100.0), np.zeros(C), np.full(C, 255.0)], 1).astype(np.float32)).cuda()
+        loss = be.zeros_f64((1, C), 'cuda')
+        for kt in (0, 2, 3, 4):
+            os.environ['TQ_ORD_KTOP'] = str(kt)
+            ms = wall(lambda: be.mse_candidates_ordered(xx, tab, loss), n=5, w=1)
+            print(f'ordered kernel {shape} C={C} ktop={kt}: {ms:.3f} ms  {xx.numel()*C/ms/1e9:.2f} T cand-elem/s')
+        os.environ.pop('TQ_ORD_KTOP')

@@ -69,6 +69,8 @@ SIGNATURES = {
     'tq_mse_workspace_bytes': (_sz, [_u64, _u64, _u64]),
     'tq_mse_candidates': (_int, [_vp, _u64, _u64, _int, _vp, _u64, _vp, _vp, _sz, _vp]),
     'tq_mse_candidates_grouped': (_int, [_vp, _u64, _u64, _u64, _int, _vp, _u64, _vp, _vp, _sz, _vp]),
+    'tq_mse_ordered_workspace_bytes': (_sz, [_u64, _u64, _u64]),
+    'tq_mse_candidates_ordered': (_int, [_vp, _u64, _u64, _int, _vp, _u64, _int, _vp, _vp, _vp, _sz, _vp]),
     'tq_xent_candidates': (_int, [_vp, _u64, _u64, _vp, _u64, _vp, _vp]),
     'tq_argmin_select': (_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'tq_adaround_fwd': (_int, [_vp, _vp, _vp, _u64, _QP, _int, _int, _f, _vp]),
@@ -477,6 +479,29 @@ class HipBackend:
                                         _ptr(cand), n_cand, _ptr(loss), _ptr(ws), ws.numel(), _stream())
         _check(rc, self.lib)
         return loss
+
+    def mse_candidates_ordered(self, x, cand, loss=None, per_row=False, want_f32=False):
+        """Per-candidate squared quantisation error of x viewed as [len(x), -1], summed in the order of the
+        reference's fp32 `torch.sum(torch.sum(err.view(len(data), -1), dim=1))` (range_estimators.py:250-256).
+        per_row: keep the row sums (per_channel_loss=True).  loss (fp64 [1 | rows, C], device) gets the fp32
+        result ADDED; want_f32 additionally returns the fp32 values themselves.  -> (loss, loss_f32 | None)"""
+        _need_device(x, 'mse_candidates_ordered')
+        x = x.detach().contiguous()
+        rows = x.shape[0] if x.dim() > 0 else 1
+        row_len = x.numel() // max(rows, 1)
+        n_cand = cand.shape[0]
+        out_rows = rows if per_row else 1
+        f32 = torch.empty((out_rows, n_cand), dtype=torch.float32, device=x.device) if want_f32 else None
+        if x.numel() == 0:
+            if f32 is not None:
+                f32.zero_()
+            return loss, f32
+        ws = self._workspace(x.device, self.lib.tq_mse_ordered_workspace_bytes(rows, row_len, n_cand))
+        rc = self.lib.tq_mse_candidates_ordered(_ptr(x), rows, row_len, _dtype_code(x, 'mse_candidates_ordered'),
+                                                _ptr(cand), n_cand, int(not per_row), _ptr(loss), _ptr(f32),
+                                                _ptr(ws), ws.numel(), _stream())
+        _check(rc, self.lib)
+        return loss, f32
 
     def mse_candidates_grouped(self, x, n_groups, cand, loss):
         """loss[n_groups, C] += per-group (of the LAST axis) squared quantisation error per candidate."""

@@ -311,18 +311,21 @@ class MSE_Estimator(RangeEstimatorBase):
             return self.n_groups
         return len(data) if self.per_channel else 1
 
-    def _batch_losses(self, data, cand_dev, rows):
+    def _batch_losses(self, data, cand_dev, rows, per_row=None):
         """fp64 [rows, n_cand]: this batch's loss per candidate (summed over ranks if sharded)."""
         be = _hip.backend()
         loss = be.zeros_f64((rows, cand_dev.shape[0]), data.device)
-        self._launch_loss(be, data, rows, cand_dev, loss)
+        self._launch_loss(be, data, rows, cand_dev, loss,
+                          per_row=self.per_channel if per_row is None else per_row)
         return tq_dist.sync_sum(loss)
 
-    def _launch_loss(self, be, data, rows, cand_dev, loss):
+    def _launch_loss(self, be, data, rows, cand_dev, loss, per_row=False):
         if self._grouped(data) and rows == self.n_groups:
+            # extension without a reference order: fp64-accumulated sums
             be.mse_candidates_grouped(data, self.n_groups, cand_dev, loss)
         else:
-            be.mse_candidates(data, rows, cand_dev, loss)
+            # the fp32 value of the reference's two torch.sum calls (:250-256), in ATen's CPU order
+            be.mse_candidates_ordered(data, cand_dev, loss, per_row=per_row)
 
     def _cand_table(self, neg_thr, pos_thr):
         q = self.quantizer
@@ -331,16 +334,17 @@ class MSE_Estimator(RangeEstimatorBase):
         return candidate_params(neg_thr, pos_thr, q.n_bits, q.symmetric, q.eps)
 
     def loss_fx(self, data, neg_thr, pos_thr, per_channel_loss=False):
-        """Loss of ONE candidate as a host value (golden-section path; reference :248-256).
-        The reference returns the fp32 sum; the device accumulates in fp64 and narrows."""
+        """Loss of ONE candidate as a host fp32 value (golden-section path; reference :248-256): the same
+        bits as the reference's `torch.sum(torch.sum(err.view(len(data), -1), dim=1))` on the CPU, so that
+        scipy's iterates -- hence the returned thresholds -- follow the reference's."""
         if not (neg_thr or pos_thr):
             # quirk q7 (reference :292): both thresholds falsy -> the quantizer's current range
             neg_thr, pos_thr = float(self.quantizer.x_min), float(self.quantizer.x_max)
         be = _hip.backend()
         cand = be.candidate_table(self._cand_table([neg_thr], [pos_thr]), data.device)
         rows = len(data) if per_channel_loss else 1
-        loss = self._batch_losses(data, cand, rows)
-        host = loss.cpu().numpy().astype(np.float32)
+        loss = self._batch_losses(data, cand, rows, per_row=per_channel_loss)
+        host = loss.cpu().numpy().astype(np.float32)     # exact: the fp64 cell holds one fp32 value
         return host[:, 0] if per_channel_loss else host[0, 0]
 
     def quantize(self, x_float, x_min=None, x_max=None):
@@ -496,7 +500,7 @@ class CrossEntropyEstimator(MSE_Estimator):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
 
-    def _launch_loss(self, be, data, rows, cand_dev, loss):
+    def _launch_loss(self, be, data, rows, cand_dev, loss, per_row=False):
         # per_channel_loss only exists for signature compatibility upstream: one loss row
         be.xent_candidates(data, cand_dev, loss)
 
