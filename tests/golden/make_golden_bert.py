@@ -10,6 +10,10 @@ no longer match, so the script drives the reference's quantized blocks directly 
 modified; shims: HF layers get the 4.1-style functional GELU, `utils` namespace package with no-op TensorBoard hooks, and
 transformers.modeling_utils.apply_chunking_to_forward re-exported from pytorch_utils.
 
+`python tests/golden/make_golden_bert.py readme` writes bert_base_w8a8_readme.npz: the README's standard
+W8A8 recipe (README.md:149-157: MSE / golden-section weight ranges, current min-max activations, ONE
+calibration sample), i.e. the recipe BASELINE configs[0] is quoted on.
+
 Stores: logits, the 161 activation ranges (call order) and the 102 weight-quantizer deltas.
 Weights are NOT stored (440 MB): the test rebuilds them from the same seed with the same
 transformers / torch versions (same container image on the GPU box).
@@ -69,12 +73,25 @@ def inputs():
     return torch.randint(0, 30522, (8, 128), generator=g)
 
 
-def main():
+def main(recipe='default'):
     torch.set_num_threads(8)
     hf = build_hf()
-    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8,
-              n_bits_act=8, weight_range_method=RangeEstimators.current_minmax,
-              act_range_method=RangeEstimators.running_minmax, quant_dict={})
+    if recipe == 'default':
+        qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8,
+                  n_bits_act=8, weight_range_method=RangeEstimators.current_minmax,
+                  act_range_method=RangeEstimators.running_minmax, quant_dict={})
+        out_name, n_calib = 'bert_base_w8a8.npz', 8
+    else:
+        # README.md:149-157 "Standard (naive) W8A8 per-tensor PTQ": --qmethod symmetric_uniform
+        # --qmethod-act asymmetric_uniform --weight-quant-method MSE --weight-opt-method golden_section
+        # --act-quant-method current_minmax --est-ranges-batch-size 1 --num-est-batches 1
+        # (make_qparams, utils/quant_click_options.py:356-380)
+        from quantization.range_estimators import OptMethod
+        qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8,
+                  n_bits_act=8, weight_range_method=RangeEstimators.MSE,
+                  weight_range_options=dict(opt_method=OptMethod.golden_section),
+                  act_range_method=RangeEstimators.current_minmax, quant_dict={})
+        out_name, n_calib = 'bert_base_w8a8_readme.npz', 1
     emb = QuantizedBertEmbeddings(hf.bert.embeddings, **qp)
     layers = [QuantizedBertLayer(l, **qp) for l in hf.bert.encoder.layer]
     pooler = QuantizedBertPooler(hf.bert.pooler, **qp)
@@ -103,7 +120,7 @@ def main():
     apply('quantized')
     ids = inputs()
     with torch.no_grad():
-        forward(ids)                         # calibration batch (estimate_ranges state)
+        forward(ids[:n_calib])               # calibration batch (estimate_ranges state)
         for m in blocks.modules():
             if isinstance(m, QuantizationManager) and m.quantizer.is_initialized:
                 m.fix_ranges()
@@ -120,8 +137,8 @@ def main():
     print('activation quantizers:', len(act), 'weight quantizers:', len(wts))
     print('logits', logits)
     np.savez_compressed(
-        os.path.join(OUT, 'bert_base_w8a8.npz'),
-        logits=logits.numpy(), input_ids=ids.numpy(),
+        os.path.join(OUT, out_name),
+        logits=logits.numpy(), input_ids=ids.numpy(), n_calib=np.array(n_calib),
         act_names=np.array([a[0] for a in act]), act_min=np.array([a[1] for a in act], np.float32),
         act_max=np.array([a[2] for a in act], np.float32),
         w_names=np.array([w[0] for w in wts]), w_delta=np.array([w[1] for w in wts], np.float32),
@@ -165,6 +182,8 @@ def gen_nonorm():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'nonorm':
         gen_nonorm()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'readme':
+        main('readme')
     else:
         main()
         gen_nonorm()

@@ -126,3 +126,87 @@ def test_bert_base_w8a8_gpu():
         assert torch.equal(q._zero_float.cpu().reshape(()), zf)
         _, ref = O.fake_quant(x, delta, zf, 8, False)
         assert torch.equal(y, ref)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The README's standard W8A8 recipe (reference README.md:149-157; BASELINE configs[0]):
+#   --weight-quant-method MSE --weight-opt-method golden_section --act-quant-method current_minmax
+#   --est-ranges-batch-size 1 --num-est-batches 1
+# Fixture tests/golden/bert_base_w8a8_readme.npz (make_golden_bert.py readme): the 102 weight `_delta`s the
+# reference's scipy-driven golden-section search returns.  They are reproduced BIT FOR BIT because every
+# loss evaluation returns the reference's own fp32 torch.sum value (tq_mse_candidates_ordered), so scipy's
+# bounded Brent iterates coincide (reference range_estimators.py:248-256, 296-327, 422-470).
+def _readme_fixture():
+    import os
+    return np.load(os.path.join(GOLDEN, 'bert_base_w8a8_readme.npz'))
+
+
+def _build_readme(device):
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators, OptMethod
+    from tests.harness_bert import build_bert_base
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8,
+              n_bits_act=8, weight_range_method=RangeEstimators.MSE,
+              weight_range_options=dict(opt_method=OptMethod.golden_section),
+              act_range_method=RangeEstimators.current_minmax)
+    model, hf = build_bert_base(seed=1000, **qp)
+    return model.to(device).eval(), hf
+
+
+def _calibrate_readme(model, ids, n_calib):
+    from utils.utils import pass_data_for_range_estimation
+    with torch.no_grad():
+        pass_data_for_range_estimation([(ids[:n_calib],)], model, act_quant=True, weight_quant=True,
+                                       max_num_batches=1)
+        model.fix_ranges()
+        return model(ids.to(next(model.parameters()).device))
+
+
+def test_bert_base_readme_recipe_cpu_exact():
+    from quantization import _hip
+    from tests._oracle_backend import OracleBackend
+    from tests.harness_bert import quantizer_census
+    z = _readme_fixture()
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        torch.set_num_threads(8)
+        model, hf = _build_readme('cpu')
+        _check_weights_reproduced(hf, z)
+        ids = torch.from_numpy(z['input_ids'])
+        logits = _calibrate_readme(model, ids, int(z['n_calib']))
+        act, wts = quantizer_census(model)
+        assert len(act) == 161 and len(wts) == 102
+        wd = np.array([float(m.quantizer._delta) for _, m in wts], np.float32)
+        assert np.array_equal(wd, z['w_delta'])
+        amin = np.array([float(m.range_estimator.current_xmin) for _, m in act], np.float32)
+        amax = np.array([float(m.range_estimator.current_xmax) for _, m in act], np.float32)
+        assert np.array_equal(amin, z['act_min']) and np.array_equal(amax, z['act_max'])
+        assert np.array_equal(logits.numpy(), z['logits'])
+    finally:
+        _hip.set_backend(prev)
+        torch.set_num_threads(1)
+
+
+@pytest.mark.gpu
+def test_bert_base_readme_recipe_gpu_weight_deltas_bit_exact():
+    """All 102 golden-section weight ranges == the reference's, bit for bit, through the HIP kernels."""
+    from tests.harness_bert import quantizer_census
+    z = _readme_fixture()
+    model, hf = _build_readme('cuda')
+    _check_weights_reproduced(hf, z)
+    ids = torch.from_numpy(z['input_ids'])
+    logits = _calibrate_readme(model, ids, int(z['n_calib']))
+    act, wts = quantizer_census(model)
+    assert len(act) == 161 and len(wts) == 102
+    wd = torch.stack([m.quantizer._delta.reshape(()).cpu() for _, m in wts])
+    assert torch.equal(wd, torch.from_numpy(z['w_delta'])), \
+        [(n, float(a), float(b)) for (n, _), a, b in zip(wts, wd, z['w_delta']) if float(a) != float(b)]
+    # activations: GEMM round-off (hipBLASLt vs CPU) propagates as in test_bert_base_w8a8_gpu
+    amin = np.array([float(m.range_estimator.current_xmin) for _, m in act], np.float32)
+    amax = np.array([float(m.range_estimator.current_xmax) for _, m in act], np.float32)
+    span = z['act_max'] - z['act_min']
+    rel = np.maximum(np.abs(amin - z['act_min']), np.abs(amax - z['act_max'])) / span
+    assert rel[0] == 0 and rel[1] == 0
+    assert rel.max() <= 0.10 and np.median(rel) <= 0.01, (rel.max(), np.median(rel))
+    lspan = float(z['logits'].max() - z['logits'].min())
+    assert np.abs(logits.cpu().numpy() - z['logits']).max() <= 0.10 * lspan
