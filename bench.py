@@ -9,10 +9,13 @@ ctypes -> libtq_hip.so), not through a private fast path.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--seq S] [--sweep]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): each rank owns its own
-[B, S, 768] shard (weak scaling, no data-path collective in the fixed-range forward).  The
-calibration phase before the timed region DOES exchange statistics: one fused MAX all-reduce of
-[-min; max] per quantizer call; its throughput is reported under "calibration".
+N > 1: one rank per GPU over RCCL.  Either the caller wraps the command in torch.distributed.run (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment), or -- when `--gpus N` is given without such an environment --
+bench.py re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1`.  Each rank owns its own [B, S, 768] shard (weak scaling, no data-path collective
+in the fixed-range forward).  The calibration phase before the timed region DOES exchange statistics: one
+fused MAX all-reduce of [-min; max] per quantizer call; its throughput at N ranks is reported under
+"calibration" (the north-star's 1/2/4/8-GPU calibration throughput).
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
@@ -145,6 +148,41 @@ def timed_region(fn, steps, use_dist):
     return wall, start.elapsed_time(end) / steps
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a torchrun environment: spawn the N ranks ourselves."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, rank, world):
+    """TQ_BENCH_DRY_RUN=1: launcher / rendezvous / reporting control flow WITHOUT a GPU and without any kernel
+    (CPU test of `--gpus N`, tests/test_dist_gloo.py).  The line it prints is labelled and carries no measurement."""
+    if world > 1 or 'RANK' in os.environ:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+        dist.barrier()
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t[0]) == world
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': 'DRY RUN (no kernels launched, not a measurement)', 'value': None, 'dry_run': True,
+                          'n_gpus': world, 'rccl_world_size': world, 'steps': args.steps, 'warmup': args.warmup}),
+              flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -156,9 +194,14 @@ def main():
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        relaunch_under_torchrun(args.gpus)
+
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if os.environ.get('TQ_BENCH_DRY_RUN') == '1':
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (there is no CPU fallback in the product path)')
     # TQ_BENCH_SAME_DEVICE=1 + TQ_BENCH_BACKEND=gloo: control-flow test of the N>1 path on a
@@ -232,6 +275,7 @@ def main():
         'value': round(value, 1),
         'unit': 'M elems/s',
         'n_gpus': world,
+        'rccl_world_size': dist.get_world_size() if use_dist else 1,
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': round(wall / args.steps * 1e3, 4),

@@ -238,6 +238,24 @@ int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mode, const fl
                         float* zero_float, uint8_t* signed_flag, void* y, void* workspace,
                         size_t workspace_bytes, uint32_t* counter, tq_stream_t stream);
 
+/* Sharded calibration (calibration batches split across ranks, one process per GPU): the fused
+ * step split at the exchange.  tq_calibrate_stats writes the LOCAL shard's statistics as stats[2 * n_params] =
+ * [-min | max] straight from the statistics kernel (one launch for a single range of <= 512 blocks, statistics +
+ * finalize otherwise); the caller all-reduces `stats` IN PLACE with MAX over RCCL (min and max fused into one
+ * collective; exact, min/max are associative); tq_calibrate_apply then performs the estimator update +
+ * range -> parameters (one launch) and, if y != NULL, the quantizer: 3 launches + 1 collective per
+ * calibrating call.  Arguments as tq_calibrate_minmax; counter as tq_calibrate_tensor (may be NULL: always
+ * the two-launch statistics); workspace tq_calibrate_workspace_bytes(n, n_params, inner).                  */
+int tq_calibrate_stats(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner,
+                       float* stats, void* workspace, size_t workspace_bytes, uint32_t* counter,
+                       tq_stream_t stream);
+int tq_calibrate_apply(const float* stats, const void* x, uint64_t n, int dtype, uint64_t n_params,
+                       uint64_t inner, int mode, const float* prev_min, const float* prev_max,
+                       float* cur_min, float* cur_max, double momentum, uint64_t n_groups,
+                       const int64_t* order, int n_bits, int symmetric, float eps, int log_domain,
+                       float* delta, float* zero_float, uint8_t* signed_flag, void* y,
+                       tq_stream_t stream);
+
 /* PEG phase 1 (range_estimators.py:68-80): ranges = max - min per embedding dim; on later
  * batches the reference stores 0.1*r + 0.9*r of the NEW ranges (quirk q4).                    */
 int tq_axis_ranges(const float* new_min, const float* new_max, float* ranges, uint64_t n,

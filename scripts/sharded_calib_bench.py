@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""BERT-base calibrating forward (B=8, T=128; 161 activation + 102 weight quantizer calls): single-GPU fused path vs the
+sharded-calibration path over RCCL.  Run under torch.distributed.run on the GPU box (one rank per GPU; a 1-GPU box gives
+a 1-rank RCCL group with the collectives forced on, which exercises the same launches + one ncclAllReduce per call):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 scripts/sharded_calib_bench.py
+
+Prints one JSON document (commit it under profiles/rNN/sharded_calibration.json)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, 'transformer-quantization_amd'), ROOT):
+    sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+rank = int(os.environ.get('RANK', 0))
+world = int(os.environ.get('WORLD_SIZE', 1))
+local = int(os.environ.get('LOCAL_RANK', 0))
+torch.cuda.set_device(local)
+dev = torch.device('cuda', local)
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+os.environ.setdefault('MASTER_PORT', '29533')
+dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
+
+from quantization import distributed as tq_dist, quantization_manager as qm
+from tests.test_bert_e2e import _build, _fixture
+
+
+def wall(fn, n=20, w=3):
+    for _ in range(w):
+        fn()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+z = _fixture()
+model, _ = _build(dev)
+ids_all = torch.from_numpy(z['input_ids']).to(dev)          # global batch 8 x 128
+out = {'world_size': world, 'global_batch': list(ids_all.shape)}
+with torch.no_grad():
+    model.set_quant_state(True, True)
+    model.estimate_ranges()
+    out['single_gpu_fused_ms'] = wall(lambda: model(ids_all))
+    tq_dist.enable(force=(world == 1))
+    ids = tq_dist.shard_batch(ids_all)
+    out['local_batch'] = list(ids.shape)
+    before = tq_dist.stats()
+    out['sharded_fused_split_ms'] = wall(lambda: model(ids))
+    after = tq_dist.stats()
+    out['collectives_per_forward'] = (after['minmax_calls'] - before['minmax_calls']) / 23
+    out['bytes_per_forward'] = (after['bytes'] - before['bytes']) / 23
+    qm.FUSED_CALIBRATION = False                                # round-1 path: layered estimator + sync_minmax
+    out['sharded_layered_ms'] = wall(lambda: model(ids))
+    qm.FUSED_CALIBRATION = True
+    tq_dist.disable()
+    out['ratio_split_vs_single'] = out['sharded_fused_split_ms'] / out['single_gpu_fused_ms']
+t = torch.tensor([out['sharded_fused_split_ms']], device=dev, dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+out['sharded_fused_split_ms_max_over_ranks'] = float(t[0])
+if rank == 0:
+    print(json.dumps(out, indent=1))
+dist.destroy_process_group()

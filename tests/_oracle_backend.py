@@ -87,6 +87,42 @@ class OracleBackend:
         v = xf.reshape(outer, n_params, inner).permute(1, 0, 2).reshape(n_params, -1)
         return v.min(-1)[0], v.max(-1)[0]
 
+    # ---- fused calibration step (tq_calibrate_minmax / tq_calibrate_stats + tq_calibrate_apply) ----------
+    accepts_cpu = True
+    CALIB_MAX_PARAMS = 4096
+
+    def calibrate_stats(self, x, n_params, inner):
+        mn, mx = self.minmax(x, n_params, inner)
+        return torch.cat([(-mn).reshape(-1), mx.reshape(-1)]).contiguous()
+
+    def calibrate_apply(self, stats, x, n_params, inner, mode, prev_min, prev_max, momentum, n_groups, order,
+                        n_bits, symmetric, eps, log_domain, want_y=True, out=None):
+        new_min, new_max = -stats[:n_params], stats[n_params:].clone()
+        if n_params == 1:
+            new_min, new_max = new_min.reshape(()), new_max.reshape(())
+        cur_min, cur_max = self.range_update(mode, new_min, new_max, prev_min, prev_max, momentum, n_groups, order)
+        signed = zero_float = None
+        if symmetric:
+            delta, signed = self.set_range_sym(cur_min, cur_max, n_bits, eps, log_domain)
+        else:
+            delta, zero_float = self.set_range_asym(cur_min, cur_max, n_bits, eps, log_domain)
+        if out is not None:          # in-place state (options.INPLACE_CALIBRATION_STATE)
+            for dst, src in zip(out, (cur_min, cur_max, delta, zero_float, signed)):
+                if dst is not None:
+                    dst.copy_(src.reshape(dst.shape))
+            cur_min, cur_max, delta, zero_float, signed = out
+        y = None
+        if want_y:
+            y = self._quant(x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner)[1]
+            y = y.to(x.dtype)
+        return cur_min, cur_max, delta, zero_float, signed, y
+
+    def calibrate_minmax(self, x, n_params, inner, mode, prev_min, prev_max, momentum, n_groups, order,
+                         n_bits, symmetric, eps, log_domain, want_y=True, out=None):
+        return self.calibrate_apply(self.calibrate_stats(x, n_params, inner), x, n_params, inner, mode, prev_min,
+                                    prev_max, momentum, n_groups, order, n_bits, symmetric, eps, log_domain,
+                                    want_y=want_y, out=out)
+
     def range_update(self, mode, new_min, new_max, cur_min, cur_max, momentum=0.9, n_groups=0,
                      order=None):
         if n_groups:

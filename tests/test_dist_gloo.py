@@ -64,7 +64,8 @@ def _run_managers(xs, shard):
             ('asymmetric_uniform', 'current_minmax', 'per_embd', {}),
             ('asymmetric_uniform', 'running_minmax', 'peg4', {}),
             ('symmetric_uniform', 'MSE', None, dict(num_candidates=40)),
-            ('asymmetric_uniform', 'MSE', None, dict(num_candidates=8))]
+            ('asymmetric_uniform', 'MSE', None, dict(num_candidates=8)),
+            ('asymmetric_uniform', 'cross_entropy', 'logits', dict(num_candidates=16))]
     res = []
     for method, init, layout, ip in cfgs:
         mgr = QuantizationManager(qmethod=QMethods[method], init=RangeEstimators[init],
@@ -74,11 +75,12 @@ def _run_managers(xs, shard):
         elif layout == 'peg4':
             set_act_quant_axis_and_groups(mgr, axis=2, n_groups=4)
         for x in xs:
-            mgr(shard(x))
+            # cross-entropy estimator: [B, num_labels] logits (rows shard cleanly: softmax is per row)
+            mgr(shard(x[:, 0, :3].contiguous() if layout == 'logits' else x))
         est = mgr.range_estimator
         rec = dict(xmin=est.current_xmin.clone(), xmax=est.current_xmax.clone(),
                    delta=mgr.quantizer._delta.clone())
-        if init == 'MSE':
+        if init in ('MSE', 'cross_entropy'):
             rec['loss'] = est.loss_array.copy()
         res.append(rec)
     return res
@@ -111,7 +113,7 @@ def test_sharded_calibration_equals_single_rank(tmp_path):
     for rank in range(WORLD):
         got = torch.load(os.path.join(tmp_path, f'calib_{rank}.pt'), weights_only=False)
         for i, (g, r) in enumerate(zip(got, ref)):
-            assert torch.equal(g['xmin'], r['xmin']), (rank, i)
+            assert torch.equal(g['xmin'], r['xmin']), (rank, i)      # min/max: exact; searches: same argmin
             assert torch.equal(g['xmax'], r['xmax']), (rank, i)
             assert torch.equal(g['delta'], r['delta']), (rank, i)
             if 'loss' in r:
@@ -190,7 +192,7 @@ def test_sharded_pass_data_for_range_estimation(tmp_path):
                 assert torch.allclose(got[k], ref[k], rtol=1e-5, atol=1e-6), k
 
 
-def _ada_problem():
+def _ada_problem(device='cpu'):
     from quantization.quantizers import QMethods
     from quantization.autoquant_utils import QuantLinear
     from quantization.adaround.quantizer import ADAROUND_QUANTIZER_MAP
@@ -202,8 +204,9 @@ def _ada_problem():
     layer.bias.data = torch.randn(12, generator=g) * 0.1
     layer.quantized_weights()
     layer.caching = False
-    X = torch.randn(16, 5, 16, generator=g)
-    tgt = torch.randn(16, 5, 12, generator=g)
+    layer.to(device)
+    X = torch.randn(16, 5, 16, generator=g).to(device)
+    tgt = torch.randn(16, 5, 12, generator=g).to(device)
     with torch.no_grad():
         layer(X)
     oq = layer.weight_quantizer.quantizer
@@ -253,3 +256,21 @@ def test_data_parallel_adaround_equals_single_rank(tmp_path):
     a1 = torch.load(os.path.join(tmp_path, 'alpha_1.pt'), weights_only=False)
     assert torch.equal(a0, a1)                                    # replicas stay in lock-step
     assert torch.allclose(a0, ref, rtol=1e-4, atol=1e-5)          # and follow the 1-rank trajectory
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` (no torchrun environment) re-executes itself under torch.distributed.run with 2
+    ranks.  TQ_BENCH_DRY_RUN=1 keeps it to the launcher / rendezvous / all-reduce / rank-0 reporting control flow
+    (gloo, no kernels): this box has no GPU, and the product path has no CPU fallback to run instead."""
+    import json
+    import subprocess
+    env = dict(os.environ, TQ_BENCH_DRY_RUN='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                           # rank 0 only
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_world_size'] == 2 and out['dry_run'] is True and out['value'] is None

@@ -51,6 +51,21 @@ s = tq_dist.sync_sum(torch.arange(5, dtype=torch.float64, device='cuda'))
 assert s.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
 st = tq_dist.stats()
 assert st['minmax_calls'] >= len(cases) + 1 and st['sum_calls'] >= 2, st
+
+# data-parallel AdaRound over RCCL (1 rank): SUM all-reduce of dL/dW_q before the fused Adam step
+from tests.test_dist_gloo import _ada_problem
+from quantization.adaround.adaround import optimize_local_loss
+def ada():
+    layer, wq, X, get_inp_out, loss_fn, opt, idx = _ada_problem('cuda')
+    optimize_local_loss(layer, get_inp_out, X, opt, loss_fn, 8, 6, batch_indices=idx)
+    return wq.alpha.detach().clone()
+before = tq_dist.stats()['sum_calls']
+a_dist = ada()
+assert tq_dist.stats()['sum_calls'] >= before + 6          # one gradient all-reduce per iteration
+tq_dist.disable()
+a_local = ada()
+assert torch.equal(a_dist, a_local)
+tq_dist.enable(force=True)
 tq_dist.disable()
 dist.destroy_process_group()
 print('RCCL_SINGLE_RANK_OK', st)
@@ -100,3 +115,20 @@ def test_bench_single_process_with_sweep():
     assert out['steps'] == 3 and out['warmup'] == 1 and out['config']['workload']
     assert set(out['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
     assert len(out['sweep']) >= 3
+
+
+def test_bench_gpus_2_spawns_two_ranks_with_real_kernels():
+    """`python bench.py --gpus 2` with no torchrun environment: bench.py launches the two ranks itself.  A GPU box
+    of the test pool has ONE device and RCCL refuses two ranks per device, so the ranks share cuda:0 and the
+    collectives are host-staged (gloo); kernels, sharded calibration exchange and timing reduction are the real ones."""
+    env = dict(os.environ, TQ_BENCH_SAME_DEVICE='1', TQ_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu', '--batch', '64',
+                        '--seq', '128'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_world_size'] == 2 and out['value'] > 0
+    assert out['calibration']['value'] > 0 and 'all-reduce' in out['calibration']['what']

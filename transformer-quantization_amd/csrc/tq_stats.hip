@@ -157,8 +157,9 @@ __global__ __launch_bounds__(kBlock) void mm_rows(const void* __restrict__ x, ui
 // ------------------------------------------------------------------------------ finalize
 // ws [P][2][n_params] -> out_min[n_params], out_max[n_params].  block = (cx, sy): cx adjacent
 // parameters, sy slices of P.
+// neg_min: store -min (the [-min ; max] layout of the sharded-calibration exchange buffer, tq_calibrate_stats).
 __global__ void mm_final(const float* __restrict__ ws, uint64_t P, uint64_t n_params, float* __restrict__ out_min,
-                         float* __restrict__ out_max) {
+                         float* __restrict__ out_max, bool neg_min) {
   extern __shared__ float s_f[];   // [2][sy][cx]
   const uint32_t cx = blockDim.x, sy = blockDim.y;
   const uint64_t col = (uint64_t)blockIdx.x * cx + threadIdx.x;
@@ -196,7 +197,7 @@ __global__ void mm_final(const float* __restrict__ ws, uint64_t P, uint64_t n_pa
     __syncthreads();
   }
   if (threadIdx.y == 0 && col < n_params) {
-    out_min[col] = s_f[threadIdx.x];
+    out_min[col] = neg_min ? -s_f[threadIdx.x] : s_f[threadIdx.x];
     out_max[col] = s_f[sy * cx + threadIdx.x];
   }
 }
@@ -236,7 +237,7 @@ static MMPlan plan_minmax(uint64_t n, uint64_t n_params, uint64_t inner, int V, 
 
 template <int DT>
 static int launch_minmax(const void* x, uint64_t n, uint64_t n_params, uint64_t inner, float* out_min,
-                         float* out_max, float* ws, size_t ws_bytes, hipStream_t st) {
+                         float* out_max, float* ws, size_t ws_bytes, hipStream_t st, bool neg_min = false) {
   constexpr int V = Store<DT>::kVec;
   const bool al = aligned16(x);
   const MMPlan pl = plan_minmax(n, n_params, inner, V, al);
@@ -258,7 +259,7 @@ static int launch_minmax(const void* x, uint64_t n, uint64_t n_params, uint64_t 
   const unsigned cx = (unsigned)std::min<uint64_t>(n_params, 64);
   const unsigned sy = std::max(1u, std::min<unsigned>(1024 / cx, (unsigned)std::max<uint64_t>(1, pl.P)));
   hipLaunchKernelGGL(mm_final, dim3((unsigned)ceil_div(n_params, cx)), dim3(cx, sy), 2 * sy * cx * sizeof(float), st,
-                     ws, pl.P, n_params, out_min, out_max);
+                     ws, pl.P, n_params, out_min, out_max, neg_min);
   return check_launch("tq_minmax final");
 }
 
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(1024) void calib_update_k(int mode, const float* __
                                                        float* cur_max, uint32_t n, double momentum_d,
                                                        uint32_t n_groups, const int64_t* __restrict__ order, int n_bits,
                                                        int symmetric, float eps, int log_domain, float* __restrict__ delta,
-                                                       float* __restrict__ zero_float, uint8_t* __restrict__ signed_flag) {
+                                                       float* __restrict__ zero_float, uint8_t* __restrict__ signed_flag,
+                                                       int neg_min /* new_min holds -min (exchange-buffer layout) */) {
   extern __shared__ float s_c[];          // [2][n] new state, then [2][n_groups]
   float* s_lo = s_c;
   float* s_hi = s_c + n;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(1024) void calib_update_k(int mode, const float* __
       float mn = kInf, mx = -kInf;
       for (uint32_t k = 0; k < gs; ++k) {
         const uint32_t dim = order ? (uint32_t)order[g * gs + k] : g * gs + k;
-        mn = min_nanprop(mn, new_min[dim]);
+        mn = min_nanprop(mn, neg_min ? -new_min[dim] : new_min[dim]);
         mx = max_nanprop(mx, new_max[dim]);
       }
       s_g[g] = mn;
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(1024) void calib_update_k(int mode, const float* __
       a = s_g[j / gs];
       b = s_g[n_groups + j / gs];
     } else {
-      a = new_min[j];
+      a = neg_min ? -new_min[j] : new_min[j];
       b = new_max[j];
     }
     if (!(mode == TQ_EST_CURRENT || first)) {
@@ -446,7 +448,8 @@ __global__ __launch_bounds__(kBlock) void calib_tensor_k(const void* __restrict_
                                                          const float* prev_max, float* cur_min, float* cur_max,
                                                          double momentum_d, int n_bits, int symmetric, float eps,
                                                          int log_domain, float* delta, float* zero_float,
-                                                         uint8_t* signed_flag) {
+                                                         uint8_t* signed_flag,
+                                                         float* stats_out /* non-NULL: only write [-min, max] */) {
   constexpr int V = Store<DT>::kVec;
   typedef typename Store<DT>::elem_t E;
   __shared__ float s_red[2][kBlock / kWave];
@@ -521,6 +524,12 @@ __global__ __launch_bounds__(kBlock) void calib_tensor_k(const void* __restrict_
   __syncthreads();
   if (threadIdx.x != 0) return;
   for (int k = 1; k < kBlock / kWave; ++k) { mn = min_nanprop(mn, s_red[0][k]); mx = max_nanprop(mx, s_red[1][k]); }
+  if (stats_out != nullptr) {            // sharded calibration: the exchange happens between this and the update
+    stats_out[0] = -mn;
+    stats_out[1] = mx;
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   float a = mn, b = mx;
   if (!(mode == TQ_EST_CURRENT || prev_min == nullptr)) {
     const float pa = prev_min[0], pb = prev_max[0];
@@ -646,7 +655,7 @@ extern "C" int tq_calibrate_minmax(const void* x, uint64_t n, int dtype, uint64_
   const size_t lds = (2 * n_params + 2 * n_groups) * sizeof(float);
   hipLaunchKernelGGL(calib_update_k, dim3(1), dim3(n_params >= 256 ? 1024 : 256), lds, static_cast<hipStream_t>(stream), mode,
                      stats, stats + n_params, prev_min, prev_max, cur_min, cur_max, (uint32_t)n_params, momentum,
-                     (uint32_t)n_groups, order, n_bits, symmetric, eps, log_domain, delta, zero_float, signed_flag);
+                     (uint32_t)n_groups, order, n_bits, symmetric, eps, log_domain, delta, zero_float, signed_flag, 0);
   if (int e = check_launch("calib_update_k")) return e;
   if (y != nullptr) {
     tq_quantizer q{delta, zero_float, signed_flag, n_bits, symmetric, log_domain, eps, n_params, inner};
@@ -682,22 +691,90 @@ extern "C" int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mod
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
   const bool vec = aligned16(x);
+  float* stats_out = nullptr;
 #define TQ_CALIB(DTV)                                                                                              \
   if (vec) hipLaunchKernelGGL((calib_tensor_k<DTV, true>), dim3(pl.gx), dim3(kBlock), 0, st, x, n, ws, counter, mode, prev_min, \
                               prev_max, cur_min, cur_max, momentum, n_bits, symmetric, eps, log_domain, delta, zero_float,     \
-                              signed_flag);                                                                          \
+                              signed_flag, stats_out);                                                               \
   else hipLaunchKernelGGL((calib_tensor_k<DTV, false>), dim3(pl.gx), dim3(kBlock), 0, st, x, n, ws, counter, mode, prev_min,   \
                           prev_max, cur_min, cur_max, momentum, n_bits, symmetric, eps, log_domain, delta, zero_float,         \
-                          signed_flag)
+                          signed_flag, stats_out)
   switch (dtype) {
     case TQ_F32: TQ_CALIB(TQ_F32); break;
     case TQ_BF16: TQ_CALIB(TQ_BF16); break;
     default: TQ_CALIB(TQ_F16); break;
   }
-#undef TQ_CALIB
   if (int e = check_launch("calib_tensor_k")) return e;
   if (y != nullptr) {
     tq_quantizer q{delta, zero_float, signed_flag, n_bits, symmetric, log_domain, eps, 1, 1};
+    return tq_fake_quant_fwd(x, y, nullptr, TQ_IDX_NONE, n, dtype, &q, stream);
+  }
+  return TQ_OK;
+}
+
+// ---- sharded calibration: the fused step split at the exchange ---------------------------------------------
+// stats: fp32 [2 * n_params] = [-min | max] of the LOCAL shard, written by the statistics kernel itself; the
+// caller all-reduces it in place with MAX (one collective: min and max fused) and hands it to tq_calibrate_apply.
+extern "C" int tq_calibrate_stats(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner, float* stats,
+                                  void* workspace, size_t workspace_bytes, uint32_t* counter, tq_stream_t stream) {
+  TQ_REQUIRE(x && n > 0 && stats, "tq_calibrate_stats: empty tensor / NULL output");
+  TQ_REQUIRE(n_params >= 1 && n_params <= kCalibMaxN, "tq_calibrate_stats: n_params=%llu > %u", (unsigned long long)n_params, kCalibMaxN);
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_calibrate_stats: bad dtype %d", dtype);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* ws = static_cast<float*>(workspace);
+  if (n_params == 1 && counter != nullptr) {
+    const int V = dtype == TQ_F32 ? 4 : 8;
+    const MMPlan pl = plan_minmax(n, 1, 1, V, aligned16(x));
+    if (pl.gx <= kTicketMaxBlocks) {      // one launch: the last-ticket block writes [-min, max]
+      TQ_REQUIRE(workspace && workspace_bytes >= (size_t)pl.gx * 2 * sizeof(float), "tq_calibrate_stats: workspace too small");
+      const bool vec = aligned16(x);
+      float* stats_out = stats;
+      const int mode = TQ_EST_CURRENT, n_bits = 8, symmetric = 0, log_domain = 0;
+      const float *prev_min = nullptr, *prev_max = nullptr;
+      float *cur_min = nullptr, *cur_max = nullptr, *delta = nullptr, *zero_float = nullptr;
+      uint8_t* signed_flag = nullptr;
+      const double momentum = 0.0;
+      const float eps = 0.0f;
+      switch (dtype) {
+        case TQ_F32: TQ_CALIB(TQ_F32); break;
+        case TQ_BF16: TQ_CALIB(TQ_BF16); break;
+        default: TQ_CALIB(TQ_F16); break;
+      }
+      return check_launch("calib_tensor_k(stats)");
+    }
+  }
+  if (n_params > 1) {
+    TQ_REQUIRE(inner >= 1 && n % (n_params * inner) == 0, "tq_calibrate_stats: n not a multiple of n_params*inner");
+  }
+  switch (dtype) {
+    case TQ_F32: return launch_minmax<TQ_F32>(x, n, n_params, inner, stats, stats + n_params, ws, workspace_bytes, st, true);
+    case TQ_BF16: return launch_minmax<TQ_BF16>(x, n, n_params, inner, stats, stats + n_params, ws, workspace_bytes, st, true);
+    default: return launch_minmax<TQ_F16>(x, n, n_params, inner, stats, stats + n_params, ws, workspace_bytes, st, true);
+  }
+}
+#undef TQ_CALIB
+
+// stats: [-min | max] over ALL ranks -> estimator update + range -> parameters (one launch) [-> quantize x].
+extern "C" int tq_calibrate_apply(const float* stats, const void* x, uint64_t n, int dtype, uint64_t n_params,
+                                  uint64_t inner, int mode, const float* prev_min, const float* prev_max, float* cur_min,
+                                  float* cur_max, double momentum, uint64_t n_groups, const int64_t* order, int n_bits,
+                                  int symmetric, float eps, int log_domain, float* delta, float* zero_float,
+                                  uint8_t* signed_flag, void* y, tq_stream_t stream) {
+  TQ_REQUIRE(stats && cur_min && cur_max && delta, "tq_calibrate_apply: NULL pointer");
+  TQ_REQUIRE((prev_min == nullptr) == (prev_max == nullptr), "tq_calibrate_apply: prev_min / prev_max mismatch");
+  TQ_REQUIRE(symmetric ? signed_flag != nullptr : zero_float != nullptr, "tq_calibrate_apply: missing parameter output");
+  TQ_REQUIRE(mode >= TQ_EST_CURRENT && mode <= TQ_EST_RUNNING, "tq_calibrate_apply: bad mode %d", mode);
+  TQ_REQUIRE(n_params >= 1 && n_params <= kCalibMaxN, "tq_calibrate_apply: n_params=%llu > %u", (unsigned long long)n_params, kCalibMaxN);
+  TQ_REQUIRE(n_groups == 0 || n_params % n_groups == 0, "tq_calibrate_apply: n_params %% n_groups != 0");
+  TQ_REQUIRE(n_bits >= 1 && n_bits <= 24, "tq_calibrate_apply: n_bits=%d", n_bits);
+  const size_t lds = (2 * n_params + 2 * n_groups) * sizeof(float);
+  hipLaunchKernelGGL(calib_update_k, dim3(1), dim3(n_params >= 256 ? 1024 : 256), lds, static_cast<hipStream_t>(stream), mode,
+                     stats, stats + n_params, prev_min, prev_max, cur_min, cur_max, (uint32_t)n_params, momentum,
+                     (uint32_t)n_groups, order, n_bits, symmetric, eps, log_domain, delta, zero_float, signed_flag, 1);
+  if (int e = check_launch("calib_update_k")) return e;
+  if (y != nullptr) {
+    TQ_REQUIRE(x != nullptr, "tq_calibrate_apply: y without x");
+    tq_quantizer q{delta, zero_float, signed_flag, n_bits, symmetric, log_domain, eps, n_params, inner};
     return tq_fake_quant_fwd(x, y, nullptr, TQ_IDX_NONE, n, dtype, &q, stream);
   }
   return TQ_OK;

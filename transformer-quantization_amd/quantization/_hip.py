@@ -62,6 +62,9 @@ SIGNATURES = {
                                    _int, _f, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'tq_calibrate_tensor': (_int, [_vp, _u64, _int, _int, _vp, _vp, _vp, _vp, _d, _int, _int, _f, _int, _vp, _vp, _vp,
                                    _vp, _vp, _sz, _vp, _vp]),
+    'tq_calibrate_stats': (_int, [_vp, _u64, _int, _u64, _u64, _vp, _vp, _sz, _vp, _vp]),
+    'tq_calibrate_apply': (_int, [_vp, _vp, _u64, _int, _u64, _u64, _int, _vp, _vp, _vp, _vp, _d, _u64, _vp, _int, _int, _f,
+                                  _int, _vp, _vp, _vp, _vp, _vp]),
     'tq_range_update': (_int, [_int, _vp, _vp, _vp, _vp, _u64, _int, _d, _u64, _vp, _vp]),
     'tq_axis_ranges': (_int, [_vp, _vp, _vp, _u64, _int, _vp]),
     'tq_set_range_asym': (_int, [_vp, _vp, _u64, _int, _f, _int, _vp, _vp, _vp]),
@@ -417,6 +420,49 @@ class HipBackend:
         if n_params == 1:
             return (cur[0, 0], cur[1, 0], par[0, 0], None if symmetric else par[1, 0], signed, y)
         return (cur[0], cur[1], par[0], None if symmetric else par[1], signed, y)
+
+    def calibrate_stats(self, x, n_params, inner):
+        """Sharded calibration, first half: fp32 [2 * n_params] = [-min | max] of the local shard, written by the
+        statistics kernel itself into a buffer the caller all-reduces in place (MAX)."""
+        _need_device(x, 'calibrate_stats')
+        x = x.contiguous()
+        dev = x.device
+        st = _stream()
+        stats = torch.empty(2 * n_params, dtype=torch.float32, device=dev)
+        counter = None
+        if n_params == 1:
+            key = (dev.index, st)
+            counter = self._counters.get(key)
+            if counter is None:
+                counter = self._counters[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), n_params, inner))
+        rc = self.lib.tq_calibrate_stats(x.data_ptr(), x.numel(), _dtype_code(x, 'calibrate_stats'), n_params, inner,
+                                         stats.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(counter), st)
+        _check(rc, self.lib)
+        return stats
+
+    def calibrate_apply(self, stats, x, n_params, inner, mode, prev_min, prev_max, momentum, n_groups, order,
+                        n_bits, symmetric, eps, log_domain, want_y=True, out=None):
+        """Sharded calibration, second half (after the all-reduce of `stats`): estimator update + quantizer
+        parameters + y.  Same returns / `out` convention as calibrate_minmax."""
+        x = x.contiguous()
+        dev = x.device
+        if out is None:
+            cur = torch.empty(2, n_params, dtype=torch.float32, device=dev)
+            par = torch.empty(1 if symmetric else 2, n_params, dtype=torch.float32, device=dev)
+            signed = torch.empty((), dtype=torch.bool, device=dev) if symmetric else None
+            if n_params == 1:
+                out = (cur[0, 0], cur[1, 0], par[0, 0], None if symmetric else par[1, 0], signed)
+            else:
+                out = (cur[0], cur[1], par[0], None if symmetric else par[1], signed)
+        y = torch.empty_like(x) if want_y else None
+        rc = self.lib.tq_calibrate_apply(
+            stats.data_ptr(), x.data_ptr(), x.numel(), _dtype_code(x, 'calibrate_apply'), n_params, inner, mode,
+            _ptr(prev_min), _ptr(prev_max), _ptr(out[0]), _ptr(out[1]), float(momentum), int(n_groups or 0),
+            _ptr(order), int(n_bits), int(bool(symmetric)), float(eps), int(bool(log_domain)), _ptr(out[2]),
+            _ptr(out[3]), _ptr(out[4]), _ptr(y), _stream())
+        _check(rc, self.lib)
+        return (*out, y)
 
     def range_update(self, mode, new_min, new_max, cur_min, cur_max, momentum=0.9, n_groups=0,
                      order=None):

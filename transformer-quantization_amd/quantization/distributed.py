@@ -61,6 +61,15 @@ def sync_minmax(mn, mx):
     return (-buf[:n]).reshape(shape), buf[n:].reshape(shape)
 
 
+def sync_max_inplace(buf):
+    """MAX all-reduce of a `[-min | max]` statistics buffer the kernel wrote (tq_calibrate_stats), in place: the
+    whole exchange of a calibrating call is this one collective -- no cat / neg / slice launches around it."""
+    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=_group)
+    _stats['minmax_calls'] += 1
+    _stats['bytes'] += buf.numel() * buf.element_size()
+    return buf
+
+
 def sync_sum(t):
     """-> element-wise sum over all ranks (fp64 candidate losses, AdaRound gradients)."""
     if not is_enabled():

@@ -114,14 +114,16 @@ class QuantizationManager(nn.Module):
             self.state == Qstates.estimate_ranges_train and self.training)
 
     def _fused_estimating_forward(self, x):
-        """estimator(x) -> set_quant_range -> quantizer(x) as one backend call, or None when the
-        configuration needs the layered path (sharded calibration, percentiles, custom classes,
-        autograd, CPU tensors, > 4096 ranges).  Leaves exactly the state the layered path leaves."""
+        """estimator(x) -> set_quant_range -> quantizer(x) as one backend call (two around the all-reduce when
+        calibration is sharded), or None when the configuration needs the layered path (percentiles, custom
+        classes, autograd, CPU tensors, > 4096 ranges).  Leaves exactly the state the layered path leaves."""
         est, q = self.range_estimator, self.quantizer
         mode = _FUSED_ESTIMATORS.get(type(est))
         be = _hip.backend()
+        sharded = tq_dist.is_enabled()
         if (mode is None or type(q) not in _FUSED_QUANTIZERS or not FUSED_CALIBRATION
-                or not hasattr(be, 'calibrate_minmax') or not x.is_cuda or tq_dist.is_enabled()
+                or not hasattr(be, 'calibrate_stats' if sharded else 'calibrate_minmax')
+                or not (x.is_cuda or getattr(be, 'accepts_cpu', False))
                 or getattr(est, 'percentile', None) or '_delta' not in q._buffers     # trainable ranges
                 or (torch.is_grad_enabled() and x.requires_grad)):
             return None
@@ -150,9 +152,16 @@ class QuantizationManager(nn.Module):
         out = None
         if options.INPLACE_CALIBRATION_STATE:
             out = self._inplace_state(est, q, n_params, x.device)
-        cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_minmax(
-            x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0), n_groups, order,
-            q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log', out=out)
+        if sharded:
+            # split at the exchange: local [-min | max] -> one in-place MAX all-reduce -> update + quantize
+            stats = tq_dist.sync_max_inplace(be.calibrate_stats(x, n_params, inner))
+            cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_apply(
+                stats, x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0), n_groups,
+                order, q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log', out=out)
+        else:
+            cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_minmax(
+                x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0), n_groups, order,
+                q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log', out=out)
         # registered buffers: rebinding through the dict skips nn.Module.__setattr__'s type dispatch
         # (4 rebinds per call x 161 quantizers per calibration batch)
         est._buffers['current_xmin'], est._buffers['current_xmax'] = cur_min, cur_max
