@@ -51,6 +51,14 @@ with torch.no_grad():
     model.set_quant_state(True, True)
     model.estimate_ranges()
     out['single_gpu_fused_ms'] = wall(lambda: model(ids_all))
+    from quantization import options
+    from quantization.graphs import GraphedForward
+    options.INPLACE_CALIBRATION_STATE = True
+    model(ids_all)
+    g1 = GraphedForward(model, ids_all)
+    out['single_gpu_hipgraph_ms'] = wall(lambda: g1(ids_all))
+    del g1
+    options.INPLACE_CALIBRATION_STATE = False
     tq_dist.enable(force=(world == 1))
     ids = tq_dist.shard_batch(ids_all)
     out['local_batch'] = list(ids.shape)
@@ -62,6 +70,18 @@ with torch.no_grad():
     qm.FUSED_CALIBRATION = False                                # round-1 path: layered estimator + sync_minmax
     out['sharded_layered_ms'] = wall(lambda: model(ids))
     qm.FUSED_CALIBRATION = True
+    # the same sharded forward captured as ONE hipGraph, the 161 ncclAllReduce launches included: no host work
+    # between the statistics kernel, the collective and the update kernel of a site
+    try:
+        options.INPLACE_CALIBRATION_STATE = True
+        model(ids)
+        g2 = GraphedForward(model, ids)
+        out['sharded_hipgraph_ms'] = wall(lambda: g2(ids))
+        out['ratio_sharded_graph_vs_single_graph'] = out['sharded_hipgraph_ms'] / out['single_gpu_hipgraph_ms']
+        out['ratio_sharded_graph_vs_single_eager'] = out['sharded_hipgraph_ms'] / out['single_gpu_fused_ms']
+    except Exception as e:                                         # noqa: BLE001
+        out['sharded_hipgraph_error'] = repr(e)[:500]
+    options.INPLACE_CALIBRATION_STATE = False
     tq_dist.disable()
     out['ratio_split_vs_single'] = out['sharded_fused_split_ms'] / out['single_gpu_fused_ms']
 t = torch.tensor([out['sharded_fused_split_ms']], device=dev, dtype=torch.float64)

@@ -132,3 +132,48 @@ def test_bench_gpus_2_spawns_two_ranks_with_real_kernels():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['rccl_world_size'] == 2 and out['value'] > 0
     assert out['calibration']['value'] > 0 and 'all-reduce' in out['calibration']['what']
+
+
+GRAPH_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.path.join(ROOT, 'transformer-quantization_amd')); sys.path.insert(0, ROOT)
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+from quantization import distributed as tq_dist, options
+from quantization.graphs import GraphedForward
+from tests.test_calibration_graph import _model, _batches
+batches = _batches(4)
+tq_dist.enable(force=True)
+with torch.no_grad():
+    ref = _model(2)
+    for b in batches:
+        ref_out = ref(tq_dist.shard_batch(b))
+    ref_sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    options.INPLACE_CALIBRATION_STATE = True
+    m = _model(2)
+    m(batches[0])                                  # first batch eager: allocates every state buffer
+    n0 = tq_dist.stats()['minmax_calls']
+    g = GraphedForward(m, batches[1])              # captures the ncclAllReduce launches with the kernels
+    n1 = tq_dist.stats()['minmax_calls']
+    for b in batches[1:]:
+        out = g(b)
+    assert tq_dist.stats()['minmax_calls'] == n1 and n1 > n0      # replay issues no python-side collective call
+    sd = m.state_dict()
+    assert sd.keys() == ref_sd.keys()
+    for k in sd:
+        assert torch.equal(sd[k], ref_sd[k]), k
+    assert torch.equal(out, ref_out)
+dist.destroy_process_group()
+print('RCCL_GRAPH_CALIBRATION_OK')
+"""
+
+
+def test_sharded_calibration_replays_as_hipgraph_with_rccl(tmp_path):
+    """A sharded calibrating forward -- statistics kernel -> in-place MAX all-reduce (RCCL) -> update + quantize at
+    every site -- captured ONCE as a hipGraph (collectives included) and replayed per batch == eager sharded
+    calibration, bit for bit (state_dict and outputs)."""
+    script = tmp_path / 'graph_worker.py'
+    script.write_text('ROOT = %r\n' % ROOT + GRAPH_WORKER)
+    r = _torchrun([str(script)])
+    assert r.returncode == 0 and 'RCCL_GRAPH_CALIBRATION_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
