@@ -7,6 +7,57 @@ import os
 import sys
 from collections import defaultdict
 
+
+
+def kernel_table(out_dir, dest_dir):
+    """`summarize_profiles.py kernel-table OUT DEST`: join scripts/kernel_bench.py's manifest (algorithmic bytes /
+    ops per launch) with rocprofv3's per-dispatch kernel trace of the same run -> DEST/kernel_table.md
+    + kernel_table.json: avg ns -> achieved -> fraction of the bounding peak, per kernel and shape."""
+    man = json.load(open(os.path.join(out_dir, 'manifest.json')))
+    traces = glob.glob(os.path.join(out_dir, '**', '*kernel_trace.csv'), recursive=True)
+    if not traces:
+        raise SystemExit('no *kernel_trace.csv under ' + out_dir)
+    disp = []
+    for r in csv.DictReader(open(traces[0])):
+        disp.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+    disp.sort()
+    cursor = defaultdict(int)       # per pattern: how many matching dispatches earlier manifest rows consumed
+    rows = []
+    for m in man:
+        pat = m['pattern']
+        match = [d for d in disp if pat in d[2]]
+        per_run = None
+        # each run() = 3 warm + reps timed launches of its kernel; rows sharing a pattern follow each other in time
+        same = [x for x in man if x['pattern'] == pat]
+        per_run = len(match) // len(same) if same else 0
+        mine = match[cursor[pat]:cursor[pat] + per_run]
+        cursor[pat] += per_run
+        timed = mine[3:] if len(mine) > 3 else mine
+        if not timed:
+            continue
+        ns = [e - s for s, e, _ in timed]
+        avg = sum(ns) / len(ns)
+        ach = m['unit_per_launch'] / avg          # bytes/ns = GB/s ; ops/ns = GOP/s
+        rows.append({**m, 'kernel_name': timed[0][2].split('(')[0][:80], 'dispatches': len(timed),
+                     'rocprof_avg_ns': round(avg, 1), 'rocprof_min_ns': min(ns), 'rocprof_max_ns': max(ns),
+                     'achieved': round(ach, 1), 'frac': round(ach / m['peak'], 4)})
+    os.makedirs(dest_dir, exist_ok=True)
+    json.dump(rows, open(os.path.join(dest_dir, 'kernel_table.json'), 'w'), indent=1)
+    with open(os.path.join(dest_dir, 'kernel_table.md'), 'w') as f:
+        f.write('| family | what | kernel (rocprofv3) | launches | avg ns | min ns | algorithmic bytes / ops per launch | '
+                'achieved | peak | frac | HIP-event us (same run) |\n|---|---|---|---|---|---|---|---|---|---|---|\n')
+        for r in rows:
+            f.write(f"| {r['family']} | {r['label']} | `{r['kernel_name']}` | {r['dispatches']} | {r['rocprof_avg_ns']:.0f} | "
+                    f"{r['rocprof_min_ns']} | {r['unit_per_launch']:.4g} {r['unit']} | {r['achieved']:.0f} {r['peak_unit']} | "
+                    f"{r['peak']:.0f} | **{100 * r['frac']:.1f} %** | {r['event_us']} |\n")
+    for r in rows:
+        print(f"{r['label'][:50]:50s} {r['rocprof_avg_ns']:10.0f} ns  {r['achieved']:9.0f} {r['peak_unit']}  {100 * r['frac']:5.1f} %")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'kernel-table':
+    kernel_table(sys.argv[2], sys.argv[3])
+    sys.exit(0)
+
 out, tag = sys.argv[1], sys.argv[2]
 
 
