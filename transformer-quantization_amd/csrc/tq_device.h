@@ -92,6 +92,61 @@ __device__ __forceinline__ void rne_quot(const float (&x)[V], float scale, float
   for (int j = 0; j < V; ++j) h[j] = rne_quot1(x[j], scale, r);
 }
 
+// ------------------------------------------------------------------ exact, branch-free, two elements per instruction
+// gfx950 issues fp32 mul / add / fma on register PAIRS at full rate (v_pk_mul_f32, v_pk_add_f32, v_pk_fma_f32); rounding
+// (v_rndne_f32) and median stay scalar.  Kernels that run several quantizers per element (fused layer tails) or many
+// candidate quantizers per element (range search) are VALU-bound with the IEEE division (~11 issue slots) and were
+// latency-bound with the guarded reciprocal above (a data-dependent branch per pair serialises the element chains).
+// Two exact identities remove both, for every finite or infinite input:
+//
+//  (1) Correctly rounded quotient from a correctly rounded reciprocal (Markstein's theorem, fused multiply-add):
+//          r = RN(1 / s)  (true division, once per parameter)
+//          q0 = RN(x * r);   e = RN(x - q0 * s)  [fma, exact];   q1 = RN(q0 + e * r)  [fma]     ==>  q1 == RN(x / s)
+//      3 packed instructions per pair instead of v_div_scale / v_rcp / 4 x v_fma / v_div_fmas / v_div_fixup per element.
+//  (2) The clamp can be applied to x instead of to the index: with k_lo = lo - zp, k_hi = hi - zp and
+//          y_lo = RN(s * k_lo), y_hi = RN(s * k_hi)            (the dequantised grid ends),
+//      Q(x) = rne(RN(x / s)) is monotone and Q(y_hi) = k_hi, Q(y_lo) = k_lo (|k| < 2^22), hence
+//          clamp(Q(x) + zp, lo, hi) - zp  ==  Q(med3(x, y_lo, y_hi)).
+//      One v_med3_f32 bounds the operand (no overflow / Inf inside (1)) AND replaces the two-sided clamp; the
+//      dequantised value is s * Q(.) because (h + zp) - zp == h exactly.
+// => 4 issue slots per element: med3, pk_mul, 2 x pk_fma, rndne, pk_mul (pairs).  Both identities are checked with exact
+// rational arithmetic on tie-adjacent and grid-end inputs in tests/test_exact_quotient.py, and through the kernels by
+// tests/test_hip_parity.py::test_rounding_ties_are_bit_exact.  NaN is NOT preserved by v_med3 (it returns an operand that
+// is not NaN): callers propagate NaN separately.  Valid for scales in [2^-100, 2^100] and grids below 2^22 steps
+// (`ok`); kernels take their division path otherwise.
+struct QF {
+  f32x2 scale, nscale, rcp;
+  float ylo, yhi, zp;
+  bool ok;
+};
+
+__device__ __forceinline__ QF make_qf(const QP& p) {
+  QF f;
+  const float rc = guarded_rcp(p.scale);
+  const float klo = p.lo - p.zp, khi = p.hi - p.zp;
+  f.scale = f32x2{p.scale, p.scale};
+  f.nscale = f32x2{-p.scale, -p.scale};
+  f.rcp = f32x2{rc, rc};
+  f.ylo = p.scale * klo;
+  f.yhi = p.scale * khi;
+  f.zp = p.zp;
+  f.ok = (rc == rc) && fabsf(klo) < 4194304.0f && fabsf(khi) < 4194304.0f;
+  return f;
+}
+
+// h = clamp(rne(x / s) + zp, lo, hi) - zp for two values (requires q.ok; NaN inputs give an unspecified grid value)
+__device__ __forceinline__ f32x2 qf_round2(f32x2 x, const QF& q) {
+  f32x2 xc;
+  xc.x = __builtin_amdgcn_fmed3f(x.x, q.ylo, q.yhi);
+  xc.y = __builtin_amdgcn_fmed3f(x.y, q.ylo, q.yhi);
+  const f32x2 q0 = xc * q.rcp;
+  const f32x2 e = __builtin_elementwise_fma(q0, q.nscale, xc);
+  const f32x2 q1 = __builtin_elementwise_fma(e, q.rcp, q0);
+  return f32x2{rintf(q1.x), rintf(q1.y)};
+}
+// fake-quantized pair: s * h
+__device__ __forceinline__ f32x2 qf_fake_quant2(f32x2 x, const QF& q) { return q.scale * qf_round2(x, q); }
+
 // x_int = clamp(round(x / scale) + zp, lo, hi)   (quantizers.py:184-185)
 __device__ __forceinline__ float q_index(float x, const QP& p) {
   return clamp_nanprop(rintf(x / p.scale) + p.zp, p.lo, p.hi);

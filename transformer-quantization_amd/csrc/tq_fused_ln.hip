@@ -48,85 +48,163 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-// NV = 16-byte vectors per lane per row (d == LPR * NV * V)
-template <int DT, int LPR, int NV>
-__global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
-                                                         u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
-                                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                         float ln_eps, tq_quantizer q1, tq_quantizer q2, tq_quantizer q3,
-                                                         int on1, int on2, int on3, int affine_only, int nt) {
+struct FusedF {
+  QF f;
+  int on;
+};
+__device__ __forceinline__ FusedF make_ff(const tq_quantizer& q, int on) {
+  FusedF r;
+  r.on = on;
+  r.f = make_qf(on ? make_qp(q, 0) : QP{1.f, 0.f, 0.f, 1.f});
+  return r;
+}
+__device__ __forceinline__ f32x2 apply_f2(f32x2 v, const FusedF& q) { return q.on ? qf_fake_quant2(v, q.f) : v; }
+
+// NV = 16-byte vectors per lane per row (d == LPR * NV * V).  All element math runs on register pairs with the exact
+// branch-free quantizer of tq_device.h (QF): three quantizers per element made the scalar version VALU- / latency-bound
+// on bf16 rows (3.1-3.3 TB/s).  NaN: an unordered input pair poisons its element before the statistics (so a LayerNorm
+// row turns NaN as a whole, like the reference) and a NaN pre-quantizer value is passed through at the end.  FAST = false
+// is the division path (scales outside [2^-100, 2^100], grids of 2^22+ steps); IDX also emits int8(index - 128).
+template <int DT, int LPR, int NV, bool IDX, bool FAST>
+__device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
+                                            u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
+                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                            float ln_eps, const tq_quantizer& q1, const tq_quantizer& q2,
+                                            const tq_quantizer& q3, int on1, int on2, int on3, int affine_only, int nt,
+                                            uint32_t iters) {
   constexpr int V = Store<DT>::kVec;
+  constexpr int H = V / 2;                          // register pairs per 16-byte vector
   constexpr int RPB = kBlock / LPR;                 // rows per block iteration
   constexpr uint32_t d = LPR * NV * V;
-  const FusedQ f1 = make_fq(q1, on1), f2 = make_fq(q2, on2), f3 = make_fq(q3, on3);
+  const FusedF f1 = make_ff(q1, on1), f2 = make_ff(q2, on2), f3 = make_ff(q3, on3);
+  const FusedQ g1 = make_fq(q1, on1), g2 = make_fq(q2, on2), g3 = make_fq(q3, on3);     // division path (FAST = false)
   const int lane = threadIdx.x % LPR;
   const int sub = threadIdx.x / LPR;
   const float inv_d = 1.0f / (float)d;
 
-  // this lane's slice of the affine parameters stays in registers for every row it handles
-  float w[NV][V], b[NV][V];
-#pragma unroll
-  for (int v = 0; v < NV; ++v)
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      w[v][j] = ln_w[(v * LPR + lane) * V + j];
-      b[v][j] = ln_b[(v * LPR + lane) * V + j];
-    }
+  // affine parameters: staged once per block in LDS, read as 8-byte pairs where they are used (keeping this lane's
+  // 2 x d / LPR values in registers cost 48 VGPRs on bf16 rows and with them half the occupancy)
+  __shared__ __attribute__((aligned(16))) float s_w[d], s_b[d];
+  for (uint32_t c = threadIdx.x; c < d; c += kBlock) { s_w[c] = ln_w[c]; s_b[c] = ln_b[c]; }
+  __syncthreads();
 
-  for (uint64_t row = (uint64_t)blockIdx.x * RPB + sub; row < rows; row += (uint64_t)gridDim.x * RPB) {
-    const uint64_t base = row * (d / V);
-    u32x4 va[NV], vr[NV];
+  // A block owns `iters` consecutive groups of RPB rows (one-shot tiles in row order: the resident blocks sweep one
+  // contiguous window of HBM); the loads of group i + 1 are issued before group i is computed, and the affine
+  // parameters / quantizer constants are set up once per block instead of once per RPB rows.
+  const uint64_t row0 = (uint64_t)blockIdx.x * RPB * iters + sub;
+  u32x4 va[NV], vr[NV], na[NV], nr[NV];
+  if (row0 < rows) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
+      const uint64_t o = row0 * (d / V) + v * LPR + lane;
       // streaming hints only for tensors that cannot stay in L2 / MALL anyway: in a model forward the inputs were
       // just written by the GEMM and the output is read by the next layer
-      va[v] = nt ? ld_stream(a + base + v * LPR + lane) : a[base + v * LPR + lane];
-      vr[v] = nt ? ld_stream(r + base + v * LPR + lane) : r[base + v * LPR + lane];
+      va[v] = nt ? ld_stream(a + o) : a[o];
+      vr[v] = nt ? ld_stream(r + o) : r[o];
     }
-    float u[NV][V];
-    float s = 0.f;
+  }
+  for (uint32_t it = 0; it < iters; ++it) {
+    const uint64_t row = row0 + (uint64_t)it * RPB;
+    if (row >= rows) break;
+    const uint64_t base = row * (d / V);
+    const uint64_t nrow = row + RPB;
+    if (it + 1 < iters && nrow < rows) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const uint64_t o = nrow * (d / V) + v * LPR + lane;
+        na[v] = nt ? ld_stream(a + o) : a[o];
+        nr[v] = nt ? ld_stream(r + o) : r[o];
+      }
+    }
+    f32x2 u[NV][H];
+    f32x2 s2 = {0.f, 0.f};
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float fa[V], fr[V];
       Store<DT>::unpack(va[v], fa);
       Store<DT>::unpack(vr[v], fr);
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        u[v][j] = apply_q(apply_q(fa[j], f1) + fr[j], f2);
-        s += u[v][j];
+      for (int j = 0; j < H; ++j) {
+        const f32x2 xa = {fa[2 * j], fa[2 * j + 1]}, xr = {fr[2 * j], fr[2 * j + 1]};
+        if (FAST) {
+          f32x2 t = apply_f2(apply_f2(xa, f1) + xr, f2);
+          t.x = __builtin_isunordered(xa.x, xr.x) ? __builtin_nanf("") : t.x;
+          t.y = __builtin_isunordered(xa.y, xr.y) ? __builtin_nanf("") : t.y;
+          u[v][j] = t;
+        } else {
+          u[v][j] = f32x2{apply_q(apply_q(xa.x, g1) + xr.x, g2), apply_q(apply_q(xa.y, g1) + xr.y, g2)};
+        }
+        s2 = s2 + u[v][j];
       }
     }
     // MobileBERT's NoNorm (models/quantized_mobilebert.py:58-72) is the affine part alone: u * w + b.  With
     // mean = 0 and rstd = 1 the expression below evaluates exactly that ((u - 0) * 1 is exact).
     float mean = 0.0f, rstd = 1.0f;
     if (!affine_only) {
-      mean = group_sum<LPR>(s) * inv_d;
-      float ss = 0.f;
+      mean = group_sum<LPR>(s2.x + s2.y) * inv_d;
+      const f32x2 m2 = {mean, mean};
+      f32x2 ss2 = {0.f, 0.f};
 #pragma unroll
       for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int j = 0; j < V; ++j) { const float c = u[v][j] - mean; ss += c * c; }
-      rstd = 1.0f / sqrtf(group_sum<LPR>(ss) * inv_d + ln_eps);
+        for (int j = 0; j < H; ++j) { const f32x2 c = u[v][j] - m2; ss2 = ss2 + c * c; }
+      rstd = 1.0f / sqrtf(group_sum<LPR>(ss2.x + ss2.y) * inv_d + ln_eps);
     }
+    const f32x2 m2 = {mean, mean}, r2 = {rstd, rstd};
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float o[V];
       struct alignas(V) { int8_t e[V]; } oi;
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const float t = (u[v][j] - mean) * rstd * w[v][j] + b[v][j];
+      for (int j = 0; j < H; ++j) {
+        const uint32_t c = (v * LPR + lane) * V + 2 * j;
+        const f32x2 wv = *reinterpret_cast<const f32x2*>(s_w + c), bv = *reinterpret_cast<const f32x2*>(s_b + c);
+        f32x2 t = (u[v][j] - m2) * r2 * wv + bv;
         if (f3.on) {
-          const float xi = index_q(t, f3);
-          oi.e[j] = (int8_t)((int)xi - 128);
-          o[j] = q_dequant(xi, f3.p);
-        } else {
-          o[j] = t;
+          if (FAST) {
+            const f32x2 h = qf_round2(t, f3.f);
+            if (IDX) {
+              oi.e[2 * j] = (int8_t)((int)(h.x + f3.f.zp) - 128);
+              oi.e[2 * j + 1] = (int8_t)((int)(h.y + f3.f.zp) - 128);
+            }
+            const f32x2 yq = f3.f.scale * h;
+            t.x = (t.x != t.x) ? t.x : yq.x;
+            t.y = (t.y != t.y) ? t.y : yq.y;
+          } else {
+            const float x0 = index_q(t.x, g3), x1 = index_q(t.y, g3);
+            if (IDX) {
+              oi.e[2 * j] = (int8_t)((int)x0 - 128);
+              oi.e[2 * j + 1] = (int8_t)((int)x1 - 128);
+            }
+            t = f32x2{q_dequant(x0, g3.p), q_dequant(x1, g3.p)};
+          }
         }
+        o[2 * j] = t.x;
+        o[2 * j + 1] = t.y;
       }
       if (nt) st_stream(y + base + v * LPR + lane, Store<DT>::pack(o)); else y[base + v * LPR + lane] = Store<DT>::pack(o);
-      if (y_idx != nullptr) *reinterpret_cast<decltype(oi)*>(y_idx + (base + v * LPR + lane) * V) = oi;
+      if (IDX) *reinterpret_cast<decltype(oi)*>(y_idx + (base + v * LPR + lane) * V) = oi;
     }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { va[v] = na[v]; vr[v] = nr[v]; }
   }
+}
+
+template <int DT, int LPR, int NV, bool IDX>
+__global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
+                                                         u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
+                                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                         float ln_eps, tq_quantizer q1, tq_quantizer q2, tq_quantizer q3,
+                                                         int on1, int on2, int on3, int affine_only, int nt, uint32_t iters) {
+  // wave-uniform: every enabled quantizer admits the branch-free exact path (tq_device.h, QF)
+  bool fast = true;
+  if (on1) fast = fast && make_qf(make_qp(q1, 0)).ok;
+  if (on2) fast = fast && make_qf(make_qp(q2, 0)).ok;
+  if (on3) fast = fast && make_qf(make_qp(q3, 0)).ok;
+  if (fast)
+    res_ln_body<DT, LPR, NV, IDX, true>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, affine_only, nt, iters);
+  else
+    res_ln_body<DT, LPR, NV, IDX, false>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, affine_only, nt, iters);
 }
 
 template <int DT>
@@ -144,9 +222,14 @@ static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, u
 #define TQ_LN(LPR, NV)                                                                                          \
   if (vpr == (uint64_t)(LPR) * (NV)) {                                                                          \
     const unsigned rpb = kBlock / (LPR);                                                                        \
-    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(rows, rpb), 1), 1u << 20);   \
-    hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, eps, \
-                       c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, affine_only, nt);               \
+    const uint32_t iters = (uint32_t)std::max<int>(1, std::min<uint64_t>(tuning("TQ_TAIL_ITERS", 4), ceil_div(rows, (uint64_t)rpb * 2048))); \
+    const unsigned grid = (unsigned)std::max<uint64_t>(ceil_div(rows, (uint64_t)rpb * iters), 1);               \
+    if (y_idx != nullptr)                                                                                       \
+      hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV, true>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, \
+                         eps, c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, affine_only, nt, iters); \
+    else                                                                                                        \
+      hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV, false>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, \
+                         eps, c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, affine_only, nt, iters); \
     return check_launch("res_ln_quant_k");                                                                      \
   }
   // d (bf16 | fp32): 768 -> 96 | 192 vectors, 3072 -> 384 | 768, 512 -> 64 | 128, 128 -> 16 | 32, 1024 -> 128 | 256
