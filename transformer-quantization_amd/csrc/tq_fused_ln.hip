@@ -65,13 +65,16 @@ __device__ __forceinline__ f32x2 apply_f2(f32x2 v, const FusedF& q) { return q.o
 // on bf16 rows (3.1-3.3 TB/s).  NaN: an unordered input pair poisons its element before the statistics (so a LayerNorm
 // row turns NaN as a whole, like the reference) and a NaN pre-quantizer value is passed through at the end.  FAST = false
 // is the division path (scales outside [2^-100, 2^100], grids of 2^22+ steps); IDX also emits int8(index - 128).
-template <int DT, int LPR, int NV, bool IDX, bool FAST>
+template <int DT, int LPR, int NV, bool IDX, bool FAST, bool ALLON>
 __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
                                             u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                             float ln_eps, const tq_quantizer& q1, const tq_quantizer& q2,
-                                            const tq_quantizer& q3, int on1, int on2, int on3, int affine_only, int nt,
+                                            const tq_quantizer& q3, int on1_, int on2_, int on3_, int affine_only, int nt,
                                             uint32_t iters) {
+  // ALLON: the three quantizers are present (the configuration the tails exist for) -> compile-time flags, no uniform
+  // branch around every quantizer application (those branches split the row into ~40 basic blocks and serialised it)
+  const int on1 = ALLON ? 1 : on1_, on2 = ALLON ? 1 : on2_, on3 = ALLON ? 1 : on3_;
   constexpr int V = Store<DT>::kVec;
   constexpr int H = V / 2;                          // register pairs per 16-byte vector
   constexpr int RPB = kBlock / LPR;                 // rows per block iteration
@@ -93,29 +96,25 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
   // parameters / quantizer constants are set up once per block instead of once per RPB rows.
   const uint64_t row0 = (uint64_t)blockIdx.x * RPB * iters + sub;
   u32x4 va[NV], vr[NV], na[NV], nr[NV];
-  if (row0 < rows) {
+  // streaming hints only for tensors that cannot stay in L2 / MALL anyway: in a model forward the inputs were just
+  // written by the GEMM and the output is read by the next layer.  ONE uniform branch per group of loads / stores.
+  auto load_row = [&](uint64_t row, u32x4 (&pa)[NV], u32x4 (&pr)[NV]) {
+    const uint64_t o = row * (d / V) + lane;
+    if (nt) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const uint64_t o = row0 * (d / V) + v * LPR + lane;
-      // streaming hints only for tensors that cannot stay in L2 / MALL anyway: in a model forward the inputs were
-      // just written by the GEMM and the output is read by the next layer
-      va[v] = nt ? ld_stream(a + o) : a[o];
-      vr[v] = nt ? ld_stream(r + o) : r[o];
+      for (int v = 0; v < NV; ++v) { pa[v] = ld_stream(a + o + v * LPR); pr[v] = ld_stream(r + o + v * LPR); }
+    } else {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) { pa[v] = a[o + v * LPR]; pr[v] = r[o + v * LPR]; }
     }
-  }
+  };
+  if (row0 < rows) load_row(row0, va, vr);
   for (uint32_t it = 0; it < iters; ++it) {
     const uint64_t row = row0 + (uint64_t)it * RPB;
     if (row >= rows) break;
     const uint64_t base = row * (d / V);
     const uint64_t nrow = row + RPB;
-    if (it + 1 < iters && nrow < rows) {
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const uint64_t o = nrow * (d / V) + v * LPR + lane;
-        na[v] = nt ? ld_stream(a + o) : a[o];
-        nr[v] = nt ? ld_stream(r + o) : r[o];
-      }
-    }
+    if (it + 1 < iters && nrow < rows) load_row(nrow, na, nr);
     f32x2 u[NV][H];
     f32x2 s2 = {0.f, 0.f};
 #pragma unroll
@@ -151,6 +150,7 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
       rstd = 1.0f / sqrtf(group_sum<LPR>(ss2.x + ss2.y) * inv_d + ln_eps);
     }
     const f32x2 m2 = {mean, mean}, r2 = {rstd, rstd};
+    u32x4 packed[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float o[V];
@@ -182,8 +182,15 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
         o[2 * j] = t.x;
         o[2 * j + 1] = t.y;
       }
-      if (nt) st_stream(y + base + v * LPR + lane, Store<DT>::pack(o)); else y[base + v * LPR + lane] = Store<DT>::pack(o);
+      packed[v] = Store<DT>::pack(o);
       if (IDX) *reinterpret_cast<decltype(oi)*>(y_idx + (base + v * LPR + lane) * V) = oi;
+    }
+    if (nt) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) st_stream(y + base + v * LPR + lane, packed[v]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) y[base + v * LPR + lane] = packed[v];
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) { va[v] = na[v]; vr[v] = nr[v]; }
@@ -201,10 +208,12 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
   if (on1) fast = fast && make_qf(make_qp(q1, 0)).ok;
   if (on2) fast = fast && make_qf(make_qp(q2, 0)).ok;
   if (on3) fast = fast && make_qf(make_qp(q3, 0)).ok;
-  if (fast)
-    res_ln_body<DT, LPR, NV, IDX, true>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, affine_only, nt, iters);
+  if (fast && on1 && on2 && on3)
+    res_ln_body<DT, LPR, NV, IDX, true, true>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, 1, 1, 1, affine_only, nt, iters);
+  else if (fast)
+    res_ln_body<DT, LPR, NV, IDX, true, false>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, affine_only, nt, iters);
   else
-    res_ln_body<DT, LPR, NV, IDX, false>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, affine_only, nt, iters);
+    res_ln_body<DT, LPR, NV, IDX, false, false>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, affine_only, nt, iters);
 }
 
 template <int DT>
