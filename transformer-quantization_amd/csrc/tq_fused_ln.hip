@@ -93,7 +93,9 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
 
   // A block owns `iters` consecutive groups of RPB rows (one-shot tiles in row order: the resident blocks sweep one
   // contiguous window of HBM); the loads of group i + 1 are issued before group i is computed, and the affine
-  // parameters / quantizer constants are set up once per block instead of once per RPB rows.
+  // parameters / quantizer constants are set up once per block instead of once per RPB rows.  Measured on
+  // [131072, 768] (tools/tuning/tail_sweep.py): bf16 LayerNorm 3.6 / 4.6 / 4.9 / 4.9 TB/s for iters = 1 / 2 / 4 / 8,
+  // fp32 5.4 / 5.8 / 5.4 / 5.2 -> 8 for 2-byte storage, 2 for fp32 (launch_res_ln).
   const uint64_t row0 = (uint64_t)blockIdx.x * RPB * iters + sub;
   u32x4 va[NV], vr[NV], na[NV], nr[NV];
   // streaming hints only for tensors that cannot stay in L2 / MALL anyway: in a model forward the inputs were just
@@ -231,7 +233,7 @@ static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, u
 #define TQ_LN(LPR, NV)                                                                                          \
   if (vpr == (uint64_t)(LPR) * (NV)) {                                                                          \
     const unsigned rpb = kBlock / (LPR);                                                                        \
-    const uint32_t iters = (uint32_t)std::max<int>(1, std::min<uint64_t>(tuning("TQ_TAIL_ITERS", 4), ceil_div(rows, (uint64_t)rpb * 2048))); \
+    const uint32_t iters = (uint32_t)std::max<int>(1, std::min<uint64_t>(tuning("TQ_TAIL_ITERS", DT == TQ_F32 ? 2 : 8), ceil_div(rows, (uint64_t)rpb * 2048))); \
     const unsigned grid = (unsigned)std::max<uint64_t>(ceil_div(rows, (uint64_t)rpb * iters), 1);               \
     if (y_idx != nullptr)                                                                                       \
       hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV, true>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, \

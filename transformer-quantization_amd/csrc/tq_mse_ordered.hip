@@ -147,18 +147,68 @@ __global__ __launch_bounds__(kBlock) void mse_ord_unit_k(const void* __restrict_
 #pragma unroll
     for (int c = 0; c < NC; ++c) a[j][c] = 0.0f;
 
+  // Two CANDIDATES per VALU instruction (same x, packed fp32 pairs) with the exact branch-free quantizer of
+  // tq_device.h (QF): per candidate-element  med3 + 1/2 (pk_mul + 2 pk_fma) + rndne + 1/2 (pk_mul, pk_add, pk_mul,
+  // pk_add) = 5.5 issue slots, against ~12 plus a data-dependent branch for the guarded reciprocal.  The per-candidate
+  // sum over the 16 steps of a chunk keeps its sequential order (the pair lanes are two different candidates).
+  constexpr int NP = NC / 2;
+  f32x2 sc2[NP], ns2[NP], rc2[NP];
+  float ylo[NC], yhi[NC];
+  bool fast = true;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const QF f = make_qf(QP{cp[c].scale, cp[c].zp, cp[c].lo, cp[c].hi});
+    fast = fast && f.ok;
+    ylo[c] = f.ylo;
+    yhi[c] = f.yhi;
+    if (c & 1) { sc2[c / 2].y = f.scale.x; ns2[c / 2].y = f.nscale.x; rc2[c / 2].y = f.rcp.x; }
+    else { sc2[c / 2].x = f.scale.x; ns2[c / 2].x = f.nscale.x; rc2[c / 2].x = f.rcp.x; }
+  }
+
   for (uint64_t t = t0; t < t1;) {
     const uint32_t n = (uint32_t)min((uint64_t)16, t1 - t);
     float xs[16];
     // padding with zeros is exact: 0 quantizes to 0 for every candidate, and s + 0 = s
 #pragma unroll
     for (int j = 0; j < 16; ++j) xs[j] = (uint32_t)j < n ? view((t + j) * 32 + col) : 0.0f;
+    if (fast) {
+      f32x2 s2[NP];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      float s = a[0][c];
+      for (int c = 0; c < NP; ++c) s2[c] = f32x2{a[0][2 * c], a[0][2 * c + 1]};
+      // step-major, candidate pairs side by side: NP independent dependency chains per step in source order (a
+      // dependent packed op needs a wait state; one chain per element made the scheduler emit an s_nop after every
+      // packed instruction)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) s += sq_err(xs[j], cp[c]);
-      a[0][c] = s;
+      for (int j = 0; j < 16; ++j) {
+        const float xv = xs[j];
+        const f32x2 x2 = {xv, xv};
+        f32x2 xc[NP], q0[NP], e[NP], q1[NP], h[NP], dl[NP];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+          xc[c].x = __builtin_amdgcn_fmed3f(xv, ylo[2 * c], yhi[2 * c]);
+          xc[c].y = __builtin_amdgcn_fmed3f(xv, ylo[2 * c + 1], yhi[2 * c + 1]);
+        }
+#pragma unroll
+        for (int c = 0; c < NP; ++c) q0[c] = xc[c] * rc2[c];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) e[c] = __builtin_elementwise_fma(q0[c], ns2[c], xc[c]);
+#pragma unroll
+        for (int c = 0; c < NP; ++c) q1[c] = __builtin_elementwise_fma(e[c], rc2[c], q0[c]);
+#pragma unroll
+        for (int c = 0; c < NP; ++c) h[c] = f32x2{rintf(q1[c].x), rintf(q1[c].y)};
+#pragma unroll
+        for (int c = 0; c < NP; ++c) dl[c] = x2 - sc2[c] * h[c];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) s2[c] = s2[c] + dl[c] * dl[c];
+      }
+#pragma unroll
+      for (int c = 0; c < NP; ++c) { a[0][2 * c] = s2[c].x; a[0][2 * c + 1] = s2[c].y; }
+    } else {          // scales outside [2^-100, 2^100] / grids of 2^22+ steps: division path (rare: keep it small)
+#pragma unroll 1
+      for (int j = 0; j < 16; ++j) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) a[0][c] += sq_err(xs[j], cp[c]);
+      }
     }
     t += n;
     if ((t & (L - 1)) == 0) TQ_ORD_DUMP(a, t, p, L, k_top, NC);
@@ -277,7 +327,7 @@ static OrdPlan plan_ord(uint64_t rows, uint64_t row_len, uint64_t n_cand) {
   OrdPlan pl;
   pl.steps = (row_len / 8) / 4;
   pl.p = level_power(pl.steps);
-  pl.nc = n_cand < 4 ? 1 : kOrdNC;
+  pl.nc = n_cand < 4 ? 2 : kOrdNC;
   pl.n_ctiles = (uint32_t)ceil_div(n_cand, pl.nc);
   const uint64_t L = 1ull << pl.p;
   // Largest unit that still gives >= 8 waves per SIMD (1024 SIMDs; measured: fewer, longer waves lose 15-20 % to
@@ -318,8 +368,8 @@ static int launch_ord(const void* x, uint64_t rows, uint64_t row_len, const floa
   const uint64_t n_ru = rows * pl.units_per_row;
   const uint64_t waves = ceil_div(n_ru, 2) * pl.n_ctiles;
   const dim3 grid((unsigned)ceil_div(waves, kBlock / kWave));
-  if (pl.nc == 1)
-    hipLaunchKernelGGL((mse_ord_unit_k<DT, 1>), grid, dim3(kBlock), 0, st, x, row_len, pl.steps, pl.p,
+  if (pl.nc == 2)
+    hipLaunchKernelGGL((mse_ord_unit_k<DT, 2>), grid, dim3(kBlock), 0, st, x, row_len, pl.steps, pl.p,
                        pl.k_top, pl.span, pl.units_per_row, n_ru, c4, (uint32_t)n_cand, pl.n_ctiles, state, row_loss);
   else
     hipLaunchKernelGGL((mse_ord_unit_k<DT, kOrdNC>), grid, dim3(kBlock), 0, st, x, row_len, pl.steps,
