@@ -147,6 +147,34 @@ __device__ __forceinline__ f32x2 qf_round2(f32x2 x, const QF& q) {
 // fake-quantized pair: s * h
 __device__ __forceinline__ f32x2 qf_fake_quant2(f32x2 x, const QF& q) { return q.scale * qf_round2(x, q); }
 
+// N pairs, stage by stage: N independent dependency chains side by side in source order.  (A dependent packed op
+// needs a wait state; written one pair after the other the scheduler kept the chains serial and emitted an s_nop after
+// nearly every packed instruction.)
+template <int N>
+__device__ __forceinline__ void qf_round2_n(const f32x2 (&x)[N], const QF& q, f32x2 (&h)[N]) {
+  f32x2 xc[N], q0[N], e[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    xc[i].x = __builtin_amdgcn_fmed3f(x[i].x, q.ylo, q.yhi);
+    xc[i].y = __builtin_amdgcn_fmed3f(x[i].y, q.ylo, q.yhi);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) q0[i] = xc[i] * q.rcp;
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i] = __builtin_elementwise_fma(q0[i], q.nscale, xc[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) q0[i] = __builtin_elementwise_fma(e[i], q.rcp, q0[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) h[i] = f32x2{rintf(q0[i].x), rintf(q0[i].y)};
+}
+template <int N>
+__device__ __forceinline__ void qf_fake_quant2_n(f32x2 (&x)[N], const QF& q) {
+  f32x2 h[N];
+  qf_round2_n<N>(x, q, h);
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = q.scale * h[i];
+}
+
 // x_int = clamp(round(x / scale) + zp, lo, hi)   (quantizers.py:184-185)
 __device__ __forceinline__ float q_index(float x, const QP& p) {
   return clamp_nanprop(rintf(x / p.scale) + p.zp, p.lo, p.hi);

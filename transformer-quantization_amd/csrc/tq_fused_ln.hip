@@ -124,19 +124,29 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
       float fa[V], fr[V];
       Store<DT>::unpack(va[v], fa);
       Store<DT>::unpack(vr[v], fr);
+      if (FAST) {
+        // the H pairs of this 16-byte vector move through the stages side by side (qf_*_n)
+        f32x2 t[H];
 #pragma unroll
-      for (int j = 0; j < H; ++j) {
-        const f32x2 xa = {fa[2 * j], fa[2 * j + 1]}, xr = {fr[2 * j], fr[2 * j + 1]};
-        if (FAST) {
-          f32x2 t = apply_f2(apply_f2(xa, f1) + xr, f2);
-          t.x = __builtin_isunordered(xa.x, xr.x) ? __builtin_nanf("") : t.x;
-          t.y = __builtin_isunordered(xa.y, xr.y) ? __builtin_nanf("") : t.y;
-          u[v][j] = t;
-        } else {
-          u[v][j] = f32x2{apply_q(apply_q(xa.x, g1) + xr.x, g2), apply_q(apply_q(xa.y, g1) + xr.y, g2)};
+        for (int j = 0; j < H; ++j) t[j] = f32x2{fa[2 * j], fa[2 * j + 1]};
+        if (f1.on) qf_fake_quant2_n<H>(t, f1.f);
+#pragma unroll
+        for (int j = 0; j < H; ++j) t[j] = t[j] + f32x2{fr[2 * j], fr[2 * j + 1]};
+        if (f2.on) qf_fake_quant2_n<H>(t, f2.f);
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+          t[j].x = __builtin_isunordered(fa[2 * j], fr[2 * j]) ? __builtin_nanf("") : t[j].x;
+          t[j].y = __builtin_isunordered(fa[2 * j + 1], fr[2 * j + 1]) ? __builtin_nanf("") : t[j].y;
+          u[v][j] = t[j];
         }
-        s2 = s2 + u[v][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < H; ++j)
+          u[v][j] = f32x2{apply_q(apply_q(fa[2 * j], g1) + fr[2 * j], g2),
+                          apply_q(apply_q(fa[2 * j + 1], g1) + fr[2 * j + 1], g2)};
       }
+#pragma unroll
+      for (int j = 0; j < H; ++j) s2 = s2 + u[v][j];
     }
     // MobileBERT's NoNorm (models/quantized_mobilebert.py:58-72) is the affine part alone: u * w + b.  With
     // mean = 0 and rstd = 1 the expression below evaluates exactly that ((u - 0) * 1 is exact).
@@ -157,33 +167,41 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
     for (int v = 0; v < NV; ++v) {
       float o[V];
       struct alignas(V) { int8_t e[V]; } oi;
+      f32x2 t[H];
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         const uint32_t c = (v * LPR + lane) * V + 2 * j;
         const f32x2 wv = *reinterpret_cast<const f32x2*>(s_w + c), bv = *reinterpret_cast<const f32x2*>(s_b + c);
-        f32x2 t = (u[v][j] - m2) * r2 * wv + bv;
-        if (f3.on) {
-          if (FAST) {
-            const f32x2 h = qf_round2(t, f3.f);
+        t[j] = (u[v][j] - m2) * r2 * wv + bv;
+      }
+      if (f3.on) {
+        if (FAST) {
+          f32x2 h[H];
+          qf_round2_n<H>(t, f3.f, h);
+#pragma unroll
+          for (int j = 0; j < H; ++j) {
             if (IDX) {
-              oi.e[2 * j] = (int8_t)((int)(h.x + f3.f.zp) - 128);
-              oi.e[2 * j + 1] = (int8_t)((int)(h.y + f3.f.zp) - 128);
+              oi.e[2 * j] = (int8_t)((int)(h[j].x + f3.f.zp) - 128);
+              oi.e[2 * j + 1] = (int8_t)((int)(h[j].y + f3.f.zp) - 128);
             }
-            const f32x2 yq = f3.f.scale * h;
-            t.x = (t.x != t.x) ? t.x : yq.x;
-            t.y = (t.y != t.y) ? t.y : yq.y;
-          } else {
-            const float x0 = index_q(t.x, g3), x1 = index_q(t.y, g3);
+            const f32x2 yq = f3.f.scale * h[j];
+            t[j].x = (t[j].x != t[j].x) ? t[j].x : yq.x;
+            t[j].y = (t[j].y != t[j].y) ? t[j].y : yq.y;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < H; ++j) {
+            const float x0 = index_q(t[j].x, g3), x1 = index_q(t[j].y, g3);
             if (IDX) {
               oi.e[2 * j] = (int8_t)((int)x0 - 128);
               oi.e[2 * j + 1] = (int8_t)((int)x1 - 128);
             }
-            t = f32x2{q_dequant(x0, g3.p), q_dequant(x1, g3.p)};
+            t[j] = f32x2{q_dequant(x0, g3.p), q_dequant(x1, g3.p)};
           }
         }
-        o[2 * j] = t.x;
-        o[2 * j + 1] = t.y;
       }
+#pragma unroll
+      for (int j = 0; j < H; ++j) { o[2 * j] = t[j].x; o[2 * j + 1] = t[j].y; }
       packed[v] = Store<DT>::pack(o);
       if (IDX) *reinterpret_cast<decltype(oi)*>(y_idx + (base + v * LPR + lane) * V) = oi;
     }

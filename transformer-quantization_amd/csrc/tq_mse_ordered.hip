@@ -330,8 +330,8 @@ static OrdPlan plan_ord(uint64_t rows, uint64_t row_len, uint64_t n_cand) {
   pl.nc = n_cand < 4 ? 2 : kOrdNC;
   pl.n_ctiles = (uint32_t)ceil_div(n_cand, pl.nc);
   const uint64_t L = 1ull << pl.p;
-  // Largest unit that still gives >= 8 waves per SIMD (1024 SIMDs; measured: fewer, longer waves lose 15-20 % to
-  // the tail of the last round): splitting rows costs state traffic + the fold kernel.
+  // Largest unit that still gives >= 4 waves per SIMD (1024 SIMDs): splitting rows costs state traffic + the fold
+  // kernel ([8,128,768] x 12800 candidates: 1.88 ms unsplit vs 2.11 ms split into 12 units per row).
   // TQ_ORD_KTOP forces a level (tests).
   const int forced = tuning("TQ_ORD_KTOP", 0);
   pl.k_top = 4;
@@ -348,7 +348,7 @@ static OrdPlan plan_ord(uint64_t rows, uint64_t row_len, uint64_t n_cand) {
     pl.k_top = k;
     pl.span = span;
     pl.units_per_row = (uint32_t)upr;
-    if (forced ? (int)k <= forced : ceil_div(rows * upr, 2) * pl.n_ctiles >= 8192) break;
+    if (forced ? (int)k <= forced : ceil_div(rows * upr, 2) * pl.n_ctiles >= 4096) break;
   }
   pl.state_bytes = pl.k_top < 4 ? (size_t)rows * pl.units_per_row * n_cand * 32 * sizeof(float4) : 0;
   pl.row_loss_bytes = ((size_t)rows * n_cand * sizeof(float) + 15) & ~(size_t)15;
