@@ -144,8 +144,11 @@ __device__ __forceinline__ f32x2 qf_round2(f32x2 x, const QF& q) {
   const f32x2 q1 = __builtin_elementwise_fma(e, q.rcp, q0);
   return f32x2{rintf(q1.x), rintf(q1.y)};
 }
-// fake-quantized pair: s * h
-__device__ __forceinline__ f32x2 qf_fake_quant2(f32x2 x, const QF& q) { return q.scale * qf_round2(x, q); }
+// fake-quantized pair: s * ((h + zp) - zp) == s * (h + 0): the addition turns h = -0 (x = -0) into the +0 the reference's
+// `x_int - zero_point` produces, everything else is unchanged
+__device__ __forceinline__ f32x2 qf_fake_quant2(f32x2 x, const QF& q) {
+  return q.scale * (qf_round2(x, q) + f32x2{0.0f, 0.0f});
+}
 
 // N pairs, stage by stage: N independent dependency chains side by side in source order.  (A dependent packed op
 // needs a wait state; written one pair after the other the scheduler kept the chains serial and emitted an s_nop after
@@ -172,7 +175,7 @@ __device__ __forceinline__ void qf_fake_quant2_n(f32x2 (&x)[N], const QF& q) {
   f32x2 h[N];
   qf_round2_n<N>(x, q, h);
 #pragma unroll
-  for (int i = 0; i < N; ++i) x[i] = q.scale * h[i];
+  for (int i = 0; i < N; ++i) x[i] = q.scale * (h[i] + f32x2{0.0f, 0.0f});      // + 0: see qf_fake_quant2
 }
 
 // x_int = clamp(round(x / scale) + zp, lo, hi)   (quantizers.py:184-185)
