@@ -173,3 +173,46 @@ def test_every_instantiated_row_length(dtype, d):
             assert torch.equal(y, ref), (str(dtype), d)
         else:
             assert float((diff == 0).float().mean()) >= 0.998 and float(diff.max()) <= float(p3[0]) * 1.01 + (0.1 if dtype != torch.float32 else 0)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_tails_special_values(dtype):
+    """NaN / +-Inf / -0.0 inputs through the fused tails follow the reference chain: a NaN anywhere in a LayerNorm
+    row makes the whole row NaN (the statistics are NaN), in a NoNorm row only its own element; +-Inf clamps to the
+    grid ends like torch.clamp; outputs are never -0.0 where the reference produces +0.0."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(9)
+    rows, d = 64, 768
+    a = (torch.randn(rows, d, generator=g) * 2).to(dtype)
+    r = (torch.randn(rows, d, generator=g) * 1.5).to(dtype)
+    a[3, 17] = float('nan')
+    r[7, 700] = float('nan')
+    a[9, 5] = float('inf')
+    r[11, 6] = -float('inf')
+    a[13, :] = -0.0
+    r[13, :] = -0.0
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    b = 0.05 * torch.randn(d, generator=g)
+    p1, p2, p3 = (O.asym_params_from_range(lo, hi, 8) for lo, hi in ((-7.0, 7.5), (-9.0, 11.0), (-6.0, 11.0)))
+    k = lambda q: (q[0].cuda(), q[1].cuda(), None, 8, False, False, 1e-8)
+    fq = lambda v, p: O.fake_quant(v, p[0], p[1], 8, False)[1]
+    u = fq(fq(a.float(), p1) + r.float(), p2)
+    for eps in (1e-12, None):
+        if eps is None:
+            ref = fq(u * w + b, p3)
+        else:
+            ref = fq(torch.nn.functional.layer_norm(u, (d,), w, b, eps), p3)
+        ref = ref.to(dtype).float()
+        y = be.residual_layernorm_quant(a.cuda(), r.cuda(), k(p1), k(p2), w.cuda(), b.cuda(), eps, k(p3)).cpu().float()
+        assert torch.equal(torch.isnan(y), torch.isnan(ref)), eps
+        if eps is None:
+            assert int(torch.isnan(y).sum()) == 2
+            ok = ~torch.isnan(ref)
+            assert torch.equal(y[ok].view(torch.int32), ref[ok].view(torch.int32))       # bit patterns incl. sign of zero
+        else:
+            assert torch.isnan(y[3]).all() and torch.isnan(y[7]).all() and int(torch.isnan(y).sum()) == 2 * d
+            ok = ~torch.isnan(ref)
+            same = (y[ok] == ref[ok]).float().mean().item()
+            assert same >= 0.999
+            assert not (y[ok].view(torch.int32) == -2 ** 31).any()                      # no -0.0

@@ -223,6 +223,16 @@ def test_special_values_nan_inf(q):
     ok = ~torch.isnan(ref_idx)
     assert torch.equal(idx.cpu()[ok], ref_idx[ok])
     assert torch.equal(y.cpu()[ok], ref_y[ok])
+    # bit patterns, i.e. the sign of zero too (x = -0.0 dequantises to +0.0 in the reference: x_int - zero_point)
+    assert torch.equal(y.cpu()[ok].view(torch.int32), ref_y[ok].view(torch.int32))
+    assert torch.equal(idx.cpu()[ok].view(torch.int32), ref_idx[ok].view(torch.int32))
+    # symmetric grid (zero_point = 0): round(-0.0) + 0.0 = +0.0 upstream
+    ds, sg = O.sym_params_from_range(-4.0, 4.0, 8)
+    ref_idx, ref_y = O.fake_quant(x, ds, None, 8, True, True)
+    y, idx = _hip.backend().fake_quant(x.to(DEV), ds.to(DEV), None, sg.to(DEV), 8, True, False, 1e-8, 1, 1,
+                                       idx_dtype=torch.float32)
+    assert torch.equal(y.cpu()[ok].view(torch.int32), ref_y[ok].view(torch.int32))
+    assert torch.equal(idx.cpu()[ok].view(torch.int32), ref_idx[ok].view(torch.int32))
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

@@ -119,6 +119,7 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
     if (it + 1 < iters && nrow < rows) load_row(nrow, na, nr);
     f32x2 u[NV][H];
     f32x2 s2 = {0.f, 0.f};
+    bool lane_nan = false;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float fa[V], fr[V];
@@ -133,12 +134,20 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
 #pragma unroll
         for (int j = 0; j < H; ++j) t[j] = t[j] + f32x2{fr[2 * j], fr[2 * j + 1]};
         if (f2.on) qf_fake_quant2_n<H>(t, f2.f);
+        if (affine_only) {        // NoNorm: a NaN input is an element-local NaN output
 #pragma unroll
-        for (int j = 0; j < H; ++j) {
-          t[j].x = __builtin_isunordered(fa[2 * j], fr[2 * j]) ? __builtin_nanf("") : t[j].x;
-          t[j].y = __builtin_isunordered(fa[2 * j + 1], fr[2 * j + 1]) ? __builtin_nanf("") : t[j].y;
-          u[v][j] = t[j];
+          for (int j = 0; j < H; ++j) {
+            t[j].x = __builtin_isunordered(fa[2 * j], fr[2 * j]) ? __builtin_nanf("") : t[j].x;
+            t[j].y = __builtin_isunordered(fa[2 * j + 1], fr[2 * j + 1]) ? __builtin_nanf("") : t[j].y;
+          }
+        } else {                  // LayerNorm: any NaN turns the WHOLE row NaN -> one compare per element, masks OR-ed
+#pragma unroll
+          for (int j = 0; j < H; ++j)
+            lane_nan = lane_nan || __builtin_isunordered(fa[2 * j], fr[2 * j]) ||
+                       __builtin_isunordered(fa[2 * j + 1], fr[2 * j + 1]);
         }
+#pragma unroll
+        for (int j = 0; j < H; ++j) u[v][j] = t[j];
       } else {
 #pragma unroll
         for (int j = 0; j < H; ++j)
@@ -160,6 +169,12 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
 #pragma unroll
         for (int j = 0; j < H; ++j) { const f32x2 c = u[v][j] - m2; ss2 = ss2 + c * c; }
       rstd = 1.0f / sqrtf(group_sum<LPR>(ss2.x + ss2.y) * inv_d + ln_eps);
+      if (FAST) {
+        // rows with a NaN input: the statistics are NaN upstream, hence every output of the row
+        const uint64_t m = __ballot(lane_nan);
+        const uint64_t grp = LPR == 64 ? ~0ull : (((1ull << (LPR % 64)) - 1) << ((threadIdx.x & 63) / LPR * LPR));
+        if (m & grp) mean = __builtin_nanf("");
+      }
     }
     const f32x2 m2 = {mean, mean}, r2 = {rstd, rstd};
     u32x4 packed[NV];
