@@ -176,11 +176,15 @@ int tq_scores_softmax_quant_fwd(const float* scores, float* probs, uint64_t rows
 
 /* STE backward of the same op (autograd through quantizers.py:12-19,
  * 184-185, 209): dx = ((g * scale) * mask) / scale with mask = [int_min <= round(x/s)+zp <=
- * int_max]: 3 streams, 6 B/elem bf16.  For a per-tensor quantizer, non-NULL grad_delta /
- * grad_zero_float (fp32 [1], overwritten) also receive d loss / d _delta and d loss / d _zero_float
+ * int_max]: 3 streams, 6 B/elem bf16.  Non-NULL grad_delta / grad_zero_float (fp32 [n_params], overwritten)
+ * also receive d loss / d _delta and d loss / d _zero_float
  * (make_range_trainable, quantizers.py:284-288, 346-349) through deterministic block partials in
  * `workspace` (tq_fake_quant_bwd_workspace_bytes).                                                */
 size_t tq_fake_quant_bwd_workspace_bytes(uint64_t n);
+/* Per-channel / per-axis quantizers (n_params > 1: `learn_ranges()` on per-channel weights or per-embedding / PEG
+ * activations, which the reference differentiates through plain autograd): grad_delta / grad_zero_float are
+ * fp32 [n_params]; workspace as below (one deterministic reduction block per parameter and slice).            */
+size_t tq_fake_quant_bwd_params_workspace_bytes(uint64_t n, uint64_t n_params, uint64_t inner);
 int tq_fake_quant_bwd(const void* x, const void* grad_y, void* grad_x, float* grad_delta,
                       float* grad_zero_float, uint64_t n, int dtype, const tq_quantizer* q,
                       void* workspace, size_t workspace_bytes, tq_stream_t stream);

@@ -75,9 +75,9 @@ class OracleBackend:
         _, dx, dd, dz = O.fake_quant_with_grads(x.float(), delta.detach(), None if zero_float is None
                                                 else zero_float.detach(), n_bits, symmetric, sgn, eps,
                                                 grad_out=grad_y.float())
-        return dx.to(x.dtype), (dd.reshape(1) if param_grads else None), (
-            dz.reshape(1) if (param_grads and dz is not None) else
-            (torch.zeros(1) if param_grads else None))
+        return dx.to(x.dtype), (dd.reshape(-1) if param_grads else None), (
+            dz.reshape(-1) if (param_grads and dz is not None) else
+            (torch.zeros(delta.numel()) if param_grads else None))
 
     def minmax(self, x, n_params=1, inner=1):
         xf = x.detach().float()

@@ -72,3 +72,46 @@ def test_qat_with_estimated_ranges(fix_act):
         d0 = [m.quantizer._delta.detach().clone() for m in acts]
         model(batches[1][0])                       # eval mode: estimate_ranges_train must not move the ranges
     assert all(torch.equal(a, m.quantizer._delta.detach()) for a, m in zip(d0, acts)) and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize('layout', ['per_channel', 'per_embd', 'axis1'])
+@pytest.mark.parametrize('symmetric', [True, False])
+def test_learnable_vector_ranges_gradients_vs_autograd(layout, symmetric):
+    """`learn_ranges()` on per-channel weights / per-embedding activations: d loss / d _delta and d loss / d _zero_float
+    per parameter (tq_fake_quant_bwd with n_params > 1) against plain autograd through the reference's op chain with
+    the STE round (reference quantizers.py:12-19, 142-153, 184-185, 209).  Tolerance 1e-4 relative (fp32 sums)."""
+    from oracle import tq_oracle as O
+    from quantization.quantizers import AsymmetricUniformQuantizer, SymmetricUniformQuantizer
+    g = torch.Generator().manual_seed(3)
+    if layout == 'per_channel':
+        x = torch.randn(48, 96, generator=g) * torch.linspace(0.5, 3, 48)[:, None]
+        axis, per_channel, pshape = None, True, (48, 1)
+        mn, mx = x.min(1)[0], x.max(1)[0]
+    elif layout == 'per_embd':
+        x = torch.randn(4, 16, 96, generator=g) * torch.linspace(0.5, 3, 96)
+        axis, per_channel, pshape = 2, False, (1, 1, 96)
+        mn, mx = x.reshape(-1, 96).min(0)[0], x.reshape(-1, 96).max(0)[0]
+    else:
+        x = torch.randn(4, 16, 96, generator=g)
+        axis, per_channel, pshape = 1, False, (1, 16, 1)
+        mn, mx = x.permute(1, 0, 2).reshape(16, -1).min(1)[0], x.permute(1, 0, 2).reshape(16, -1).max(1)[0]
+    mn, mx = mn * 0.7, mx * 0.7                       # clip: both gradient branches are exercised
+    cls = SymmetricUniformQuantizer if symmetric else AsymmetricUniformQuantizer
+    q = cls(n_bits=4, per_channel=per_channel, axis=axis).cuda()
+    q.set_quant_range(mn.cuda(), mx.cuda())
+    xd = x.cuda().requires_grad_(True)
+    with torch.no_grad():
+        q(xd)                                          # shapes the parameter views ([C,1] / [1,1,d])
+    q.make_range_trainable()
+    gy = torch.randn(x.shape, generator=g)
+    y = q(xd)
+    y.backward(gy.cuda())
+    delta = q._delta.detach().cpu().reshape(pshape)
+    zf = None if symmetric else q._zero_float.detach().cpu().reshape(pshape)
+    signed = bool(q._signed.item()) if symmetric else False
+    _, dx, dd, dz = O.fake_quant_with_grads(x, delta, zf, 4, symmetric, signed, grad_out=gy)
+    assert torch.allclose(xd.grad.cpu(), dx, rtol=1e-5, atol=1e-6)
+    assert q._delta.grad is not None and q._delta.grad.shape == q._delta.shape
+    assert torch.allclose(q._delta.grad.cpu().reshape(pshape), dd, rtol=1e-4, atol=1e-4), layout
+    if not symmetric:
+        assert torch.allclose(q._zero_float.grad.cpu().reshape(pshape), dz, rtol=1e-4, atol=1e-4), layout

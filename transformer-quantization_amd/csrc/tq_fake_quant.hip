@@ -643,12 +643,89 @@ __global__ void fq_bwd_final(const float* __restrict__ partial, uint32_t nb, tq_
   }
 }
 
+// ---- parameter gradients for per-channel / per-axis ranges (learn_ranges with vector parameters) ----------------
+// x viewed as [outer, n_params, inner].  Block (p, s) reduces parameter p over slice s of the `outer` index
+// (deterministic: block partials + a final kernel, no atomics).  The element gradient gx comes from fq_bwd.
+constexpr unsigned kBwdSlices = 64;
+__host__ __device__ inline unsigned bwd_param_slices(uint64_t outer, uint64_t inner) {
+  const uint64_t per_param = outer * inner;
+  uint64_t s = per_param / 4096;
+  if (s < 1) s = 1;
+  if (s > kBwdSlices) s = kBwdSlices;
+  if (s > outer) s = outer;
+  return (unsigned)s;
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void fq_bwd_params_k(const void* __restrict__ x, const void* __restrict__ gy,
+                                                          uint64_t outer, tq_quantizer q, float* __restrict__ partial) {
+  typedef typename Store<DT>::elem_t E;
+  __shared__ float s_red[2][kBlock / kWave];
+  const uint64_t prm = blockIdx.x;
+  const QP p = make_qp(q, prm);
+  const uint64_t chunk = (outer + gridDim.y - 1) / gridDim.y;
+  const uint64_t o0 = (uint64_t)blockIdx.y * chunk, o1 = min(outer, o0 + chunk);
+  BwdAcc acc = {0.f, 0.f};
+  const uint64_t per = (o1 > o0 ? o1 - o0 : 0) * q.inner;
+  for (uint64_t e = threadIdx.x; e < per; e += kBlock) {
+    const uint64_t o = o0 + e / q.inner, i = e % q.inner;
+    const uint64_t at = (o * q.n_params + prm) * q.inner + i;
+    ste_bwd_elem(Store<DT>::load1(static_cast<const E*>(x) + at), Store<DT>::load1(static_cast<const E*>(gy) + at), p, true,
+                 acc);
+  }
+  acc.d = wave_sum(acc.d);
+  acc.z = wave_sum(acc.z);
+  const int w = threadIdx.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_red[0][w] = acc.d; s_red[1][w] = acc.z; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float d = 0.f, z = 0.f;
+    for (int k = 0; k < kBlock / kWave; ++k) { d += s_red[0][k]; z += s_red[1][k]; }
+    partial[(prm * gridDim.y + blockIdx.y) * 2] = d;
+    partial[(prm * gridDim.y + blockIdx.y) * 2 + 1] = z;
+  }
+}
+
+// per parameter: sum the slices (fixed order, fp64) and apply the chain rule through scale = clamp(delta, eps) | exp(delta)
+// and zp = clamp(round_ste(zero_float), lo, hi)
+__global__ void fq_bwd_params_final_k(const float* __restrict__ partial, uint32_t slices, tq_quantizer q,
+                                      float* __restrict__ g_delta, float* __restrict__ g_zf) {
+  const uint64_t prm = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (prm >= q.n_params) return;
+  double d = 0.0, z = 0.0;
+  for (uint32_t s = 0; s < slices; ++s) { d += (double)partial[(prm * slices + s) * 2]; z += (double)partial[(prm * slices + s) * 2 + 1]; }
+  const float delta = q.delta[prm];
+  const float pass = q.log_domain ? expf(delta) : (delta >= q.eps ? 1.0f : 0.0f);
+  g_delta[prm] = (float)d * pass;
+  if (g_zf != nullptr && !q.symmetric) {
+    const QP p = make_qp(q, prm);
+    const float zf = rintf(q.zero_float[prm]);
+    g_zf[prm] = (zf >= p.lo && zf <= p.hi) ? (float)z : 0.0f;
+  }
+}
+
 template <int DT>
 static int launch_bwd(const void* x, const void* gy, void* gx, float* g_delta, float* g_zf, uint64_t n,
                       const tq_quantizer& q, float* ws, size_t ws_bytes, hipStream_t st) {
   constexpr int V = Store<DT>::kVec;
+  const bool vector_params = g_delta != nullptr && q.n_params != 1;
+  if (vector_params) {
+    // element gradient first (scalar kernel), then one reduction block per (parameter, slice)
+    const uint64_t outer = n / (q.n_params * q.inner);
+    const unsigned slices = bwd_param_slices(outer, q.inner);
+    const size_t need = (size_t)q.n_params * slices * 2 * sizeof(float);
+    if (ws == nullptr || ws_bytes < need) return set_error(TQ_EWORKSPACE, "tq_fake_quant_bwd: workspace %zu < %zu bytes", ws_bytes, need);
+    if (q.n_params > 0x7fffffffull) return set_error(TQ_EUNSUPPORTED, "tq_fake_quant_bwd: too many parameters");
+    const unsigned grid1 = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, kBlock), 1), kMaxGrid);
+    hipLaunchKernelGGL((fq_bwd<DT, false>), dim3(grid1), dim3(kBlock), 0, st, x, gy, gx, ws, n, q);
+    if (int e = check_launch("fq_bwd")) return e;
+    hipLaunchKernelGGL((fq_bwd_params_k<DT>), dim3((unsigned)q.n_params, slices), dim3(kBlock), 0, st, x, gy, outer, q, ws);
+    if (int e = check_launch("fq_bwd_params_k")) return e;
+    hipLaunchKernelGGL(fq_bwd_params_final_k, dim3((unsigned)ceil_div(q.n_params, 256)), dim3(256), 0, st, ws, slices, q, g_delta,
+                       g_zf);
+    return check_launch("fq_bwd_params_final_k");
+  }
   const bool pgrad = g_delta != nullptr;
-  if (pgrad && q.n_params != 1) return set_error(TQ_EUNSUPPORTED, "tq_fake_quant_bwd: parameter gradients need a per-tensor quantizer");
   const bool vec_ok = q.n_params == 1 && aligned16(x) && aligned16(gy) && aligned16(gx);
   const uint64_t n_vec = n / V;
   constexpr int U = 2;
@@ -737,6 +814,12 @@ extern "C" int tq_affine_fake_quant_fwd(const void* x, const float* w, const flo
 }
 
 extern "C" size_t tq_fake_quant_bwd_workspace_bytes(uint64_t n) { return (size_t)65536 * 2 * sizeof(float); }
+
+extern "C" size_t tq_fake_quant_bwd_params_workspace_bytes(uint64_t n, uint64_t n_params, uint64_t inner) {
+  if (n_params <= 1) return tq_fake_quant_bwd_workspace_bytes(n);
+  const uint64_t outer = inner ? n / (n_params * inner) : 0;
+  return (size_t)n_params * bwd_param_slices(outer, inner) * 2 * sizeof(float);
+}
 
 extern "C" int tq_fake_quant_bwd(const void* x, const void* grad_y, void* grad_x, float* grad_delta,
                                  float* grad_zero_float, uint64_t n, int dtype, const tq_quantizer* q,

@@ -54,6 +54,7 @@ SIGNATURES = {
     'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
                                 _int, _QP, _vp]),
     'tq_fake_quant_bwd_workspace_bytes': (_sz, [_u64]),
+    'tq_fake_quant_bwd_params_workspace_bytes': (_sz, [_u64, _u64, _u64]),
     'tq_fake_quant_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _int, _QP, _vp, _sz, _vp]),
     'tq_minmax_workspace_bytes': (_sz, [_u64, _u64, _u64]),
     'tq_minmax': (_int, [_vp, _u64, _int, _u64, _u64, _vp, _vp, _vp, _sz, _vp]),
@@ -339,9 +340,9 @@ class HipBackend:
         gd = gz = None
         ws = None
         if param_grads:
-            gd = torch.zeros(1, dtype=torch.float32, device=x.device)
-            gz = torch.zeros(1, dtype=torch.float32, device=x.device)
-            ws = self._workspace(x.device, self.lib.tq_fake_quant_bwd_workspace_bytes(x.numel()))
+            gd = torch.zeros(n_params, dtype=torch.float32, device=x.device)
+            gz = torch.zeros(n_params, dtype=torch.float32, device=x.device)
+            ws = self._workspace(x.device, self.lib.tq_fake_quant_bwd_params_workspace_bytes(x.numel(), n_params, inner))
         q = self._qdesc(delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner)
         rc = self.lib.tq_fake_quant_bwd(_ptr(x), _ptr(grad_y), _ptr(gx), _ptr(gd), _ptr(gz), x.numel(),
                                         _dtype_code(x, 'fake_quant_bwd'), C.byref(q), _ptr(ws),

@@ -105,8 +105,6 @@ class _FakeQuantSTE(Function):
         x, delta, zero_float = ctx.saved_tensors
         signed, n_bits, symmetric, log_domain, eps, n_params, inner = ctx.cfg
         want_p = ctx.needs_input_grad[1] or (zero_float is not None and ctx.needs_input_grad[2])
-        if want_p and n_params != 1:
-            raise NotImplementedError('learnable ranges are implemented for per-tensor quantizers')
         gx, gd, gz = _hip.backend().fake_quant_bwd(
             x, grad_y, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params,
             inner, param_grads=want_p)
