@@ -138,6 +138,14 @@ def _need_device(t, what):
                       'ROCm device (no CPU fallback)')
 
 
+def _need_f32(what, *tensors):
+    """The AdaRound kernels are fp32-only (weights, alpha, Adam moments): refuse anything else instead of
+    reinterpreting its bytes."""
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise TQError(f'{what}: fp32 tensors required, got {t.dtype} (call .float() on the layer first)')
+
+
 def _dtype_code(t, what):
     try:
         return _DTYPES[t.dtype]
@@ -145,8 +153,35 @@ def _dtype_code(t, what):
         raise TQError(f'{what}: dtype {t.dtype} not supported (fp32 / bf16 / fp16)') from None
 
 
+def _device_guarded(fn):
+    """Run a backend method on the device its tensor operands live on: workspaces, ticket words, the raw stream
+    handle and every output allocation follow torch's CURRENT device, so a tensor on cuda:1 while cuda:0 is current
+    (nn.DataParallel replicas, `keep_gpu` caches, a model moved to another GPU) would be launched on the wrong
+    device's stream against foreign pointers.  ATen ops switch device automatically; so does this.  Operands on
+    different devices raise instead of faulting."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        idx = None
+        for a in args:
+            if type(a) is torch.Tensor or isinstance(a, torch.Tensor):
+                if a.is_cuda:
+                    i = a.device.index
+                    if idx is None:
+                        idx = i
+                    elif i != idx:
+                        raise TQError(f'{fn.__name__}: operands live on different devices (cuda:{idx} and cuda:{i})')
+        if idx is None or idx == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(idx):
+            return fn(self, *args, **kwargs)
+    return wrapper
+
+
 class HipBackend:
-    """Tensor-level wrappers; one instance per process.  All work goes to torch's current stream."""
+    """Tensor-level wrappers; one instance per process.  All work goes to torch's current stream on the device of
+    the operands (every public method is wrapped by `_device_guarded`, see the bottom of the class)."""
 
     name = 'hip'
 
@@ -595,6 +630,7 @@ class HipBackend:
     # -- K10/K11/K13 -----------------------------------------------------------------------
     def adaround_fwd(self, w, alpha, qargs, mode, soft, temperature):
         _need_device(w, 'adaround_fwd')
+        _need_f32('adaround_fwd', w, alpha)
         w = w.detach().contiguous()
         out = torch.empty_like(w)
         q = self._qdesc(*qargs)
@@ -605,6 +641,7 @@ class HipBackend:
 
     def adaround_init_alpha(self, w, qargs, mode, temperature):
         _need_device(w, 'adaround_init_alpha')
+        _need_f32('adaround_init_alpha', w)
         w = w.detach().contiguous()
         alpha = torch.empty_like(w)
         q = self._qdesc(*qargs)
@@ -615,6 +652,8 @@ class HipBackend:
 
     def adaround_bwd(self, w, alpha, grad_wq, qargs, mode, temperature):
         _need_device(w, 'adaround_bwd')
+        _need_f32('adaround_bwd', w, alpha)
+        grad_wq = grad_wq.float()
         g = torch.empty_like(alpha)
         q = self._qdesc(*qargs)
         rc = self.lib.tq_adaround_bwd(_ptr(w.detach().contiguous()), _ptr(alpha.detach().contiguous()),
@@ -626,6 +665,8 @@ class HipBackend:
     def adaround_bwd_adam(self, w, grad_wq, alpha, exp_avg, exp_avg_sq, qargs, mode, temperature,
                           reg_weight, beta, lr, b1, b2, adam_eps, step, want_grad=False):
         _need_device(w, 'adaround_bwd_adam')
+        _need_f32('adaround_bwd_adam', w, alpha, exp_avg, exp_avg_sq)
+        grad_wq = grad_wq.float()
         g = torch.empty_like(alpha) if want_grad else None
         q = self._qdesc(*qargs)
         rc = self.lib.tq_adaround_bwd_adam(_ptr(w.detach().contiguous()), _ptr(grad_wq.contiguous()),
@@ -638,6 +679,7 @@ class HipBackend:
 
     def adaround_reg(self, alpha, mode, temperature, beta, weight):
         _need_device(alpha, 'adaround_reg')
+        _need_f32('adaround_reg', alpha)
         out = torch.zeros(1, dtype=torch.float64, device=alpha.device)
         ws = self._workspace(alpha.device, self.lib.tq_reduce_workspace_bytes(alpha.numel()))
         rc = self.lib.tq_adaround_reg(_ptr(alpha.detach().contiguous()), alpha.numel(), mode,
@@ -659,6 +701,11 @@ class HipBackend:
         _check(rc, self.lib)
         return out[0]
 
+
+for _name, _fn in list(vars(HipBackend).items()):
+    if callable(_fn) and not _name.startswith('_') and _name not in ('candidate_table', 'zeros_f64', 'argsort'):
+        setattr(HipBackend, _name, _device_guarded(_fn))
+del _name, _fn
 
 _backend = None
 

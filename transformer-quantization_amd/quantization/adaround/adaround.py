@@ -192,6 +192,16 @@ def apply_mse_out_init(model, layer, data_tensor, batch_size, asym=False):
         q.set_quant_range(-best_max, best_max)
 
 
+def _fused_step_is_exact(layer):
+    """The closed-form / fused AdaRound step optimises run_forward(+activation function) against the cached FP32
+    output; that equals the reference's objective iff nothing else happens in layer.forward."""
+    from quantization.quantization_manager import Qstates
+    if getattr(layer, '_quant_a', False):
+        return False
+    mgr = layer.weight_quantizer
+    return getattr(mgr, 'state', Qstates.fix_ranges) == Qstates.fix_ranges
+
+
 def _cache_layer_io(get_inp_out, data_tensor, batch_size, keep_gpu):
     """Layer inputs / FP32 outputs for every sample this rank owns, resident in HBM when they
     fit (288 GB per MI355X: BERT-base needs 0.4 + 1.6 GB for the widest layer)."""
@@ -217,6 +227,18 @@ def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, bat
     `batch_indices` optionally fixes the sample indices of every iteration (tests); otherwise
     ``torch.randperm`` on the global RNG is used like the reference (:236)."""
     fused = isinstance(optimizer, FusedAlphaAdam)
+    if fused and not _fused_step_is_exact(layer):
+        # The fused step evaluates run_forward (+ activation function) only.  With the layer's ACTIVATION quantizer on,
+        # or the weight manager still estimating ranges, the reference's objective loss_fn(layer(x), target)
+        # (adaround/adaround.py:246-248) contains more than that: take the generic autograd path through layer.forward.
+        if tq_dist.is_enabled():
+            raise NotImplementedError('data-parallel AdaRound needs the fused step: switch the layer\'s activation '
+                                      'quantizer off (model.full_precision(); layer.quantized_weights()) and fix the '
+                                      'weight ranges first, as apply_adaround_to_model does')
+        logger.info('activation quantizer on / weight ranges not fixed: generic autograd AdaRound step')
+        q_ = layer.weight_quantizer.quantizer
+        optimizer = torch.optim.Adam([q_.alpha], lr=optimizer.lr, betas=optimizer.betas, eps=optimizer.eps)
+        fused = False
     if use_cached_data:
         logger.info('Caching data for local loss optimization')
         cached_inps, cached_outs, device, ws, rk = _cache_layer_io(
