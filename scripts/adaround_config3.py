@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""BASELINE config 3 at its stated size: AdaRound W4 on a BERT-base FFN layer, weight [3072, 768], 1024 cached samples of
+128 tokens, batch 8, 1000 iterations, learned_hard_sigmoid (reference defaults adaround/config.py).
+
+Two input distributions, because AdaRound can only beat round-to-nearest where the layer inputs are correlated: for
+i.i.d. inputs E[x x^T] = I, the output error equals the weight error and nearest rounding is already optimal.
+  iid        : hidden = randn
+  structured : BERT-like hidden states: a rank-64 mixing component + 2 outlier embedding dimensions (x20) + noise
+Prints one JSON document (commit under profiles/rNN/adaround_config3.json).
+"""
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, 'transformer-quantization_amd'), ROOT):
+    sys.path.insert(0, p)
+
+import torch
+
+from quantization.adaround import apply_adaround_to_layer
+from quantization.adaround.config import DEFAULT_ADAROUND_CONFIG
+from quantization.adaround.utils import AdaRoundMode, AdaRoundInitMode
+from quantization.autoquant_utils import quantize_model
+from quantization.base_quantized_model import QuantizedModel
+from quantization.quantizers import QMethods
+from quantization.range_estimators import RangeEstimators, OptMethod
+
+dev = 'cuda'
+N, T, FIN, FOUT = 1024, 128, 768, 3072
+ITERS = int(os.environ.get('TQ_ADA_ITERS', 1000))
+
+
+def inputs(kind):
+    g = torch.Generator(device=dev).manual_seed(1000)
+    if kind == 'iid':
+        return torch.randn(N, T, FIN, generator=g, device=dev)
+    z = torch.randn(N, T, 64, generator=g, device=dev)
+    mix = torch.randn(64, FIN, generator=g, device=dev) / 8.0
+    x = z @ mix + 0.3 * torch.randn(N, T, FIN, generator=g, device=dev)
+    x[..., 308] *= 20.0
+    x[..., 381] *= 20.0
+    return x
+
+
+class Net(QuantizedModel):
+    def __init__(self, init):
+        super().__init__()
+        lin = torch.nn.Linear(FIN, FOUT)
+        self.fc = quantize_model(lin, method=QMethods.symmetric_uniform, n_bits=4,
+                                 weight_range_method=RangeEstimators.MSE,
+                                 weight_range_options=dict(opt_method=OptMethod.grid, num_candidates=100))
+
+    def forward(self, x):
+        return self.fc(x)
+
+
+out = {'layer': [FOUT, FIN], 'samples': N, 'tokens': T, 'batch': 8, 'iters': ITERS, 'bits': 4,
+       'round_mode': 'learned_hard_sigmoid', 'runs': {}}
+for kind in ('iid', 'structured'):
+    for init in ('range_estimator', 'mse_out'):
+        torch.manual_seed(1000)
+        net = Net(init).to(dev)
+        net.eval()
+        data = inputs(kind)
+        net.set_quant_state(True, False)
+        with torch.no_grad():
+            net(data[:8])
+        cfg = copy.deepcopy(DEFAULT_ADAROUND_CONFIG)
+        cfg.iters = ITERS
+        cfg.round_mode = AdaRoundMode.learned_hard_sigmoid
+        cfg.init = AdaRoundInitMode[init]
+        net.full_precision()
+        net.fc.quantized_weights()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = apply_adaround_to_layer(net, net.fc, data, batch_size=8, act_quant=False, adaround_config=cfg)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # whole-dataset hard-rounding output MSE, nearest vs learned
+        with torch.no_grad():
+            net.full_precision()
+            ref = torch.cat([net(data[i:i + 64]) for i in range(0, N, 64)])
+            net.fc.quantized_weights()
+            got = torch.cat([net(data[i:i + 64]) for i in range(0, N, 64)])
+            full_after = float(torch.nn.functional.mse_loss(got, ref))
+        out['runs'][f'{kind}/{init}'] = {
+            'loss_hard_before_first_batch': res.loss_hard_before, 'loss_hard_after_first_batch': res.loss_hard_after,
+            'loss_soft_before': res.loss_soft_before, 'loss_soft_after': res.loss_soft_after,
+            'hard_loss_drop_pct': round(100 * (1 - res.loss_hard_after / res.loss_hard_before), 2),
+            'output_mse_all_1024_samples_after': full_after, 'seconds_total': round(dt, 2),
+            'ms_per_iter_incl_caching_and_inits': round(dt / ITERS * 1e3, 3)}
+        del net, data
+        torch.cuda.empty_cache()
+print(json.dumps(out, indent=1))

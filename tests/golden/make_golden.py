@@ -437,11 +437,110 @@ def gen_adaround():
     print('adaround cases:', k)
 
 
+# ----------------------------------------------------------------------------------- 5
+def gen_adaround_inits():
+    """AdaRound grid inits (adaround/adaround.py:160-201) and whole apply_adaround_to_layer runs on the 2-layer toy
+    QuantizedModel, plus sampled values of the annealing schedule (adaround/utils.py:93-128)."""
+    import copy
+    from quantization.adaround.adaround import apply_mse_init, apply_mse_out_init
+    from quantization.adaround.utils import (TempDecay, AdaRoundTempDecayType, AdaRoundInitMode, GetLayerInpOut,
+                                            LayerOutputMSE)
+    data, meta = {}, []
+    torch.manual_seed(5000)
+    org = ToyNet()
+    for kname, v in org.state_dict().items():
+        data['w_' + kname] = np32(v)
+    X = hidden_like((32, 12, 24), 5100, outlier_dims=(3, 11))
+    data['X'] = np32(X)
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=4, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+
+    def fresh():
+        m = QuantToy(copy.deepcopy(org), **qp)
+        m.eval()
+        m.set_quant_state(weight_quant=True, act_quant=False)
+        with torch.no_grad():
+            m(X[:8])                                   # initialises the weight ranges
+        m.fix_ranges() if False else None
+        for mod in m.modules():
+            if isinstance(mod, QuantizationManager) and mod.quantizer.is_initialized:
+                mod.fix_ranges()
+        return m
+
+    k = 0
+    for lname in ('fc1', 'fc2'):
+        # (a) weight-MSE init
+        m = fresh()
+        layer = getattr(m, lname)
+        d0 = np32(layer.weight_quantizer.quantizer._delta)
+        apply_mse_init(layer)
+        data[f'i{k}_delta0'] = d0
+        data[f'i{k}_delta_mse'] = np32(layer.weight_quantizer.quantizer._delta)
+        # (b) output-MSE inits, with the 80 scores the reference's LayerOutputMSE yields
+        for asym in (False, True):
+            m = fresh()
+            layer = getattr(m, lname)
+            layer.caching = False
+            w = layer.weight
+            q = layer.weight_quantizer.quantizer
+            loss_fn = LayerOutputMSE(layer, GetLayerInpOut(m, layer, asym=asym), X, 8)
+            scores = []
+            with torch.no_grad():
+                w_absmax = torch.max(w.max(), torch.abs(w.min()))
+                for i in range(80):
+                    sv = w_absmax * (1.0 - 0.01 * i)
+                    q.set_quant_range(-sv, sv)
+                    scores.append(loss_fn())
+            m = fresh()
+            layer = getattr(m, lname)
+            layer.caching = False
+            apply_mse_out_init(m, layer, X, 8, asym=asym)
+            tag = 'asym' if asym else 'sym'
+            data[f'i{k}_scores_out_{tag}'] = np.array(scores, dtype=np.float64)
+            data[f'i{k}_delta_out_{tag}'] = np32(layer.weight_quantizer.quantizer._delta)
+        # (c) whole-layer AdaRound runs (global torch RNG seeded right before, quirk q11)
+        for init in ('range_estimator', 'mse', 'mse_out'):
+            m = fresh()
+            layer = getattr(m, lname)
+            cfg = copy.deepcopy(DEFAULT_ADAROUND_CONFIG)
+            cfg.iters = 40
+            cfg.lr = 1e-2
+            cfg.init = AdaRoundInitMode[init]
+            m.full_precision()
+            layer.quantized_weights()
+            torch.manual_seed(5200 + k)
+            res = apply_adaround_to_layer(m, layer, X, batch_size=8, act_quant=False, adaround_config=cfg)
+            wq = layer.weight_quantizer.quantizer
+            with torch.no_grad():
+                hard = wq(layer.weight)
+            data[f'i{k}_{init}_alpha'] = np32(wq.alpha)
+            data[f'i{k}_{init}_hard'] = np32(hard)
+            data[f'i{k}_{init}_delta'] = np32(wq._delta)
+            data[f'i{k}_{init}_losses'] = np.array([res.loss_soft_before, res.loss_hard_before, res.loss_soft_after,
+                                                    res.loss_hard_after], dtype=np.float64)
+        meta.append(dict(k=k, layer=lname, iters=40, lr=1e-2, bs=8, seed=5200 + k))
+        k += 1
+    # annealing schedule samples
+    sched = {}
+    for name in ('linear', 'cosine', 'sigmoid', 'power', 'exp', 'log'):
+        for shape in (1.0, 2.5):
+            td = TempDecay(1000, (20, 2), 0.2, AdaRoundTempDecayType[name], shape)
+            sched[f'{name}_{shape}'] = [float(td(t)) for t in range(0, 1001, 25)]
+    data['schedule'] = np.array(json.dumps(sched))
+    data['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, 'adaround_inits.npz'), **data)
+    print('adaround init cases:', k)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'adaround_inits':
+        gen_adaround_inits()
+        sys.exit(0)
     gen_fake_quant()
     gen_estimators()
     gen_toy_model()
     gen_adaround()
+    gen_adaround_inits()
     for f in sorted(os.listdir(OUT)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')

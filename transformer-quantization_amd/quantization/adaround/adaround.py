@@ -174,22 +174,27 @@ def apply_mse_init(layer):
 
 
 def apply_mse_out_init(model, layer, data_tensor, batch_size, asym=False):
-    """Same 80 candidates, scored on the layer OUTPUT error (needs a layer forward per candidate)."""
+    """The same 80 candidate grids, scored on the layer OUTPUT error (reference adaround/adaround.py:181-201).  The
+    80 scores stay on the device (LayerOutputMSE adds fp64 cells through tq_recon_loss); first-minimum selection and
+    the final set_quant_range run there too: one host synchronisation per layer (for the log line) instead of the
+    reference's 80 x #mini-batches `.item()` calls."""
     w = layer.weight
     q = layer.weight_quantizer.quantizer
     get_inp_out = GetLayerInpOut(model, layer, asym=asym)
     loss_fn = LayerOutputMSE(layer, get_inp_out, data_tensor, batch_size)
     with torch.no_grad():
         w_absmax, _ = _shrink_candidates(w)
-        best_score, best_max = np.inf, w_absmax
-        for i in range(80):
-            s = w_absmax * (1.0 - 0.01 * i)
+        cands = [w_absmax * (1.0 - 0.01 * i) for i in range(80)]
+        scores = []
+        for s in cands:
             q.set_quant_range(-s, s)
-            score = loss_fn()
-            if score < best_score:
-                best_score, best_max = score, s
-        logger.info(f'Finished: set max={float(best_max):.3f} (mse={best_score:.7f})')
+            scores.append(loss_fn())
+        scores = torch.stack(scores)
+        best = torch.argmin(scores)                       # first minimum, like the reference's strict `<` scan
+        best_max = torch.stack(cands)[best]
+        logger.info(f'Finished: set max={float(best_max):.3f} (mse={float(scores[best]):.7f})')
         q.set_quant_range(-best_max, best_max)
+    return scores
 
 
 def _fused_step_is_exact(layer):
@@ -219,13 +224,14 @@ def _cache_layer_io(get_inp_out, data_tensor, batch_size, keep_gpu):
 
 
 def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, batch_size, iters,
-                        use_cached_data=True, keep_gpu=True, batch_indices=None):
+                        use_cached_data=True, keep_gpu=True, batch_indices=None, on_step=None):
     """AdaRound optimisation loop.
 
     `optimizer` is a ``FusedAlphaAdam`` (fused K11 path, default) or any torch optimizer over
     ``quantizer.alpha`` (generic autograd path through ``_AdaRoundFn`` and ``loss_fn``).
     `batch_indices` optionally fixes the sample indices of every iteration (tests); otherwise
-    ``torch.randperm`` on the global RNG is used like the reference (:236)."""
+    ``torch.randperm`` on the global RNG is used like the reference (:236).  `on_step(it, layer)` is called
+    after every update (trace replay in the parity tests)."""
     fused = isinstance(optimizer, FusedAlphaAdam)
     if fused and not _fused_step_is_exact(layer):
         # The fused step evaluates run_forward (+ activation function) only.  With the layer's ACTIVATION quantizer on,
@@ -280,6 +286,8 @@ def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, bat
             loss = loss_fn(layer(cur_inp), cur_out)
             loss.backward()
             optimizer.step()
+            if on_step is not None:
+                on_step(i + 1, layer)
             continue
 
         # ---- fused path -----------------------------------------------------------------
@@ -323,6 +331,8 @@ def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, bat
             # temperature takes effect from the NEXT forward on
             q.temperature = b
 
+        if on_step is not None:
+            on_step(it, layer)
         if it == 1 or it % 100 == 0:
             round_loss = float(be.adaround_reg(q.alpha, q.mode_code(), q.temperature, b,
                                                loss_fn.weight)) if reg_on else 0.0
