@@ -68,6 +68,7 @@ for kind in ('iid', 'structured'):
         net.set_quant_state(True, False)
         with torch.no_grad():
             net(data[:8])
+        net.fix_ranges()                      # calibrate -> fix, as main.py:243-266 does before AdaRound
         cfg = copy.deepcopy(DEFAULT_ADAROUND_CONFIG)
         cfg.iters = ITERS
         cfg.round_mode = AdaRoundMode.learned_hard_sigmoid
