@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Whole-model fixture for BASELINE config 4: random-init MobileBERT (24 layers, hidden 512, bottleneck 128, 4 heads,
+4 stacked FFNs, NoNorm), W4A4 mixed precision (4-bit symmetric weights, 4-bit asymmetric activations, 8-bit attention
+probabilities through the reference's own `attn_probs_n_bits_act` switch), one calibration batch with running
+min/max, then a fixed-range forward -- produced by the REFERENCE's own models/quantized_mobilebert.py blocks,
+imported here (build container only).
+
+The reference wraps transformers-4.1 container forwards (MobileBertAttention, Bottleneck, MobileBertEncoder) that
+changed upstream; like make_golden_bert.py this script drives the reference's quantized LEAF blocks
+(QuantizedMobileBertEmbeddings :75-164, QuantizedBottleneckLayer :408-419, QuantizedMobileBertSelfAttention :167-262,
+QuantizedMobileBertSelfOutput :265-304, QuantizedFFNLayer :450-462, quantize_intermediate :307-317,
+QuantizedMobileBertOutput :361-405 incl. QuantizedOutputBottleneck :320-358, QuantizedMobileBertPooler :545-562) in the
+order the 4.1 containers did (QuantizedMobileBertLayer.forward :496-542, Bottleneck.forward with the shared key/query
+bottleneck).  No reference file is modified; shims: `utils` namespace package with no-op TensorBoard hooks,
+transformers.modeling_utils.apply_chunking_to_forward re-exported (models/__init__.py imports quantized_bert).
+
+Stores logits, every activation range (call order) and every weight-quantizer delta.  Weights are rebuilt by the test
+from the same seed with the same transformers / torch versions.
+
+    python tests/golden/make_golden_mobilebert.py
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = '/root/reference'
+sys.path.insert(0, REF)
+_u = types.ModuleType('utils')
+_u.__path__ = [os.path.join(REF, 'utils')]
+for _name in ('_tb_advance_global_step', '_tb_advance_token_counters', '_tb_hist'):
+    setattr(_u, _name, lambda *a, **k: None)
+sys.modules['utils'] = _u
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import transformers  # noqa: E402
+import transformers.modeling_utils as _mu  # noqa: E402
+from transformers.pytorch_utils import apply_chunking_to_forward  # noqa: E402
+_mu.apply_chunking_to_forward = apply_chunking_to_forward           # models/__init__ imports quantized_bert (4.1 name)
+from transformers import MobileBertConfig, MobileBertForSequenceClassification  # noqa: E402
+
+from utils.utils import DotDict  # noqa: E402
+_u.DotDict = DotDict
+from quantization.quantizers import QMethods  # noqa: E402
+from quantization.range_estimators import RangeEstimators  # noqa: E402
+from quantization.quantization_manager import QuantizationManager  # noqa: E402
+from quantization.autoquant_utils import quantize_model  # noqa: E402
+from models.quantized_mobilebert import (  # noqa: E402
+    QuantizedMobileBertEmbeddings, QuantizedBottleneckLayer, QuantizedMobileBertSelfAttention,
+    QuantizedMobileBertSelfOutput, QuantizedFFNLayer, QuantizedMobileBertOutput, QuantizedMobileBertPooler,
+    quantize_intermediate)
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+SEED = 1000
+
+
+class RefLayer(torch.nn.Module):
+    """The reference's leaf blocks of one MobileBertLayer + the 4.1 container glue."""
+
+    def __init__(self, L, **qp):
+        super().__init__()
+        self.bn_input = QuantizedBottleneckLayer(L.bottleneck.input, **qp)
+        self.bn_attention = QuantizedBottleneckLayer(L.bottleneck.attention, **qp)
+        self.self_att = QuantizedMobileBertSelfAttention(L.attention.self, **qp)
+        self.self_out = QuantizedMobileBertSelfOutput(L.attention.output, **qp)
+        self.ffn = torch.nn.ModuleList([QuantizedFFNLayer(f, **qp) for f in L.ffn])
+        for i, f in enumerate(self.ffn):
+            for m in f.modules():
+                m.ffn_idx = i                                   # set by QuantizedMobileBertLayer.forward upstream (:524-526)
+        self.intermediate = quantize_intermediate(L.intermediate, **qp)
+        self.output = QuantizedMobileBertOutput(L.output, **qp)
+
+    def forward(self, h, mask):
+        layer_input = self.bn_input(h)
+        shared = self.bn_attention(h)
+        ctx = self.self_att(shared, shared, h, mask)[0]
+        a = self.self_out(ctx, layer_input)
+        for f in self.ffn:
+            a = f(a)
+        return self.output(self.intermediate(a), a, h)
+
+
+def randomize_nonorm(hf, seed):
+    """HF initialises NoNorm to weight = 1, bias = 0.  The reference's QuantNoNorm quantizes weight AND bias with ONE
+    quantizer whose range ends up being the bias range (quirk q9, models/quantized_mobilebert.py:58-72): with an
+    all-zero bias every NoNorm weight would quantize to ~0 after fix_ranges and the network would output zeros.  A
+    trained checkpoint has non-trivial affine parameters; emulate that (same procedure in harness/mobilebert.py)."""
+    from transformers.models.mobilebert.modeling_mobilebert import NoNorm
+    g = torch.Generator().manual_seed(seed)
+    for m in hf.modules():
+        if isinstance(m, NoNorm):
+            m.weight.data = 1.0 + 0.1 * torch.randn(m.weight.shape, generator=g)
+            m.bias.data = 0.5 * torch.randn(m.bias.shape, generator=g)
+
+
+def main():
+    torch.set_num_threads(8)
+    torch.manual_seed(SEED)
+    hf = MobileBertForSequenceClassification(MobileBertConfig(num_labels=2)).eval()
+    randomize_nonorm(hf, SEED + 1)
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=4, n_bits_act=4,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax,
+              quant_dict={'attn_probs_n_bits_act': 8})
+    mb = hf.mobilebert
+    emb = QuantizedMobileBertEmbeddings(mb.embeddings, **qp)
+    layers = [RefLayer(L, **qp) for L in mb.encoder.layer]
+    pooler = QuantizedMobileBertPooler(mb.pooler, **qp)
+    qp2 = dict(qp)
+    qp2.pop('quant_dict')
+    classifier = quantize_model(hf.classifier, **qp2)
+    blocks = torch.nn.ModuleList([emb] + layers + [pooler, classifier])
+
+    def apply(fn):
+        for m in blocks.modules():
+            if hasattr(m, fn) and not isinstance(m, QuantizationManager):
+                getattr(m, fn)()
+
+    def forward(ids):
+        mask = torch.zeros(ids.shape[0], 1, 1, ids.shape[1])
+        h = emb(input_ids=ids)
+        for L in layers:
+            h = L(h, mask)
+        return classifier(hf.dropout(pooler(h)))
+
+    blocks.eval()
+    apply('quantized')
+    g = torch.Generator().manual_seed(SEED)
+    ids = torch.randint(0, 30522, (8, 128), generator=g)
+    with torch.no_grad():
+        forward(ids)
+        for m in blocks.modules():
+            if isinstance(m, QuantizationManager) and m.quantizer.is_initialized:
+                m.fix_ranges()
+        logits = forward(ids)
+
+    act, wts = [], []
+    for name, m in blocks.named_modules():
+        if isinstance(m, QuantizationManager) and m.quantizer.is_initialized:
+            if name.endswith('activation_quantizer'):
+                act.append((name, float(m.range_estimator.current_xmin), float(m.range_estimator.current_xmax),
+                            int(m.quantizer.n_bits)))
+            elif name.endswith('weight_quantizer'):
+                wts.append((name, float(m.quantizer._delta)))
+    print('activation quantizers:', len(act), 'weight quantizers:', len(wts))
+    print('logits', logits)
+    np.savez_compressed(
+        os.path.join(OUT, 'mobilebert_w4a4.npz'),
+        logits=logits.numpy(), input_ids=ids.numpy(),
+        act_names=np.array([a[0] for a in act]), act_min=np.array([a[1] for a in act], np.float32),
+        act_max=np.array([a[2] for a in act], np.float32), act_bits=np.array([a[3] for a in act], np.int32),
+        w_names=np.array([w[0] for w in wts]), w_delta=np.array([w[1] for w in wts], np.float32),
+        versions=np.array(f'torch {torch.__version__} transformers {transformers.__version__}'),
+        first_weight_sum=np.array(float(mb.encoder.layer[0].attention.self.query.weight.detach().double().sum())))
+
+
+if __name__ == '__main__':
+    main()

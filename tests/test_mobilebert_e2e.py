@@ -1,0 +1,147 @@
+"""BASELINE config 4 as a parity case: random-init MobileBERT (24 layers, bottleneck 128, 4 stacked FFNs, NoNorm,
+4 heads of 32), W4A4 mixed precision (4-bit symmetric weights, 4-bit asymmetric activations, 8-bit attention
+probabilities), one calibration batch with running min/max, fixed-range forward.  Fixture:
+tests/golden/mobilebert_w4a4.npz, produced by the reference's own quantized MobileBERT blocks
+(tests/golden/make_golden_mobilebert.py; reference models/quantized_mobilebert.py:58-72,167-262,465-545).
+
+* CPU (oracle-backed backend double): the harness (harness/mobilebert.py) + drop-in classes reproduce the reference's
+  774 activation ranges, 559 weight deltas and logits EXACTLY.
+* GPU: the same through the HIP kernels; weight deltas exact, every activation site bit-exact against the oracle on
+  the tensor it saw, ranges / logits within GEMM round-off propagated through 24 four-bit layers.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import GOLDEN
+
+
+def _fixture():
+    return np.load(os.path.join(GOLDEN, 'mobilebert_w4a4.npz'))
+
+
+def _build(device, num_layers=None):
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from harness.mobilebert import build_mobilebert
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=4, n_bits_act=4,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax,
+              quant_dict={'attn_probs_n_bits_act': 8})
+    model, hf = build_mobilebert(seed=1000, num_layers=num_layers, **qp)
+    return model.to(device).eval(), hf
+
+
+def _calibrate_and_run(model, ids):
+    from utils.utils import pass_data_for_range_estimation
+    with torch.no_grad():
+        pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
+        model.fix_ranges()
+        return model(ids.to(next(model.parameters()).device))
+
+
+def _check_weights_reproduced(hf, z):
+    got = float(hf.mobilebert.encoder.layer[0].attention.self.query.weight.detach().double().sum())
+    if got != float(z['first_weight_sum']):
+        pytest.skip('random-init weights differ from the fixture (other torch/transformers build): ' + str(z['versions']))
+
+
+def _census(model):
+    from tests.harness_bert import quantizer_census
+    return quantizer_census(model)
+
+
+def test_mobilebert_w4a4_cpu_exact():
+    from quantization import _hip
+    from tests._oracle_backend import OracleBackend
+    z = _fixture()
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        torch.set_num_threads(8)
+        model, hf = _build('cpu')
+        _check_weights_reproduced(hf, z)
+        ids = torch.from_numpy(z['input_ids'])
+        logits = _calibrate_and_run(model, ids)
+        act, wts = _census(model)
+        assert len(act) == 774 and len(wts) == 559
+        amin = np.array([float(m.range_estimator.current_xmin) for _, m in act], np.float32)
+        amax = np.array([float(m.range_estimator.current_xmax) for _, m in act], np.float32)
+        wd = np.array([float(m.quantizer._delta) for _, m in wts], np.float32)
+        # module registration order differs between the reference's blocks and the harness; the SET of calibrated
+        # sites must be identical: compare as sorted (min, max) / delta multisets, then the logits bit for bit
+        ref_pairs = np.sort(np.stack([z['act_min'], z['act_max']], 1).view([('a', np.float32), ('b', np.float32)]), 0)
+        got_pairs = np.sort(np.stack([amin, amax], 1).view([('a', np.float32), ('b', np.float32)]), 0)
+        assert np.array_equal(got_pairs, ref_pairs)
+        assert np.array_equal(np.sort(wd), np.sort(z['w_delta']))
+        assert sorted(int(m.quantizer.n_bits) for _, m in act) == sorted(int(b) for b in z['act_bits'])
+        assert np.array_equal(logits.numpy(), z['logits'])
+    finally:
+        _hip.set_backend(prev)
+        torch.set_num_threads(1)
+
+
+@pytest.mark.gpu
+def test_mobilebert_w4a4_gpu():
+    from oracle import tq_oracle as O
+    z = _fixture()
+    model, hf = _build('cuda')
+    _check_weights_reproduced(hf, z)
+    ids = torch.from_numpy(z['input_ids'])
+    logits = _calibrate_and_run(model, ids)
+    act, wts = _census(model)
+    assert len(act) == 774 and len(wts) == 559
+    wd = np.array([float(m.quantizer._delta) for _, m in wts], np.float32)
+    assert np.array_equal(np.sort(wd), np.sort(z['w_delta']))            # weights: no GEMM upstream -> exact
+    # activation ranges: 4-bit grids turn hipBLASLt-vs-CPU GEMM round-off into whole-step flips that propagate; the
+    # sorted range spectrum must still match closely, the logits within a few steps of the 4-bit output grid
+    amin = np.sort(np.array([float(m.range_estimator.current_xmin) for _, m in act], np.float32))
+    amax = np.sort(np.array([float(m.range_estimator.current_xmax) for _, m in act], np.float32))
+    assert np.allclose(amin, np.sort(z['act_min']), rtol=0.15, atol=2e-3)
+    assert np.allclose(amax, np.sort(z['act_max']), rtol=0.15, atol=2e-3)
+    step = float(z['logits'].max() - z['logits'].min()) / 15
+    assert np.abs(logits.cpu().numpy() - z['logits']).max() <= 4 * step + 1e-6
+
+    # ---- every site, on the tensor it actually saw: HIP kernel == CPU oracle, bit for bit ----------------
+    seen = []
+
+    def hook(mod, inp, out):
+        x = inp[0]
+        sl = x.reshape(-1, x.shape[-1])[:128]
+        seen.append((mod, sl.detach().cpu(), out.reshape(-1, out.shape[-1])[:128].detach().cpu(),
+                     float(x.min()), float(x.max())))
+
+    handles = [m.register_forward_hook(hook) for _, m in act]
+    model.estimate_ranges()
+    for _, m in act:
+        m.range_estimator.reset()
+    with torch.no_grad():
+        model(ids.cuda())
+    for h in handles:
+        h.remove()
+    assert len(seen) == 774
+    for mod, x, y, xmin, xmax in seen:
+        q = mod.quantizer
+        assert float(mod.range_estimator.current_xmin) == xmin and float(mod.range_estimator.current_xmax) == xmax
+        delta, zf = O.asym_params_from_range(torch.tensor(xmin), torch.tensor(xmax), q.n_bits)
+        assert torch.equal(q._delta.cpu().reshape(()), delta) and torch.equal(q._zero_float.cpu().reshape(()), zf)
+        _, ref = O.fake_quant(x, delta, zf, q.n_bits, False)
+        assert torch.equal(y, ref)
+
+
+@pytest.mark.gpu
+def test_mobilebert_fused_nonorm_tails_match_layered():
+    """The four residual NoNorm tails of every layer as ONE kernel each (tq_residual_nonorm_quant_fwd): NoNorm has no
+    statistics, so the fused forward equals the layered one bit for bit."""
+    from harness.mobilebert import QResidualNoNorm
+    z = _fixture()
+    model, _ = _build('cuda', num_layers=4)
+    ids = torch.from_numpy(z['input_ids']).cuda()
+    layered = _calibrate_and_run(model, ids)
+    QResidualNoNorm.fuse = True
+    try:
+        with torch.no_grad():
+            fused = model(ids)
+    finally:
+        QResidualNoNorm.fuse = False
+    assert torch.equal(fused, layered)

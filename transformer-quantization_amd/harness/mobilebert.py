@@ -1,0 +1,237 @@
+"""Synthetic-data MobileBERT harness on the drop-in quantization package (BASELINE config 4: MobileBERT W4A4).
+
+The reference's models/quantized_mobilebert.py is out of scope as code (it wraps transformers-4.1 container forwards
+that no longer exist), but its quantizer sites define the workload.  This module places the same quantizers at the same
+tensor edges, in the same call order, around a plain re-statement of the MobileBERT forward (24 layers, hidden 512,
+intra-bottleneck 128, 4 heads of 32, 4 stacked feed-forward networks, NoNorm everywhere, trigram embedding input),
+using only the public API of `quantization/`.  Weights come from a random-init HuggingFace
+`MobileBertForSequenceClassification` (no checkpoints offline).  Parity fixture: tests/golden/mobilebert_w4a4.npz,
+produced by the reference's own blocks (tests/golden/make_golden_mobilebert.py).
+
+Quantizer sites per layer, in call order (reference models/quantized_mobilebert.py):
+  bottleneck.input (dense, NoNorm) :421-432 | bottleneck.attention (dense, NoNorm) | query, key, value :176-178 |
+  scores :228, probs :238, context :250 | self-output dense, residual sum, NoNorm :258-304 |
+  3 x FFN (intermediate+ReLU, dense, residual sum, NoNorm) :434-462 | intermediate+ReLU :481 |
+  output dense, residual sum, NoNorm :361-405 | output bottleneck dense, residual sum, NoNorm :321-358
+= 32 activation quantizers and 23 weight quantizers per layer; 774 + 559 in the whole model.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from quantization.autoquant_utils import QuantNoNorm, quantize_model
+from quantization.base_quantized_classes import FP32Acts, QuantizedActivation
+from quantization.base_quantized_model import QuantizedModel
+from quantization.range_estimators import OptMethod, RangeEstimators
+
+# per-site switches of the reference (DEFAULT_QUANT_DICT, models/quantized_mobilebert.py:31-49)
+DEFAULT_QUANT_DICT = {
+    'sum_input_pos_embd': True, 'sum_token_type_embd': True,
+    'attn_scores': True, 'attn_probs': True, 'attn_probs_n_bits_act': None, 'attn_probs_act_range_method': None,
+    'attn_probs_act_range_options': None, 'attn_output': True,
+    'res_self_output': True, 'res_output': True, 'res_output_bottleneck': True, 'res_ffn_output': True,
+}
+
+
+def _site(enabled, **qp):
+    return QuantizedActivation(**qp) if enabled else FP32Acts()
+
+
+def _split_qp(quant_params):
+    """(kwargs for the quantized modules, resolved per-site dict)."""
+    qp = dict(quant_params)
+    sites = dict(DEFAULT_QUANT_DICT)
+    sites.update(qp.pop('quant_dict', None) or {})
+    return qp, sites
+
+
+class QMobileEmbeddings(QuantizedModel):
+    def __init__(self, hf, **quant_params):
+        super().__init__()
+        qp, sites = _split_qp(quant_params)
+        self.trigram_input = hf.trigram_input
+        self.embedding_size, self.hidden_size = hf.embedding_size, hf.hidden_size
+        self.word_embeddings = quantize_model(hf.word_embeddings, **qp)
+        self.position_embeddings = quantize_model(hf.position_embeddings, **qp)
+        self.token_type_embeddings = quantize_model(hf.token_type_embeddings, **qp)
+        self.embedding_transformation = quantize_model(hf.embedding_transformation, **qp)
+        self.LayerNorm = QuantNoNorm(hf.LayerNorm, **qp)
+        self.sum_input_pos_embd_act_quantizer = _site(sites['sum_input_pos_embd'], **qp)
+        self.sum_token_type_embd_act_quantizer = _site(sites['sum_token_type_embd'], **qp)
+
+    def forward(self, input_ids):
+        B, T = input_ids.shape
+        e = self.word_embeddings(input_ids)                                        # [B, T, 128]
+        if self.trigram_input:                                                     # kernel-3 "convolution" as a concat
+            e = torch.cat([F.pad(e[:, 1:], [0, 0, 0, 1, 0, 0], value=0.0), e,
+                           F.pad(e[:, :-1], [0, 0, 1, 0, 0, 0], value=0.0)], dim=2)   # [B, T, 384]
+        if self.trigram_input or self.embedding_size != self.hidden_size:
+            e = self.embedding_transformation(e)                                   # [B, T, 512]
+        pos = torch.arange(T, device=input_ids.device).unsqueeze(0)
+        tok = torch.zeros_like(input_ids)
+        x = self.sum_input_pos_embd_act_quantizer(e + self.position_embeddings(pos))
+        x = self.sum_token_type_embd_act_quantizer(x + self.token_type_embeddings(tok))
+        return self.LayerNorm(x)
+
+
+class QBottleneckLayer(QuantizedModel):
+    """dense -> NoNorm (512 -> 128)."""
+
+    def __init__(self, hf, **qp):
+        super().__init__()
+        self.dense = quantize_model(hf.dense, **qp)
+        self.LayerNorm = QuantNoNorm(hf.LayerNorm, **qp)
+
+    def forward(self, h):
+        return self.LayerNorm(self.dense(h))
+
+
+class QMobileSelfAttention(QuantizedModel):
+    def __init__(self, hf, **quant_params):
+        super().__init__()
+        qp, sites = _split_qp(quant_params)
+        self.heads, self.head_dim = hf.num_attention_heads, hf.attention_head_size
+        self.query = quantize_model(hf.query, **qp)
+        self.key = quantize_model(hf.key, **qp)
+        self.value = quantize_model(hf.value, **qp)
+        self.attn_scores_act_quantizer = _site(sites['attn_scores'], **qp)
+        probs_qp = dict(qp)
+        if sites['attn_probs_n_bits_act'] is not None:
+            probs_qp['n_bits_act'] = sites['attn_probs_n_bits_act']
+        if sites['attn_probs_act_range_method'] is not None:
+            probs_qp['act_range_method'] = RangeEstimators[sites['attn_probs_act_range_method']]
+        if sites['attn_probs_act_range_options'] is not None:
+            opts = dict(sites['attn_probs_act_range_options'])
+            if 'opt_method' in opts and not isinstance(opts['opt_method'], OptMethod):
+                opts['opt_method'] = OptMethod[opts['opt_method']]
+            probs_qp['act_range_options'] = opts
+        self.attn_probs_act_quantizer = _site(sites['attn_probs'], **probs_qp)
+        self.attn_output_act_quantizer = _site(sites['attn_output'], **qp)
+
+    def _split(self, x):
+        B, T, _ = x.shape
+        return x.view(B, T, self.heads, self.head_dim).permute(0, 2, 1, 3)
+
+    def forward(self, q_in, k_in, v_in, mask):
+        q, k, v = self._split(self.query(q_in)), self._split(self.key(k_in)), self._split(self.value(v_in))
+        scores = self.attn_scores_act_quantizer(torch.matmul(q, k.transpose(-1, -2)))
+        scores = scores / math.sqrt(self.head_dim)
+        if mask is not None:
+            scores = scores + mask
+        probs = self.attn_probs_act_quantizer(torch.softmax(scores, dim=-1))
+        ctx = self.attn_output_act_quantizer(torch.matmul(probs, v))              # quantized per head, before the merge
+        ctx = ctx.permute(0, 2, 1, 3).contiguous()
+        return ctx.view(ctx.shape[0], ctx.shape[1], -1)
+
+
+class QResidualNoNorm(QuantizedModel):
+    """dense -> (+ residual) -> quantize -> NoNorm: MobileBertSelfOutput / FFNOutput / MobileBertOutput /
+    OutputBottleneck all have this shape.  `fuse = True` runs the fixed-range tail as ONE kernel
+    (tq_residual_nonorm_quant_fwd, quantization/fused.py)."""
+
+    fuse = False
+
+    def __init__(self, hf, site_on=True, **qp):
+        super().__init__()
+        self.dense = quantize_model(hf.dense, **qp)
+        self.res_act_quantizer = _site(site_on, **qp)
+        self.LayerNorm = QuantNoNorm(hf.LayerNorm, **qp)
+
+    def forward(self, h, residual):
+        if self.fuse:
+            from quantization.fused import residual_layernorm_quant
+            return residual_layernorm_quant(self.dense, self.res_act_quantizer, self.LayerNorm, h, residual)
+        return self.LayerNorm(self.res_act_quantizer(self.dense(h) + residual))
+
+
+class QFFN(QuantizedModel):
+    def __init__(self, hf, **quant_params):
+        super().__init__()
+        qp, sites = _split_qp(quant_params)
+        self.intermediate = quantize_model(nn.Sequential(hf.intermediate.dense, nn.ReLU()), **qp)
+        self.output = QResidualNoNorm(hf.output, sites['res_ffn_output'], **qp)
+
+    def forward(self, h):
+        return self.output(self.intermediate(h), h)
+
+
+class QMobileLayer(QuantizedModel):
+    def __init__(self, hf, **quant_params):
+        super().__init__()
+        qp, sites = _split_qp(quant_params)
+        assert hf.use_bottleneck and hf.bottleneck.key_query_shared_bottleneck and not hf.bottleneck.use_bottleneck_attention, \
+            'harness covers the default MobileBertConfig (shared key/query bottleneck)'
+        self.bottleneck_input = QBottleneckLayer(hf.bottleneck.input, **qp)
+        self.bottleneck_attention = QBottleneckLayer(hf.bottleneck.attention, **qp)
+        self.attention_self = QMobileSelfAttention(hf.attention.self, **quant_params)
+        self.attention_output = QResidualNoNorm(hf.attention.output, sites['res_self_output'], **qp)
+        self.ffn = nn.ModuleList([QFFN(f, **quant_params) for f in hf.ffn])
+        self.intermediate = quantize_model(nn.Sequential(hf.intermediate.dense, nn.ReLU()), **qp)
+        self.output = QResidualNoNorm(hf.output, sites['res_output'], **qp)
+        self.output_bottleneck = QResidualNoNorm(hf.output.bottleneck, sites['res_output_bottleneck'], **qp)
+
+    def forward(self, h, mask):
+        layer_input = self.bottleneck_input(h)                    # [B, T, 128] residual of the attention block
+        shared = self.bottleneck_attention(h)                     # query / key input
+        a = self.attention_output(self.attention_self(shared, shared, h, mask), layer_input)
+        for f in self.ffn:
+            a = f(a)
+        o = self.output(self.intermediate(a), a)
+        return self.output_bottleneck(o, h)                       # back to 512, residual = the layer's input
+
+
+class QMobileBertForSequenceClassification(QuantizedModel):
+    def __init__(self, hf, quant_setup='all', **quant_params):
+        super().__init__()
+        qp, _ = _split_qp(quant_params)
+        mb = hf.mobilebert
+        self.embeddings = QMobileEmbeddings(mb.embeddings, **quant_params)
+        self.layers = nn.ModuleList([QMobileLayer(l, **quant_params) for l in mb.encoder.layer])
+        self.do_activate = mb.pooler.do_activate
+        if self.do_activate:
+            self.pooler = quantize_model(nn.Sequential(mb.pooler.dense, nn.Tanh()), **qp)
+        self.classifier = quantize_model(hf.classifier, **qp)
+        if quant_setup == 'FP_logits':
+            self.classifier.activation_quantizer = FP32Acts()
+        elif quant_setup not in (None, 'all'):
+            raise ValueError("Quantization setup '{}' not supported.".format(quant_setup))
+
+    def forward(self, input_ids, attention_mask=None):
+        if attention_mask is not None:
+            mask = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
+        else:
+            mask = torch.zeros(input_ids.shape[0], 1, 1, input_ids.shape[1], device=input_ids.device)
+        h = self.embeddings(input_ids)
+        for layer in self.layers:
+            h = layer(h, mask)
+        pooled = h[:, 0]
+        if self.do_activate:
+            pooled = self.pooler(pooled)
+        return self.classifier(pooled)
+
+
+def randomize_nonorm(hf, seed):
+    """HF initialises NoNorm to weight = 1, bias = 0.  QuantNoNorm quantizes weight AND bias with ONE quantizer whose
+    range ends up being the bias range (upstream quirk q9): with an all-zero bias every NoNorm weight quantizes to ~0
+    once the ranges are fixed and the network outputs zeros.  A trained checkpoint has non-trivial affine parameters;
+    emulate that with seeded values (the fixture generator applies the same procedure)."""
+    from transformers.models.mobilebert.modeling_mobilebert import NoNorm
+    g = torch.Generator().manual_seed(seed)
+    for m in hf.modules():
+        if isinstance(m, NoNorm):
+            m.weight.data = 1.0 + 0.1 * torch.randn(m.weight.shape, generator=g)
+            m.bias.data = 0.5 * torch.randn(m.bias.shape, generator=g)
+
+
+def build_mobilebert(seed=1000, num_labels=2, num_layers=None, **qp):
+    """Random-init HF MobileBERT (seeded on the CPU generator) wrapped with quantizers."""
+    from transformers import MobileBertConfig, MobileBertForSequenceClassification
+    torch.manual_seed(seed)
+    cfg = MobileBertConfig(num_labels=num_labels)
+    if num_layers is not None:
+        cfg.num_hidden_layers = num_layers
+    hf = MobileBertForSequenceClassification(cfg).eval()
+    randomize_nonorm(hf, seed + 1)
+    return QMobileBertForSequenceClassification(hf, **qp), hf

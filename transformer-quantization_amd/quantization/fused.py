@@ -36,7 +36,8 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
     """dense: QuantLinear, res_quantizer: QuantizedActivation, layer_norm: QuantLayerNorm or MobileBERT's
     QuantNoNorm (tq_residual_nonorm_quant_fwd).  Equivalent to ``layer_norm(res_quantizer(dense(x) + residual))``."""
     q1 = _fixed_per_tensor(dense._quant_a and dense.activation_function is None, dense.activation_quantizer)
-    q2 = _fixed_per_tensor(res_quantizer._quant_a, res_quantizer.activation_quantizer)
+    q2 = _fixed_per_tensor(getattr(res_quantizer, '_quant_a', False),
+                           getattr(res_quantizer, 'activation_quantizer', res_quantizer))   # FP32Acts: site switched off
     q3 = _fixed_per_tensor(layer_norm._quant_a and layer_norm.activation_function is None,
                            layer_norm.activation_quantizer)
     from quantization.autoquant_utils import QuantNoNorm
