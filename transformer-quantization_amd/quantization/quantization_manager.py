@@ -210,10 +210,9 @@ class QuantizationManager(nn.Module):
             y = self._fixed_forward_with_indices(x) if options.INT8_LINEAR else None
             if y is None:
                 y = self.quantizer(x)
-            if not y.requires_grad:
-                # provenance tag: lets a consumer (the fused integer Linear) recover the exact grid
-                # indices of this tensor from the quantizer that produced it
-                y._tq_quantizer = self.quantizer
+            # provenance tag: lets a consumer (the fused integer Linear, also under autograd in QAT) recover the
+            # exact grid indices of this tensor from the quantizer that produced it
+            y._tq_quantizer = self.quantizer
             return y
         return self.quantizer(x)
 
