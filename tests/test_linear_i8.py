@@ -181,7 +181,19 @@ def test_integer_linear_in_training_mode_qat_forward():
         y_i, gx_i, gp_i = run(True)
     finally:
         _hip.HipBackend.linear_i8 = orig
-    assert calls['n'] == 2, 'both Linears must have run on the integer MFMA kernel in training mode'
+    if calls['n'] != 2:      # diagnostics: which eligibility condition failed
+        options.INT8_LINEAR = True
+        xi = net.inp(x.clone().requires_grad_(True))
+        lin = net.fc1
+        src = getattr(xi, '_tq_quantizer', None)
+        wm = lin.weight_quantizer
+        info = dict(src=type(src).__name__, quant_w=lin._quant_w, act=type(lin.activation_function).__name__,
+                    save=lin.activation_save_target, wstate=str(wm.state), winit=wm.quantizer.is_initialized,
+                    wsym=wm.quantizer.symmetric, wbits=wm.quantizer.n_bits, wdelta=tuple(wm.quantizer._delta.shape),
+                    wreq=wm.quantizer._delta.requires_grad, astate=str(lin.activation_quantizer.state),
+                    plan=lin._int8_plan(xi) is not None, training=lin.training, xdtype=str(xi.dtype))
+        options.INT8_LINEAR = False
+        raise AssertionError(f'integer kernel calls: {calls["n"]} (expected 2): {info}')
     y_l, gx_l, gp_l = run(False)
     step = float(net.fc2.activation_quantizer.quantizer._delta)
     diff = (y_i - y_l).abs()
