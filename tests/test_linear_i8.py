@@ -184,7 +184,7 @@ def test_integer_linear_in_training_mode_qat_forward():
     if calls['n'] != 2:      # diagnostics: which eligibility condition failed
         options.INT8_LINEAR = True
         xi = net.inp(x.clone().requires_grad_(True))
-        lin = net.fc1
+        lin = net.fc1[0]
         src = getattr(xi, '_tq_quantizer', None)
         wm = lin.weight_quantizer
         info = dict(src=type(src).__name__, quant_w=lin._quant_w, act=type(lin.activation_function).__name__,
