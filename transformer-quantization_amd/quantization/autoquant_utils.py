@@ -20,6 +20,7 @@ from quantization.quantization_manager import QuantizationManager
 
 
 # The integer path is switched on with quantization.options.INT8_LINEAR (see there).
+INT8_STATS = {'kernel_calls': 0, 'autograd_calls': 0}     # how often the MFMA Linear ran (plain / under autograd)
 _ACT_CODES = {type(None): _hip.ACT_NONE, nn.ReLU: _hip.ACT_RELU, nn.GELU: _hip.ACT_GELU, nn.Tanh: _hip.ACT_TANH}
 
 
@@ -109,6 +110,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         amgr = self.activation_quantizer
         want_idx = q_out is not None and not amgr.quantizer.symmetric and amgr.quantizer.n_bits <= 8
         bias = None if self.bias is None else self.bias.detach()
+        INT8_STATS['kernel_calls'] += 1
         out = be.linear_i8(x_idx, w_idx, rowsum, bias, (src._delta, src._zero_float, src.n_bits, src.eps),
                            wq._delta.reshape(-1), wq.eps, act_code, q_out, torch.float32, want_idx=want_idx)
         y = out[0] if want_idx else out
@@ -149,6 +151,7 @@ class _Int8LinearSTE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, layer, plan):
+        INT8_STATS['autograd_calls'] += 1
         y = layer._int8_compute(x, plan)
         if y is None:
             raise _hip.TQError('integer Linear: unsigned weight grid under autograd (disable options.INT8_LINEAR)')
