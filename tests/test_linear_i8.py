@@ -175,7 +175,6 @@ def test_integer_linear_in_training_mode_qat_forward():
     assert INT8_STATS['autograd_calls'] - before['autograd_calls'] == 2 and \
         INT8_STATS['kernel_calls'] - before['kernel_calls'] == 2, \
         'both Linears must have run on the integer MFMA kernel in training mode'
-    assert type(y_i.grad_fn).__name__ == 'NoneType' or True
     y_l, gx_l, gp_l = run(False)
     step = float(net.fc2.activation_quantizer.quantizer._delta)
     diff = (y_i - y_l).abs()
