@@ -170,6 +170,7 @@ for (fin, fout) in ((768, 3072), (768, 768)):
     net.eval()
     with torch.no_grad():
         net(data[:8])
+    net.fix_ranges()                                   # calibrate -> fix (main.py:243-266) -> fused AdaRound step
     cfg = copy.deepcopy(DEFAULT_ADAROUND_CONFIG)
     cfg.iters = 300
     net.full_precision()
@@ -184,6 +185,8 @@ for (fin, fout) in ((768, 3072), (768, 768)):
                                  'loss_hard_before': res.loss_hard_before, 'loss_hard_after': res.loss_hard_after}
 c['reference_cpu_8thr'] = {'linear_768x3072_20iters_64samples_s': 3.9, 'per_iter_ms': '<= 200',
                            'source': 'BASELINE.md section 2'}
+c['note'] = ('i.i.d. random inputs: AdaRound cannot beat nearest rounding there (E[x x^T] = I); the full-size run on '
+             'structured inputs with before/after losses is scripts/adaround_config3.py -> profiles/r02/adaround_config3.json')
 out['config4_adaround_w4'] = c
 
 # ---- config 5 building blocks: MobileBERT W4A4 shapes ----------------------------------------------
@@ -246,5 +249,51 @@ for fin, fout in ((512, 128), (128, 128), (128, 512), (512, 512), (384, 512)):
                             'max_dev_in_steps': float((got - ref).abs().max()) / step}
 c['quant_linear_w4a4_1024_tokens'] = lin
 out['config5_mobilebert_w4a4_blocks'] = c
+
+# ---- config 5 as a whole model: MobileBERT W4A4 (24 layers, 774 activation + 559 weight quantizers), B=8, T=128 ----
+from tests.test_mobilebert_e2e import _build as _build_mb, _fixture as _fixture_mb
+from harness.mobilebert import QResidualNoNorm
+from quantization.graphs import GraphedForward
+zm = _fixture_mb()
+mb, _ = _build_mb(dev)
+ids_mb = torch.from_numpy(zm['input_ids']).to(dev)
+c = {}
+with torch.no_grad():
+    mb.set_quant_state(False, False)
+    c['fp32_forward_ms'] = wall(lambda: mb(ids_mb))
+    mb.set_quant_state(True, True)
+    c['calibrating_forward_ms'] = wall(lambda: mb(ids_mb))
+    mb.fix_ranges()
+    c['fixed_range_forward_eager_ms'] = wall(lambda: mb(ids_mb))
+    g0 = GraphedForward(mb, ids_mb)
+    c['fixed_range_forward_hipgraph_ms'] = wall(lambda: g0(ids_mb), n=30)
+    base = g0(ids_mb).clone()
+    QResidualNoNorm.fuse = True
+    g1 = GraphedForward(mb, ids_mb)
+    c['fixed_range_forward_fused_nonorm_tails_hipgraph_ms'] = wall(lambda: g1(ids_mb), n=30)
+    c['fused_tails_equal_layered'] = bool(torch.equal(g1(ids_mb), base))
+    options.INT8_LINEAR = True
+    g2 = GraphedForward(mb, ids_mb)
+    c['fixed_range_forward_fused_tails_int8_linear_hipgraph_ms'] = wall(lambda: g2(ids_mb), n=30)
+    c['int8_max_logit_dev_vs_layered'] = float((g2(ids_mb) - base).abs().max())
+    options.INT8_LINEAR = False
+    QResidualNoNorm.fuse = False
+# QAT step (training mode, fixed ranges, forward + backward): layered fp32 simulation vs integer MFMA forward
+mb.train()
+lab = torch.randint(0, 2, (8,), device=dev)
+def qat_step():
+    for p_ in mb.parameters():
+        p_.grad = None
+    loss = torch.nn.functional.cross_entropy(mb(ids_mb), lab)
+    loss.backward()
+c['qat_step_layered_ms'] = wall(qat_step, n=5, w=2)
+options.INT8_LINEAR = True
+from quantization.autoquant_utils import INT8_STATS
+before = INT8_STATS['autograd_calls']
+c['qat_step_int8_forward_ms'] = wall(qat_step, n=5, w=2)
+c['int8_linears_per_training_forward'] = (INT8_STATS['autograd_calls'] - before) / 7
+options.INT8_LINEAR = False
+mb.eval()
+out['config5_mobilebert_w4a4_whole_model_b8_t128'] = c
 
 print(json.dumps(out, indent=1))
