@@ -160,6 +160,7 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
     // MobileBERT's NoNorm (models/quantized_mobilebert.py:58-72) is the affine part alone: u * w + b.  With
     // mean = 0 and rstd = 1 the expression below evaluates exactly that ((u - 0) * 1 is exact).
     float mean = 0.0f, rstd = 1.0f;
+    bool row_nan = false;                 // LayerNorm: the whole row is NaN (wave-uniform branch at the store, rare)
     if (!affine_only) {
       mean = group_sum<LPR>(s2.x + s2.y) * inv_d;
       const f32x2 m2 = {mean, mean};
@@ -173,7 +174,7 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
         // rows with a NaN input: the statistics are NaN upstream, hence every output of the row
         const uint64_t m = __ballot(lane_nan);
         const uint64_t grp = LPR == 64 ? ~0ull : (((1ull << (LPR % 64)) - 1) << ((threadIdx.x & 63) / LPR * LPR));
-        if (m & grp) mean = __builtin_nanf("");
+        if (m & grp) { mean = __builtin_nanf(""); row_nan = true; }
       }
     }
     const f32x2 m2 = {mean, mean}, r2 = {rstd, rstd};
@@ -200,8 +201,17 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
               oi.e[2 * j + 1] = (int8_t)((int)(h[j].y + f3.f.zp) - 128);
             }
             const f32x2 yq = f3.f.scale * (h[j] + f32x2{0.0f, 0.0f});     // + 0: -0 -> +0 like (x_int - zp)
-            t[j].x = (t[j].x != t[j].x) ? t[j].x : yq.x;
-            t[j].y = (t[j].y != t[j].y) ? t[j].y : yq.y;
+            if (affine_only) {            // NoNorm: element-local NaN passes through
+              t[j].x = (t[j].x != t[j].x) ? t[j].x : yq.x;
+              t[j].y = (t[j].y != t[j].y) ? t[j].y : yq.y;
+            } else {
+              t[j] = yq;                  // LayerNorm: NaN rows are patched below
+            }
+          }
+          if (!affine_only && __ballot(row_nan)) {
+#pragma unroll
+            for (int j = 0; j < H; ++j)
+              if (row_nan) t[j] = f32x2{__builtin_nanf(""), __builtin_nanf("")};
           }
         } else {
 #pragma unroll
