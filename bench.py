@@ -79,14 +79,13 @@ def cpu_baseline(budget_s=12.0):
     # torch's default (all logical cores / 2) is page-fault bound on this op chain (every ATen op
     # allocates a fresh 100 MB tensor), so sweep thread counts and report the best one as `value`
     counts = sorted({c for c in (1, 8, 16, 32, 64, threads) if c <= threads})
-    per = {}
-    reps_best = 0
+    per, reps_by = {}, {}
     for c in counts:
         v, reps = run(c, budget_s / len(counts))
         per[str(c)] = round(v, 1)
-        if v >= max(per.values()):
-            reps_best = reps
+        reps_by[str(c)] = reps
     best = max(per, key=lambda k: per[k])
+    reps_best = reps_by[best]
     torch.set_num_threads(threads)
     return {
         'value': per[best], 'unit': 'M elems/s', 'cores': int(best), 'kind': 'port',
