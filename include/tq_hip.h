@@ -260,6 +260,28 @@ int tq_calibrate_apply(const float* stats, const void* x, uint64_t n, int dtype,
                        float* delta, float* zero_float, uint8_t* signed_flag, void* y,
                        tq_stream_t stream);
 
+/* ---- latency-optimised exchange for sharded calibration: P2P "mailbox" MAX all-reduce of <= 8 KB ---------------
+ * One process per GPU.  Every rank allocates ONE mailbox (tq_mailbox_alloc: fine-grained device memory owned by the
+ * library -- the single exception to "the caller supplies every buffer": it must be mappable into other processes and
+ * outlive every launch), publishes its 64-byte IPC handle (e.g. torch.distributed.all_gather_object) and maps the
+ * peers' (tq_mailbox_open, hipIpc over xGMI).  tq_mailbox_allreduce_max then replaces the tiny ncclAllReduce(MAX) of
+ * the [-min | max] statistics buffer by ONE small kernel: post the vector + a sequence flag in the own mailbox, spin
+ * on every peer's flag, fold the peers' vectors with max (csrc/tq_mailbox.hip).  In place on `stats` (fp32 [n],
+ * n <= tq_mailbox_max_floats() = 2048); `peer_bases` is a DEVICE array of `world` mailbox pointers (entry `rank` is
+ * ignored); `status` (device, 4 bytes, zero-initialised) gets bit 0 set if a peer did not answer within `spin_budget`
+ * polls (0 = default), in which case `stats` is NaN -- the kernel cannot hang.  hipGraph-capturable (the sequence
+ * number lives in the mailbox).  All ranks must issue the same sequence of calls.                                 */
+size_t tq_mailbox_bytes(void);
+size_t tq_mailbox_max_floats(void);
+size_t tq_mailbox_handle_bytes(void);
+int tq_mailbox_alloc(void** base, void* ipc_handle_out /* host, tq_mailbox_handle_bytes() */);
+int tq_mailbox_open(const void* ipc_handle /* host */, void** peer_base);
+int tq_mailbox_close(void* peer_base);
+int tq_mailbox_free(void* base);
+int tq_mailbox_allreduce_max(float* stats, uint64_t n, void* my_base, void* const* peer_bases,
+                             uint32_t world, uint32_t rank, uint32_t* status, uint32_t spin_budget,
+                             tq_stream_t stream);
+
 /* PEG phase 1 (range_estimators.py:68-80): ranges = max - min per embedding dim; on later
  * batches the reference stores 0.1*r + 0.9*r of the NEW ranges (quirk q4).                    */
 int tq_axis_ranges(const float* new_min, const float* new_max, float* ranges, uint64_t n,

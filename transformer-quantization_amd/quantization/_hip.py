@@ -66,6 +66,14 @@ SIGNATURES = {
     'tq_calibrate_stats': (_int, [_vp, _u64, _int, _u64, _u64, _vp, _vp, _sz, _vp, _vp]),
     'tq_calibrate_apply': (_int, [_vp, _vp, _u64, _int, _u64, _u64, _int, _vp, _vp, _vp, _vp, _d, _u64, _vp, _int, _int, _f,
                                   _int, _vp, _vp, _vp, _vp, _vp]),
+    'tq_mailbox_bytes': (_sz, []),
+    'tq_mailbox_max_floats': (_sz, []),
+    'tq_mailbox_handle_bytes': (_sz, []),
+    'tq_mailbox_alloc': (_int, [C.POINTER(_vp), _vp]),
+    'tq_mailbox_open': (_int, [_vp, C.POINTER(_vp)]),
+    'tq_mailbox_close': (_int, [_vp]),
+    'tq_mailbox_free': (_int, [_vp]),
+    'tq_mailbox_allreduce_max': (_int, [_vp, _u64, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp]),
     'tq_range_update': (_int, [_int, _vp, _vp, _vp, _vp, _u64, _int, _d, _u64, _vp, _vp]),
     'tq_axis_ranges': (_int, [_vp, _vp, _vp, _u64, _int, _vp]),
     'tq_set_range_asym': (_int, [_vp, _vp, _u64, _int, _f, _int, _vp, _vp, _vp]),

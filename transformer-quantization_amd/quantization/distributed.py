@@ -20,24 +20,64 @@ issued on the current stream through ``torch.distributed`` (backend ``nccl`` == 
 import torch
 import torch.distributed as dist
 
+import logging
+import os
+
 _group = None
 _enabled = False
 _force = False     # run the collectives even in a 1-rank group (RCCL smoke tests on a 1-GPU box)
-_stats = {'minmax_calls': 0, 'sum_calls': 0, 'bytes': 0}
+_mailbox = None    # quantization.mailbox.P2PMailbox when the P2P exchange is active
+_stats = {'minmax_calls': 0, 'sum_calls': 0, 'bytes': 0, 'mailbox_calls': 0}
+logger = logging.getLogger('tq.distributed')
 
 
-def enable(group=None, force=False):
+def enable(group=None, force=False, mailbox=None):
     """Turn on statistic all-reduce (requires an initialised default process group).  A 1-rank group
-    skips the collectives unless `force` is set."""
-    global _group, _enabled, _force
+    skips the collectives unless `force` is set.
+
+    mailbox: True / False / None (= environment TQ_DIST_MAILBOX, default off): exchange the <= 8 KB min/max buffers of
+    the fused calibration step through the P2P mailbox kernel (quantization/mailbox.py) instead of an RCCL all-reduce.
+    The path is self-tested against RCCL here; if the set-up or the test fails on any rank, RCCL stays in charge."""
+    global _group, _enabled, _force, _mailbox
     if not dist.is_available() or not dist.is_initialized():
         raise RuntimeError('torch.distributed is not initialised')
     _group, _enabled, _force = group, True, bool(force)
+    if mailbox is None:
+        mailbox = os.environ.get('TQ_DIST_MAILBOX', '0') == '1'
+    if _mailbox is not None:
+        _mailbox.close()
+        _mailbox = None
+    if mailbox and torch.cuda.is_available() and (force or dist.get_world_size(group) > 1):
+        ok, box = True, None
+        try:
+            from quantization.mailbox import P2PMailbox
+            box = P2PMailbox(group)
+            ok = box.self_test()
+        except Exception as e:      # noqa: BLE001 -- any set-up problem (IPC refused, library missing): stay on RCCL
+            logger.warning('P2P mailbox unavailable (%s): statistics go through torch.distributed', e)
+            ok = False
+        if ok:
+            _mailbox = box
+        elif box is not None:
+            logger.warning('P2P mailbox self-test failed: statistics go through torch.distributed')
+            try:
+                box.close()
+            except Exception:       # noqa: BLE001
+                pass
 
 
 def disable():
-    global _group, _enabled, _force
+    global _group, _enabled, _force, _mailbox
+    if _mailbox is not None:
+        try:
+            _mailbox.close()
+        finally:
+            _mailbox = None
     _group, _enabled, _force = None, False, False
+
+
+def mailbox_active():
+    return _mailbox is not None
 
 
 def is_enabled():
@@ -64,7 +104,11 @@ def sync_minmax(mn, mx):
 def sync_max_inplace(buf):
     """MAX all-reduce of a `[-min | max]` statistics buffer the kernel wrote (tq_calibrate_stats), in place: the
     whole exchange of a calibrating call is this one collective -- no cat / neg / slice launches around it."""
-    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=_group)
+    if _mailbox is not None and _mailbox.usable(buf):
+        _mailbox.allreduce_max_(buf)
+        _stats['mailbox_calls'] += 1
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=_group)
     _stats['minmax_calls'] += 1
     _stats['bytes'] += buf.numel() * buf.element_size()
     return buf
