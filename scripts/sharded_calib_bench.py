@@ -83,6 +83,23 @@ with torch.no_grad():
         out['sharded_hipgraph_error'] = repr(e)[:500]
     options.INPLACE_CALIBRATION_STATE = False
     tq_dist.disable()
+    # the same exchange through the P2P mailbox kernel instead of ncclAllReduce (one small kernel, no c10d host work)
+    try:
+        tq_dist.enable(force=(world == 1), mailbox=True)
+        out['mailbox_active'] = tq_dist.mailbox_active()
+        model(ids)
+        b0 = tq_dist.stats()['mailbox_calls']
+        out['sharded_mailbox_eager_ms'] = wall(lambda: model(ids))
+        out['mailbox_calls_per_forward'] = (tq_dist.stats()['mailbox_calls'] - b0) / 23
+        options.INPLACE_CALIBRATION_STATE = True
+        model(ids)
+        g3 = GraphedForward(model, ids)
+        out['sharded_mailbox_hipgraph_ms'] = wall(lambda: g3(ids))
+        del g3
+    except Exception as e:                                         # noqa: BLE001
+        out['sharded_mailbox_error'] = repr(e)[:500]
+    options.INPLACE_CALIBRATION_STATE = False
+    tq_dist.disable()
     out['ratio_split_vs_single'] = out['sharded_fused_split_ms'] / out['single_gpu_fused_ms']
 t = torch.tensor([out['sharded_fused_split_ms']], device=dev, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
