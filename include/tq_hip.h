@@ -282,6 +282,18 @@ int tq_mailbox_allreduce_max(float* stats, uint64_t n, void* my_base, void* cons
                              uint32_t world, uint32_t rank, uint32_t* status, uint32_t spin_budget,
                              tq_stream_t stream);
 
+/* tq_calibrate_stats -> tq_mailbox_allreduce_max -> tq_calibrate_apply as ONE call (3-4 launches): the sharded
+ * calibrating step with the host cost of the single-GPU fused step.  2 * n_params <= tq_mailbox_max_floats();
+ * workspace >= tq_calibrate_workspace_bytes(n, n_params, inner); counter as tq_calibrate_tensor (may be NULL).    */
+int tq_calibrate_minmax_mailbox(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner,
+                                int mode, const float* prev_min, const float* prev_max, float* cur_min,
+                                float* cur_max, double momentum, uint64_t n_groups, const int64_t* order,
+                                int n_bits, int symmetric, float eps, int log_domain, float* delta,
+                                float* zero_float, uint8_t* signed_flag, void* y, void* workspace,
+                                size_t workspace_bytes, uint32_t* counter, void* my_base,
+                                void* const* peer_bases, uint32_t world, uint32_t rank, uint32_t* status,
+                                uint32_t spin_budget, tq_stream_t stream);
+
 /* PEG phase 1 (range_estimators.py:68-80): ranges = max - min per embedding dim; on later
  * batches the reference stores 0.1*r + 0.9*r of the NEW ranges (quirk q4).                    */
 int tq_axis_ranges(const float* new_min, const float* new_max, float* ranges, uint64_t n,

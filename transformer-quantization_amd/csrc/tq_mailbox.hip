@@ -165,3 +165,26 @@ extern "C" int tq_mailbox_allreduce_max(float* stats, uint64_t n, void* my_base,
                      my_base, peer_bases, world, rank, status, spin_budget ? spin_budget : 5000000u);
   return check_launch("mailbox_allreduce_max_k");
 }
+
+// The whole sharded calibrating step as ONE C call: local statistics -> mailbox MAX all-reduce -> estimator update +
+// parameters (+ quantize): 3-4 launches, no host work in between (the Python side then costs what the single-GPU
+// fused step costs).  `stats` scratch: fp32 [2 * n_params] at the start of `workspace`, 256-byte aligned; the rest of
+// the workspace is the statistics kernels' (tq_calibrate_workspace_bytes covers both).
+extern "C" int tq_calibrate_minmax_mailbox(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner, int mode,
+                                           const float* prev_min, const float* prev_max, float* cur_min, float* cur_max,
+                                           double momentum, uint64_t n_groups, const int64_t* order, int n_bits,
+                                           int symmetric, float eps, int log_domain, float* delta, float* zero_float,
+                                           uint8_t* signed_flag, void* y, void* workspace, size_t workspace_bytes,
+                                           uint32_t* counter, void* my_base, void* const* peer_bases, uint32_t world,
+                                           uint32_t rank, uint32_t* status, uint32_t spin_budget, tq_stream_t stream) {
+  TQ_REQUIRE(2 * n_params <= kMailPayloadFloats, "tq_calibrate_minmax_mailbox: %llu ranges do not fit the mailbox",
+             (unsigned long long)n_params);
+  const size_t stats_bytes = (2 * n_params * sizeof(float) + 255) / 256 * 256;
+  TQ_REQUIRE(workspace && workspace_bytes >= stats_bytes, "tq_calibrate_minmax_mailbox: workspace too small");
+  float* stats = static_cast<float*>(workspace);
+  char* rest = static_cast<char*>(workspace) + stats_bytes;
+  if (int e = tq_calibrate_stats(x, n, dtype, n_params, inner, stats, rest, workspace_bytes - stats_bytes, counter, stream)) return e;
+  if (int e = tq_mailbox_allreduce_max(stats, 2 * n_params, my_base, peer_bases, world, rank, status, spin_budget, stream)) return e;
+  return tq_calibrate_apply(stats, x, n, dtype, n_params, inner, mode, prev_min, prev_max, cur_min, cur_max, momentum, n_groups,
+                            order, n_bits, symmetric, eps, log_domain, delta, zero_float, signed_flag, y, stream);
+}

@@ -74,6 +74,9 @@ SIGNATURES = {
     'tq_mailbox_close': (_int, [_vp]),
     'tq_mailbox_free': (_int, [_vp]),
     'tq_mailbox_allreduce_max': (_int, [_vp, _u64, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp]),
+    'tq_calibrate_minmax_mailbox': (_int, [_vp, _u64, _int, _u64, _u64, _int, _vp, _vp, _vp, _vp, _d, _u64, _vp, _int, _int, _f,
+                                           _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp,
+                                           C.c_uint32, _vp]),
     'tq_range_update': (_int, [_int, _vp, _vp, _vp, _vp, _u64, _int, _d, _u64, _vp, _vp]),
     'tq_axis_ranges': (_int, [_vp, _vp, _vp, _u64, _int, _vp]),
     'tq_set_range_asym': (_int, [_vp, _vp, _u64, _int, _f, _int, _vp, _vp, _vp]),
@@ -506,6 +509,40 @@ class HipBackend:
             _ptr(order), int(n_bits), int(bool(symmetric)), float(eps), int(bool(log_domain)), _ptr(out[2]),
             _ptr(out[3]), _ptr(out[4]), _ptr(y), _stream())
         _check(rc, self.lib)
+        return (*out, y)
+
+    def calibrate_minmax_mailbox(self, box, x, n_params, inner, mode, prev_min, prev_max, momentum, n_groups, order,
+                                 n_bits, symmetric, eps, log_domain, want_y=True, out=None):
+        """Sharded calibrating step in ONE C call: statistics -> P2P mailbox MAX all-reduce (`box`:
+        quantization.mailbox.P2PMailbox) -> estimator update + parameters + y.  Returns like calibrate_minmax."""
+        _need_device(x, 'calibrate_minmax_mailbox')
+        x = x.contiguous()
+        dev = x.device
+        st = _stream()
+        if out is None:
+            cur = torch.empty(2, n_params, dtype=torch.float32, device=dev)
+            par = torch.empty(1 if symmetric else 2, n_params, dtype=torch.float32, device=dev)
+            signed = torch.empty((), dtype=torch.bool, device=dev) if symmetric else None
+            if n_params == 1:
+                out = (cur[0, 0], cur[1, 0], par[0, 0], None if symmetric else par[1, 0], signed)
+            else:
+                out = (cur[0], cur[1], par[0], None if symmetric else par[1], signed)
+        counter = None
+        if n_params == 1:
+            key = (dev.index, st)
+            counter = self._counters.get(key)
+            if counter is None:
+                counter = self._counters[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+        y = torch.empty_like(x) if want_y else None
+        ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), n_params, inner))
+        rc = self.lib.tq_calibrate_minmax_mailbox(
+            x.data_ptr(), x.numel(), _dtype_code(x, 'calibrate_minmax_mailbox'), n_params, inner, mode, _ptr(prev_min),
+            _ptr(prev_max), _ptr(out[0]), _ptr(out[1]), float(momentum), int(n_groups or 0), _ptr(order), int(n_bits),
+            int(bool(symmetric)), float(eps), int(bool(log_domain)), _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _ptr(y),
+            ws.data_ptr(), ws.numel(), _ptr(counter), box.base, box.peers.data_ptr(), box.world, box.rank,
+            box.status.data_ptr(), box.spin_budget, st)
+        _check(rc, self.lib)
+        box.calls += 1
         return (*out, y)
 
     def range_update(self, mode, new_min, new_max, cur_min, cur_max, momentum=0.9, n_groups=0,

@@ -80,6 +80,19 @@ def mailbox_active():
     return _mailbox is not None
 
 
+def mailbox_for(n_floats):
+    """The active P2P mailbox if a buffer of `n_floats` fp32 values fits it, else None (RCCL path)."""
+    if _mailbox is not None and n_floats <= _mailbox.max_floats:
+        return _mailbox
+    return None
+
+
+def count_mailbox_exchange(n_bytes):
+    _stats['mailbox_calls'] += 1
+    _stats['minmax_calls'] += 1
+    _stats['bytes'] += n_bytes
+
+
 def is_enabled():
     return _enabled and dist.is_initialized() and (_force or dist.get_world_size(_group) > 1)
 

@@ -152,7 +152,14 @@ class QuantizationManager(nn.Module):
         out = None
         if options.INPLACE_CALIBRATION_STATE:
             out = self._inplace_state(est, q, n_params, x.device)
-        if sharded:
+        box = tq_dist.mailbox_for(2 * n_params) if (sharded and hasattr(be, 'calibrate_minmax_mailbox')) else None
+        if box is not None:
+            # statistics -> P2P mailbox all-reduce -> update + quantize as one C call (3-4 launches, no host work between)
+            cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_minmax_mailbox(
+                box, x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0), n_groups, order,
+                q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log', out=out)
+            tq_dist.count_mailbox_exchange(8 * n_params)
+        elif sharded:
             # split at the exchange: local [-min | max] -> one in-place MAX all-reduce -> update + quantize
             stats = tq_dist.sync_max_inplace(be.calibrate_stats(x, n_params, inner))
             cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_apply(
