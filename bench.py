@@ -243,6 +243,19 @@ def main():
         qa(xb)
     cal_wall, cal_ms = timed_region(lambda: qa(x), max(4, min(args.steps, 20)), use_dist)
     cal_steps = max(4, min(args.steps, 20))
+    # the same step with the statistics exchanged through the P2P mailbox kernel instead of ncclAllReduce (reported
+    # next to the RCCL figure, never instead of it; skipped if the mailbox set-up or its self-test against RCCL fails)
+    mail_wall = None
+    if use_dist and backend == 'nccl' and os.environ.get('TQ_BENCH_MAILBOX', '1') == '1':
+        try:
+            tq_dist.enable(force=(world == 1), mailbox=True)
+            if tq_dist.mailbox_active():
+                qa(x)
+                mail_wall, _ = timed_region(lambda: qa(x), cal_steps, use_dist)
+        except Exception as e:       # noqa: BLE001
+            print(f'[bench] mailbox leg skipped: {e!r}', file=sys.stderr)
+        finally:
+            tq_dist.enable(force=(world == 1), mailbox=False)
     qa.activation_quantizer.fix_ranges()
     del calib_batches
 
@@ -260,9 +273,11 @@ def main():
         wall, ev_ms = timed_region(lambda: qa(x), args.steps, use_dist)
 
     if use_dist:
-        tmax = torch.tensor([wall, cal_wall], device=device, dtype=torch.float64)
+        tmax = torch.tensor([wall, cal_wall, mail_wall if mail_wall is not None else -1.0], device=device,
+                            dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, cal_wall = float(tmax[0]), float(tmax[1])
+        mail_wall = float(tmax[2]) if mail_wall is not None else None
 
     total_elems = n_elems * world * args.steps
     value = total_elems / wall / 1e6
@@ -312,6 +327,11 @@ def main():
             'ms_per_step': round(cal_wall / cal_steps * 1e3, 4),
         },
     }
+    if mail_wall is not None:
+        out['calibration']['p2p_mailbox'] = {
+            'what': 'same step, [-min;max] exchanged by the P2P mailbox kernel (tq_mailbox_allreduce_max) instead of RCCL',
+            'value': round(n_elems * world * cal_steps / mail_wall / 1e6, 1), 'unit': 'M elems/s',
+            'ms_per_step': round(mail_wall / cal_steps * 1e3, 4)}
 
     if args.sweep and rank == 0:
         sweep = []

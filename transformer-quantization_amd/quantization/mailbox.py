@@ -67,6 +67,8 @@ class P2PMailbox:
         """The mailbox result equals torch.distributed's MAX all-reduce on rank-dependent vectors of several sizes."""
         g = torch.Generator(device=self.device).manual_seed(1234 + self.rank)
         ok = True
+        budget, self.spin_budget = self.spin_budget, 500000        # fail fast (~1 s) here: the fallback is RCCL
+        dist.barrier(group=self.group)
         for i in range(rounds):
             n = (2, 12, 1536, self.max_floats)[i % 4]
             v = torch.randn(n, device=self.device, generator=g) * (1 + self.rank)
@@ -74,6 +76,7 @@ class P2PMailbox:
             dist.all_reduce(ref, op=dist.ReduceOp.MAX, group=self.group)
             got = self.allreduce_max_(v.clone())
             ok = ok and bool(torch.equal(got, ref))
+        self.spin_budget = budget
         ok = ok and not self.timed_out()
         flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)          # all ranks agree on the verdict
