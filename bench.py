@@ -191,6 +191,7 @@ def main():
     ap.add_argument('--seq', type=int, default=512)
     ap.add_argument('--sweep', action='store_true', help='also time the SURVEY.md 8d shape sweep')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--mailbox', action='store_true', help='also time calibration with the P2P mailbox exchange')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -243,10 +244,12 @@ def main():
         qa(xb)
     cal_wall, cal_ms = timed_region(lambda: qa(x), max(4, min(args.steps, 20)), use_dist)
     cal_steps = max(4, min(args.steps, 20))
-    # the same step with the statistics exchanged through the P2P mailbox kernel instead of ncclAllReduce (reported
-    # next to the RCCL figure, never instead of it; skipped if the mailbox set-up or its self-test against RCCL fails)
+    # --mailbox / TQ_BENCH_MAILBOX=1: the same step with the statistics exchanged through the P2P mailbox kernel instead
+    # of ncclAllReduce (reported next to the RCCL figure, never instead of it; skipped if the set-up or the self-test
+    # against RCCL fails).  Opt-in: the path has been validated with two processes on one device and with a 1-rank RCCL
+    # group only (no multi-GPU box was available to the build), and the headline run must not depend on it.
     mail_wall = None
-    if use_dist and backend == 'nccl' and os.environ.get('TQ_BENCH_MAILBOX', '1') == '1':
+    if use_dist and backend == 'nccl' and (args.mailbox or os.environ.get('TQ_BENCH_MAILBOX', '0') == '1'):
         try:
             tq_dist.enable(force=(world == 1), mailbox=True)
             if tq_dist.mailbox_active():

@@ -95,12 +95,13 @@ def test_estimators_over_rccl_world1(tmp_path):
 
 
 def test_bench_distributed_control_flow_over_rccl():
-    r = _torchrun(['bench.py', '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu', '--batch', '64', '--seq', '128'],
-                  extra_env={'TQ_BENCH_FORCE_DIST': '1'})
+    r = _torchrun(['bench.py', '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu', '--batch', '64', '--seq', '128',
+                   '--mailbox'], extra_env={'TQ_BENCH_FORCE_DIST': '1'})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 1 and out['value'] > 0 and out['roofline']['achieved'] > 0
+    assert out['calibration']['p2p_mailbox']['value'] > 0          # --mailbox leg (1-rank group: post + no peers)
 
 
 def test_bench_single_process_with_sweep():
