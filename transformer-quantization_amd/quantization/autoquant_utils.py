@@ -50,7 +50,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         """(int8 indices [N, K], int32 row sums [N]) of the fake-quantized weight, cached per
         (weight version, range buffers)."""
         wq = self.weight_quantizer.quantizer
-        key = (self.weight.data_ptr(), self.weight._version, wq._delta.data_ptr(), wq._delta._version)
+        key = (self.weight.data_ptr(), self.weight._version, wq.range_state_key())
         if self._int8_cache is None or self._int8_cache[0] != key:
             be = _hip.backend()
             n_par = wq._delta.numel()

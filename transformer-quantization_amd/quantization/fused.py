@@ -157,8 +157,7 @@ def quantized_attention(query, key, value, mask, num_heads, scores_quantizer, pr
 def _stacked_qkv(layers):
     """int8 weights / row sums / biases / per-row weight scales of several QuantLinears stacked along the
     output dimension, cached on the first layer until any weight or weight range changes."""
-    key = tuple((l.weight.data_ptr(), l.weight._version, l.weight_quantizer.quantizer._delta.data_ptr(),
-                 l.weight_quantizer.quantizer._delta._version) for l in layers)
+    key = tuple((l.weight.data_ptr(), l.weight._version, l.weight_quantizer.quantizer.range_state_key()) for l in layers)
     cache = getattr(layers[0], '_stacked_i8_cache', None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -207,6 +206,7 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
                 or l.activation_function is not None or l.activation_save_target is not None
                 or l.in_features != K or l.out_features != D
                 or not _fixed_per_tensor_manager(l.activation_quantizer)
+                or not isinstance(l.weight_quantizer, QuantizationManager)      # e.g. replaced by FP32Acts
                 or l.weight_quantizer.state != Qstates.fix_ranges):
             return None
         wq, oq = l.weight_quantizer.quantizer, l.activation_quantizer.quantizer

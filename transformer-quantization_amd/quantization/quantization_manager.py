@@ -172,6 +172,7 @@ class QuantizationManager(nn.Module):
         # registered buffers: rebinding through the dict skips nn.Module.__setattr__'s type dispatch
         # (4 rebinds per call x 161 quantizers per calibration batch)
         est._buffers['current_xmin'], est._buffers['current_xmax'] = cur_min, cur_max
+        object.__setattr__(q, '_range_gen', q._range_gen + 1)          # the dict rebinds below bypass __setattr__
         q._buffers['_delta'] = delta
         if q.symmetric:
             q._buffers['_signed'] = signed

@@ -120,11 +120,27 @@ class _FakeQuantSTE(Function):
 class QuantizerBase(nn.Module):
     """Protocol every quantizer implements (reference quantizers.py:36-78)."""
 
+    # Every rebinding of a range buffer / the bit width bumps `_range_gen`; derived caches (int8 weight indices, stacked
+    # QKV operands) key on it.  Keys built from data_ptr() + _version alone can collide: a recalibration binds a FRESH
+    # tensor at version 0, and the caching allocator likes to hand back the address that was just freed.
+    _RANGE_STATE = ('_delta', '_zero_float', '_signed', 'n_bits')
+
     def __init__(self, n_bits, per_channel=False, axis=None, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        object.__setattr__(self, '_range_gen', 0)
         self.n_bits = n_bits
         self.per_channel = per_channel
         self.axis = axis
+
+    def __setattr__(self, name, value):
+        if name in self._RANGE_STATE:
+            object.__setattr__(self, '_range_gen', getattr(self, '_range_gen', 0) + 1)
+        super().__setattr__(name, value)
+
+    def range_state_key(self):
+        """Changes whenever the quantization grid of this quantizer may have changed (rebinding or in-place update)."""
+        d = self._buffers.get('_delta', None) if '_delta' in self._buffers else getattr(self, '_delta', None)
+        return (self._range_gen, None if d is None else d._version, self.n_bits)
 
     @property
     def is_initialized(self):
