@@ -139,7 +139,8 @@ def test_stacked_qkv_projection_equals_three_linears():
     try:
         with torch.no_grad():
             h = model.embeddings(ids)                      # tagged with its quantizer + int8 indices
-            assert getattr(h, '_tq_idx', None) is not None
+            from quantization import provenance
+            assert provenance.indices_of(h) is not None
             A = model.layers[0].attention_self
             mask = torch.zeros(ids.shape[0], 1, 1, ids.shape[1], device='cuda')
             mask[1, ..., 100:] = -10000.0
@@ -149,7 +150,7 @@ def test_stacked_qkv_projection_equals_three_linears():
     finally:
         options.INT8_LINEAR = False
     assert one is not None and sep is not None
-    assert torch.equal(one, sep) and torch.equal(one._tq_idx, sep._tq_idx)
+    assert torch.equal(one, sep) and torch.equal(provenance.indices_of(one), provenance.indices_of(sep))
 
 
 @pytest.mark.parametrize('n_bits', [4, 6])

@@ -14,6 +14,7 @@ from torch.nn.modules.pooling import _AdaptiveAvgPoolNd, _AvgPoolNd
 
 from quantization import _hip
 from quantization import options
+from quantization import provenance
 from quantization.base_quantized_classes import FP32Acts, QuantizedActivation, QuantizedModule
 from quantization.hijacker import QuantizationHijacker, activations_list
 from quantization.quantization_manager import QuantizationManager
@@ -66,7 +67,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         """Arguments of the integer evaluation of this layer for input `x`, or None when the configuration does not
         allow it (no fixed per-tensor asymmetric <= 8-bit input quantizer known for x, unsupported weight / output
         quantizer, shapes the MFMA kernel does not tile, ...)."""
-        src = getattr(x, '_tq_quantizer', None)          # the quantizer that produced x (fixed range)
+        src = provenance.quantizer_of(x)                 # the quantizer that produced x (fixed range)
         wmgr = self.weight_quantizer
         act_code = _ACT_CODES.get(type(self.activation_function))
         if (src is None or not self._quant_w or act_code is None
@@ -102,7 +103,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         w_idx, rowsum, w_signed = self._int8_weights()
         if not w_signed:
             return None                      # all-positive weights use an unsigned grid: not handled here
-        x_idx = getattr(x, '_tq_idx', None)        # emitted by the producing quantizer in the same launch
+        x_idx = provenance.indices_of(x)           # emitted by the producing quantizer in the same launch
         if x_idx is None or x_idx.shape != x.shape:
             x_idx = be.quantize_to_int8(x.detach(), src._delta, src._zero_float, None, src.n_bits, False, False,
                                         src.eps, 1, 1, minus_128=True)
@@ -115,9 +116,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
                            wq._delta.reshape(-1), wq.eps, act_code, q_out, torch.float32, want_idx=want_idx)
         y = out[0] if want_idx else out
         if q_out is not None:
-            y._tq_quantizer = amgr.quantizer
-            if want_idx:
-                y._tq_idx = out[1]          # the next integer Linear consumes these directly
+            provenance.tag(y, amgr.quantizer, out[1] if want_idx else None)   # the next integer Linear consumes these
         return y
 
     def _int8_forward(self, x, with_output_quantizer=True):
@@ -138,7 +137,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
             return None                      # fused tails are inference-only
         y = _Int8LinearSTE.apply(x, self.weight, self.bias, self, plan)
         if y is not None and plan[2] is not None:
-            y._tq_quantizer = self.activation_quantizer.quantizer
+            provenance.tag(y, self.activation_quantizer.quantizer, provenance.indices_of(y))
         return y
 
 

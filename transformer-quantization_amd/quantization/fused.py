@@ -15,6 +15,7 @@ import torch
 
 from quantization import _hip
 from quantization import options
+from quantization import provenance
 from quantization.base_quantized_classes import FP32Acts
 from quantization.quantization_manager import QuantizationManager, Qstates
 
@@ -71,9 +72,7 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
                                                   None if is_nonorm else layer_norm.eps, arg(q3), want_idx=want_idx)
     y = out[0] if want_idx else out
     if oq is not None:
-        y._tq_quantizer = oq
-        if want_idx:
-            y._tq_idx = out[1]
+        provenance.tag(y, oq, out[1] if want_idx else None)
     return y
 
 
@@ -101,8 +100,8 @@ def scores_softmax_quant(scores_quantizer, probs_quantizer, scores, mask, denom)
 
 def _int8_source(t):
     """(int8 indices, 7-tuple) of a tensor produced by a fixed per-tensor asymmetric <= 8-bit quantizer
-    that emitted its indices (provenance tags set by QuantizationManager / the integer Linear)."""
-    q, idx = getattr(t, '_tq_quantizer', None), getattr(t, '_tq_idx', None)
+    that emitted its indices (provenance records of QuantizationManager / the integer Linear)."""
+    q, idx = provenance.of(t) or (None, None)
     if (q is None or idx is None or idx.shape != t.shape or q.symmetric or q.n_bits > 8
             or q.scale_domain != 'linear' or q._delta.numel() != 1):
         return None
@@ -148,9 +147,7 @@ def quantized_attention(query, key, value, mask, num_heads, scores_quantizer, pr
                                       srcs[0][1], srcs[1][1], srcs[2][1], arg(qs), qp, arg(qc), want_idx=want_idx)
     ctx = out[0] if want_idx else out
     if cq is not None:
-        ctx._tq_quantizer = cq
-        if want_idx:
-            ctx._tq_idx = out[1]
+        provenance.tag(ctx, cq, out[1] if want_idx else None)
     return ctx
 
 
@@ -239,7 +236,5 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
                           outs[0], outs[1], outs[2], arg(qs), qp, arg(qc), want_idx=want_idx)
     ctx = out[0] if want_idx else out
     if cq is not None:
-        ctx._tq_quantizer = cq
-        if want_idx:
-            ctx._tq_idx = out[1]
+        provenance.tag(ctx, cq, out[1] if want_idx else None)
     return ctx

@@ -18,6 +18,7 @@ from torch import nn
 from quantization import _hip
 from quantization import distributed as tq_dist
 from quantization import options
+from quantization import provenance
 from quantization.quantizers import (
     AsymmetricUniformQuantizer,
     QMethods,
@@ -218,9 +219,9 @@ class QuantizationManager(nn.Module):
             y = self._fixed_forward_with_indices(x) if options.INT8_LINEAR else None
             if y is None:
                 y = self.quantizer(x)
-            # provenance tag: lets a consumer (the fused integer Linear, also under autograd in QAT) recover the
-            # exact grid indices of this tensor from the quantizer that produced it
-            y._tq_quantizer = self.quantizer
+            # provenance record: lets a consumer (the fused integer Linear, also under autograd in QAT) recover the
+            # exact grid indices of this tensor from the quantizer that produced it (quantization/provenance.py)
+            provenance.tag(y, self.quantizer, provenance.indices_of(y))
             return y
         return self.quantizer(x)
 
@@ -236,8 +237,7 @@ class QuantizationManager(nn.Module):
         if not hasattr(be, 'fake_quant_int8'):
             return None
         y, idx = be.fake_quant_int8(x, q._delta, q._zero_float, q.n_bits, q.eps)
-        y._tq_idx = idx
-        return y
+        return provenance.tag(y, q, idx)
 
     def set_quant_range(self, x_min, x_max):
         self.quantizer.set_quant_range(x_min, x_max)
