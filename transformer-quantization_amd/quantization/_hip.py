@@ -172,18 +172,20 @@ def _device_guarded(fn):
     different devices raise instead of faulting."""
     import functools
 
+    _Tensor, _cur = torch.Tensor, torch.cuda.current_device
+
     @functools.wraps(fn)
     def wrapper(self, *args, **kwargs):
-        idx = None
+        # hot path (launch-bound calibration makes 263 such calls per batch): one pass over the positional operands
+        idx = -1
         for a in args:
-            if type(a) is torch.Tensor or isinstance(a, torch.Tensor):
-                if a.is_cuda:
-                    i = a.device.index
-                    if idx is None:
-                        idx = i
-                    elif i != idx:
-                        raise TQError(f'{fn.__name__}: operands live on different devices (cuda:{idx} and cuda:{i})')
-        if idx is None or idx == torch.cuda.current_device():
+            if a.__class__ is _Tensor and a.is_cuda:
+                i = a.device.index
+                if idx < 0:
+                    idx = i
+                elif i != idx:
+                    raise TQError(f'{fn.__name__}: operands live on different devices (cuda:{idx} and cuda:{i})')
+        if idx < 0 or idx == _cur():
             return fn(self, *args, **kwargs)
         with torch.cuda.device(idx):
             return fn(self, *args, **kwargs)

@@ -221,7 +221,8 @@ class QuantizationManager(nn.Module):
                 y = self.quantizer(x)
             # provenance record: lets a consumer (the fused integer Linear, also under autograd in QAT) recover the
             # exact grid indices of this tensor from the quantizer that produced it (quantization/provenance.py)
-            provenance.tag(y, self.quantizer, provenance.indices_of(y))
+            if options.INT8_LINEAR:          # only the integer fast paths consume the record
+                provenance.tag(y, self.quantizer, provenance.indices_of(y))
             return y
         return self.quantizer(x)
 
