@@ -179,7 +179,7 @@ def _device_guarded(fn):
         # hot path (launch-bound calibration makes 263 such calls per batch): one pass over the positional operands
         idx = -1
         for a in args:
-            if a.__class__ is _Tensor and a.is_cuda:
+            if isinstance(a, _Tensor) and a.is_cuda:
                 i = a.device.index
                 if idx < 0:
                     idx = i
