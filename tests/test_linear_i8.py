@@ -4,6 +4,8 @@ The integer contraction is exact; the reference's fp32 simulation `F.linear(Q(x)
 fp32-rounded evaluation of the same number.  Bars: pre-quantizer output within 1e-5 (relative to the
 row scale) of the CPU fp32 simulation and within fp32 epsilon of the float64 value; after the output
 quantizer >= 99.9 % of elements identical to the oracle chain, the rest one grid step away."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -60,6 +62,17 @@ def test_linear_i8_vs_fp32_simulation(shape, cfg):
     scale = sim64.abs().max().item()
     assert (y.double() - sim64).abs().max().item() <= 4e-7 * scale + 1e-7     # fp32 epsilon of the exact value
     assert (y - sim32).abs().max().item() <= 1e-5 * scale                      # north-star tolerance
+    # branch-free GELU of the fast epilogue vs the float64 value, and vs the generic (libm erff) epilogue
+    yg = be.linear_i8(x_i8, w_i8, rs, dev(p['b']), xq, dev(p['wd']).reshape(-1), 1e-8, _hip.ACT_GELU, None,
+                      torch.float32).cpu()
+    assert (yg.double() - torch.nn.functional.gelu(sim64)).abs().max().item() <= 6e-7 * scale + 2e-7
+    os.environ['TQ_I8_FAST_EPI'] = '0'
+    try:
+        yg0 = be.linear_i8(x_i8, w_i8, rs, dev(p['b']), xq, dev(p['wd']).reshape(-1), 1e-8, _hip.ACT_GELU, None,
+                           torch.float32).cpu()
+    finally:
+        del os.environ['TQ_I8_FAST_EPI']
+    assert (yg - yg0).abs().max().item() <= 2.4e-7 * max(scale, 1.0)
     # with activation + output quantizer
     for act, fn in ((_hip.ACT_GELU, torch.nn.GELU()), (_hip.ACT_RELU, torch.relu), (_hip.ACT_TANH, torch.tanh),
                     (_hip.ACT_NONE, lambda v: v)):

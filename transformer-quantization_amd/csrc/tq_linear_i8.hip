@@ -57,9 +57,179 @@ struct LinArgs {
   tq_quantizer q_out;     // group 0
   tq_quantizer q_out1, q_out2;   // groups 1, 2 of a grouped launch (Q | K | V stacked along N)
   uint32_t group_cols;    // output columns per group (N for a plain launch); multiple of 64
+  int fast_epi;           // 0 forces the generic epilogue (TQ_I8_FAST_EPI=0: A/B and tests)
 };
 
 // ---- epilogue: zero-point correction, scales, bias, activation, output quantizer ----------------------
+// The epilogue is the expensive half of this kernel at BERT's K = 768: every output element costs one GEMM column
+// of 768 MACs = 0.75 MFMA-lane-cycles, but (with the IEEE division, libm's erff and a per-element activation switch)
+// ~100 VALU instructions and 11 branches.  The fast form below is branch-free and packed (2 elements per instruction
+// where the ISA allows): ~27 issue slots per element with GELU + quantizer.
+
+// erf for two values: the minimax fits of the ROCm device library's erff (|t| < 1: odd polynomial in t; else
+// 1 - exp(-(t + t p(t)))), both evaluated and selected instead of branched on; exp through v_exp_f32 directly
+// (absolute error < 3e-8 on a result <= 1: within half an ulp of erf's own rounding there).
+template <int NP>
+__device__ __forceinline__ void gelu_erf_n(f32x2 (&v)[NP]) {
+  f32x2 a[NP], t[NP], p[NP], q[NP], s[NP];
+  const f32x2 one = {1.0f, 1.0f};
+  auto k2 = [](float c) { return f32x2{c, c}; };
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    a[i] = v[i] * k2(0.70710678118654752440f);
+    t[i] = __builtin_elementwise_abs(a[i]);
+    s[i] = t[i] * t[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    p[i] = __builtin_elementwise_fma(t[i], k2(1.699881067906972e-05f), k2(-0.00037867785431444645f));
+    q[i] = __builtin_elementwise_fma(s[i], k2(-0.000561801774892956f), k2(0.004913816228508949f));
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    p[i] = __builtin_elementwise_fma(t[i], p[i], k2(0.003857815871015191f));
+    q[i] = __builtin_elementwise_fma(s[i], q[i], k2(-0.026707515120506287f));
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    p[i] = __builtin_elementwise_fma(t[i], p[i], k2(-0.024181697517633438f));
+    q[i] = __builtin_elementwise_fma(s[i], q[i], k2(0.11280010640621185f));
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    p[i] = __builtin_elementwise_fma(t[i], p[i], k2(0.10666826367378235f));
+    q[i] = __builtin_elementwise_fma(s[i], q[i], k2(-0.37612295150756836f));
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    p[i] = __builtin_elementwise_fma(t[i], p[i], k2(0.6349332928657532f));
+    q[i] = __builtin_elementwise_fma(s[i], q[i], k2(0.12837910652160645f));
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    p[i] = __builtin_elementwise_fma(t[i], p[i], k2(0.12868940830230713f));
+    q[i] = __builtin_elementwise_fma(t[i], q[i], t[i]);               // |t| < 1:  erf = t + t q(t^2)
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    p[i] = __builtin_elementwise_fma(t[i], p[i], t[i]);               // z = t + t p(t)
+    p[i] = p[i] * k2(-1.4426950408889634f);
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    f32x2 e = {__builtin_amdgcn_exp2f(p[i].x), __builtin_amdgcn_exp2f(p[i].y)};
+    e = one - e;                                                       // |t| >= 1: erf = 1 - exp(-z)
+    f32x2 r;
+    r.x = __builtin_copysignf(t[i].x < 1.0f ? q[i].x : e.x, a[i].x);
+    r.y = __builtin_copysignf(t[i].y < 1.0f ? q[i].y : e.y, a[i].y);
+    v[i] = (v[i] * k2(0.5f)) * (one + r);                              // nn.GELU(): x * 0.5 * (1 + erf(x / sqrt(2)))
+  }
+}
+
+template <int YDT>
+__device__ __forceinline__ void store_y4(void* y, size_t at, f32x2 lo, f32x2 hi) {
+  if (YDT == TQ_F32) {
+    *reinterpret_cast<f32x4*>(static_cast<float*>(y) + at) = f32x4{lo.x, lo.y, hi.x, hi.y};
+  } else {
+    u32x2 pk;
+    pk[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
+    pk[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2));
+    *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(y) + at) = pk;
+  }
+}
+
+// Fast form: ACT in {none, relu, gelu}; HASQ needs a quantizer the exact-quotient path covers (QF::ok).
+template <int NI, int MI, int YDT, int ACT, bool HASQ>
+__device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
+                                                     int kg, const QF& qf, int shift, float sx) {
+  constexpr int NP = 2 * MI;
+  const f32x2 zpb = {qf.zp, qf.zp};
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t n = n0 + i * 16 + kg * 4;            // this lane's 4 consecutive output features
+    f32x2 sw[2], bs[2];
+    int rs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dw = p.w_delta[p.w_n_params == 1 ? 0 : n + r];
+      sw[r >> 1][r & 1] = sx * (dw < p.w_eps ? p.w_eps : dw);
+      bs[r >> 1][r & 1] = p.bias ? p.bias[n + r] : 0.0f;
+      rs[r] = p.w_rowsum[n + r] * shift;
+    }
+    f32x2 v[NP];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const f32x2 lo = {(float)(acc[i][j][0] + rs[0]), (float)(acc[i][j][1] + rs[1])};
+      const f32x2 hi = {(float)(acc[i][j][2] + rs[2]), (float)(acc[i][j][3] + rs[3])};
+      v[2 * j] = lo * sw[0] + bs[0];                      // separate mul and add as in the reference (no contraction)
+      v[2 * j + 1] = hi * sw[1] + bs[1];
+    }
+    if (ACT == ACT_GELU) gelu_erf_n<NP>(v);
+    if (ACT == ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < NP; ++e) v[e] = f32x2{v[e].x > 0.0f ? v[e].x : 0.0f, v[e].y > 0.0f ? v[e].y : 0.0f};
+    }
+    f32x2 h[NP];
+    if (HASQ) {
+      qf_round2_n<NP>(v, qf, h);
+#pragma unroll
+      for (int e = 0; e < NP; ++e) v[e] = qf.scale * (h[e] + f32x2{0.0f, 0.0f});
+    }
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const size_t at = (size_t)(m0 + j * 16 + r16) * p.N + n;
+      if (HASQ && p.y_idx != nullptr) {                   // int8(index - 128): u8 index with the top bit flipped
+        const f32x2 a = h[2 * j] + zpb, b = h[2 * j + 1] + zpb;
+        uint32_t w = 0;
+        w = __builtin_amdgcn_cvt_pk_u8_f32(a.x, 0, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(a.y, 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(b.x, 2, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(b.y, 3, w);
+        *reinterpret_cast<uint32_t*>(p.y_idx + at) = w ^ 0x80808080u;
+      }
+      if (p.y != nullptr) store_y4<YDT>(p.y, at, v[2 * j], v[2 * j + 1]);
+    }
+  }
+}
+
+// Generic form (tanh, quantizers outside the exact-quotient path): IEEE division, libm activation.
+template <int NI, int MI, int YDT>
+__device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
+                                                     int kg, const QP& qo, int shift, float sx) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t n = n0 + i * 16 + kg * 4;
+    float sw[4], bs[4];
+    int rs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dw = p.w_delta[p.w_n_params == 1 ? 0 : n + r];
+      sw[r] = sx * (dw < p.w_eps ? p.w_eps : dw);
+      bs[r] = p.bias ? p.bias[n + r] : 0.0f;
+      rs[r] = p.w_rowsum[n + r] * shift;
+    }
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const size_t at = (size_t)(m0 + j * 16 + r16) * p.N + n;
+      float o[4];
+      struct alignas(4) { int8_t e[4]; } oi4 = {{0, 0, 0, 0}};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = (float)(acc[i][j][r] + rs[r]) * sw[r] + bs[r];
+        v = apply_act(v, p.act);
+        if (p.has_q) {
+          const float xi = q_index(v, qo);
+          oi4.e[r] = (int8_t)((int)xi - 128);
+          v = q_dequant(xi, qo);
+        }
+        o[r] = v;
+      }
+      if (p.y_idx != nullptr) *reinterpret_cast<uint32_t*>(p.y_idx + at) = __builtin_bit_cast(uint32_t, oi4);
+      if (p.y != nullptr) store_y4<YDT>(p.y, at, f32x2{o[0], o[1]}, f32x2{o[2], o[3]});
+    }
+  }
+}
+
 template <int NI, int MI, int YDT>
 __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
                                                 int kg) {
@@ -72,47 +242,18 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI]
     const uint32_t grp = n0 / p.group_cols;             // a block tile never straddles two groups
     qo = make_qp(grp == 0 ? p.q_out : (grp == 1 ? p.q_out1 : p.q_out2), 0);
   }
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const uint32_t n = n0 + i * 16 + kg * 4;            // this lane's 4 consecutive output features
-    float sw[4], bs[4];
-    int rs[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float dw = p.w_delta[p.w_n_params == 1 ? 0 : n + r];
-      sw[r] = sx * (dw < p.w_eps ? p.w_eps : dw);
-      bs[r] = p.bias ? p.bias[n + r] : 0.0f;
-      rs[r] = p.w_rowsum[n + r] * shift;
-    }
-#pragma unroll
-    for (int j = 0; j < MI; ++j) {
-      const uint32_t m = m0 + j * 16 + r16;
-      float o[4];
-      struct alignas(4) { int8_t e[4]; } oi4 = {{0, 0, 0, 0}};
-      int8_t (&oi)[4] = oi4.e;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = (float)(acc[i][j][r] + rs[r]) * sw[r] + bs[r];
-        v = apply_act(v, p.act);
-        if (p.has_q) {
-          const float xi = q_index(v, qo);
-          oi[r] = (int8_t)((int)xi - 128);
-          v = q_dequant(xi, qo);
-        }
-        o[r] = v;
-      }
-      if (p.y_idx != nullptr) *reinterpret_cast<uint32_t*>(p.y_idx + (size_t)m * p.N + n) = __builtin_bit_cast(uint32_t, oi4);
-      if (p.y == nullptr) continue;                       // index-only output (grouped QKV projection)
-      if (YDT == TQ_F32) {
-        *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + (size_t)m * p.N + n) = f32x4{o[0], o[1], o[2], o[3]};
-      } else {
-        u32x2 pk;
-        f32x2 a = {o[0], o[1]}, b = {o[2], o[3]};
-        pk[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
-        pk[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2));
-        *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(p.y) + (size_t)m * p.N + n) = pk;
-      }
-    }
+  const QF qf = make_qf(qo);
+  const bool fast = p.act != ACT_TANH && (!p.has_q || qf.ok) && p.fast_epi != 0;
+  if (!fast) return linear_epilogue_generic<NI, MI, YDT>(p, acc, n0, m0, r16, kg, qo, shift, sx);
+  // wave-uniform dispatch: one straight-line body per (activation, quantizer) combination
+  if (p.has_q) {
+    if (p.act == ACT_GELU)      linear_epilogue_fast<NI, MI, YDT, ACT_GELU, true>(p, acc, n0, m0, r16, kg, qf, shift, sx);
+    else if (p.act == ACT_RELU) linear_epilogue_fast<NI, MI, YDT, ACT_RELU, true>(p, acc, n0, m0, r16, kg, qf, shift, sx);
+    else                        linear_epilogue_fast<NI, MI, YDT, ACT_NONE, true>(p, acc, n0, m0, r16, kg, qf, shift, sx);
+  } else {
+    if (p.act == ACT_GELU)      linear_epilogue_fast<NI, MI, YDT, ACT_GELU, false>(p, acc, n0, m0, r16, kg, qf, shift, sx);
+    else if (p.act == ACT_RELU) linear_epilogue_fast<NI, MI, YDT, ACT_RELU, false>(p, acc, n0, m0, r16, kg, qf, shift, sx);
+    else                        linear_epilogue_fast<NI, MI, YDT, ACT_NONE, false>(p, acc, n0, m0, r16, kg, qf, shift, sx);
   }
 }
 
@@ -259,7 +400,8 @@ __global__ __launch_bounds__(kBlock) void rowsum_i8_k(const int8_t* __restrict__
 }
 
 template <int YDT>
-static int launch_linear(const LinArgs& a, hipStream_t st) {
+static int launch_linear(LinArgs a, hipStream_t st) {
+  a.fast_epi = tuning("TQ_I8_FAST_EPI", 1);
   if (a.K % 128 == 0 && a.M % 64 == 0 && a.N % 64 == 0 && tuning("TQ_I8_LDS", 1)) {
     // 128 x 128 block tiles once they still give >= 4 blocks per CU, else 64 x 64
     const bool big = a.M % 128 == 0 && a.N % 128 == 0 && (uint64_t)(a.M / 128) * (a.N / 128) >= 1024;
