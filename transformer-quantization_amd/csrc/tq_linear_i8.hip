@@ -139,55 +139,119 @@ __device__ __forceinline__ void store_y4(void* y, size_t at, f32x2 lo, f32x2 hi)
 }
 
 // Fast form: ACT in {none, relu, gelu}; HASQ needs a quantizer the exact-quotient path covers (QF::ok).
-template <int NI, int MI, int YDT, int ACT, bool HASQ>
+// `stage` != nullptr (LDS kernel): the wave parks its results in a private LDS region, 32 token rows per pass, and
+// writes them out row-contiguously -- every store instruction covers whole 128-byte lines (fp32 y: 4 rows x 256 B)
+// instead of 16 rows x 64 B (y) or 16 rows x 16 B (indices) straight from the MFMA accumulator layout -- with
+// non-temporal stores (y is not read again by this kernel; W and X keep the L2).  Measured at M = 8192, N = 3072,
+// K = 768, fp32 y: 48.4 -> 34.5 us for the GEMM + plain store.
+template <int YDT> struct StageGeom {
+  static constexpr int esize = YDT == TQ_F32 ? 4 : 2;
+};
+
+template <int NI, int MI, int YDT, int ACT, bool HASQ, bool STAGED>
 __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
-                                                     int kg, const QF& qf, int shift, float sx) {
-  constexpr int NP = 2 * MI;
+                                                     int kg, const QF& qf, int shift, float sx, int8_t* stage,
+                                                     const float* cst) {
+  constexpr int JP = STAGED ? 2 : MI;                   // j tiles per pass (staged: 32 token rows)
+  constexpr int NP = 2 * JP;
+  constexpr int WTN = NI * 16;                          // output features of this wave
+  constexpr int ES = YDT == TQ_F32 ? 4 : 2;
+  constexpr int YP = WTN * ES + 16, IP = WTN + 16;      // staging row pitches (y, indices): + 16 B against bank conflicts
   const f32x2 zpb = {qf.zp, qf.zp};
+  const int lane = kg * 16 + r16;
+  int8_t* ystage = stage;
+  int8_t* istage = stage + 32 * YP;
+  const bool want_idx = HASQ && p.y_idx != nullptr;
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const uint32_t n = n0 + i * 16 + kg * 4;            // this lane's 4 consecutive output features
-    f32x2 sw[2], bs[2];
-    int rs[4];
+  for (int h = 0; h < MI / JP; ++h) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float dw = p.w_delta[p.w_n_params == 1 ? 0 : n + r];
-      sw[r >> 1][r & 1] = sx * (dw < p.w_eps ? p.w_eps : dw);
-      bs[r >> 1][r & 1] = p.bias ? p.bias[n + r] : 0.0f;
-      rs[r] = p.w_rowsum[n + r] * shift;
-    }
-    f32x2 v[NP];
+    for (int i = 0; i < NI; ++i) {
+      const uint32_t n = n0 + i * 16 + kg * 4;            // this lane's 4 consecutive output features
+      f32x2 sw[2], bs[2];
+      int rs[4];
+      if (STAGED) {                                        // per-column constants prepared in LDS by the kernel prologue
+        const int col = i * 16 + kg * 4;
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(cst + col);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(cst + 2 * WTN + col);
+        const v4i r4 = *reinterpret_cast<const v4i*>(cst + 4 * WTN + col);
+        sw[0] = f32x2{s4.x, s4.y}; sw[1] = f32x2{s4.z, s4.w};
+        bs[0] = f32x2{b4.x, b4.y}; bs[1] = f32x2{b4.z, b4.w};
+        rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+      } else {
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
-      const f32x2 lo = {(float)(acc[i][j][0] + rs[0]), (float)(acc[i][j][1] + rs[1])};
-      const f32x2 hi = {(float)(acc[i][j][2] + rs[2]), (float)(acc[i][j][3] + rs[3])};
-      v[2 * j] = lo * sw[0] + bs[0];                      // separate mul and add as in the reference (no contraction)
-      v[2 * j + 1] = hi * sw[1] + bs[1];
-    }
-    if (ACT == ACT_GELU) gelu_erf_n<NP>(v);
-    if (ACT == ACT_RELU) {
-#pragma unroll
-      for (int e = 0; e < NP; ++e) v[e] = f32x2{v[e].x > 0.0f ? v[e].x : 0.0f, v[e].y > 0.0f ? v[e].y : 0.0f};
-    }
-    f32x2 h[NP];
-    if (HASQ) {
-      qf_round2_n<NP>(v, qf, h);
-#pragma unroll
-      for (int e = 0; e < NP; ++e) v[e] = qf.scale * (h[e] + f32x2{0.0f, 0.0f});
-    }
-#pragma unroll
-    for (int j = 0; j < MI; ++j) {
-      const size_t at = (size_t)(m0 + j * 16 + r16) * p.N + n;
-      if (HASQ && p.y_idx != nullptr) {                   // int8(index - 128): u8 index with the top bit flipped
-        const f32x2 a = h[2 * j] + zpb, b = h[2 * j + 1] + zpb;
-        uint32_t w = 0;
-        w = __builtin_amdgcn_cvt_pk_u8_f32(a.x, 0, w);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(a.y, 1, w);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(b.x, 2, w);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(b.y, 3, w);
-        *reinterpret_cast<uint32_t*>(p.y_idx + at) = w ^ 0x80808080u;
+        for (int r = 0; r < 4; ++r) {
+          const float dw = p.w_delta[p.w_n_params == 1 ? 0 : n + r];
+          sw[r >> 1][r & 1] = sx * (dw < p.w_eps ? p.w_eps : dw);
+          bs[r >> 1][r & 1] = p.bias ? p.bias[n + r] : 0.0f;
+          rs[r] = p.w_rowsum[n + r] * shift;
+        }
       }
-      if (p.y != nullptr) store_y4<YDT>(p.y, at, v[2 * j], v[2 * j + 1]);
+      f32x2 v[NP];
+#pragma unroll
+      for (int jj = 0; jj < JP; ++jj) {
+        const int j = h * JP + jj;
+        const f32x2 lo = {(float)(acc[i][j][0] + rs[0]), (float)(acc[i][j][1] + rs[1])};
+        const f32x2 hi = {(float)(acc[i][j][2] + rs[2]), (float)(acc[i][j][3] + rs[3])};
+        v[2 * jj] = lo * sw[0] + bs[0];                    // separate mul and add as in the reference (no contraction)
+        v[2 * jj + 1] = hi * sw[1] + bs[1];
+      }
+      if (ACT == ACT_GELU) gelu_erf_n<NP>(v);
+      if (ACT == ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < NP; ++e) v[e] = f32x2{v[e].x > 0.0f ? v[e].x : 0.0f, v[e].y > 0.0f ? v[e].y : 0.0f};
+      }
+      f32x2 hq[NP];
+      if (HASQ) {
+        qf_round2_n<NP>(v, qf, hq);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) v[e] = qf.scale * (hq[e] + f32x2{0.0f, 0.0f});
+      }
+#pragma unroll
+      for (int jj = 0; jj < JP; ++jj) {
+        const int j = h * JP + jj;
+        uint32_t w = 0;
+        if (want_idx) {                                   // int8(index - 128): u8 index with the top bit flipped
+          const f32x2 a = hq[2 * jj] + zpb, b = hq[2 * jj + 1] + zpb;
+          w = __builtin_amdgcn_cvt_pk_u8_f32(a.x, 0, w);
+          w = __builtin_amdgcn_cvt_pk_u8_f32(a.y, 1, w);
+          w = __builtin_amdgcn_cvt_pk_u8_f32(b.x, 2, w);
+          w = __builtin_amdgcn_cvt_pk_u8_f32(b.y, 3, w) ^ 0x80808080u;
+        }
+        if (STAGED) {
+          const int row = jj * 16 + r16, col = i * 16 + kg * 4;
+          if (want_idx) *reinterpret_cast<uint32_t*>(istage + row * IP + col) = w;
+          if (p.y != nullptr) store_y4<YDT>(ystage + row * YP, col, v[2 * jj], v[2 * jj + 1]);
+        } else {
+          const size_t at = (size_t)(m0 + j * 16 + r16) * p.N + n;
+          if (want_idx) *reinterpret_cast<uint32_t*>(p.y_idx + at) = w;
+          if (p.y != nullptr) store_y4<YDT>(p.y, at, v[2 * jj], v[2 * jj + 1]);
+        }
+      }
+    }
+    if (STAGED) {
+      // wave-private staging: program order (+ the compiler's lgkmcnt) is all the synchronisation needed
+      const uint32_t mrow0 = m0 + h * 32;
+      if (p.y != nullptr) {
+        constexpr int LPR = WTN * ES / 16, RPI = 64 / LPR;   // lanes per row, rows per store instruction
+#pragma unroll
+        for (int t = 0; t < 32 / RPI; ++t) {
+          const int row = t * RPI + lane / LPR;
+          const u32x4 d = *reinterpret_cast<const u32x4*>(ystage + row * YP + (lane % LPR) * 16);
+          __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(static_cast<int8_t*>(p.y) + ((size_t)(mrow0 + row) * p.N + n0) * ES +
+                                                                  (lane % LPR) * 16));
+        }
+      }
+      if (want_idx) {
+        constexpr int LPR = WTN / 16, RPI = 64 / LPR;
+#pragma unroll
+        for (int t = 0; t < (32 + RPI - 1) / RPI; ++t) {
+          const int row = t * RPI + lane / LPR;
+          if (RPI <= 32 || row < 32) {
+            const u32x4 d = *reinterpret_cast<const u32x4*>(istage + row * IP + (lane % LPR) * 16);
+            *reinterpret_cast<u32x4*>(p.y_idx + (size_t)(mrow0 + row) * p.N + n0 + (lane % LPR) * 16) = d;
+          }
+        }
+      }
     }
   }
 }
@@ -230,9 +294,9 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
   }
 }
 
-template <int NI, int MI, int YDT>
+template <int NI, int MI, int YDT, bool STAGED>
 __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
-                                                int kg) {
+                                                int kg, int8_t* stage = nullptr, const float* cst = nullptr) {
   const float dx = p.x_delta[0];
   const float sx = dx < p.x_eps ? p.x_eps : dx;
   const int zx = (int)clamp_nanprop(rintf(p.x_zero_float[0]), 0.0f, grid_top(p.x_n_bits));
@@ -246,15 +310,17 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI]
   const bool fast = p.act != ACT_TANH && (!p.has_q || qf.ok) && p.fast_epi != 0;
   if (!fast) return linear_epilogue_generic<NI, MI, YDT>(p, acc, n0, m0, r16, kg, qo, shift, sx);
   // wave-uniform dispatch: one straight-line body per (activation, quantizer) combination
+#define TQ_EPI(A, Q) linear_epilogue_fast<NI, MI, YDT, A, Q, STAGED>(p, acc, n0, m0, r16, kg, qf, shift, sx, stage, cst)
   if (p.has_q) {
-    if (p.act == ACT_GELU)      linear_epilogue_fast<NI, MI, YDT, ACT_GELU, true>(p, acc, n0, m0, r16, kg, qf, shift, sx);
-    else if (p.act == ACT_RELU) linear_epilogue_fast<NI, MI, YDT, ACT_RELU, true>(p, acc, n0, m0, r16, kg, qf, shift, sx);
-    else                        linear_epilogue_fast<NI, MI, YDT, ACT_NONE, true>(p, acc, n0, m0, r16, kg, qf, shift, sx);
+    if (p.act == ACT_GELU)      TQ_EPI(ACT_GELU, true);
+    else if (p.act == ACT_RELU) TQ_EPI(ACT_RELU, true);
+    else                        TQ_EPI(ACT_NONE, true);
   } else {
-    if (p.act == ACT_GELU)      linear_epilogue_fast<NI, MI, YDT, ACT_GELU, false>(p, acc, n0, m0, r16, kg, qf, shift, sx);
-    else if (p.act == ACT_RELU) linear_epilogue_fast<NI, MI, YDT, ACT_RELU, false>(p, acc, n0, m0, r16, kg, qf, shift, sx);
-    else                        linear_epilogue_fast<NI, MI, YDT, ACT_NONE, false>(p, acc, n0, m0, r16, kg, qf, shift, sx);
+    if (p.act == ACT_GELU)      TQ_EPI(ACT_GELU, false);
+    else if (p.act == ACT_RELU) TQ_EPI(ACT_RELU, false);
+    else                        TQ_EPI(ACT_NONE, false);
   }
+#undef TQ_EPI
 }
 
 // K step of 64 bytes, one step of register prefetch (any K % 64 == 0)
@@ -304,51 +370,58 @@ __global__ __launch_bounds__(kBlock) void linear_i8_k(LinArgs p) {
       for (int j = 0; j < MI; ++j) fx[j] = nx[j];
     }
   }
-  linear_epilogue<NI, MI, YDT>(p, acc, n0, m0, r16, kg);
+  linear_epilogue<NI, MI, YDT, false>(p, acc, n0, m0, r16, kg);
 }
 
 // LDS-staged variant (the fast path).  Measured on MI355X: the LDS-free kernel above is bound by the
 // vector-memory pipe -- each wave-level 16-byte load touches 16 different 128-byte lines and the L1/TA
 // retires ~1 line per 4 clocks (14.6 B/clk/CU; 7.6 us for 1024x768x768, 76 us for 8192x3072x768).
-// Here a block of 2 x 2 waves owns a BT x BT tile (BT = 2 * WT); per 128-byte K slab the 256 threads
-// load both operand slabs with fully coalesced accesses (8 lanes = one 128-byte line of one row),
-// park them in LDS (row pitch 160 B: conflict-free ds_read_b128, see kLdsPitch) and every wave reads its
-// MFMA fragments from there.  Double-buffered: the next slab's global loads are in flight while the
-// current slab's 2 * NI * MI MFMAs run; one barrier per slab.  4.7 us / 9.5 us / 42.6 us for the three
-// shapes above (hipBLASLt bf16: 6.8 / 11.2 / 47.1 us, fp32: 14.4 / 48 / 280 us).  M, N % BT == 0, K % 128 == 0.
-constexpr int kLdsPitch = 160;   // 32 * odd: conflict-free under ds_read_b128's 4 x 16 lane grouping (144 is 2-way)
+// Here a block of 2 x 2 waves owns a BT x BT tile (BT = 2 * WT).  Per 128-byte K slab both operand slabs go
+// straight from global memory into LDS (global_load_lds_dwordx4: no staging registers, no ds_write pass; 8 lanes
+// = one 128-byte line of one row, fully coalesced).  LDS-DMA writes lane-linearly, so rows cannot be padded; the
+// 16-byte chunks of a row are XOR-swizzled instead -- slot c of row r holds source chunk c ^ ((r >> 1) & 7), applied
+// on the per-lane SOURCE address -- which makes every ds_read_b128 fragment read conflict-free under the real
+// 4 x 16 lane grouping (rows of equal parity share a 256-byte bank row; the swizzle spreads the 8 of them over its
+// 8 chunk slots).  Double-buffered: the next slab's loads are in flight while the current slab's 2 * NI * MI MFMAs
+// run; one barrier per slab.  A 4-stage ring of 64-byte slabs with counted vmcnt waits was slower (tools/tuning/
+// i8_glds.hip: more barriers per MFMA; the loop is LDS-bandwidth-, not latency-bound).  M, N % BT == 0, K % 128 == 0.
+#define TQ_GLDS16(gp, lp)                                                                         \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp),           \
+                                   (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 
 template <int WT, int YDT>
 __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
   constexpr int BT = 2 * WT, NI = WT / 16, MI = WT / 16;
-  constexpr int LPT = BT * 128 / 16 / kBlock;     // 16-byte loads per thread per operand per slab
-  extern __shared__ __attribute__((aligned(16))) int8_t lds_i8[];   // [2 stages][2 operands][BT][pitch]
+  constexpr int LPW = WT / 16;                    // 1 KB load instructions per wave, operand and slab
+  constexpr int OPB = BT * 128, STB = 2 * OPB;    // bytes per operand tile / per stage
+  extern __shared__ __attribute__((aligned(1024))) int8_t lds_i8[];   // [2 stages][W | X][BT rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t tiles_m = p.M / BT;
   const uint32_t n0 = (blockIdx.x / tiles_m) * BT, m0 = (blockIdx.x % tiles_m) * BT;
   const int wn = (wave >> 1) * WT, wm = (wave & 1) * WT;
   const int r16 = lane & 15, kg = lane >> 4;
 
-  const int grow = tid >> 3, gcol = (tid & 7) * 16;
-  const int8_t* wsrc = p.w + (size_t)(n0 + grow) * p.K + gcol;
-  const int8_t* xsrc = p.x + (size_t)(m0 + grow) * p.K + gcol;
-  v4i rw[LPT], rx[LPT];
-  auto gload = [&](uint32_t k) {
+  // loader: wave w moves rows [w WT / 2, (w + 1) WT / 2) of both tiles, 8 rows per instruction
+  const int8_t* wsrc[LPW];
+  const int8_t* xsrc[LPW];
 #pragma unroll
-    for (int r = 0; r < LPT; ++r) {
-      rw[r] = *reinterpret_cast<const v4i*>(wsrc + (size_t)r * 32 * p.K + k);
-      rx[r] = *reinterpret_cast<const v4i*>(xsrc + (size_t)r * 32 * p.K + k);
+  for (int q = 0; q < LPW; ++q) {
+    const int row = wave * (WT / 2) + q * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    wsrc[q] = p.w + (size_t)(n0 + row) * p.K + chunk * 16;
+    xsrc[q] = p.x + (size_t)(m0 + row) * p.K + chunk * 16;
+  }
+  auto issue = [&](int stage, uint32_t k) {
+    int8_t* bw = lds_i8 + stage * STB + wave * (WT / 2) * 128;
+#pragma unroll
+    for (int q = 0; q < LPW; ++q) {
+      TQ_GLDS16(wsrc[q] + k, bw + q * 1024);
+      TQ_GLDS16(xsrc[q] + k, bw + OPB + q * 1024);
     }
   };
-  auto lstore = [&](int stage) {
-    int8_t* bw = lds_i8 + (size_t)stage * 2 * BT * kLdsPitch;
-    int8_t* bx = bw + (size_t)BT * kLdsPitch;
-#pragma unroll
-    for (int r = 0; r < LPT; ++r) {
-      *reinterpret_cast<v4i*>(bw + (grow + r * 32) * kLdsPitch + gcol) = rw[r];
-      *reinterpret_cast<v4i*>(bx + (grow + r * 32) * kLdsPitch + gcol) = rx[r];
-    }
-  };
+  // reader: k chunk c = 4 s + kg of row (16-aligned base) + r16 sits in slot c ^ ((r16 >> 1) & 7)
+  const int swz = (r16 >> 1) & 7;
+  const int off[2] = {r16 * 128 + ((kg ^ swz) << 4), r16 * 128 + (((4 + kg) ^ swz) << 4)};
 
   v4i acc[NI][MI];
 #pragma unroll
@@ -356,34 +429,44 @@ __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = v4i{0, 0, 0, 0};
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  issue(0, 0);
+  // per-column epilogue constants (combined scale, bias, zero-point correction) -> LDS behind the stages, while the
+  // first slab is in flight; the loop's first barrier publishes them.  [BT scale | BT bias | BT correction]
+  float* cst = reinterpret_cast<float*>(lds_i8 + 2 * STB);
+  if (tid < BT) {
+    const float dx = p.x_delta[0];
+    const float sx = dx < p.x_eps ? p.x_eps : dx;
+    const int zx = (int)clamp_nanprop(rintf(p.x_zero_float[0]), 0.0f, grid_top(p.x_n_bits));
+    const uint32_t n = n0 + tid;
+    const float dw = p.w_delta[p.w_n_params == 1 ? 0 : n];
+    cst[tid] = sx * (dw < p.w_eps ? p.w_eps : dw);
+    cst[BT + tid] = p.bias ? p.bias[n] : 0.0f;
+    reinterpret_cast<int*>(cst)[2 * BT + tid] = p.w_rowsum[n] * (128 - zx);
+  }
   const uint32_t nk = p.K / 128;
   for (uint32_t kb = 0; kb < nk; ++kb) {
-    const bool more = kb + 1 < nk;
-    if (more) gload((kb + 1) * 128);
-    const int8_t* bw = lds_i8 + (size_t)(kb & 1) * 2 * BT * kLdsPitch;
-    const int8_t* bx = bw + (size_t)BT * kLdsPitch;
+    __syncthreads();                              // slab kb landed (vmcnt(0) + barrier); slab kb - 1 is no longer read
+    if (kb + 1 < nk) issue((kb + 1) & 1, (kb + 1) * 128);
+    const int8_t* bw = lds_i8 + (kb & 1) * STB + wn * 128;
+    const int8_t* bx = lds_i8 + (kb & 1) * STB + OPB + wm * 128;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       v4i fw[NI], fx[MI];
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
-        fw[i] = *reinterpret_cast<const v4i*>(bw + (wn + i * 16 + r16) * kLdsPitch + s * 64 + kg * 16);
+      for (int i = 0; i < NI; ++i) fw[i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
 #pragma unroll
-      for (int j = 0; j < MI; ++j)
-        fx[j] = *reinterpret_cast<const v4i*>(bx + (wm + j * 16 + r16) * kLdsPitch + s * 64 + kg * 16);
+      for (int j = 0; j < MI; ++j) fx[j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s]);
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[i], fx[j], acc[i][j], 0, 0, 0);
     }
-    if (more) lstore((kb + 1) & 1);
-    __syncthreads();
   }
-  linear_epilogue<NI, MI, YDT>(p, acc, n0 + wn, m0 + wm, r16, kg);
+  __syncthreads();                                // the operand stages become the waves' output staging areas
+  constexpr int kStageBytes = 32 * (WT * 4 + 16) + 32 * (WT + 16);
+  static_assert(4 * kStageBytes <= 2 * STB, "output staging must fit the operand stages");
+  linear_epilogue<NI, MI, YDT, true>(p, acc, n0 + wn, m0 + wm, r16, kg, lds_i8 + wave * kStageBytes, cst + wn);
 }
 
 // rowsum[n] = sum_k w[n, k]   (once per weight tensor)
@@ -404,11 +487,11 @@ static int launch_linear(LinArgs a, hipStream_t st) {
   a.fast_epi = tuning("TQ_I8_FAST_EPI", 1);
   if (a.K % 128 == 0 && a.M % 64 == 0 && a.N % 64 == 0 && tuning("TQ_I8_LDS", 1)) {
     // 128 x 128 block tiles once they still give >= 4 blocks per CU, else 64 x 64
-    const bool big = a.M % 128 == 0 && a.N % 128 == 0 && (uint64_t)(a.M / 128) * (a.N / 128) >= 1024;
+    const bool big = a.M % 128 == 0 && a.N % 128 == 0 && (uint64_t)(a.M / 128) * (a.N / 128) >= (uint64_t)tuning("TQ_I8_BIG_MIN", 1024);
     if (big) hipLaunchKernelGGL((linear_i8_lds_k<64, YDT>), dim3((a.M / 128) * (a.N / 128)), dim3(kBlock),
-                                2 * 2 * 128 * kLdsPitch, st, a);
+                                2 * 2 * 128 * 128 + 3 * 128 * 4, st, a);
     else     hipLaunchKernelGGL((linear_i8_lds_k<32, YDT>), dim3((a.M / 64) * (a.N / 64)), dim3(kBlock),
-                                2 * 2 * 64 * kLdsPitch, st, a);
+                                2 * 2 * 64 * 128 + 3 * 64 * 4, st, a);
     return check_launch("linear_i8_lds_k");
   }
   // odd shapes (M, N % 32 == 0, K % 64 == 0): LDS-free kernel, 32 x 32 wave tiles
