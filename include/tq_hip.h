@@ -398,6 +398,47 @@ size_t tq_reduce_workspace_bytes(uint64_t n);
 int tq_recon_loss(const float* pred, const float* tgt, uint64_t d0, uint64_t d1, uint64_t rest,
                   double* out, void* workspace, size_t workspace_bytes, tq_stream_t stream);
 
+/* ---- FP64 (`--double`, reference main.py:227-231: modules cast to float64) --------------------------------
+ * The quantizer path with every operation in IEEE double: fake-quant forward / STE backward (quantizers.py:
+ * 172-211, 291-349), batch min / max (range_estimators.py:82-85, 114-130), estimator state update (:87-112,
+ * 162-167, 183-193, 209-214), PEG ranges (:68-80), range -> parameters (quantizers.py:234-282, 334-344) and the
+ * MSE candidate loss (range_estimators.py:248-256; the candidate table stays fp32 like the fp32 tensors the
+ * reference builds from python-float thresholds).  Same (n_params, inner) layout convention as tq_quantizer.   */
+typedef struct tq_quantizer_f64 {
+  const double*  delta;
+  const double*  zero_float;   /* NULL for symmetric */
+  const uint8_t* signed_flag;
+  int32_t        n_bits;       /* 1..52 */
+  int32_t        symmetric;
+  int32_t        log_domain;
+  int32_t        reserved;
+  double         eps;
+  uint64_t       n_params;
+  uint64_t       inner;
+} tq_quantizer_f64;
+int tq_fake_quant_fwd_f64(const double* x, double* y /* or NULL */, double* idx /* or NULL */, uint64_t n,
+                          const tq_quantizer_f64* q, tq_stream_t stream);
+size_t tq_fake_quant_bwd_f64_workspace_bytes(uint64_t n, uint64_t n_params, uint64_t inner);
+int tq_fake_quant_bwd_f64(const double* x, const double* grad_y, double* grad_x,
+                          double* g_delta /* [n_params] or NULL */, double* g_zero_float /* [n_params] or NULL */,
+                          uint64_t n, const tq_quantizer_f64* q, void* workspace, size_t workspace_bytes,
+                          tq_stream_t stream);
+size_t tq_minmax_f64_workspace_bytes(uint64_t n, uint64_t n_params, uint64_t inner);
+int tq_minmax_f64(const double* x, uint64_t n, uint64_t n_params, uint64_t inner, double* out_min, double* out_max,
+                  void* workspace, size_t workspace_bytes, tq_stream_t stream);
+int tq_range_update_f64(int mode, const double* new_min, const double* new_max, double* cur_min, double* cur_max,
+                        uint64_t n, int initialised, double momentum, uint64_t n_groups, const int64_t* order,
+                        tq_stream_t stream);
+int tq_axis_ranges_f64(const double* new_min, const double* new_max, double* ranges, uint64_t n, int first,
+                       tq_stream_t stream);
+int tq_set_range_asym_f64(const double* x_min, const double* x_max, uint64_t n, int n_bits, double eps, int log_domain,
+                          double* delta, double* zero_float, tq_stream_t stream);
+int tq_set_range_sym_f64(const double* x_min, const double* x_max, uint64_t n, int n_bits, double eps, int log_domain,
+                         double* delta, uint8_t* signed_flag, tq_stream_t stream);
+int tq_mse_candidates_f64(const double* x, uint64_t rows, uint64_t row_len, const float* cand /* [n_cand, 4] */,
+                          uint64_t n_cand, int reduce_rows, double* loss /* += [rows | 1, n_cand] */,
+                          tq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,10 +19,21 @@ class OracleBackend:
             return v.detach().float()
         return torch.tensor(v, dtype=torch.float64).float()
 
+    @staticmethod
+    def _work(x):
+        """compute dtype: fp32 for fp32 / bf16 / fp16 storage, float64 stays float64 (--double)"""
+        return x if x.dtype == torch.float64 else x.float()
+
+    def _range_tensor(self, v):
+        # float64 range TENSORS keep their dtype, python floats become fp32 tensors (quantizers.py:248-250)
+        if torch.is_tensor(v) and v.dtype == torch.float64:
+            return v.detach()
+        return self.to_device_f32(v)
+
     def _quant(self, x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params,
                inner):
         sgn = bool(signed.item()) if signed is not None else False
-        xf = x.float()
+        xf = self._work(x)
         dom = 'log' if log_domain else 'linear'
         if n_params == 1:
             return O.fake_quant(xf, delta.reshape(()), None if zero_float is None else
@@ -38,6 +49,8 @@ class OracleBackend:
                    n_params, inner, want_y=True, idx_dtype=None):
         idx, y = self._quant(x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps,
                              n_params, inner)
+        if x.dtype == torch.float64 and idx_dtype is not None:
+            idx_dtype = torch.float64
         return (y.to(x.dtype) if want_y else None,
                 idx.to(idx_dtype) if idx_dtype is not None else None)
 
@@ -72,15 +85,15 @@ class OracleBackend:
             return self._bwd(x, grad_y, delta, zero_float, sgn, n_bits, symmetric, eps, param_grads)
 
     def _bwd(self, x, grad_y, delta, zero_float, sgn, n_bits, symmetric, eps, param_grads):
-        _, dx, dd, dz = O.fake_quant_with_grads(x.float(), delta.detach(), None if zero_float is None
+        _, dx, dd, dz = O.fake_quant_with_grads(self._work(x), delta.detach(), None if zero_float is None
                                                 else zero_float.detach(), n_bits, symmetric, sgn, eps,
-                                                grad_out=grad_y.float())
+                                                grad_out=self._work(grad_y).to(self._work(x).dtype))
         return dx.to(x.dtype), (dd.reshape(-1) if param_grads else None), (
             dz.reshape(-1) if (param_grads and dz is not None) else
             (torch.zeros(delta.numel()) if param_grads else None))
 
     def minmax(self, x, n_params=1, inner=1):
-        xf = x.detach().float()
+        xf = self._work(x.detach())
         if n_params == 1:
             return xf.min(), xf.max()
         outer = x.numel() // (n_params * inner)
@@ -146,11 +159,11 @@ class OracleBackend:
         return torch.argsort(v)
 
     def set_range_asym(self, x_min, x_max, n_bits, eps, log_domain):
-        return O.asym_params_from_range(self.to_device_f32(x_min), self.to_device_f32(x_max), n_bits,
+        return O.asym_params_from_range(self._range_tensor(x_min), self._range_tensor(x_max), n_bits,
                                         eps, 'log' if log_domain else 'linear')
 
     def set_range_sym(self, x_min, x_max, n_bits, eps, log_domain):
-        return O.sym_params_from_range(self.to_device_f32(x_min), self.to_device_f32(x_max), n_bits,
+        return O.sym_params_from_range(self._range_tensor(x_min), self._range_tensor(x_max), n_bits,
                                        eps, 'log' if log_domain else 'linear')
 
     # ---- searches: direct evaluation of the (scale, zp, lo, hi) table in fp64 ----------------
@@ -176,7 +189,7 @@ class OracleBackend:
 
     def mse_candidates_ordered(self, x, cand, loss=None, per_row=False, want_f32=False):
         # literally the reference's two torch.sum calls (range_estimators.py:250-256)
-        xf = x.detach().float()
+        xf = self._work(x.detach())
         rows = xf.shape[0] if xf.dim() > 0 else 1
         f32 = torch.zeros((rows if per_row else 1, cand.shape[0]), dtype=torch.float32) if want_f32 else None
         if xf.numel() == 0:

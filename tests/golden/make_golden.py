@@ -532,7 +532,57 @@ def gen_adaround_inits():
     print('adaround init cases:', k)
 
 
+# ----------------------------------------------------------------------------------- 6
+def gen_double():
+    """`--double` (main.py:227-231): the reference's QuantizationManager (quantizer + estimator) on float64 tensors,
+    2-3 calibration batches then a fixed-range forward.  Everything stored as float64."""
+    cases = [
+        # (method, estimator, per_channel, axis, n_bits, shape, batches)
+        ('asymmetric_uniform', 'current_minmax', False, -1, 8, (4, 24, 48), 2),
+        ('asymmetric_uniform', 'running_minmax', False, -1, 8, (4, 24, 48), 3),
+        ('asymmetric_uniform', 'allminmax', False, -1, 6, (4, 24, 48), 3),
+        ('symmetric_uniform', 'current_minmax', False, -1, 8, (64, 96), 1),
+        ('symmetric_uniform', 'current_minmax', True, -1, 4, (64, 96), 1),
+        ('asymmetric_uniform', 'current_minmax', True, -1, 8, (32, 50), 1),
+        ('asymmetric_uniform', 'running_minmax', False, 2, 8, (4, 24, 48), 3),
+        ('asymmetric_uniform', 'current_minmax', False, 2, 4, (2, 16, 64), 2),
+        ('symmetric_uniform', 'MSE', False, -1, 4, (48, 64), 1),
+        ('asymmetric_uniform', 'MSE', False, -1, 4, (48, 64), 2),
+    ]
+    data = {'n_cases': np.array(len(cases))}
+    for i, (method, est, per_channel, axis, n_bits, shape, nb) in enumerate(cases):
+        qparams = dict(n_bits=n_bits)
+        kw = dict(axis=axis) if axis >= 0 else {}
+        init_params = dict(num_candidates=20) if est == 'MSE' else {}
+        m = QuantizationManager(QMethods[method], init=RangeEstimators[est], per_channel=per_channel, qparams=qparams,
+                                init_params=init_params, **kw)
+        m.estimate_ranges()
+        xs = torch.stack([hidden_like(shape, 7000 + 10 * i + b).double() * (1.0 + 0.3 * b) for b in range(nb)])
+        with torch.no_grad():
+            for b in range(nb):
+                y = m(xs[b])
+            assert y.dtype == torch.float64
+            m.fix_ranges()
+            y_fixed = m(xs[0])
+        data[f'c{i}_method'] = np.array(method)
+        data[f'c{i}_estimator'] = np.array(est)
+        data[f'c{i}_per_channel'] = np.array(per_channel)
+        data[f'c{i}_axis'] = np.array(axis)
+        data[f'c{i}_n_bits'] = np.array(n_bits)
+        data[f'c{i}_x'] = xs.numpy()
+        data[f'c{i}_delta'] = m.quantizer._delta.detach().numpy().copy()       # float64, or float32 after MSE (python floats)
+        if getattr(m.quantizer, '_zero_float', None) is not None:
+            data[f'c{i}_zero_float'] = m.quantizer._zero_float.detach().numpy().copy()
+        data[f'c{i}_y'] = y.numpy()
+        data[f'c{i}_y_fixed'] = y_fixed.numpy()
+        print(i, method, est, 'delta dtype', data[f'c{i}_delta'].dtype)
+    np.savez_compressed(os.path.join(OUT, 'double.npz'), **data)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'double':
+        gen_double()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'adaround_inits':
         gen_adaround_inits()
         sys.exit(0)

@@ -54,9 +54,11 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 SEED = 1000
 
 
-def build_hf():
+def build_hf(num_layers=None):
     torch.manual_seed(SEED)
     cfg = BertConfig(num_labels=2)
+    if num_layers is not None:
+        cfg.num_hidden_layers = num_layers
     model = BertForSequenceClassification(cfg)
     model.eval()
     # transformers 4.1 semantics: ACT2FN['gelu'] was torch.nn.functional.gelu, which the reference
@@ -75,12 +77,14 @@ def inputs():
 
 def main(recipe='default'):
     torch.set_num_threads(8)
-    hf = build_hf()
-    if recipe == 'default':
+    hf = build_hf(2 if recipe == 'double' else None)
+    if recipe in ('default', 'double'):
         qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8,
                   n_bits_act=8, weight_range_method=RangeEstimators.current_minmax,
                   act_range_method=RangeEstimators.running_minmax, quant_dict={})
         out_name, n_calib = 'bert_base_w8a8.npz', 8
+        if recipe == 'double':
+            out_name, n_calib = 'bert_2l_double.npz', 4
     else:
         # README.md:149-157 "Standard (naive) W8A8 per-tensor PTQ": --qmethod symmetric_uniform
         # --qmethod-act asymmetric_uniform --weight-quant-method MSE --weight-opt-method golden_section
@@ -117,8 +121,18 @@ def main(recipe='default'):
         return classifier(pooled)
 
     blocks.eval()
+    if recipe == 'double':
+        # main.py:227-231 (--double).  Parameter caching off: the reference's cache narrows float64 weights to fp32
+        # (hijacker.py:81-85, torch.Tensor(ndarray)), after which its second forward fails on a double x float matmul.
+        for m in blocks.modules():
+            if hasattr(m, 'weight') or hasattr(m, 'bias'):
+                m.double()
+            if hasattr(m, '_caching'):
+                m._caching = False
     apply('quantized')
     ids = inputs()
+    if recipe == 'double':
+        ids = ids[:4, :64]
     with torch.no_grad():
         forward(ids[:n_calib])               # calibration batch (estimate_ranges state)
         for m in blocks.modules():
@@ -134,14 +148,15 @@ def main(recipe='default'):
                             float(m.range_estimator.current_xmax)))
             elif name.endswith('weight_quantizer'):
                 wts.append((name, float(m.quantizer._delta)))
+    ftype = np.float64 if recipe == 'double' else np.float32
     print('activation quantizers:', len(act), 'weight quantizers:', len(wts))
     print('logits', logits)
     np.savez_compressed(
         os.path.join(OUT, out_name),
         logits=logits.numpy(), input_ids=ids.numpy(), n_calib=np.array(n_calib),
-        act_names=np.array([a[0] for a in act]), act_min=np.array([a[1] for a in act], np.float32),
-        act_max=np.array([a[2] for a in act], np.float32),
-        w_names=np.array([w[0] for w in wts]), w_delta=np.array([w[1] for w in wts], np.float32),
+        act_names=np.array([a[0] for a in act]), act_min=np.array([a[1] for a in act], ftype),
+        act_max=np.array([a[2] for a in act], ftype),
+        w_names=np.array([w[0] for w in wts]), w_delta=np.array([w[1] for w in wts], ftype),
         versions=np.array(f'torch {torch.__version__} transformers {transformers.__version__}'),
         first_weight_sum=np.array(float(hf.bert.encoder.layer[0].attention.self.query.weight.double().sum())))
 
@@ -182,6 +197,8 @@ def gen_nonorm():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'nonorm':
         gen_nonorm()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'double':
+        main('double')
     elif len(sys.argv) > 1 and sys.argv[1] == 'readme':
         main('readme')
     else:

@@ -46,8 +46,9 @@ def test_flag_cross_checks_match_the_reference():
         _cfg('--qmethod', 'symmetric_uniform', '--act-num-candidates', '10')            # only valid with MSE
     with pytest.raises(ValueError, match='momentum'):
         _cfg('--qmethod', 'symmetric_uniform', '--act-quant-method', 'MSE', '--act-momentum', '0.1')
+    assert _cfg('--qmethod', 'symmetric_uniform', '--double').double is True
     with pytest.raises(ValueError, match='double'):
-        _cfg('--qmethod', 'symmetric_uniform', '--double')
+        _cfg('--qmethod', 'symmetric_uniform', '--double', '--fast-inference')            # fp32-only kernels
     with pytest.raises(SystemExit):
         V.build_parser().parse_args([])                                                 # --qmethod is required
 
@@ -64,7 +65,11 @@ def test_flag_cross_checks_match_the_reference():
      '--adaround-num-samples', '16'],
     ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--n-bits', '4', '--n-bits-act', '8',
      '--adaround', 'all', '--adaround-iters', '12', '--adaround-num-samples', '16'],
-], ids=['w8a8', 'peg6-permute-fp-logits', 'per-embd-mixed-precision', 'w4a8-adaround', 'w4a8-adaround-all-layers'])
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--num-est-batches', '2', '--double'],
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--per-embd', '--double',
+     '--weight-quant-method', 'MSE', '--weight-opt-method', 'golden_section', '--act-quant-method', 'current_minmax'],
+], ids=['w8a8', 'peg6-permute-fp-logits', 'per-embd-mixed-precision', 'w4a8-adaround', 'w4a8-adaround-all-layers',
+        'w8a8-double', 'per-embd-mse-double'])
 def test_end_to_end_on_two_layers(flags, tmp_path, capsys):
     layers = '1' if 'all' in flags else '2'      # 'all' also walks embeddings (incl. the [1, T] position ids) and LayerNorms
     rep = V.main(flags + ['--num-layers', layers, '--num-eval-batches', '2', '--output-dir', str(tmp_path)])
@@ -73,6 +78,9 @@ def test_end_to_end_on_two_layers(flags, tmp_path, capsys):
     # sanity only: random-init logits are tiny, so the low-bit configurations (W4, 6-bit activations) sit near 0 dB
     assert f['samples'] == 16 and f['logit_sqnr_db'] > (3.0 if not ({'--quant-dict', '--adaround'} & set(flags)) else -10.0), f
     sd = torch.load(os.path.join(tmp_path, 'state_dict.pth'))
+    if '--double' in flags:
+        assert f['logit_sqnr_db'] > 3.0
+        assert all(v.dtype == torch.float64 for k, v in sd.items() if k.endswith('activation_quantizer.quantizer._delta'))
     assert any(k.endswith('activation_quantizer.quantizer._delta') for k in sd)
     assert any(k.endswith('weight_quantizer.range_estimator.quantizer._delta') for k in sd)
     if '--adaround' in flags:

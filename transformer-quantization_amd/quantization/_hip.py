@@ -35,11 +35,28 @@ class tq_quantizer(C.Structure):
                 ('eps', C.c_float), ('n_params', C.c_uint64), ('inner', C.c_uint64)]
 
 
+class tq_quantizer_f64(C.Structure):
+    _fields_ = [('delta', C.c_void_p), ('zero_float', C.c_void_p), ('signed_flag', C.c_void_p),
+                ('n_bits', C.c_int32), ('symmetric', C.c_int32), ('log_domain', C.c_int32),
+                ('reserved', C.c_int32), ('eps', C.c_double), ('n_params', C.c_uint64), ('inner', C.c_uint64)]
+
+
 _u64, _vp, _int, _sz, _f, _d = C.c_uint64, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double
 _QP = C.POINTER(tq_quantizer)
+_QPD = C.POINTER(tq_quantizer_f64)
 
 # name -> (restype, argtypes); must list every symbol include/tq_hip.h declares
 SIGNATURES = {
+    'tq_fake_quant_fwd_f64': (_int, [_vp, _vp, _vp, _u64, _QPD, _vp]),
+    'tq_fake_quant_bwd_f64_workspace_bytes': (_sz, [_u64, _u64, _u64]),
+    'tq_fake_quant_bwd_f64': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _QPD, _vp, _sz, _vp]),
+    'tq_minmax_f64_workspace_bytes': (_sz, [_u64, _u64, _u64]),
+    'tq_minmax_f64': (_int, [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _sz, _vp]),
+    'tq_range_update_f64': (_int, [_int, _vp, _vp, _vp, _vp, _u64, _int, _d, _u64, _vp, _vp]),
+    'tq_axis_ranges_f64': (_int, [_vp, _vp, _vp, _u64, _int, _vp]),
+    'tq_set_range_asym_f64': (_int, [_vp, _vp, _u64, _int, _d, _int, _vp, _vp, _vp]),
+    'tq_set_range_sym_f64': (_int, [_vp, _vp, _u64, _int, _d, _int, _vp, _vp, _vp]),
+    'tq_mse_candidates_f64': (_int, [_vp, _u64, _u64, _vp, _u64, _int, _vp, _vp]),
     'tq_abi_version': (_int, []),
     'tq_last_error': (C.c_char_p, []),
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
@@ -161,7 +178,8 @@ def _dtype_code(t, what):
     try:
         return _DTYPES[t.dtype]
     except KeyError:
-        raise TQError(f'{what}: dtype {t.dtype} not supported (fp32 / bf16 / fp16)') from None
+        hint = ' -- float64 (--double) runs the layered quantizer path only' if t.dtype == torch.float64 else ''
+        raise TQError(f'{what}: dtype {t.dtype} not supported (fp32 / bf16 / fp16){hint}') from None
 
 
 def _device_guarded(fn):
@@ -229,10 +247,42 @@ class HipBackend:
                             int(bool(symmetric)), int(bool(log_domain)), float(eps),
                             int(n_params), int(inner))
 
+    # -- FP64 (`--double`) ------------------------------------------------------------------
+    @staticmethod
+    def _as_f64(t, like):
+        """Range buffer -> contiguous float64 device tensor (exact widening of an fp32 buffer: torch's own type
+        promotion in `x / scale`); None stays None."""
+        if t is None:
+            return None
+        t = t.detach()
+        if t.dtype != torch.float64 or t.device != like.device:
+            t = t.to(device=like.device, dtype=torch.float64)
+        return t.contiguous()
+
+    def _qdesc_f64(self, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner):
+        return tq_quantizer_f64(_ptr(delta), _ptr(zero_float), _ptr(signed), int(n_bits), int(bool(symmetric)),
+                                int(bool(log_domain)), 0, float(eps), int(n_params), int(inner))
+
+    def _fake_quant_f64(self, x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner,
+                        want_y, want_idx):
+        x = x.contiguous()
+        d, z = self._as_f64(delta, x), self._as_f64(zero_float, x)
+        y = torch.empty_like(x) if want_y else None
+        idx = torch.empty_like(x) if want_idx else None
+        q = self._qdesc_f64(d, z, signed, n_bits, symmetric, log_domain, eps, n_params, inner)
+        rc = self.lib.tq_fake_quant_fwd_f64(_ptr(x), _ptr(y), _ptr(idx), x.numel(), C.byref(q), _stream())
+        _check(rc, self.lib)
+        return y, idx
+
     # -- K1/K2/K3 ------------------------------------------------------------------------
     def fake_quant(self, x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps,
                    n_params, inner, want_y=True, idx_dtype=None):
         _need_device(x, 'fake_quant')
+        if x.dtype == torch.float64:
+            if idx_dtype not in (None, torch.float32, torch.float64):
+                raise TQError('fake_quant: float64 tensors emit float64 indices only')
+            return self._fake_quant_f64(x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params,
+                                        inner, want_y, idx_dtype is not None)
         x = x.contiguous()
         y = torch.empty_like(x) if want_y else None
         idx = torch.empty(x.shape, dtype=idx_dtype, device=x.device) if idx_dtype is not None else None
@@ -384,6 +434,22 @@ class HipBackend:
         _need_device(x, 'fake_quant_bwd')
         x = x.contiguous()
         grad_y = grad_y.contiguous().to(x.dtype)
+        if x.dtype == torch.float64:
+            d, z = self._as_f64(delta, x), self._as_f64(zero_float, x)
+            gx = torch.empty_like(x)
+            gd = gz = ws = None
+            if param_grads:
+                gd = torch.zeros(n_params, dtype=torch.float64, device=x.device)
+                gz = torch.zeros(n_params, dtype=torch.float64, device=x.device)
+                ws = self._workspace(x.device, self.lib.tq_fake_quant_bwd_f64_workspace_bytes(x.numel(), n_params, inner))
+            q = self._qdesc_f64(d, z, signed, n_bits, symmetric, log_domain, eps, n_params, inner)
+            rc = self.lib.tq_fake_quant_bwd_f64(_ptr(x), _ptr(grad_y), _ptr(gx), _ptr(gd), _ptr(gz), x.numel(), C.byref(q),
+                                                _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+            _check(rc, self.lib)
+            if gd is not None:        # gradients in the dtype of the buffers they belong to
+                gd = gd.to(delta.dtype)
+                gz = gz.to(zero_float.dtype) if zero_float is not None else gz
+            return gx, gd, gz
         gx = torch.empty_like(x)
         gd = gz = None
         ws = None
@@ -404,6 +470,13 @@ class HipBackend:
         _need_device(x, 'minmax')
         x = x.detach().contiguous()
         n = x.numel()
+        if x.dtype == torch.float64:
+            out = torch.empty(2, n_params, dtype=torch.float64, device=x.device)
+            ws = self._workspace(x.device, self.lib.tq_minmax_f64_workspace_bytes(n, n_params, inner))
+            rc = self.lib.tq_minmax_f64(_ptr(x), n, n_params, inner, _ptr(out[0]), _ptr(out[1]), _ptr(ws), ws.numel(),
+                                        _stream())
+            _check(rc, self.lib)
+            return (out[0, 0], out[1, 0]) if n_params == 1 else (out[0], out[1])
         out = torch.empty(2, n_params, dtype=torch.float32, device=x.device)
         nbytes = self.lib.tq_minmax_workspace_bytes(n, n_params, inner)
         ws = self._workspace(x.device, nbytes)
@@ -558,17 +631,20 @@ class HipBackend:
         else:
             # the reference rebinds fresh tensors every batch; keep earlier results un-aliased
             cur_min, cur_max = cur_min.clone(), cur_max.clone()
-        rc = self.lib.tq_range_update(mode, _ptr(new_min), _ptr(new_max), _ptr(cur_min), _ptr(cur_max),
-                                      new_min.numel(), int(initialised), float(momentum),
-                                      int(n_groups or 0), _ptr(order), _stream())
+        fn = self.lib.tq_range_update
+        if new_min.dtype == torch.float64:
+            fn = self.lib.tq_range_update_f64
+            new_max, cur_min, cur_max = new_max.double(), cur_min.double(), cur_max.double()
+        rc = fn(mode, _ptr(new_min), _ptr(new_max), _ptr(cur_min), _ptr(cur_max), new_min.numel(), int(initialised),
+                float(momentum), int(n_groups or 0), _ptr(order), _stream())
         _check(rc, self.lib)
         return cur_min, cur_max
 
     def axis_ranges(self, new_min, new_max, first):
         _need_device(new_min, 'axis_ranges')
         r = torch.empty_like(new_min)
-        rc = self.lib.tq_axis_ranges(_ptr(new_min.contiguous()), _ptr(new_max.contiguous()), _ptr(r),
-                                     r.numel(), int(first), _stream())
+        fn = self.lib.tq_axis_ranges_f64 if new_min.dtype == torch.float64 else self.lib.tq_axis_ranges
+        rc = fn(_ptr(new_min.contiguous()), _ptr(new_max.contiguous()), _ptr(r), r.numel(), int(first), _stream())
         _check(rc, self.lib)
         return r
 
@@ -576,7 +652,32 @@ class HipBackend:
         return torch.argsort(v).contiguous()
 
     # -- range -> params -------------------------------------------------------------------
+    @staticmethod
+    def _f64_range(x_min, x_max):
+        """float64 range TENSORS keep their dtype (python floats become fp32 tensors, reference quantizers.py:248-250)."""
+        return (torch.is_tensor(x_min) and x_min.dtype == torch.float64) or (
+            torch.is_tensor(x_max) and x_max.dtype == torch.float64)
+
+    def _set_range_f64(self, x_min, x_max, n_bits, eps, log_domain, symmetric):
+        dev = next((t.device for t in (x_min, x_max) if torch.is_tensor(t) and t.is_cuda),
+                   torch.device('cuda', torch.cuda.current_device()))
+        x_min = torch.as_tensor(x_min).detach().to(device=dev, dtype=torch.float64).contiguous()
+        x_max = torch.as_tensor(x_max).detach().to(device=dev, dtype=torch.float64).contiguous()
+        delta = torch.empty_like(x_min)
+        if symmetric:
+            other = torch.empty((), dtype=torch.bool, device=dev)
+            fn = self.lib.tq_set_range_sym_f64
+        else:
+            other = torch.empty_like(x_min)
+            fn = self.lib.tq_set_range_asym_f64
+        rc = fn(_ptr(x_min), _ptr(x_max), max(x_min.numel(), 1), int(n_bits), float(eps), int(log_domain), _ptr(delta),
+                _ptr(other), _stream())
+        _check(rc, self.lib)
+        return delta, other
+
     def set_range_asym(self, x_min, x_max, n_bits, eps, log_domain):
+        if self._f64_range(x_min, x_max):
+            return self._set_range_f64(x_min, x_max, n_bits, eps, log_domain, False)
         x_min = self.to_device_f32(x_min).contiguous()
         x_max = self.to_device_f32(x_max, like=x_min).contiguous()
         delta, zf = torch.empty_like(x_min), torch.empty_like(x_min)
@@ -586,6 +687,8 @@ class HipBackend:
         return delta, zf
 
     def set_range_sym(self, x_min, x_max, n_bits, eps, log_domain):
+        if self._f64_range(x_min, x_max):
+            return self._set_range_f64(x_min, x_max, n_bits, eps, log_domain, True)
         x_min = self.to_device_f32(x_min).contiguous()
         x_max = self.to_device_f32(x_max, like=x_min).contiguous()
         delta = torch.empty_like(x_min)
@@ -620,6 +723,13 @@ class HipBackend:
         row_len = x.numel() // max(rows, 1)
         n_cand = cand.shape[0]
         out_rows = rows if per_row else 1
+        if x.dtype == torch.float64:
+            # --double: element arithmetic and sums in float64 (no fp32 value to reproduce); the fp64 cells are the result
+            if x.numel():
+                rc = self.lib.tq_mse_candidates_f64(_ptr(x), rows, row_len, _ptr(cand), n_cand, int(not per_row), _ptr(loss),
+                                                    _stream())
+                _check(rc, self.lib)
+            return loss, (loss.float() if want_f32 else None)
         f32 = torch.empty((out_rows, n_cand), dtype=torch.float32, device=x.device) if want_f32 else None
         if x.numel() == 0:
             if f32 is not None:
@@ -649,6 +759,9 @@ class HipBackend:
 
     def xent_candidates(self, x, cand, loss):
         _need_device(x, 'xent_candidates')
+        if x.dtype == torch.float64:
+            raise TQError('xent_candidates: the cross-entropy range search is fp32 only (no float64 kernel); '
+                          'use min-max or MSE estimators with --double')
         x = x.detach().float().contiguous()
         rows = x.shape[0]
         cols = x.numel() // rows

@@ -44,7 +44,7 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
     from quantization.autoquant_utils import QuantNoNorm
     is_nonorm = isinstance(layer_norm, QuantNoNorm)
     fusable = ('no' not in (q1, q2, q3) and dense.activation_function is None
-               and layer_norm.activation_function is None and x.is_cuda
+               and layer_norm.activation_function is None and x.is_cuda and x.dtype != torch.float64
                and not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad))
                and (is_nonorm or len(layer_norm.normalized_shape) == 1)
                and dense.activation_save_target is None and layer_norm.activation_save_target is None)

@@ -73,9 +73,12 @@ class QuantizationHijacker(QuantizedModule):
             weight = self.weight_quantizer(weight)
 
         if cache_usable and self._caching and self.cached_params is None:
-            # detached fp32 copies, like the reference's numpy round trip -- but resident in HBM
-            self.cached_params = (weight.detach().to(torch.float32),
-                                  None if bias is None else bias.detach().to(torch.float32))
+            # detached copies, like the reference's numpy round trip -- but resident in HBM.  Low-precision parameters
+            # are widened to fp32 like `torch.Tensor(ndarray)` does; float64 (--double) is KEPT: the reference's
+            # constructor narrows it to fp32 as well, which makes its second eval forward fail on a double x float
+            # matmul (or silently continue in fp32 behind an embedding) -- not a behaviour worth reproducing.
+            keep = weight.dtype if weight.dtype == torch.float64 else torch.float32
+            self.cached_params = (weight.detach().to(keep), None if bias is None else bias.detach().to(keep))
         return weight, bias
 
     def _save(self, suffix, tensor):

@@ -124,7 +124,7 @@ class QuantizationManager(nn.Module):
         sharded = tq_dist.is_enabled()
         if (mode is None or type(q) not in _FUSED_QUANTIZERS or not FUSED_CALIBRATION
                 or not hasattr(be, 'calibrate_stats' if sharded else 'calibrate_minmax')
-                or not (x.is_cuda or getattr(be, 'accepts_cpu', False))
+                or not (x.is_cuda or getattr(be, 'accepts_cpu', False)) or x.dtype == torch.float64   # --double: layered
                 or getattr(est, 'percentile', None) or '_delta' not in q._buffers     # trainable ranges
                 or (torch.is_grad_enabled() and x.requires_grad)):
             return None
@@ -150,6 +150,8 @@ class QuantizationManager(nn.Module):
             order = be.argsort(est.ranges)
         prev_min = est.current_xmin if mode != _hip.EST_CURRENT else None
         prev_max = est.current_xmax if mode != _hip.EST_CURRENT else None
+        if prev_min is not None and (prev_min.dtype != torch.float32 or prev_max.dtype != torch.float32):
+            return None                      # state left by a float64 pass: the layered path promotes like torch
         out = None
         if options.INPLACE_CALIBRATION_STATE:
             out = self._inplace_state(est, q, n_params, x.device)

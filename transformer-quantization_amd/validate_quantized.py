@@ -85,7 +85,8 @@ def build_parser():
     g.add_argument('--per-groups', type=int, default=None)
     g.add_argument('--per-groups-permute', action='store_true')
     g.add_argument('--per-groups-permute-shared-h', action='store_true')
-    g.add_argument('--double', action='store_true', help='Unsupported on this path (fp64 tensors are refused).')
+    g.add_argument('--double', action='store_true',
+                   help='float64 model and quantizer path (reference main.py:227-231); layered kernels only.')
     g.add_argument('--dynamic', action='store_true', help='Ranges follow every batch (no fix_ranges).')
 
     g = ap.add_argument_group('AdaRound (utils/quant_click_options.py:229-353)')
@@ -141,8 +142,9 @@ def make_config(args):
         if not isinstance(config.quant.quant_dict, dict):
             raise ValueError('--quant-dict must be a python dict literal')
     config.double = args.double
-    if args.double:
-        raise ValueError('--double is not supported: the MI355X kernels compute in fp32 (DESIGN.md section 7)')
+    if args.double and (args.fast_inference or args.adaround):
+        raise ValueError('--double runs the layered float64 quantizer path: not combinable with --fast-inference '
+                         '(fused / int8 kernels are fp32) or --adaround (fp32 kernels)')
 
     config.act_quant = DotDict(quant_method=args.act_quant_method, cross_entropy_layer=args.cross_entropy_layer,
                                num_batches=args.num_est_batches, options={})
@@ -226,6 +228,12 @@ def run(config, args):
     qp = make_qparams(config)
     model, hf = build_bert_base(seed=args.seed, num_layers=args.num_layers, **qp)
     model, hf = model.to(dev).eval(), hf.to(dev).eval()
+    if config.double:
+        # reference main.py:227-231
+        for holder in (model, hf):
+            for m in holder.modules():
+                if hasattr(m, 'weight') or hasattr(m, 'bias'):
+                    m.double()
     vocab = hf.config.vocab_size
     est = synthetic_batches(max(config.act_quant.num_batches, 1), config.quant.est_ranges_batch_size,
                             args.max_seq_length, vocab, args.seed + 1, with_labels=True)
