@@ -41,10 +41,24 @@ __device__ __forceinline__ float apply_q(float v, const FusedQ& q) {
   return q.on ? q_dequant(index_q(v, q), q.p) : v;
 }
 
+// Sum over the LPR lanes that own one row (every lane gets the total).  The first four butterfly steps run on the
+// VALU's data-parallel-primitive path (quad permutes, half-row / row mirrors: one v_add_f32_dpp each, no index
+// arithmetic, no LDS crossbar round trip); lanes 16 apart through ds_swizzle, 32 apart through ds_bpermute.
+// (__shfl_xor costs 4 VALU instructions of index math + a dependent ds_bpermute per step: 10 steps per LayerNorm row
+// were ~110 instructions and the longest dependency chain of the kernel.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR);
+  static_assert(LPR >= 4 && LPR <= 64 && (LPR & (LPR - 1)) == 0, "LPR");
+  v += dpp_f32<0xB1>(v);                        // quad_perm [1, 0, 3, 2]
+  v += dpp_f32<0x4E>(v);                        // quad_perm [2, 3, 0, 1]
+  if (LPR >= 8) v += dpp_f32<0x141>(v);         // row_half_mirror: the other quad of the 8 (all its lanes agree by now)
+  if (LPR >= 16) v += dpp_f32<0x140>(v);        // row_mirror: the other half of the 16
+  if (LPR >= 32) v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
+  if (LPR >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 
