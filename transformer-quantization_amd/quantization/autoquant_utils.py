@@ -21,7 +21,9 @@ from quantization.quantization_manager import QuantizationManager
 
 
 # The integer path is switched on with quantization.options.INT8_LINEAR (see there).
-INT8_STATS = {'kernel_calls': 0, 'autograd_calls': 0}     # how often the MFMA Linear ran (plain / under autograd)
+# how often the MFMA Linear ran (plain / under autograd) and how often an unsigned weight grid sent a layer back to
+# the layered path
+INT8_STATS = {'kernel_calls': 0, 'autograd_calls': 0, 'unsigned_weight_fallbacks': 0}
 _ACT_CODES = {type(None): _hip.ACT_NONE, nn.ReLU: _hip.ACT_RELU, nn.GELU: _hip.ACT_GELU, nn.Tanh: _hip.ACT_TANH}
 
 
@@ -102,7 +104,10 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         be = _hip.backend()
         w_idx, rowsum, w_signed = self._int8_weights()
         if not w_signed:
-            return None                      # all-positive weights use an unsigned grid: not handled here
+            # all-positive weights use the unsigned grid [0, 2^n): indices do not fit int8.  The layered path runs
+            # instead; counted so that the fallback is visible (INT8_STATS['unsigned_weight_fallbacks']).
+            INT8_STATS['unsigned_weight_fallbacks'] += 1
+            return None
         x_idx = provenance.indices_of(x)           # emitted by the producing quantizer in the same launch
         if x_idx is None or x_idx.shape != x.shape:
             x_idx = be.quantize_to_int8(x.detach(), src._delta, src._zero_float, None, src.n_bits, False, False,
