@@ -293,6 +293,24 @@ before = INT8_STATS['autograd_calls']
 c['qat_step_int8_forward_ms'] = wall(qat_step, n=5, w=2)
 c['int8_linears_per_training_forward'] = (INT8_STATS['autograd_calls'] - before) / 7
 options.INT8_LINEAR = False
+# the same step (+ SGD update) recorded once as a hipGraph and replayed (quantization/graphs.py GraphedTrainStep)
+from quantization.graphs import GraphedTrainStep
+for m_ in mb.modules():
+    if isinstance(m_, torch.nn.Dropout):
+        m_.p = 0.0
+def graphed_qat(tag):
+    try:
+        opt_ = torch.optim.SGD([p_ for p_ in mb.parameters() if p_.requires_grad], lr=1e-6)
+        step_ = GraphedTrainStep(mb, torch.nn.functional.cross_entropy, opt_, (ids_mb,), (lab,))
+        c[f'qat_step_{tag}_hipgraph_ms'] = wall(lambda: step_((ids_mb,), (lab,)), n=10, w=2)
+        del step_, opt_
+    except Exception as e:      # noqa: BLE001
+        c[f'qat_step_{tag}_hipgraph_ms'] = f'failed: {e!r}'[:200]
+    torch.cuda.synchronize()
+graphed_qat('layered')
+options.INT8_LINEAR = True
+graphed_qat('int8_forward')
+options.INT8_LINEAR = False
 mb.eval()
 out['config5_mobilebert_w4a4_whole_model_b8_t128'] = c
 

@@ -115,3 +115,65 @@ def test_learnable_vector_ranges_gradients_vs_autograd(layout, symmetric):
     assert torch.allclose(q._delta.grad.cpu().reshape(pshape), dd, rtol=1e-4, atol=1e-4), layout
     if not symmetric:
         assert torch.allclose(q._zero_float.grad.cpu().reshape(pshape), dz, rtol=1e-4, atol=1e-4), layout
+
+
+@pytest.mark.parametrize('optimizer,int8', [('sgd', False), ('adam', False), ('sgd', True)])
+def test_graphed_qat_step_equals_eager(optimizer, int8):
+    """quantization.graphs.GraphedTrainStep: zero_grad + forward + loss + STE backward + optimizer.step() as ONE
+    hipGraph.  Same parameters (weights AND learnable ranges) after N replays as after N eager steps from the same
+    state: the backward kernels reduce range gradients in a fixed order, dropout is switched off, rocBLAS is
+    deterministic for a fixed shape."""
+    import copy
+    from quantization import options
+    from quantization.autoquant_utils import INT8_STATS
+    from quantization.graphs import GraphedTrainStep
+    # int8: the Linears run on the i8 matrix cores under autograd (_Int8LinearSTE); that path needs fixed ranges
+    model, batches, labels = _setup(learn_ranges=not int8, fix_act=int8)
+    if int8:
+        model.fix_ranges()
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    twin = copy.deepcopy(model)
+
+    def make_opt(net):
+        params = [p for p in net.parameters() if p.requires_grad]
+        if optimizer == 'sgd':
+            return torch.optim.SGD(params, lr=1e-3, momentum=0.9)
+        return torch.optim.Adam(params, lr=1e-4, capturable=True)
+
+    loss_fn = torch.nn.functional.cross_entropy
+    opt = make_opt(model)
+    options.INT8_LINEAR = int8
+    try:
+        _graphed_vs_eager(model, twin, make_opt, opt, loss_fn, batches, labels, int8, INT8_STATS, GraphedTrainStep)
+    finally:
+        options.INT8_LINEAR = False
+
+
+def _graphed_vs_eager(model, twin, make_opt, opt, loss_fn, batches, labels, int8, INT8_STATS, GraphedTrainStep):
+    before = INT8_STATS['autograd_calls']
+    step = GraphedTrainStep(model, loss_fn, opt, (batches[0][0],), (labels,))
+    assert (INT8_STATS['autograd_calls'] > before) == int8
+    # capture (with its warm-up steps) left the model where it was
+    for (n, a), (_, b) in zip(model.state_dict().items(), twin.state_dict().items()):
+        assert torch.equal(a, b), n
+    graph_losses = []
+    for i in range(4):
+        graph_losses.append(float(step((batches[i % 3][0],), (labels,)).clone()))
+
+    opt2 = make_opt(twin)
+    eager_losses = []
+    for i in range(4):
+        opt2.zero_grad(set_to_none=True)
+        loss = loss_fn(twin(batches[i % 3][0]), labels)
+        loss.backward()
+        opt2.step()
+        eager_losses.append(float(loss.detach()))
+    assert graph_losses == eager_losses, (graph_losses, eager_losses)
+    moved = 0
+    for (n, a), (_, b) in zip(model.named_parameters(), twin.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), n
+        moved += int(a.requires_grad)
+    assert moved > (30 if int8 else 100)

@@ -37,6 +37,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._int8_cache = None
+        self._int8_signed = None
 
     def run_forward(self, x, weight, bias, offsets=None):
         return F.linear(x.contiguous(), weight.contiguous(), bias=bias)
@@ -50,20 +51,26 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
 
     # ---- integer path ---------------------------------------------------------------------------
     def _int8_weights(self):
-        """(int8 indices [N, K], int32 row sums [N]) of the fake-quantized weight, cached per
-        (weight version, range buffers)."""
+        """(int8 indices [N, K], int32 row sums [N], signed grid?) of the fake-quantized weight.  The indices are
+        cached per (weight version, range state); the `signed` flag -- the one host read of this path -- per range
+        state only, so that a training step (weights change every iteration, ranges fixed or learnable) re-quantizes
+        its weights without a host synchronisation and stays hipGraph-capturable.  While a TRAINING step is being
+        captured the weights are always re-quantized: the recorded launches must not depend on a cache hit."""
         wq = self.weight_quantizer.quantizer
-        key = (self.weight.data_ptr(), self.weight._version, wq.range_state_key())
-        if self._int8_cache is None or self._int8_cache[0] != key:
+        rkey = wq.range_state_key()
+        if self._int8_signed is None or self._int8_signed[0] != rkey:
+            self._int8_signed = (rkey, bool(wq.signed))          # host sync, once per range state
+        key = (self.weight.data_ptr(), self.weight._version, rkey)
+        recording = (torch.is_grad_enabled() and self.weight.requires_grad and torch.cuda.is_available()
+                     and torch.cuda.is_current_stream_capturing())
+        if self._int8_cache is None or self._int8_cache[0] != key or recording:
             be = _hip.backend()
             n_par = wq._delta.numel()
             w_idx = be.quantize_to_int8(self.weight.detach(), wq._delta, None, wq._signed, wq.n_bits, True,
                                         False, wq.eps, n_par, self.in_features if n_par > 1 else 1,
                                         minus_128=False)
-            # `signed` is read once here (host sync) so that the per-forward path stays sync-free and
-            # hipGraph-capturable
-            self._int8_cache = (key, w_idx, be.rowsum_i8(w_idx), bool(wq.signed))
-        return self._int8_cache[1:]
+            self._int8_cache = (key, w_idx, be.rowsum_i8(w_idx))
+        return self._int8_cache[1], self._int8_cache[2], self._int8_signed[1]
 
     def _int8_plan(self, x, with_output_quantizer=True):
         """Arguments of the integer evaluation of this layer for input `x`, or None when the configuration does not
