@@ -388,6 +388,13 @@ int tq_adaround_bwd_adam(const float* w, const float* grad_wq, float* alpha, flo
                          const tq_quantizer* q, int mode, float temperature, float reg_weight,
                          float beta, float lr, float adam_b1, float adam_b2, float adam_eps,
                          int step, tq_stream_t stream);
+/* K11 with its per-iteration scalars in device memory: sched[4] = {reg_weight, beta, 1 - b1^t, sqrt(1 - b2^t)}
+ * (fp32).  Nothing in the argument list changes between iterations: the AdaRound loop body (adaround/adaround.py:
+ * 236-262) can be recorded once as a hipGraph and replayed.                                                    */
+int tq_adaround_bwd_adam_sched(const float* w, const float* grad_wq, float* alpha, float* exp_avg,
+                               float* exp_avg_sq, uint64_t n, const tq_quantizer* q, int mode, float temperature,
+                               const float* sched, float lr, float adam_b1, float adam_b2, float adam_eps,
+                               tq_stream_t stream);
 /* regulariser value: out[0] += weight * sum(1 - |2h(alpha)-1|^beta)   (fp64 accumulate).        */
 int tq_adaround_reg(const float* alpha, uint64_t n, int mode, float temperature, float beta,
                     float weight, double* out, void* workspace, size_t workspace_bytes,

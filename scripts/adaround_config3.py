@@ -29,8 +29,11 @@ from quantization.quantizers import QMethods
 from quantization.range_estimators import RangeEstimators, OptMethod
 
 dev = 'cuda'
-N, T, FIN, FOUT = 1024, 128, 768, 3072
+N, T, FIN = 1024, 128, 768
+FOUT = int(os.environ.get('TQ_ADA_FOUT', 3072))       # 768: the attention projections of BERT-base
 ITERS = int(os.environ.get('TQ_ADA_ITERS', 1000))
+from quantization import options  # noqa: E402
+options.GRAPH_ADAROUND = os.environ.get('TQ_GRAPH_ADAROUND', '1') != '0'     # A/B: hipGraph replay of the loop body
 
 
 def inputs(kind):
@@ -58,6 +61,7 @@ class Net(QuantizedModel):
 
 
 out = {'layer': [FOUT, FIN], 'samples': N, 'tokens': T, 'batch': 8, 'iters': ITERS, 'bits': 4,
+       'graph_replay': options.GRAPH_ADAROUND,
        'round_mode': 'learned_hard_sigmoid', 'runs': {}}
 for kind in ('iid', 'structured'):
     for init in ('range_estimator', 'mse_out'):

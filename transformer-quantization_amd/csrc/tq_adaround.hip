@@ -95,7 +95,10 @@ __global__ __launch_bounds__(kBlock) void ada_bwd_adam_k(const float* __restrict
                                                          float* __restrict__ v, float* __restrict__ g_out, uint64_t n,
                                                          tq_quantizer q, int mode, float temp, float reg_w, float beta,
                                                          float lr, float b1, float b2, float adam_eps, float bc1,
-                                                         float bc2_sqrt) {
+                                                         float bc2_sqrt, const float* __restrict__ sched) {
+  if (sched != nullptr) {      // per-iteration scalars from device memory (hipGraph replay of the optimisation loop)
+    reg_w = sched[0]; beta = sched[1]; bc1 = sched[2]; bc2_sqrt = sched[3];
+  }
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     const QP p = make_qp(q, par_index(q, i));
     const float a = alpha[i];
@@ -238,7 +241,24 @@ extern "C" int tq_adaround_bwd_adam(const float* w, const float* grad_wq, float*
   const double bc2 = 1.0 - pow((double)adam_b2, (double)step);
   hipLaunchKernelGGL(ada_bwd_adam_k, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq, alpha,
                      exp_avg, exp_avg_sq, grad_alpha_out, n, *q, mode, temperature, reg_weight, beta, lr, adam_b1,
-                     adam_b2, adam_eps, (float)bc1, (float)sqrt(bc2));
+                     adam_b2, adam_eps, (float)bc1, (float)sqrt(bc2), (const float*)nullptr);
+  return check_launch("ada_bwd_adam_k");
+}
+
+// The same step with its four per-iteration scalars read from DEVICE memory: sched = {reg_weight, beta,
+// 1 - b1^t, sqrt(1 - b2^t)} (fp32, prepared by the host for every iteration up front).  No launch argument changes
+// from one iteration to the next, so the whole AdaRound iteration can be recorded once as a hipGraph and replayed.
+extern "C" int tq_adaround_bwd_adam_sched(const float* w, const float* grad_wq, float* alpha, float* exp_avg,
+                                          float* exp_avg_sq, uint64_t n, const tq_quantizer* q, int mode, float temperature,
+                                          const float* sched, float lr, float adam_b1, float adam_b2, float adam_eps,
+                                          tq_stream_t stream) {
+  TQ_REQUIRE(w && grad_wq && alpha && exp_avg && exp_avg_sq && sched, "tq_adaround_bwd_adam_sched: NULL pointer");
+  if (int e = check_quantizer(q, n, "tq_adaround_bwd_adam_sched")) return e;
+  if (int e = check_mode(mode, temperature, "tq_adaround_bwd_adam_sched")) return e;
+  if (n == 0) return TQ_OK;
+  hipLaunchKernelGGL(ada_bwd_adam_k, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq, alpha,
+                     exp_avg, exp_avg_sq, (float*)nullptr, n, *q, mode, temperature, 0.0f, 0.0f, lr, adam_b1, adam_b2, adam_eps,
+                     1.0f, 1.0f, sched);
   return check_launch("ada_bwd_adam_k");
 }
 

@@ -108,6 +108,7 @@ SIGNATURES = {
     'tq_adaround_fwd': (_int, [_vp, _vp, _vp, _u64, _QP, _int, _int, _f, _vp]),
     'tq_adaround_init_alpha': (_int, [_vp, _vp, _u64, _QP, _int, _f, _vp]),
     'tq_adaround_bwd': (_int, [_vp, _vp, _vp, _vp, _u64, _QP, _int, _f, _vp]),
+    'tq_adaround_bwd_adam_sched': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _QP, _int, _f, _vp, _f, _f, _f, _f, _vp]),
     'tq_adaround_bwd_adam': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _QP, _int, _f, _f, _f, _f,
                                     _f, _f, _f, _int, _vp]),
     'tq_adaround_reg': (_int, [_vp, _u64, _int, _f, _f, _f, _vp, _vp, _sz, _vp]),
@@ -836,6 +837,18 @@ class HipBackend:
                                            float(b2), float(adam_eps), int(step), _stream())
         _check(rc, self.lib)
         return g
+
+    def adaround_bwd_adam_sched(self, w, grad_wq, alpha, exp_avg, exp_avg_sq, qargs, mode, temperature, sched, lr, b1, b2,
+                                adam_eps):
+        """K11 with (reg_weight, beta, 1 - b1^t, sqrt(1 - b2^t)) read from the fp32 device tensor `sched`."""
+        _need_device(w, 'adaround_bwd_adam_sched')
+        _need_f32('adaround_bwd_adam_sched', w, alpha, exp_avg, exp_avg_sq, sched, grad_wq)
+        q = self._qdesc(*qargs)
+        rc = self.lib.tq_adaround_bwd_adam_sched(_ptr(w.detach().contiguous()), _ptr(grad_wq.contiguous()), _ptr(alpha),
+                                                 _ptr(exp_avg), _ptr(exp_avg_sq), alpha.numel(), C.byref(q), mode,
+                                                 float(temperature or 0.0), _ptr(sched.contiguous()), float(lr), float(b1),
+                                                 float(b2), float(adam_eps), _stream())
+        _check(rc, self.lib)
 
     def adaround_reg(self, alpha, mode, temperature, beta, weight):
         _need_device(alpha, 'adaround_reg')

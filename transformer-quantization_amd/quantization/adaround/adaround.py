@@ -64,6 +64,73 @@ class FusedAlphaAdam:
             self.eps, self.t, want_grad=want_grad)
 
 
+    # ---- graph replay support ---------------------------------------------------------------------------
+    def schedule_row(self, t, reg_weight, beta):
+        """(reg_weight, beta, 1 - b1^t, sqrt(1 - b2^t)) of Adam step t as the fp32 values `step` hands to K11: the
+        betas are narrowed to fp32 first (they cross the C ABI as floats), the powers are evaluated in double."""
+        import math
+        import numpy as np
+        b1, b2 = float(np.float32(self.betas[0])), float(np.float32(self.betas[1]))
+        return (np.float32(reg_weight), np.float32(beta), np.float32(1.0 - math.pow(b1, t)),
+                np.float32(math.sqrt(1.0 - math.pow(b2, t))))
+
+    def step_scheduled(self, w, grad_wq, sched_row):
+        """`step` with its per-iteration scalars in the device tensor `sched_row` (fp32 [4], see schedule_row)."""
+        self.t += 1
+        q = self.quantizer
+        _hip.backend().adaround_bwd_adam_sched(w, grad_wq, q.alpha.data, self.exp_avg, self.exp_avg_sq, q.kernel_args(w),
+                                               q.mode_code(), q.temperature, sched_row, self.lr, self.betas[0],
+                                               self.betas[1], self.eps)
+
+
+class _GraphedIterations:
+    """Iterations first..iters of the fused AdaRound loop as replays of ONE hipGraph.
+
+    The body is recorded (not executed) after the eager warm-up iterations; what differs between iterations -- the
+    sample indices and K11's four scalars -- comes from device tables indexed by a device-side iteration counter, so a
+    replay needs no host input at all."""
+
+    def __init__(self, layer, q, optimizer, loss_fn, cached_inps, cached_outs, idx_rows, first, iters):
+        import numpy as np
+        be = _hip.backend()
+        dev = cached_inps.device
+        self.layer, self.q, self.opt = layer, q, optimizer
+        self.idx_all = torch.stack(idx_rows).to(dev)                               # [iters - first + 1, batch]
+        rows = [optimizer.schedule_row(it, loss_fn.weight if loss_fn.schedule(it)[1] else 0.0, loss_fn.schedule(it)[0])
+                for it in range(first, iters + 1)]
+        self.sched_all = torch.from_numpy(np.asarray(rows, dtype=np.float32)).to(dev)
+        self.pos = torch.zeros(1, dtype=torch.int64, device=dev)
+        n_global = self.idx_all.shape[1]
+        w = layer.weight
+        bias = layer.bias if hasattr(layer, 'bias') else None
+
+        def body():
+            idx = self.idx_all.index_select(0, self.pos).view(-1)
+            sched = self.sched_all.index_select(0, self.pos).view(-1)
+            cur_inp = cached_inps.index_select(0, idx)
+            cur_out = cached_outs.index_select(0, idx)
+            w_q = be.adaround_fwd(w, q.alpha.detach(), q.kernel_args(w), q.mode_code(), True, q.temperature)
+            with torch.no_grad():               # closed-form gradient of the plain Linear, as in the eager loop
+                out = layer.run_forward(cur_inp, w_q.detach(), bias)
+                n_means = out.numel() // out.size(1) if out.dim() > 1 else 1
+                grad_out = (out - cur_out) * (2.0 / n_means)
+                grad_wq = grad_out.reshape(-1, grad_out.shape[-1]).t().mm(cur_inp.reshape(-1, cur_inp.shape[-1]))
+            optimizer.step_scheduled(w, grad_wq, sched)
+            self.pos.add_(1)
+            return out.detach(), cur_out
+
+        t_before = optimizer.t
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out, self.cur_out = body()
+        optimizer.t = t_before                        # recording executed nothing
+        self.n_global = n_global
+
+    def replay(self):
+        self.opt.t += 1
+        self.graph.replay()
+
+
 def apply_adaround_to_layer(model, layer, data_tensor, batch_size, act_quant, adaround_config,
                             keep_gpu=True):
     """Learn the rounding of `layer`'s weights so that its output matches the FP32 layer."""
@@ -267,9 +334,44 @@ def optimize_local_loss(layer, get_inp_out, data_tensor, optimizer, loss_fn, bat
     from quantization.autoquant_utils import QuantLinear
     manual_linear = fused and type(layer) is QuantLinear and layer.activation_function is None
 
+    # hipGraph replay of the iterations after a short eager warm-up (options.GRAPH_ADAROUND): same kernels, same order,
+    # same sample sequence -- the indices of ALL iterations are drawn up front, in the order the eager loop draws them
+    from quantization import options
+    n_warm = 3
+    graphable = (fused and manual_linear and options.GRAPH_ADAROUND and use_cached_data and ws == 1 and on_step is None
+                 and cached_inps.is_cuda and iters > n_warm + 8 and n_total >= 1
+                 and loss_fn.loss_type == AdaRoundLossType.relaxation and hasattr(be, 'adaround_bwd_adam_sched'))
+    drawn = None
+    if graphable:
+        drawn = [(torch.as_tensor(batch_indices[i]) if batch_indices is not None
+                  else torch.randperm(n_total)[:batch_size]) for i in range(iters)]
+        if len({d.numel() for d in drawn}) != 1 or max(int(d.max()) for d in drawn) >= cached_inps.size(0):
+            graphable = False                  # ragged / out-of-range index rows: the eager loop reports them
+    replayer = None
+
     for i in range(iters):
-        idx = (torch.as_tensor(batch_indices[i]) if batch_indices is not None
-               else torch.randperm(n_total)[:batch_size])
+        if graphable and i == n_warm and replayer is None:
+            try:
+                replayer = _GraphedIterations(layer, q, optimizer, loss_fn, cached_inps, cached_outs, drawn[n_warm:],
+                                              n_warm + 1, iters)
+            except Exception as e:       # noqa: BLE001 -- recording executes nothing: carry on eagerly
+                logger.info(f'AdaRound loop not captured as a hipGraph ({e!r}); eager iterations')
+                graphable = False
+                torch.cuda.synchronize()
+        if replayer is not None:
+            it = i + 1
+            loss_fn.iter = it
+            replayer.replay()
+            if it == 1 or it % 100 == 0:
+                b, reg_on = loss_fn.schedule(it)
+                round_loss = float(be.adaround_reg(q.alpha, q.mode_code(), q.temperature, b, loss_fn.weight)) if reg_on else 0.0
+                rec_v = float(be.recon_loss(replayer.out, replayer.cur_out))
+                logger.info(f'Total loss:\t{rec_v + round_loss:.4f} (rec:{rec_v:.4f}, '
+                            f'round:{round_loss:.3f})\tb={b:.2f}\titer={it}')
+            continue
+        idx = (drawn[i] if drawn is not None else
+               (torch.as_tensor(batch_indices[i]) if batch_indices is not None
+                else torch.randperm(n_total)[:batch_size]))
         n_global = idx.numel()
         if use_cached_data:
             if ws > 1:

@@ -17,3 +17,11 @@ INT8_LINEAR = False
 # allocation, no host synchronisation between the 161 + 102 quantizers of a BERT-base.  Off by
 # default because code that keeps references to earlier state tensors would see them change.
 INPLACE_CALIBRATION_STATE = False
+
+# AdaRound: after three eager iterations the loop body (sample gather, soft-quantized weight, layer forward, gradient
+# GEMM, fused backward + regulariser + Adam) is recorded once as a hipGraph and replayed for the remaining iterations,
+# with the per-iteration sample indices and schedule scalars read from device tables.  Same kernels in the same order
+# on the same data: the learned rounding is bit-identical to the eager loop (tests/test_adaround_inits.py).  Applies to
+# the fused step of plain Linear layers (closed-form gradient, no folded activation function) on one GPU with the
+# relaxation loss; anything else runs the eager loop.
+GRAPH_ADAROUND = True
