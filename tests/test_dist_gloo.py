@@ -274,3 +274,92 @@ def test_bench_gpus_flag_spawns_ranks():
     assert len(lines) == 1                                           # rank 0 only
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['rccl_world_size'] == 2 and out['dry_run'] is True and out['value'] is None
+
+
+# ---- layer-parallel AdaRound (asym=False: independent per-layer problems, layers shard over ranks) -------------------
+def _layer_parallel_problem():
+    import copy
+    from quantization.adaround.config import DEFAULT_ADAROUND_CONFIG
+    from quantization.adaround.utils import AdaRoundInitMode, AdaRoundMode
+    from quantization.quantization_manager import QuantizationManager
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from tests.test_host_logic import ToyNet, _quant_toy
+    from utils.utils import DotDict
+    torch.manual_seed(4242)
+    org = ToyNet()
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=4, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    m = _quant_toy(org, **qp)
+    m.eval()
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(16, 5, 24, generator=g)
+    m.set_quant_state(weight_quant=True, act_quant=False)
+    with torch.no_grad():
+        m(X[:8])
+    for mod in m.modules():
+        if isinstance(mod, QuantizationManager) and mod.quantizer.is_initialized:
+            mod.fix_ranges()
+    cfg = copy.deepcopy(DEFAULT_ADAROUND_CONFIG)
+    cfg.layers, cfg.num_samples, cfg.iters = ('fc1', 'fc2'), 16, 12
+    cfg.asym = False
+    cfg.init = AdaRoundInitMode.mse
+    cfg.round_mode = AdaRoundMode.learned_hard_sigmoid
+    from quantization.adaround.utils import AdaRoundActQuantMode
+    cfg.act_quant_mode = AdaRoundActQuantMode.no_act_quant
+    config = DotDict(adaround=cfg, quant=DotDict(act_quant=False, weight_quant=True),
+                     act_quant=DotDict(num_batches=1, cross_entropy_layer=None))
+    loader = [(X[i:i + 8],) for i in (0, 8)]
+    return m, config, loader
+
+
+def _run_layer_parallel(m, config, loader):
+    from utils.adaround_utils import apply_adaround_to_model
+    torch.manual_seed(99)                          # the loops draw their sample indices from the global RNG
+    res = apply_adaround_to_model(config, m, loader, loader, batch_size=8)
+    state = {n: (mod.weight_quantizer.quantizer.alpha.detach().clone(),
+                 mod.weight_quantizer.quantizer._delta.detach().clone())
+             for n, mod in m.named_modules()
+             if n in ('fc1', 'fc2') and hasattr(mod.weight_quantizer.quantizer, 'alpha')}
+    return res, state
+
+
+def _worker_layer_parallel(rank, port, outdir):
+    tq = _setup(rank, port)
+    m, config, loader = _layer_parallel_problem()
+    res, state = _run_layer_parallel(m, config, loader)
+    assert tq.is_enabled()                         # suspended() restored the exchange
+    with torch.no_grad():
+        y = m(loader[0][0])
+    torch.save({'res': {k: dict(v) for k, v in res.items()}, 'state': state, 'y': y}, os.path.join(outdir, f'lp_{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_layer_parallel_adaround_equals_single_process(tmp_path):
+    """asym=False: rank 0 learns fc1, rank 1 learns fc2 (full sample set each, no exchange inside the loops), the learned
+    alphas / ranges / losses are broadcast -- both ranks end with exactly the model a single process produces when the
+    per-layer RNG streams coincide (each layer's loop is the first consumer of the seed on its owner; the
+    single-process reference re-seeds before each layer accordingly)."""
+    port = _free_port()
+    mp.spawn(_worker_layer_parallel, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    from quantization import _hip, distributed as tq_dist
+    from tests._oracle_backend import OracleBackend
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        tq_dist.disable()
+        ref_state = {}
+        for only in ('fc1', 'fc2'):                # one layer per run = what each owner did (same seed, same order)
+            m, config, loader = _layer_parallel_problem()
+            config.adaround.layers = (only,)
+            _, st = _run_layer_parallel(m, config, loader)
+            ref_state[only] = st[only]
+    finally:
+        _hip.set_backend(prev)
+    r0 = torch.load(os.path.join(tmp_path, 'lp_0.pt'), weights_only=False)
+    r1 = torch.load(os.path.join(tmp_path, 'lp_1.pt'), weights_only=False)
+    assert set(r0['res']) == set(r1['res']) == {'fc1', 'fc2'} and r0['res'] == r1['res']
+    assert torch.equal(r0['y'], r1['y'])
+    for n in ('fc1', 'fc2'):
+        for k in (0, 1):
+            assert torch.equal(r0['state'][n][k], r1['state'][n][k]), n
+            assert torch.equal(r0['state'][n][k], ref_state[n][k]), n

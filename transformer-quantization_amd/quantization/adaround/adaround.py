@@ -131,6 +131,25 @@ class _GraphedIterations:
         self.graph.replay()
 
 
+def install_adaround_quantizer(layer, cfg):
+    """Swap in the AdaRound flavour of `layer`'s weight quantizer, sharing the range buffers (reference
+    adaround/adaround.py:75-90).  Separate from the optimisation so that a rank that did not optimise this layer
+    (layer-parallel AdaRound, utils/adaround_utils.py) can build the same module and receive the learned state."""
+    org_q = layer.weight_quantizer.quantizer
+    if org_q.__class__ not in ADAROUND_QUANTIZER_MAP:
+        raise NotImplementedError(f'AdaRound is not supported for "{org_q.__class__}"')
+    w_quantizer = ADAROUND_QUANTIZER_MAP[org_q.__class__](
+        n_bits=org_q.n_bits, scale_domain=org_q.scale_domain, per_channel=org_q.per_channel,
+        eps=org_q.eps)
+    for name in ('_delta', '_zero_float', '_signed'):
+        if hasattr(org_q, name):
+            w_quantizer.register_buffer(name, getattr(org_q, name))
+    layer.weight_quantizer.quantizer = w_quantizer
+    w_quantizer.round_mode = cfg.round_mode
+    w_quantizer.temperature = cfg.annealing[0]
+    return w_quantizer
+
+
 def apply_adaround_to_layer(model, layer, data_tensor, batch_size, act_quant, adaround_config,
                             keep_gpu=True):
     """Learn the rounding of `layer`'s weights so that its output matches the FP32 layer."""
@@ -153,19 +172,7 @@ def apply_adaround_to_layer(model, layer, data_tensor, batch_size, act_quant, ad
         org_act_func = layer.activation_function
         layer.activation_function = None
 
-    # swap in the AdaRound flavour of the weight quantizer, sharing the range buffers
-    org_q = layer.weight_quantizer.quantizer
-    if org_q.__class__ not in ADAROUND_QUANTIZER_MAP:
-        raise NotImplementedError(f'AdaRound is not supported for "{org_q.__class__}"')
-    w_quantizer = ADAROUND_QUANTIZER_MAP[org_q.__class__](
-        n_bits=org_q.n_bits, scale_domain=org_q.scale_domain, per_channel=org_q.per_channel,
-        eps=org_q.eps)
-    for name in ('_delta', '_zero_float', '_signed'):
-        if hasattr(org_q, name):
-            w_quantizer.register_buffer(name, getattr(org_q, name))
-    layer.weight_quantizer.quantizer = w_quantizer
-    w_quantizer.round_mode = cfg.round_mode
-    w_quantizer.temperature = cfg.annealing[0]
+    w_quantizer = install_adaround_quantizer(layer, cfg)
 
     # first pass also initialises alpha
     get_inp_out = GetLayerInpOut(model, layer, asym=cfg.asym, act_quant=act_quant)

@@ -76,6 +76,27 @@ def disable():
     _group, _enabled, _force = None, False, False
 
 
+class suspended:
+    """``with tq_dist.suspended(): ...`` -- the statistics / gradient exchanges are off inside the block (the process
+    group stays): for work that is partitioned by OBJECT rather than by sample, e.g. layer-parallel AdaRound, where
+    every rank runs complete, independent per-layer problems and only the results travel."""
+
+    def __enter__(self):
+        global _enabled
+        self._was = _enabled
+        _enabled = False
+        return self
+
+    def __exit__(self, *exc):
+        global _enabled
+        _enabled = self._was
+        return False
+
+
+def group():
+    return _group
+
+
 def mailbox_active():
     return _mailbox is not None
 

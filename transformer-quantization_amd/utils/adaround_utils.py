@@ -7,6 +7,12 @@ does shard is the data: with ``quantization.distributed`` enabled every rank kee
 ``i % world == rank`` and the per-step weight gradient is SUM all-reduced over RCCL before the fused Adam update
 (quantization/adaround/adaround.py), so all ranks walk through the same sequence of roundings in lock-step.
 Sample collection stays replicated: every rank reads the same `data_loader` (the samples are a few MB of token ids).
+
+With ``asym=False`` the per-layer problems are independent (inputs AND targets come from the FP32 network), so the
+LAYERS shard instead: rank r optimises layers r, r + world, ... on the full sample set with no collective in the data
+path, and every layer's learned state (alpha, the range buffers a grid init may have moved, its losses) is broadcast
+from its owner at the end -- one small exchange per layer instead of a [N, K] gradient all-reduce per iteration.
+(`config.adaround.layer_parallel = False` keeps the data-parallel scheme.)
 """
 import logging
 
@@ -14,7 +20,8 @@ import torch
 
 from quantization import distributed as tq_dist
 from quantization.adaround import apply_adaround_to_layer
-from quantization.adaround.utils import AdaRoundActQuantMode
+from quantization.adaround.adaround import install_adaround_quantizer
+from quantization.adaround.utils import AdaRoundActQuantMode, AdaRoundInitMode
 from quantization.base_quantized_classes import QuantizedModule
 from utils.utils import pass_data_for_range_estimation, Stopwatch
 
@@ -51,6 +58,33 @@ def adaround_layers(model, wanted):
     return [(n, m) for n, m in owners if n in wanted]
 
 
+def _gather_layer_results(todo, results, cfg, world, rank):
+    """Layer-parallel AdaRound: every layer's learned rounding (alpha), its range buffers and its losses go from the
+    owner (layer index % world) to everybody.  Non-owners first build the same AdaRound quantizer module."""
+    dist, grp = torch.distributed, tq_dist.group()
+    for i, (name, module) in enumerate(todo):
+        owner = i % world
+        src = dist.get_global_rank(grp, owner) if grp is not None else owner
+        if rank != owner:
+            q = install_adaround_quantizer(module, cfg)
+            with torch.no_grad():
+                q(module.weight)                      # allocates alpha with the right shape (values replaced below)
+            q.soft_targets = False
+            module.caching = True
+        q = module.weight_quantizer.quantizer
+        for t in (q.alpha.data, q._delta, getattr(q, '_zero_float', None)):
+            if t is not None:
+                dist.broadcast(t, src=src, group=grp)
+        sgn = getattr(q, '_signed', None)
+        if sgn is not None:
+            flag = sgn.to(torch.uint8).reshape(1).clone()
+            dist.broadcast(flag, src=src, group=grp)
+            q._signed = flag.reshape(()).to(torch.bool)
+        box = [results.get(name)]
+        dist.broadcast_object_list(box, src=src, group=grp)
+        results[name] = box[0]
+
+
 def apply_adaround_to_model(config, model, data_loader, range_est_data_loader, batch_size, driver=None,
                             get_samples_fn=get_train_samples, inp_idx=0):
     """AdaRound on every selected layer of a QuantizedModel, then (act mode `post_adaround`) a fresh activation
@@ -74,18 +108,34 @@ def apply_adaround_to_model(config, model, data_loader, range_est_data_loader, b
     model.reset_act_ranges()
     model.full_precision_acts()
 
+    layer_parallel = (tq_dist.is_enabled() and not cfg.asym and cfg.get('layer_parallel', True)
+                      and cfg.init != AdaRoundInitMode.mse_out_asym)
+    world = torch.distributed.get_world_size(tq_dist.group()) if layer_parallel else 1
+    rank = torch.distributed.get_rank(tq_dist.group()) if layer_parallel else 0
+    if layer_parallel:
+        logger.info(f'layer-parallel AdaRound: {len(todo)} independent layers over {world} ranks')
+
     results, total = {}, Stopwatch()
-    for name, module in todo:
+    for i, (name, module) in enumerate(todo):
+        if i % world != rank:
+            continue                                  # another rank's layer; its result arrives below
         logger.info(f'Started AdaRound for layer {name}')
         model.full_precision()
         module.quantized_weights()
         total.start()
         with Stopwatch() as per_layer:
-            results[name] = apply_adaround_to_layer(model, module, samples, batch_size=batch_size,
-                                                    act_quant=config.quant.act_quant, adaround_config=cfg)
+            if layer_parallel:
+                with tq_dist.suspended():             # a complete local problem: nothing to exchange inside
+                    results[name] = apply_adaround_to_layer(model, module, samples, batch_size=batch_size,
+                                                            act_quant=config.quant.act_quant, adaround_config=cfg)
+            else:
+                results[name] = apply_adaround_to_layer(model, module, samples, batch_size=batch_size,
+                                                        act_quant=config.quant.act_quant, adaround_config=cfg)
         total.stop()
         logger.info(f'Done AdaRound for layer {name}. {per_layer.format()}\n')
     logger.info(f'Done optimizing all layers. {total.format()}')
+    if layer_parallel:
+        _gather_layer_results(todo, results, cfg, world, rank)
 
     if cfg.act_quant_mode == AdaRoundActQuantMode.post_adaround:
         if driver is not None:
