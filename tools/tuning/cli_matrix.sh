@@ -26,3 +26,6 @@ run --n-bits 4 --adaround layers.0.output.dense --adaround-iters 20 --adaround-n
 run --n-bits 4 --adaround layers.0.intermediate.0 --adaround-iters 20 --adaround-num-samples 16 --no-adaround-asym --adaround-act-quant no_act_quant
 run --act-quant-method current_minmax --quant-dict "{'y': 'ngp6', 'h': 16, 'Et': 4, 's': 'fp32', 'wC': 'fp32', 'x0': 'per_embd'}"
 run --fast-inference --hip-graph --num-est-batches 3
+run --double --num-est-batches 2
+run --double --per-embd --act-quant-method current_minmax --weight-quant-method MSE
+run --double --act-quant-method MSE --act-num-candidates 20
