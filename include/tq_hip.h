@@ -85,8 +85,9 @@ int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtype, uint64_t
  * QuantNoNorm.forward followed by quantize_activations): y = Q(x * w[col] + b[col]) for x viewed
  * as [n / d, d]; w, b fp32 [d] (the already fake-quantized affine parameters); per-tensor output
  * quantizer.  mul and add are separate fp32 operations like the reference's `x * weight + bias`. */
-int tq_affine_fake_quant_fwd(const void* x, const float* w, const float* b, void* y, uint64_t n,
-                             uint64_t d, int dtype, const tq_quantizer* q, tq_stream_t stream);
+int tq_affine_fake_quant_fwd(const void* x, const float* w, const float* b, void* y,
+                             int8_t* y_idx /* optional int8(index - 128) of y for a following integer Linear, or NULL */,
+                             uint64_t n, uint64_t d, int dtype, const tq_quantizer* q, tq_stream_t stream);
 
 /* (f2) Fused tail of BertSelfOutput / BertOutput with fixed ranges (reference
  * models/quantized_bert.py:238-248, 264-280):

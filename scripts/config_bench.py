@@ -276,6 +276,12 @@ with torch.no_grad():
     g2 = GraphedForward(mb, ids_mb)
     c['fixed_range_forward_fused_tails_int8_linear_hipgraph_ms'] = wall(lambda: g2(ids_mb), n=30)
     c['int8_max_logit_dev_vs_layered'] = float((g2(ids_mb) - base).abs().max())
+    from harness.mobilebert import QMobileSelfAttention
+    QMobileSelfAttention.fuse = True
+    g3 = GraphedForward(mb, ids_mb)
+    c['fixed_range_forward_fused_tails_int8_linear_int8_attention_hipgraph_ms'] = wall(lambda: g3(ids_mb), n=30)
+    c['int8_attention_max_logit_dev_vs_layered'] = float((g3(ids_mb) - base).abs().max())
+    QMobileSelfAttention.fuse = False
     options.INT8_LINEAR = False
     QResidualNoNorm.fuse = False
 # QAT step (training mode, fixed ranges, forward + backward): layered fp32 simulation vs integer MFMA forward

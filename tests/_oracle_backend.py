@@ -54,9 +54,11 @@ class OracleBackend:
         return (y.to(x.dtype) if want_y else None,
                 idx.to(idx_dtype) if idx_dtype is not None else None)
 
-    def affine_fake_quant(self, x, w, b, delta, zero_float, signed, n_bits, symmetric, log_domain, eps):
+    def affine_fake_quant(self, x, w, b, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, want_idx=False):
         r = x.float() * w.float() + b.float()
-        _, y = self._quant(r, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, 1, 1)
+        idx, y = self._quant(r, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, 1, 1)
+        if want_idx:
+            return y.to(x.dtype), (idx - 128).to(torch.int8)
         return y.to(x.dtype)
 
     def residual_layernorm_quant(self, dense_out, residual, q_dense, q_sum, ln_weight, ln_bias, ln_eps, q_out,

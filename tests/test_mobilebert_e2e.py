@@ -154,3 +154,42 @@ def test_mobilebert_fused_nonorm_tails_match_layered():
     finally:
         QResidualNoNorm.fuse = False
     assert torch.equal(fused, layered)
+
+
+@pytest.mark.gpu
+def test_mobilebert_integer_attention_core_in_harness():
+    """`QMobileSelfAttention.fuse` + options.INT8_LINEAR: 4 heads x 32, the attention core of every layer as one integer
+    kernel (tq_attention_i8_fwd) fed by the int8 indices of the query / key / value Linears.  Run on an 8-bit
+    configuration (the 4-bit fixture model is chaotic: one flipped index moves the logits visibly): the kernel is
+    used in every layer and the logits stay within a few output-quantizer steps of the layered forward."""
+    import torch.nn as nn
+    from harness.mobilebert import QMobileSelfAttention, build_mobilebert
+    from quantization import _hip, options
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from utils.utils import pass_data_for_range_estimation
+    z = _fixture()
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    model, _ = build_mobilebert(seed=1000, num_layers=2, **qp)
+    model = model.cuda().eval()
+    ids = torch.from_numpy(z['input_ids']).cuda()
+    with torch.no_grad():
+        pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
+        model.fix_ranges()
+        layered = model(ids)
+        calls = []
+        be = _hip.backend()
+        orig = be.attention_i8
+        be.attention_i8 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        options.INT8_LINEAR = True
+        QMobileSelfAttention.fuse = True
+        try:
+            fast = model(ids)
+        finally:
+            QMobileSelfAttention.fuse = False
+            options.INT8_LINEAR = False
+            be.attention_i8 = orig
+    assert len(calls) == 2, 'one integer attention launch per layer'
+    span = float(layered.max() - layered.min())
+    assert torch.isfinite(fast).all() and float((fast - layered).abs().max()) <= 0.05 * span

@@ -81,3 +81,8 @@ def test_fused_affine_quant_matches_unfused_at_mobilebert_shapes(dtype):
         y = be.affine_fake_quant(x.cuda(), w.cuda(), b.cuda(), delta.cuda(), zf.cuda(), None, 4, False,
                                  False, 1e-8)
         assert torch.equal(y.cpu(), ref.to(dtype)), (rows, d, dtype)
+        # optional int8(index - 128) output for a following integer Linear: same launch, same y
+        y2, yi = be.affine_fake_quant(x.cuda(), w.cuda(), b.cuda(), delta.cuda(), zf.cuda(), None, 4, False,
+                                      False, 1e-8, want_idx=True)
+        ref_i, _ = O.fake_quant(r, delta, zf, 4, False)
+        assert torch.equal(y2.cpu(), ref.to(dtype)) and torch.equal(yi.cpu().int() + 128, ref_i.int())

@@ -354,8 +354,8 @@ __global__ __launch_bounds__(MAXB) void fq_axis_reg(const u32x4* __restrict__ x,
 // x viewed as [rows, d], d % V == 0; w, b (fp32 [d], already fake-quantized) staged in LDS.
 template <int DT, bool NT, int U>
 __global__ __launch_bounds__(kBlock) void fq_affine(const u32x4* __restrict__ x, const float* __restrict__ w,
-                                                    const float* __restrict__ b, u32x4* __restrict__ y, uint64_t n,
-                                                    uint32_t d, tq_quantizer q) {
+                                                    const float* __restrict__ b, u32x4* __restrict__ y,
+                                                    int8_t* __restrict__ y_idx, uint64_t n, uint32_t d, tq_quantizer q) {
   constexpr int V = Store<DT>::kVec;
   constexpr uint32_t TILE = kBlock * U;
   extern __shared__ __attribute__((aligned(16))) float s_par[];
@@ -387,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void fq_affine(const u32x4* __restrict__ x,
   for (int u = 0; u < U; ++u) {
     const uint64_t k = i0 + (uint64_t)u * kBlock;
     float f[V];
+    struct alignas(V) { int8_t e[V]; } oi;
     Store<DT>::unpack(v[u], f);
 #pragma unroll
     for (int j = 0; j < V; j += 4) {
@@ -395,10 +396,19 @@ __global__ __launch_bounds__(kBlock) void fq_affine(const u32x4* __restrict__ x,
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const float r = f[j + m] * w4[m] + b4[m];          // mul, then add (no fma: -ffp-contract=off)
-        f[j + m] = q_dequant(q_index(r, p), p);
+        const float xi = q_index(r, p);
+        oi.e[j + m] = (int8_t)((int)xi - 128);             // only stored for asymmetric <= 8-bit quantizers (host check)
+        f[j + m] = q_dequant(xi, p);
       }
     }
-    if (full || k < n_vec) { const u32x4 o = Store<DT>::pack(f); if (NT) st_stream(y + k, o); else y[k] = o; }
+    if (full || k < n_vec) {
+      const u32x4 o = Store<DT>::pack(f);
+      if (NT) st_stream(y + k, o); else y[k] = o;
+      if (y_idx != nullptr) {                             // int8(index - 128) for a following integer Linear
+        if constexpr (V == 4) *reinterpret_cast<uint32_t*>(y_idx + k * V) = __builtin_bit_cast(uint32_t, oi);
+        else                  *reinterpret_cast<u32x2*>(y_idx + k * V) = __builtin_bit_cast(u32x2, oi);
+      }
+    }
     cv += blk_mod;
     if (cv >= vpr) cv -= vpr;
   }
@@ -778,7 +788,7 @@ extern "C" int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtyp
 }
 
 template <int DT>
-static int launch_affine(const void* x, const float* w, const float* b, void* y, uint64_t n, uint64_t d,
+static int launch_affine(const void* x, const float* w, const float* b, void* y, int8_t* y_idx, uint64_t n, uint64_t d,
                          const tq_quantizer& q, hipStream_t st) {
   constexpr int V = Store<DT>::kVec;
   const uint64_t n_vec = n / V;
@@ -787,15 +797,15 @@ static int launch_affine(const void* x, const float* w, const float* b, void* y,
   const size_t lds = d * 2 * sizeof(float);
   const auto xv = static_cast<const u32x4*>(x);
   auto yv = static_cast<u32x4*>(y);
-#define TQ_LAUNCH_AFF(NTV, UV) hipLaunchKernelGGL((fq_affine<DT, NTV, UV>), dim3((unsigned)std::max<uint64_t>(ceil_div(n_vec, kBlock * UV), 1)), dim3(kBlock), lds, st, xv, w, b, yv, n, (uint32_t)d, q)
+#define TQ_LAUNCH_AFF(NTV, UV) hipLaunchKernelGGL((fq_affine<DT, NTV, UV>), dim3((unsigned)std::max<uint64_t>(ceil_div(n_vec, kBlock * UV), 1)), dim3(kBlock), lds, st, xv, w, b, yv, y_idx, n, (uint32_t)d, q)
   if (big) { if (nt) TQ_LAUNCH_AFF(true, 4); else TQ_LAUNCH_AFF(false, 4); }
   else     { if (nt) TQ_LAUNCH_AFF(true, 1); else TQ_LAUNCH_AFF(false, 1); }
 #undef TQ_LAUNCH_AFF
   return check_launch("fq_affine");
 }
 
-extern "C" int tq_affine_fake_quant_fwd(const void* x, const float* w, const float* b, void* y, uint64_t n, uint64_t d,
-                                        int dtype, const tq_quantizer* q, tq_stream_t stream) {
+extern "C" int tq_affine_fake_quant_fwd(const void* x, const float* w, const float* b, void* y, int8_t* y_idx, uint64_t n,
+                                        uint64_t d, int dtype, const tq_quantizer* q, tq_stream_t stream) {
   if (n == 0) return TQ_OK;
   TQ_REQUIRE(x && w && b && y, "tq_affine_fake_quant_fwd: NULL pointer");
   TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_affine_fake_quant_fwd: bad dtype %d", dtype);
@@ -804,12 +814,14 @@ extern "C" int tq_affine_fake_quant_fwd(const void* x, const float* w, const flo
   const uint64_t V = dtype == TQ_F32 ? 4 : 8;
   TQ_REQUIRE(d >= V && d % V == 0 && d <= 8192 && n % d == 0, "tq_affine_fake_quant_fwd: d=%llu unsupported", (unsigned long long)d);
   TQ_REQUIRE(aligned16(x) && aligned16(y), "tq_affine_fake_quant_fwd: x / y must be 16-byte aligned");
+  TQ_REQUIRE(y_idx == nullptr || (!q->symmetric && q->n_bits <= 8 && (reinterpret_cast<uintptr_t>(y_idx) & 7u) == 0),
+             "tq_affine_fake_quant_fwd: y_idx needs an asymmetric <= 8-bit quantizer and 8-byte alignment");
   TQ_REQUIRE(n / V / (kBlock) < (1ull << 31), "tq_affine_fake_quant_fwd: tensor too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case TQ_F32: return launch_affine<TQ_F32>(x, w, b, y, n, d, *q, st);
-    case TQ_BF16: return launch_affine<TQ_BF16>(x, w, b, y, n, d, *q, st);
-    default: return launch_affine<TQ_F16>(x, w, b, y, n, d, *q, st);
+    case TQ_F32: return launch_affine<TQ_F32>(x, w, b, y, y_idx, n, d, *q, st);
+    case TQ_BF16: return launch_affine<TQ_BF16>(x, w, b, y, y_idx, n, d, *q, st);
+    default: return launch_affine<TQ_F16>(x, w, b, y, y_idx, n, d, *q, st);
   }
 }
 

@@ -114,8 +114,19 @@ class QMobileSelfAttention(QuantizedModel):
         B, T, _ = x.shape
         return x.view(B, T, self.heads, self.head_dim).permute(0, 2, 1, 3)
 
+    fuse = False   # set True to run the fixed-range attention core as one integer kernel (quantization/fused.py)
+
     def forward(self, q_in, k_in, v_in, mask):
-        q, k, v = self._split(self.query(q_in)), self._split(self.key(k_in)), self._split(self.value(v_in))
+        qo, ko, vo = self.query(q_in), self.key(k_in), self.value(v_in)
+        if self.fuse:
+            # Q K^T -> quantizer -> / sqrt(d) + mask -> softmax -> quantizer -> P V -> quantizer (per-tensor, so "per head
+            # before the merge" and "after the merge" coincide) on the i8 matrix cores; None = layered modules
+            from quantization.fused import quantized_attention
+            ctx = quantized_attention(qo, ko, vo, mask, self.heads, self.attn_scores_act_quantizer,
+                                      self.attn_probs_act_quantizer, self.attn_output_act_quantizer)
+            if ctx is not None:
+                return ctx
+        q, k, v = self._split(qo), self._split(ko), self._split(vo)
         scores = self.attn_scores_act_quantizer(torch.matmul(q, k.transpose(-1, -2)))
         scores = scores / math.sqrt(self.head_dim)
         if mask is not None:

@@ -60,7 +60,7 @@ SIGNATURES = {
     'tq_abi_version': (_int, []),
     'tq_last_error': (C.c_char_p, []),
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
-    'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
+    'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
     'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
     'tq_residual_nonorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _QP, _vp]),
     'tq_attention_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u64, _u64, _vp, _f, _QP, _QP, _QP, _QP, _QP, _QP, _vp]),
@@ -294,18 +294,20 @@ class HipBackend:
         _check(rc, self.lib)
         return y, idx
 
-    def affine_fake_quant(self, x, w, b, delta, zero_float, signed, n_bits, symmetric, log_domain, eps):
-        """y = Q(x * w + b) (w, b fp32 [d] over the last axis), per-tensor output quantizer."""
+    def affine_fake_quant(self, x, w, b, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, want_idx=False):
+        """y = Q(x * w + b) (w, b fp32 [d] over the last axis), per-tensor output quantizer.  want_idx (asymmetric
+        <= 8-bit quantizer): also int8(index - 128) of y, from the same launch -> (y, idx)."""
         _need_device(x, 'affine_fake_quant')
         x = x.contiguous()
         y = torch.empty_like(x)
+        idx = torch.empty(x.shape, dtype=torch.int8, device=x.device) if want_idx else None
         q = self._qdesc(delta, zero_float, signed, n_bits, symmetric, log_domain, eps, 1, 1)
         rc = self.lib.tq_affine_fake_quant_fwd(_ptr(x), _ptr(w.detach().float().contiguous()),
-                                               _ptr(b.detach().float().contiguous()), _ptr(y), x.numel(),
+                                               _ptr(b.detach().float().contiguous()), _ptr(y), _ptr(idx), x.numel(),
                                                x.shape[-1], _dtype_code(x, 'affine_fake_quant'),
                                                C.byref(q), _stream())
         _check(rc, self.lib)
-        return y
+        return (y, idx) if want_idx else y
 
     def residual_layernorm_quant(self, dense_out, residual, q_dense, q_sum, ln_weight, ln_bias, ln_eps, q_out,
                                  want_idx=False):

@@ -232,16 +232,42 @@ class QuantNoNorm(QuantizationHijacker):
                 and not torch.is_grad_enabled() and x.dim() >= 1
                 and x.shape[-1] == self.weight.numel() and x.shape[-1] % 8 == 0)
 
+    def quantized_params(self):
+        """(Q(weight), Q(bias)) through the ONE weight quantizer, weight first (upstream order).  With fixed ranges in
+        inference the pair is constant: cached per (parameter versions, range state) -- the reference re-quantizes both
+        vectors on every forward (2 launches per NoNorm, 7 NoNorms per MobileBERT layer)."""
+        if not self._quant_w:
+            return self.weight, self.bias
+        from quantization.quantization_manager import Qstates
+        mgr = self.weight_quantizer
+        cacheable = (not self.training and not torch.is_grad_enabled() and isinstance(mgr, QuantizationManager)
+                     and mgr.state == Qstates.fix_ranges and mgr.quantizer.is_initialized)
+        key = None
+        if cacheable:
+            key = (self.weight.data_ptr(), self.weight._version, self.bias.data_ptr(), self.bias._version,
+                   mgr.quantizer.range_state_key())
+            hit = getattr(self, '_qparam_cache', None)
+            if hit is not None and hit[0] == key:
+                return hit[1], hit[2]
+        weight = mgr(self.weight)
+        bias = mgr(self.bias)
+        if cacheable:
+            self._qparam_cache = (key, weight.detach(), bias.detach())
+        return weight, bias
+
     def forward(self, x, offsets=None):
-        weight, bias = self.weight, self.bias
-        if self._quant_w:
-            weight = self.weight_quantizer(weight)
-            bias = self.weight_quantizer(bias)
+        weight, bias = self.quantized_params()
         if self._fusable(x):
             q = self.activation_quantizer.quantizer
-            return _hip.backend().affine_fake_quant(
+            # feeding integer Linears (MobileBERT's bottlenecks -> query / key): emit the int8 indices in the same launch
+            want_idx = (options.INT8_LINEAR and not q.symmetric and q.n_bits <= 8 and q.scale_domain == 'linear'
+                        and x.is_cuda and x.dtype == torch.float32)
+            out = _hip.backend().affine_fake_quant(
                 x, weight, bias, q._delta, q._zero_float, getattr(q, '_signed', None), q.n_bits,
-                q.symmetric, q.scale_domain == 'log', q.eps)
+                q.symmetric, q.scale_domain == 'log', q.eps, **({'want_idx': True} if want_idx else {}))
+            if want_idx:
+                return provenance.tag(out[0], q, out[1])
+            return out
         return self.quantize_activations(x * weight + bias)
 
 

@@ -58,10 +58,7 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
         gemm = dense.run_forward(x, w, b)                   # hipBLASLt through torch (fp32 simulation)
     if is_nonorm:
         # one weight quantizer serves weight and bias, in this order (upstream quirk, autoquant_utils.QuantNoNorm)
-        ln_w, ln_b = layer_norm.weight, layer_norm.bias
-        if layer_norm._quant_w:
-            ln_w = layer_norm.weight_quantizer(ln_w)
-            ln_b = layer_norm.weight_quantizer(ln_b)
+        ln_w, ln_b = layer_norm.quantized_params()          # cached with fixed ranges in inference
     else:
         ln_w, ln_b = layer_norm.get_params()                # fake-quantized (cached in eval) affine
     arg = lambda q: None if q == 'off' else q
