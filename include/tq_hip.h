@@ -136,6 +136,20 @@ int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_
                      const float* w_delta, uint64_t w_n_params, float w_eps, int activation,
                      const tq_quantizer* q_out, tq_stream_t stream);
 
+/* Linear -> (+ residual) -> NoNorm -> quantizers as one launch (MobileBERT bottlenecks / residual tails; reference
+ * models/quantized_mobilebert.py:58-72 with :287-304, :330-352 behind hijacker.py:66-116):
+ *   residual == NULL:  y = Q_out( Q_dense(lin) * nn_weight + nn_bias )
+ *   else:              y = Q_out( Q_sum( Q_dense(lin) + residual ) * nn_weight + nn_bias )
+ * lin as in tq_linear_i8_fwd (no activation function); residual fp32 [M, N]; nn_weight / nn_bias fp32 [N], already
+ * fake-quantized; every quantizer per-tensor, NULL = identity.  Bit-identical to tq_linear_i8_fwd followed by
+ * tq_residual_nonorm_quant_fwd / tq_affine_fake_quant_fwd.                                                        */
+int tq_linear_i8_nonorm_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum, const float* bias,
+                            const float* residual, const float* nn_weight, const float* nn_bias, void* y,
+                            int8_t* y_idx, int y_dtype, uint64_t M, uint64_t N, uint64_t K, const float* x_delta,
+                            const float* x_zero_float, int x_n_bits, float x_eps, const float* w_delta,
+                            uint64_t w_n_params, float w_eps, const tq_quantizer* q_dense,
+                            const tq_quantizer* q_sum, const tq_quantizer* q_out, tq_stream_t stream);
+
 /* Several quantized Linears that share their input, as ONE launch: the weights (and row sums, biases,
  * per-row weight scales w_delta[N]) of n_groups <= 3 layers are stacked along N; group g owns output
  * columns [g N / n_groups, (g+1) N / n_groups) and has its own per-tensor output quantizer q_out[g]

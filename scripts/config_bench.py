@@ -276,11 +276,17 @@ with torch.no_grad():
     g2 = GraphedForward(mb, ids_mb)
     c['fixed_range_forward_fused_tails_int8_linear_hipgraph_ms'] = wall(lambda: g2(ids_mb), n=30)
     c['int8_max_logit_dev_vs_layered'] = float((g2(ids_mb) - base).abs().max())
-    from harness.mobilebert import QMobileSelfAttention
+    from harness.mobilebert import QBottleneckLayer, QMobileSelfAttention
     QMobileSelfAttention.fuse = True
     g3 = GraphedForward(mb, ids_mb)
     c['fixed_range_forward_fused_tails_int8_linear_int8_attention_hipgraph_ms'] = wall(lambda: g3(ids_mb), n=30)
     c['int8_attention_max_logit_dev_vs_layered'] = float((g3(ids_mb) - base).abs().max())
+    # + NoNorm tails in the GEMM epilogue (tq_linear_i8_nonorm_fwd: QResidualNoNorm.fuse is on already; the bottlenecks too)
+    QBottleneckLayer.fuse = True
+    g4 = GraphedForward(mb, ids_mb)
+    c['fixed_range_forward_all_fused_nonorm_in_gemm_epilogue_hipgraph_ms'] = wall(lambda: g4(ids_mb), n=30)
+    c['nonorm_in_epilogue_equal_to_separate_launches'] = bool(torch.equal(g4(ids_mb), g3(ids_mb)))
+    QBottleneckLayer.fuse = False
     QMobileSelfAttention.fuse = False
     options.INT8_LINEAR = False
     QResidualNoNorm.fuse = False

@@ -198,3 +198,53 @@ def test_integer_linear_in_training_mode_qat_forward():
     for n in gp_l:
         assert torch.allclose(gp_i[n], gp_l[n], rtol=5e-2, atol=5e-3 * float(gp_l[n].abs().max())), n
     assert torch.allclose(gx_i, gx_l, rtol=5e-2, atol=5e-3 * float(gx_l.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(1024, 128, 512), (1024, 512, 128), (256, 512, 512), (4096, 4096, 128), (96, 160, 192)])
+@pytest.mark.parametrize('with_res', [False, True])
+@pytest.mark.parametrize('quantizers', ['all', 'no_dense', 'no_out'])
+def test_linear_i8_nonorm_tail_equals_two_launches(shape, with_res, quantizers):
+    """tq_linear_i8_nonorm_fwd (Linear -> (+ residual -> Q_sum) -> NoNorm -> Q_out in the GEMM epilogue) against the
+    forms it replaces -- tq_linear_i8_fwd without output quantizer, then the quantizers / affine one kernel each, or
+    tq_residual_nonorm_quant_fwd: bit-identical y and indices, on LDS-staged 64 / 128 tiles and the LDS-free kernel."""
+    from quantization import _hip
+    be = _hip.backend()
+    M, N, K = shape
+    p = _problem(M, N, K, 4, 4, False, seed=M + N + K + 7)
+    dev = lambda t: t.cuda()
+    x_i8 = be.quantize_to_int8(dev(p['x_q']), dev(p['xd']), dev(p['xz']), None, 4, False, False, 1e-8, 1, 1, minus_128=True)
+    w_i8 = be.quantize_to_int8(dev(p['w_q']), dev(p['wd']), None, dev(torch.tensor(True)), 4, True, False, 1e-8, 1, 1,
+                               minus_128=False)
+    rs = be.rowsum_i8(w_i8)
+    xq = (dev(p['xd']), dev(p['xz']), 4, 1e-8)
+    wd = dev(p['wd']).reshape(-1)
+    g = torch.Generator().manual_seed(5)
+    res = (torch.randn(M, N, generator=g) * 0.8).cuda() if with_res else None
+    nw = (1 + 0.3 * torch.randn(N, generator=g)).cuda()
+    nb = (0.2 * torch.randn(N, generator=g)).cuda()
+    lin = be.linear_i8(x_i8, w_i8, rs, dev(p['b']), xq, wd, 1e-8, _hip.ACT_NONE, None, torch.float32)
+
+    def q7(lo, hi, bits):
+        d, z = O.asym_params_from_range(lo, hi, bits)
+        return (d.cuda(), z.cuda(), None, bits, False, False, 1e-8)
+    s = float(lin.abs().max())
+    q_dense = None if quantizers == 'no_dense' else q7(-0.8 * s, 0.7 * s, 4)
+    q_sum = q7(-0.9 * s - 1, 0.9 * s + 1, 8) if with_res else None
+    q_out = None if quantizers == 'no_out' else q7(-1.1 * s, 1.2 * s, 4)
+    # the layered form: one kernel per quantizer / affine (each bit-exact against the oracle, tests/test_hip_parity.py)
+    t = lin if q_dense is None else be.fake_quant(lin, *q_dense, 1, 1)[0]
+    if with_res:
+        t = be.fake_quant(t + res, *q_sum, 1, 1)[0]
+    ref = be.affine_fake_quant(t, nw, nb, *q_out, want_idx=True) if q_out is not None else t * nw + nb
+    if with_res and N in (128, 512):        # and the fused tail kernel of the two-launch form
+        two = be.residual_layernorm_quant(lin, res, q_dense, q_sum, nw, nb, None, q_out)
+        assert torch.equal(two, ref[0] if isinstance(ref, tuple) else ref)
+    ref_y, ref_i = (ref if isinstance(ref, tuple) else (ref, None))
+    got = be.linear_i8_nonorm(x_i8, w_i8, rs, dev(p['b']), res, nw, nb, xq, wd, 1e-8, q_dense, q_sum, q_out, torch.float32,
+                              want_idx=q_out is not None)
+    got_y, got_i = (got if isinstance(got, tuple) else (got, None))
+    assert torch.equal(got_y, ref_y)
+    if ref_i is not None:
+        assert torch.equal(got_i, ref_i)
+    yb = be.linear_i8_nonorm(x_i8, w_i8, rs, dev(p['b']), res, nw, nb, xq, wd, 1e-8, q_dense, q_sum, q_out, torch.bfloat16)
+    assert torch.equal(yb, ref_y.to(torch.bfloat16))

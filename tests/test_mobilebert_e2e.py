@@ -193,3 +193,40 @@ def test_mobilebert_integer_attention_core_in_harness():
     assert len(calls) == 2, 'one integer attention launch per layer'
     span = float(layered.max() - layered.min())
     assert torch.isfinite(fast).all() and float((fast - layered).abs().max()) <= 0.05 * span
+
+
+@pytest.mark.gpu
+def test_mobilebert_linear_nonorm_tails_in_gemm_epilogue():
+    """options.INT8_LINEAR with the NoNorm tails fused behind the integer GEMMs (tq_linear_i8_nonorm_fwd: the four
+    residual tails of a layer through QResidualNoNorm.fuse, the two bottlenecks through QBottleneckLayer.fuse): the
+    logits equal those of the integer Linears followed by separate NoNorm / quantizer launches bit for bit -- same
+    integer contraction, same element arithmetic, fewer launches."""
+    from harness.mobilebert import QBottleneckLayer, QResidualNoNorm, build_mobilebert
+    from quantization import _hip, options
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from utils.utils import pass_data_for_range_estimation
+    z = _fixture()
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    model, _ = build_mobilebert(seed=1000, num_layers=2, **qp)
+    model = model.cuda().eval()
+    ids = torch.from_numpy(z['input_ids']).cuda()
+    be = _hip.backend()
+    calls = []
+    orig = be.linear_i8_nonorm
+    with torch.no_grad():
+        pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
+        model.fix_ranges()
+        options.INT8_LINEAR = True
+        try:
+            separate = model(ids)
+            be.linear_i8_nonorm = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            QResidualNoNorm.fuse = QBottleneckLayer.fuse = True
+            fused = model(ids)
+        finally:
+            QResidualNoNorm.fuse = QBottleneckLayer.fuse = False
+            options.INT8_LINEAR = False
+            be.linear_i8_nonorm = orig
+    assert len(calls) >= 2 * 6 - 2, len(calls)        # per layer: 2 bottlenecks + 4 residual tails (the first layer's inputs
+    assert torch.equal(fused, separate)               # come from the embeddings without int8 provenance)

@@ -58,6 +58,16 @@ struct LinArgs {
   tq_quantizer q_out1, q_out2;   // groups 1, 2 of a grouped launch (Q | K | V stacked along N)
   uint32_t group_cols;    // output columns per group (N for a plain launch); multiple of 64
   int fast_epi;           // 0 forces the generic epilogue (TQ_I8_FAST_EPI=0: A/B and tests)
+  // optional NoNorm tail fused behind the output quantizer (MobileBERT; models/quantized_mobilebert.py:58-72, 287-352):
+  //   tail 1:  y = Q_t2( Q_out(v) * nn_w + nn_b )                       bottleneck Linear -> NoNorm
+  //   tail 2:  y = Q_t2( Q_t1( Q_out(v) + residual ) * nn_w + nn_b )    Linear -> + residual -> NoNorm
+  // y / y_idx are then the outputs of Q_t2.  mul and add separate, like the reference's `x * weight + bias`.
+  int tail;
+  const float* residual;  // [M, N] fp32 (tail 2)
+  const float* nn_w;      // [N] fake-quantized NoNorm weight
+  const float* nn_b;      // [N] fake-quantized NoNorm bias
+  tq_quantizer q_t1, q_t2;
+  int on_t1, on_t2;
 };
 
 // ---- epilogue: zero-point correction, scales, bias, activation, output quantizer ----------------------
@@ -148,20 +158,23 @@ template <int YDT> struct StageGeom {
   static constexpr int esize = YDT == TQ_F32 ? 4 : 2;
 };
 
-template <int NI, int MI, int YDT, int ACT, bool HASQ, bool STAGED>
+template <int NI, int MI, int YDT, int ACT, bool HASQ, bool STAGED, int TAIL = 0>
 __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
                                                      int kg, const QF& qf, int shift, float sx, int8_t* stage,
-                                                     const float* cst) {
+                                                     const float* cst, const QF& qf1 = QF{}, const QF& qf2 = QF{}) {
   constexpr int JP = STAGED ? 2 : MI;                   // j tiles per pass (staged: 32 token rows)
   constexpr int NP = 2 * JP;
   constexpr int WTN = NI * 16;                          // output features of this wave
   constexpr int ES = YDT == TQ_F32 ? 4 : 2;
   constexpr int YP = WTN * ES + 16, IP = WTN + 16;      // staging row pitches (y, indices): + 16 B against bank conflicts
-  const f32x2 zpb = {qf.zp, qf.zp};
+  // the quantizer whose grid y (and y_idx) live on: Q_out, or the tail's last quantizer
+  const bool fin_q = TAIL ? (p.on_t2 != 0) : HASQ;
+  const float zfin = TAIL ? qf2.zp : qf.zp;
+  const f32x2 zpb = {zfin, zfin};
   const int lane = kg * 16 + r16;
   int8_t* ystage = stage;
   int8_t* istage = stage + 32 * YP;
-  const bool want_idx = HASQ && p.y_idx != nullptr;
+  const bool want_idx = fin_q && p.y_idx != nullptr;
 #pragma unroll
   for (int h = 0; h < MI / JP; ++h) {
 #pragma unroll
@@ -205,6 +218,42 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
         qf_round2_n<NP>(v, qf, hq);
 #pragma unroll
         for (int e = 0; e < NP; ++e) v[e] = qf.scale * (hq[e] + f32x2{0.0f, 0.0f});
+      }
+      if (TAIL == 2) {                                      // + residual, then the sum quantizer
+#pragma unroll
+        for (int jj = 0; jj < JP; ++jj) {
+          const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(m0 + (h * JP + jj) * 16 + r16) * p.N + n);
+          v[2 * jj] = v[2 * jj] + f32x2{r4.x, r4.y};
+          v[2 * jj + 1] = v[2 * jj + 1] + f32x2{r4.z, r4.w};
+        }
+        if (p.on_t1) {
+          qf_round2_n<NP>(v, qf1, hq);
+#pragma unroll
+          for (int e = 0; e < NP; ++e) v[e] = qf1.scale * (hq[e] + f32x2{0.0f, 0.0f});
+        }
+      }
+      if (TAIL >= 1) {                                      // NoNorm affine (mul, then add), then its output quantizer
+        f32x2 nw[2], nb[2];
+        if (STAGED) {
+          const int col = i * 16 + kg * 4;
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(cst + 6 * WTN + col);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(cst + 8 * WTN + col);
+          nw[0] = f32x2{w4.x, w4.y}; nw[1] = f32x2{w4.z, w4.w};
+          nb[0] = f32x2{b4.x, b4.y}; nb[1] = f32x2{b4.z, b4.w};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { nw[r >> 1][r & 1] = p.nn_w[n + r]; nb[r >> 1][r & 1] = p.nn_b[n + r]; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < JP; ++jj) {
+          v[2 * jj] = v[2 * jj] * nw[0] + nb[0];
+          v[2 * jj + 1] = v[2 * jj + 1] * nw[1] + nb[1];
+        }
+        if (p.on_t2) {
+          qf_round2_n<NP>(v, qf2, hq);
+#pragma unroll
+          for (int e = 0; e < NP; ++e) v[e] = qf2.scale * (hq[e] + f32x2{0.0f, 0.0f});
+        }
       }
 #pragma unroll
       for (int jj = 0; jj < JP; ++jj) {
@@ -286,6 +335,19 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
           oi4.e[r] = (int8_t)((int)xi - 128);
           v = q_dequant(xi, qo);
         }
+        if (p.tail == 2) {
+          v = v + p.residual[at + r];
+          if (p.on_t1) v = q_dequant(q_index(v, make_qp(p.q_t1, 0)), make_qp(p.q_t1, 0));
+        }
+        if (p.tail >= 1) {
+          v = v * p.nn_w[n + r] + p.nn_b[n + r];
+          if (p.on_t2) {
+            const QP q2 = make_qp(p.q_t2, 0);
+            const float xi = q_index(v, q2);
+            oi4.e[r] = (int8_t)((int)xi - 128);
+            v = q_dequant(xi, q2);
+          }
+        }
         o[r] = v;
       }
       if (p.y_idx != nullptr) *reinterpret_cast<uint32_t*>(p.y_idx + at) = __builtin_bit_cast(uint32_t, oi4);
@@ -294,7 +356,7 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
   }
 }
 
-template <int NI, int MI, int YDT, bool STAGED>
+template <int NI, int MI, int YDT, bool STAGED, bool WITH_TAIL>
 __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
                                                 int kg, int8_t* stage = nullptr, const float* cst = nullptr) {
   const float dx = p.x_delta[0];
@@ -307,7 +369,18 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI]
     qo = make_qp(grp == 0 ? p.q_out : (grp == 1 ? p.q_out1 : p.q_out2), 0);
   }
   const QF qf = make_qf(qo);
-  const bool fast = p.act != ACT_TANH && (!p.has_q || qf.ok) && p.fast_epi != 0;
+  bool fast = p.act != ACT_TANH && (!p.has_q || qf.ok) && p.fast_epi != 0;
+  if (WITH_TAIL) {                 // separate kernel instantiation: the plain Linear keeps its register budget
+    const QF qf1 = make_qf(p.on_t1 ? make_qp(p.q_t1, 0) : QP{1.f, 0.f, 0.f, 1.f});
+    const QF qf2 = make_qf(p.on_t2 ? make_qp(p.q_t2, 0) : QP{1.f, 0.f, 0.f, 1.f});
+    fast = fast && p.act == ACT_NONE && qf1.ok && qf2.ok;
+    if (!fast) return linear_epilogue_generic<NI, MI, YDT>(p, acc, n0, m0, r16, kg, qo, shift, sx);
+#define TQ_EPI_T(Q, T) linear_epilogue_fast<NI, MI, YDT, ACT_NONE, Q, STAGED, T>(p, acc, n0, m0, r16, kg, qf, shift, sx, stage, cst, qf1, qf2)
+    if (p.tail == 2) { if (p.has_q) TQ_EPI_T(true, 2); else TQ_EPI_T(false, 2); }
+    else             { if (p.has_q) TQ_EPI_T(true, 1); else TQ_EPI_T(false, 1); }
+#undef TQ_EPI_T
+    return;
+  }
   if (!fast) return linear_epilogue_generic<NI, MI, YDT>(p, acc, n0, m0, r16, kg, qo, shift, sx);
   // wave-uniform dispatch: one straight-line body per (activation, quantizer) combination
 #define TQ_EPI(A, Q) linear_epilogue_fast<NI, MI, YDT, A, Q, STAGED>(p, acc, n0, m0, r16, kg, qf, shift, sx, stage, cst)
@@ -324,7 +397,7 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI]
 }
 
 // K step of 64 bytes, one step of register prefetch (any K % 64 == 0)
-template <int TN, int TM, int YDT>
+template <int TN, int TM, int YDT, bool WITH_TAIL>
 __global__ __launch_bounds__(kBlock) void linear_i8_k(LinArgs p) {
   constexpr int NI = TN / 16, MI = TM / 16;
   const int lane = threadIdx.x & 63;
@@ -370,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void linear_i8_k(LinArgs p) {
       for (int j = 0; j < MI; ++j) fx[j] = nx[j];
     }
   }
-  linear_epilogue<NI, MI, YDT, false>(p, acc, n0, m0, r16, kg);
+  linear_epilogue<NI, MI, YDT, false, WITH_TAIL>(p, acc, n0, m0, r16, kg);
 }
 
 // LDS-staged variant (the fast path).  Measured on MI355X: the LDS-free kernel above is bound by the
@@ -389,7 +462,7 @@ __global__ __launch_bounds__(kBlock) void linear_i8_k(LinArgs p) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp),           \
                                    (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 
-template <int WT, int YDT>
+template <int WT, int YDT, bool WITH_TAIL>
 __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
   constexpr int BT = 2 * WT, NI = WT / 16, MI = WT / 16;
   constexpr int LPW = WT / 16;                    // 1 KB load instructions per wave, operand and slab
@@ -431,7 +504,8 @@ __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
 
   issue(0, 0);
   // per-column epilogue constants (combined scale, bias, zero-point correction) -> LDS behind the stages, while the
-  // first slab is in flight; the loop's first barrier publishes them.  [BT scale | BT bias | BT correction]
+  // first slab is in flight; the loop's first barrier publishes them.  [BT scale | BT bias | BT correction | BT NoNorm
+  // weight | BT NoNorm bias]
   float* cst = reinterpret_cast<float*>(lds_i8 + 2 * STB);
   if (tid < BT) {
     const float dx = p.x_delta[0];
@@ -442,6 +516,7 @@ __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
     cst[tid] = sx * (dw < p.w_eps ? p.w_eps : dw);
     cst[BT + tid] = p.bias ? p.bias[n] : 0.0f;
     reinterpret_cast<int*>(cst)[2 * BT + tid] = p.w_rowsum[n] * (128 - zx);
+    if (WITH_TAIL) { cst[3 * BT + tid] = p.nn_w[n]; cst[4 * BT + tid] = p.nn_b[n]; }
   }
   const uint32_t nk = p.K / 128;
   for (uint32_t kb = 0; kb < nk; ++kb) {
@@ -466,7 +541,7 @@ __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
   __syncthreads();                                // the operand stages become the waves' output staging areas
   constexpr int kStageBytes = 32 * (WT * 4 + 16) + 32 * (WT + 16);
   static_assert(4 * kStageBytes <= 2 * STB, "output staging must fit the operand stages");
-  linear_epilogue<NI, MI, YDT, true>(p, acc, n0 + wn, m0 + wm, r16, kg, lds_i8 + wave * kStageBytes, cst + wn);
+  linear_epilogue<NI, MI, YDT, true, WITH_TAIL>(p, acc, n0 + wn, m0 + wm, r16, kg, lds_i8 + wave * kStageBytes, cst + wn);
 }
 
 // rowsum[n] = sum_k w[n, k]   (once per weight tensor)
@@ -482,22 +557,27 @@ __global__ __launch_bounds__(kBlock) void rowsum_i8_k(const int8_t* __restrict__
   if (lane == 0) out[n] = s;
 }
 
-template <int YDT>
-static int launch_linear(LinArgs a, hipStream_t st) {
-  a.fast_epi = tuning("TQ_I8_FAST_EPI", 1);
+template <int YDT, bool WITH_TAIL>
+static int launch_linear_t(const LinArgs& a, hipStream_t st) {
   if (a.K % 128 == 0 && a.M % 64 == 0 && a.N % 64 == 0 && tuning("TQ_I8_LDS", 1)) {
     // 128 x 128 block tiles once they still give >= 4 blocks per CU, else 64 x 64
     const bool big = a.M % 128 == 0 && a.N % 128 == 0 && (uint64_t)(a.M / 128) * (a.N / 128) >= (uint64_t)tuning("TQ_I8_BIG_MIN", 1024);
-    if (big) hipLaunchKernelGGL((linear_i8_lds_k<64, YDT>), dim3((a.M / 128) * (a.N / 128)), dim3(kBlock),
-                                2 * 2 * 128 * 128 + 3 * 128 * 4, st, a);
-    else     hipLaunchKernelGGL((linear_i8_lds_k<32, YDT>), dim3((a.M / 64) * (a.N / 64)), dim3(kBlock),
-                                2 * 2 * 64 * 128 + 3 * 64 * 4, st, a);
+    if (big) hipLaunchKernelGGL((linear_i8_lds_k<64, YDT, WITH_TAIL>), dim3((a.M / 128) * (a.N / 128)), dim3(kBlock),
+                                2 * 2 * 128 * 128 + 5 * 128 * 4, st, a);
+    else     hipLaunchKernelGGL((linear_i8_lds_k<32, YDT, WITH_TAIL>), dim3((a.M / 64) * (a.N / 64)), dim3(kBlock),
+                                2 * 2 * 64 * 128 + 5 * 64 * 4, st, a);
     return check_launch("linear_i8_lds_k");
   }
   // odd shapes (M, N % 32 == 0, K % 64 == 0): LDS-free kernel, 32 x 32 wave tiles
   const unsigned grid = (unsigned)ceil_div((uint64_t)(a.M / 32) * (a.N / 32), kBlock / kWave);
-  hipLaunchKernelGGL((linear_i8_k<32, 32, YDT>), dim3(grid), dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((linear_i8_k<32, 32, YDT, WITH_TAIL>), dim3(grid), dim3(kBlock), 0, st, a);
   return check_launch("linear_i8_k");
+}
+
+template <int YDT>
+static int launch_linear(LinArgs a, hipStream_t st) {
+  a.fast_epi = tuning("TQ_I8_FAST_EPI", 1);
+  return a.tail ? launch_linear_t<YDT, true>(a, st) : launch_linear_t<YDT, false>(a, st);
 }
 
 }  // namespace tq
@@ -577,6 +657,56 @@ extern "C" int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const 
     TQ_REQUIRE(q_out->n_params == 1, "tq_linear_i8_fwd: per-tensor output quantizer only");
     a.q_out = *q_out;
   }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return y_dtype == TQ_F32 ? launch_linear<TQ_F32>(a, st) : launch_linear<TQ_BF16>(a, st);
+}
+
+// Linear -> (+ residual) -> NoNorm -> quantizers as ONE launch (MobileBERT's bottlenecks and its four residual tails per
+// layer; reference models/quantized_mobilebert.py:58-72 with :287-304, :330-352):
+//   residual == NULL:  y = Q_out( Q_dense(lin) * nn_weight + nn_bias )
+//   else:              y = Q_out( Q_sum( Q_dense(lin) + residual ) * nn_weight + nn_bias ),   lin = F.linear(Q_x(x), Q_w(W), b)
+// Each quantizer may be NULL (identity).  Same integer contraction and the same element arithmetic as
+// tq_linear_i8_fwd followed by tq_residual_nonorm_quant_fwd / tq_affine_fake_quant_fwd: bit-identical results.
+extern "C" int tq_linear_i8_nonorm_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum, const float* bias,
+                                       const float* residual, const float* nn_weight, const float* nn_bias, void* y,
+                                       int8_t* y_idx, int y_dtype, uint64_t M, uint64_t N, uint64_t K, const float* x_delta,
+                                       const float* x_zero_float, int x_n_bits, float x_eps, const float* w_delta,
+                                       uint64_t w_n_params, float w_eps, const tq_quantizer* q_dense,
+                                       const tq_quantizer* q_sum, const tq_quantizer* q_out, tq_stream_t stream) {
+  if (M == 0 || N == 0) return TQ_OK;
+  TQ_REQUIRE(x_idx && w_idx && w_rowsum && y && x_delta && x_zero_float && w_delta && nn_weight && nn_bias,
+             "tq_linear_i8_nonorm_fwd: NULL pointer");
+  TQ_REQUIRE(y_dtype == TQ_F32 || y_dtype == TQ_BF16, "tq_linear_i8_nonorm_fwd: y dtype must be fp32 or bf16");
+  TQ_REQUIRE(M % 32 == 0 && N % 32 == 0 && K % 64 == 0 && K >= 64 && K <= 16384 && M < (1u << 31) && N < (1u << 31),
+             "tq_linear_i8_nonorm_fwd: unsupported shape M=%llu N=%llu K=%llu (M,N %% 32, K %% 64)", (unsigned long long)M,
+             (unsigned long long)N, (unsigned long long)K);
+  TQ_REQUIRE(x_n_bits >= 1 && x_n_bits <= 8, "tq_linear_i8_nonorm_fwd: input quantizer must have <= 8 bits");
+  TQ_REQUIRE(w_n_params == 1 || w_n_params == N, "tq_linear_i8_nonorm_fwd: weight scales must be per-tensor or per-output-channel");
+  TQ_REQUIRE(aligned16(x_idx) && aligned16(w_idx) && aligned16(y) && (residual == nullptr || aligned16(residual)),
+             "tq_linear_i8_nonorm_fwd: 16-byte alignment required");
+  TQ_REQUIRE(q_sum == nullptr || residual != nullptr, "tq_linear_i8_nonorm_fwd: q_sum without a residual");
+  TQ_REQUIRE(y_idx == nullptr || (q_out != nullptr && !q_out->symmetric && q_out->n_bits <= 8),
+             "tq_linear_i8_nonorm_fwd: y_idx needs an asymmetric <= 8-bit output quantizer");
+  LinArgs a{};
+  a.x = x_idx; a.w = w_idx; a.w_rowsum = w_rowsum; a.bias = bias; a.y = y; a.y_idx = y_idx;
+  a.M = (uint32_t)M; a.N = (uint32_t)N; a.K = (uint32_t)K;
+  a.x_delta = x_delta; a.x_zero_float = x_zero_float; a.x_eps = x_eps; a.x_n_bits = x_n_bits;
+  a.w_delta = w_delta; a.w_n_params = (uint32_t)w_n_params; a.w_eps = w_eps; a.act = ACT_NONE;
+  a.group_cols = (uint32_t)N;
+  a.tail = residual != nullptr ? 2 : 1;
+  a.residual = residual; a.nn_w = nn_weight; a.nn_b = nn_bias;
+  const tq_quantizer* qs[3] = {q_dense, q_sum, q_out};
+  for (const tq_quantizer* q : qs)
+    if (q != nullptr) {
+      if (int e = check_quantizer(q, M * N, "tq_linear_i8_nonorm_fwd")) return e;
+      TQ_REQUIRE(q->n_params == 1, "tq_linear_i8_nonorm_fwd: per-tensor quantizers only");
+    }
+  a.has_q = q_dense != nullptr;
+  if (q_dense) a.q_out = *q_dense;
+  a.on_t1 = q_sum != nullptr;
+  if (q_sum) a.q_t1 = *q_sum;
+  a.on_t2 = q_out != nullptr;
+  if (q_out) a.q_t2 = *q_out;
   hipStream_t st = static_cast<hipStream_t>(stream);
   return y_dtype == TQ_F32 ? launch_linear<TQ_F32>(a, st) : launch_linear<TQ_BF16>(a, st);
 }

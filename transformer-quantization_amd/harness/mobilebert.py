@@ -84,7 +84,12 @@ class QBottleneckLayer(QuantizedModel):
         self.dense = quantize_model(hf.dense, **qp)
         self.LayerNorm = QuantNoNorm(hf.LayerNorm, **qp)
 
+    fuse = False   # set True: dense + NoNorm + both quantizers as one integer launch (quantization/fused.py)
+
     def forward(self, h):
+        if self.fuse:
+            from quantization.fused import linear_nonorm_quant
+            return linear_nonorm_quant(self.dense, self.LayerNorm, h)
         return self.LayerNorm(self.dense(h))
 
 

@@ -68,6 +68,8 @@ SIGNATURES = {
                                         _u64, C.POINTER(_QP), _vp]),
     'tq_scores_softmax_quant_fwd': (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _f, _QP, _QP, _vp]),
     'tq_rowsum_i8': (_int, [_vp, _vp, _u64, _u64, _vp]),
+    'tq_linear_i8_nonorm_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f,
+                                       _vp, _u64, _f, _QP, _QP, _QP, _vp]),
     'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
                                 _int, _QP, _vp]),
     'tq_fake_quant_bwd_workspace_bytes': (_sz, [_u64]),
@@ -429,6 +431,26 @@ class HipBackend:
             _ptr(x_idx), _ptr(w_idx), _ptr(w_rowsum), _ptr(bias), _ptr(y), _ptr(y_idx), _DTYPES[out_dtype], M, N, K,
             _ptr(x_q[0]), _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(w_delta), w_delta.numel(),
             float(w_eps), int(activation), None if qd is None else C.byref(qd), _stream())
+        _check(rc, self.lib)
+        return (y, y_idx) if want_idx else y
+
+    def linear_i8_nonorm(self, x_idx, w_idx, w_rowsum, bias, residual, nn_w, nn_b, x_q, w_delta, w_eps, q_dense, q_sum,
+                         q_out, out_dtype, want_idx=False):
+        """Integer Linear -> (+ residual) -> NoNorm -> quantizers in one launch; q_* None or 7-tuples. -> y [, y_idx]."""
+        K = x_idx.shape[-1]
+        M = x_idx.numel() // K
+        N = w_idx.shape[0]
+        y = torch.empty(x_idx.shape[:-1] + (N,), dtype=out_dtype, device=x_idx.device)
+        y_idx = torch.empty(y.shape, dtype=torch.int8, device=y.device) if want_idx else None
+        descs = [None if q is None else self._qdesc(*q, 1, 1) for q in (q_dense, q_sum, q_out)]
+        refs = [None if d is None else C.byref(d) for d in descs]
+        if residual is not None:
+            residual = residual.detach().float().contiguous()
+        rc = self.lib.tq_linear_i8_nonorm_fwd(
+            _ptr(x_idx), _ptr(w_idx), _ptr(w_rowsum), _ptr(bias), _ptr(residual), _ptr(nn_w.detach().float().contiguous()),
+            _ptr(nn_b.detach().float().contiguous()), _ptr(y), _ptr(y_idx), _DTYPES[out_dtype], M, N, K, _ptr(x_q[0]),
+            _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(w_delta), w_delta.numel(), float(w_eps), refs[0], refs[1],
+            refs[2], _stream())
         _check(rc, self.lib)
         return (y, y_idx) if want_idx else y
 

@@ -105,14 +105,13 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
                      oq.scale_domain == 'log', oq.eps)
         return src, act_code, q_out
 
-    def _int8_compute(self, x, plan):
-        """The fused integer Linear itself (no autograd): y [, its int8 indices] or None (unsigned weight grid)."""
-        src, act_code, q_out = plan
+    def _int8_operands(self, x, plan):
+        """Kernel operands of the integer evaluation: (x_idx, w_idx, rowsum, bias, x_q, w_delta, w_eps), or None when
+        the weight grid is unsigned (indices do not fit int8: the layered path runs, counted in INT8_STATS)."""
+        src = plan[0]
         be = _hip.backend()
         w_idx, rowsum, w_signed = self._int8_weights()
         if not w_signed:
-            # all-positive weights use the unsigned grid [0, 2^n): indices do not fit int8.  The layered path runs
-            # instead; counted so that the fallback is visible (INT8_STATS['unsigned_weight_fallbacks']).
             INT8_STATS['unsigned_weight_fallbacks'] += 1
             return None
         x_idx = provenance.indices_of(x)           # emitted by the producing quantizer in the same launch
@@ -120,12 +119,20 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
             x_idx = be.quantize_to_int8(x.detach(), src._delta, src._zero_float, None, src.n_bits, False, False,
                                         src.eps, 1, 1, minus_128=True)
         wq = self.weight_quantizer.quantizer
+        bias = None if self.bias is None else self.bias.detach()
+        return (x_idx, w_idx, rowsum, bias, (src._delta, src._zero_float, src.n_bits, src.eps), wq._delta.reshape(-1),
+                wq.eps)
+
+    def _int8_compute(self, x, plan):
+        """The fused integer Linear itself (no autograd): y [, its int8 indices] or None (unsigned weight grid)."""
+        _, act_code, q_out = plan
+        ops = self._int8_operands(x, plan)
+        if ops is None:
+            return None
         amgr = self.activation_quantizer
         want_idx = q_out is not None and not amgr.quantizer.symmetric and amgr.quantizer.n_bits <= 8
-        bias = None if self.bias is None else self.bias.detach()
         INT8_STATS['kernel_calls'] += 1
-        out = be.linear_i8(x_idx, w_idx, rowsum, bias, (src._delta, src._zero_float, src.n_bits, src.eps),
-                           wq._delta.reshape(-1), wq.eps, act_code, q_out, torch.float32, want_idx=want_idx)
+        out = _hip.backend().linear_i8(*ops[:5], ops[5], ops[6], act_code, q_out, torch.float32, want_idx=want_idx)
         y = out[0] if want_idx else out
         if q_out is not None:
             provenance.tag(y, amgr.quantizer, out[1] if want_idx else None)   # the next integer Linear consumes these

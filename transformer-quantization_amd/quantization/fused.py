@@ -50,6 +50,10 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
                and dense.activation_save_target is None and layer_norm.activation_save_target is None)
     if not fusable:
         return layer_norm(res_quantizer(dense(x) + residual))
+    if is_nonorm:
+        y = _linear_nonorm_i8(dense, layer_norm, x, residual, q1, q2, q3)      # GEMM + whole tail as ONE integer launch
+        if y is not None:
+            return y
     gemm = None
     if options.INT8_LINEAR and hasattr(dense, '_int8_forward'):
         gemm = dense._int8_forward(x, with_output_quantizer=False)     # exact integer GEMM (MFMA i8)
@@ -71,6 +75,50 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
     if oq is not None:
         provenance.tag(y, oq, out[1] if want_idx else None)
     return y
+
+
+def _linear_nonorm_i8(dense, layer_norm, x, residual, q1, q2, q3):
+    """Integer Linear -> (+ residual -> Q_sum) -> NoNorm -> Q_out in one launch (tq_linear_i8_nonorm_fwd), or None when
+    the integer path does not apply to `dense` / `x` (then the caller runs GEMM and tail separately).  Bit-identical to
+    that two-launch form: same integer contraction, same element arithmetic."""
+    if not options.INT8_LINEAR or not hasattr(dense, '_int8_plan') or (residual is not None and (
+            residual.dtype != torch.float32 or not residual.is_cuda)):
+        return None
+    plan = dense._int8_plan(x, with_output_quantizer=False)
+    if plan is None or plan[1] != _hip.ACT_NONE:
+        return None
+    ops = dense._int8_operands(x, plan)
+    if ops is None:
+        return None
+    from quantization.autoquant_utils import INT8_STATS
+    arg = lambda q: None if q == 'off' else q
+    ln_w, ln_b = layer_norm.quantized_params()
+    oq = layer_norm.activation_quantizer.quantizer if q3 != 'off' else None
+    want_idx = oq is not None and not oq.symmetric and oq.n_bits <= 8
+    INT8_STATS['kernel_calls'] += 1
+    out = _hip.backend().linear_i8_nonorm(ops[0], ops[1], ops[2], ops[3], residual, ln_w, ln_b, ops[4], ops[5], ops[6],
+                                          arg(q1), arg(q2), arg(q3), torch.float32, want_idx=want_idx)
+    y = out[0] if want_idx else out
+    if oq is not None:
+        provenance.tag(y, oq, out[1] if want_idx else None)
+    return y
+
+
+def linear_nonorm_quant(dense, layer_norm, x):
+    """MobileBERT bottleneck: ``layer_norm(dense(x))`` with a QuantLinear and a QuantNoNorm, fixed per-tensor ranges:
+    one integer launch when options.INT8_LINEAR applies, the layered modules otherwise."""
+    from quantization.autoquant_utils import QuantNoNorm
+    if (isinstance(layer_norm, QuantNoNorm) and x.is_cuda and x.dtype == torch.float32
+            and dense.activation_function is None and layer_norm.activation_function is None
+            and dense.activation_save_target is None and layer_norm.activation_save_target is None
+            and not (torch.is_grad_enabled() and x.requires_grad)):
+        q1 = _fixed_per_tensor(dense._quant_a, dense.activation_quantizer)
+        q3 = _fixed_per_tensor(layer_norm._quant_a, layer_norm.activation_quantizer)
+        if 'no' not in (q1, q3):
+            y = _linear_nonorm_i8(dense, layer_norm, x, None, q1, 'off', q3)
+            if y is not None:
+                return y
+    return layer_norm(dense(x))
 
 
 def scores_softmax_quant(scores_quantizer, probs_quantizer, scores, mask, denom):
