@@ -154,10 +154,6 @@ __device__ __forceinline__ void store_y4(void* y, size_t at, f32x2 lo, f32x2 hi)
 // instead of 16 rows x 64 B (y) or 16 rows x 16 B (indices) straight from the MFMA accumulator layout -- with
 // non-temporal stores (y is not read again by this kernel; W and X keep the L2).  Measured at M = 8192, N = 3072,
 // K = 768, fp32 y: 48.4 -> 34.5 us for the GEMM + plain store.
-template <int YDT> struct StageGeom {
-  static constexpr int esize = YDT == TQ_F32 ? 4 : 2;
-};
-
 template <int NI, int MI, int YDT, int ACT, bool HASQ, bool STAGED, int TAIL = 0>
 __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
                                                      int kg, const QF& qf, int shift, float sx, int8_t* stage,

@@ -100,7 +100,6 @@ class _GraphedIterations:
                 for it in range(first, iters + 1)]
         self.sched_all = torch.from_numpy(np.asarray(rows, dtype=np.float32)).to(dev)
         self.pos = torch.zeros(1, dtype=torch.int64, device=dev)
-        n_global = self.idx_all.shape[1]
         w = layer.weight
         bias = layer.bias if hasattr(layer, 'bias') else None
 
@@ -124,7 +123,6 @@ class _GraphedIterations:
         with torch.cuda.graph(self.graph):
             self.out, self.cur_out = body()
         optimizer.t = t_before                        # recording executed nothing
-        self.n_global = n_global
 
     def replay(self):
         self.opt.t += 1
