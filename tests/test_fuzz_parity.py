@@ -295,3 +295,79 @@ def test_adaround_kernels_fuzz(seed):
                 assert float(((got - ref).abs() / step).max()) <= 2e-5, (shape, mode, sym, n_bits, per_channel)
             else:
                 assert torch.equal(got, ref), (shape, mode, sym, n_bits, per_channel)
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_integer_linear_epilogue_fuzz(seed):
+    """Seeded fuzz of the integer Linear's fused epilogues: random tile-able shapes (LDS-staged 64 / 128 tiles and the
+    LDS-free kernel), per-tensor / per-channel weight scales, bit widths, activation, output quantizer on / off, index
+    output, NoNorm tail with / without residual and with any subset of its quantizers.  Reference: the SAME integer
+    GEMM without epilogue extras followed by the stand-alone kernels (each bit-exact against the oracle elsewhere):
+    quantizer and NoNorm-tail epilogues must agree bit for bit; GELU (branch-free erf vs libm) within 2.4e-7 before
+    the quantizer and >= 99.95 % identical indices after it."""
+    from quantization import _hip
+    be = _hip.backend()
+    rs = np.random.RandomState(4000 + seed)
+    for case in range(10):
+        M = int(rs.choice([32, 64, 96, 128, 256, 1024]))
+        N = int(rs.choice([32, 64, 128, 160, 512, 768]))
+        K = int(rs.choice([64, 128, 192, 256, 512, 768]))
+        per_channel = bool(rs.randint(2))
+        bw, ba = int(rs.choice([4, 8])), int(rs.choice([4, 6, 8]))
+        g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+        w = torch.randn(N, K, generator=g) * 0.05
+        x = torch.randn(M, K, generator=g) * 1.5 + 0.3
+        b = torch.randn(N, generator=g) * 0.1
+        wd, _ = O.sym_params_from_range(w.amin(1) if per_channel else w.min(), w.amax(1) if per_channel else w.max(), bw)
+        xd, xz = O.asym_params_from_range(x.min(), x.max(), ba)
+        x_i8 = be.quantize_to_int8(x.cuda(), xd.cuda(), xz.cuda(), None, ba, False, False, 1e-8, 1, 1, minus_128=True)
+        w_i8 = be.quantize_to_int8(w.cuda(), wd.cuda(), None, torch.tensor(True).cuda(), bw, True, False, 1e-8,
+                                   N if per_channel else 1, K if per_channel else 1, minus_128=False)
+        rsum = be.rowsum_i8(w_i8)
+        xq = (xd.cuda(), xz.cuda(), ba, 1e-8)
+        wdd = wd.cuda().reshape(-1)
+        lin = be.linear_i8(x_i8, w_i8, rsum, b.cuda(), xq, wdd, 1e-8, _hip.ACT_NONE, None, torch.float32)
+        s = float(lin.abs().max()) + 1e-3
+
+        def q7(lo, hi, bits):
+            d, z = O.asym_params_from_range(lo, hi, bits)
+            return (d.cuda(), z.cuda(), None, bits, False, False, 1e-8)
+        tag = (seed, case, M, N, K, per_channel, bw, ba)
+        # -- output quantizer (+ indices), no activation / ReLU: bit-exact
+        qo = q7(-rs.uniform(0.3, 1.1) * s, rs.uniform(0.3, 1.1) * s, int(rs.choice([4, 8])))
+        for act, fn in ((_hip.ACT_NONE, lambda v: v), (_hip.ACT_RELU, torch.relu)):
+            y, yi = be.linear_i8(x_i8, w_i8, rsum, b.cuda(), xq, wdd, 1e-8, act, qo, torch.float32, want_idx=True)
+            ref_y, ref_i = be.fake_quant(fn(lin), *qo, 1, 1, idx_dtype=torch.float32)
+            assert torch.equal(y, ref_y), tag
+            assert torch.equal(yi.int() + 128, ref_i.int()), tag
+        # -- GELU
+        yg = be.linear_i8(x_i8, w_i8, rsum, b.cuda(), xq, wdd, 1e-8, _hip.ACT_GELU, None, torch.float32)
+        ref_g = torch.nn.functional.gelu(lin)
+        assert float((yg - ref_g).abs().max()) <= 2.4e-7 * max(s, 1.0), tag
+        ygq = be.linear_i8(x_i8, w_i8, rsum, b.cuda(), xq, wdd, 1e-8, _hip.ACT_GELU, qo, torch.float32)
+        same = (ygq == be.fake_quant(ref_g, *qo, 1, 1)[0]).float().mean().item()
+        assert same >= 0.9995, (tag, same)
+        # -- NoNorm tail
+        with_res = bool(rs.randint(2))
+        res = (torch.randn(M, N, generator=g) * 0.5 * s).cuda() if with_res else None
+        nw = (1 + 0.3 * torch.randn(N, generator=g)).cuda()
+        nb = (0.2 * s * torch.randn(N, generator=g)).cuda()
+        q_dense = q7(-0.8 * s, 0.9 * s, int(rs.choice([4, 8]))) if rs.randint(3) else None
+        q_sum = q7(-1.5 * s, 1.4 * s, 8) if (with_res and rs.randint(3)) else None
+        q_out = q7(-1.6 * s, 1.7 * s, int(rs.choice([4, 8]))) if rs.randint(4) else None
+        t = lin if q_dense is None else be.fake_quant(lin, *q_dense, 1, 1)[0]
+        if with_res:
+            t = t + res
+            if q_sum is not None:
+                t = be.fake_quant(t, *q_sum, 1, 1)[0]
+        t = t * nw + nb
+        if q_out is not None:
+            ref_y, ref_i = be.fake_quant(t, *q_out, 1, 1, idx_dtype=torch.float32)
+        else:
+            ref_y, ref_i = t, None
+        got = be.linear_i8_nonorm(x_i8, w_i8, rsum, b.cuda(), res, nw, nb, xq, wdd, 1e-8, q_dense, q_sum, q_out,
+                                  torch.float32, want_idx=q_out is not None)
+        got_y, got_i = got if isinstance(got, tuple) else (got, None)
+        assert torch.equal(got_y, ref_y), (tag, 'tail', with_res, q_dense is None, q_sum is None, q_out is None)
+        if ref_i is not None:
+            assert torch.equal(got_i.int() + 128, ref_i.int()), (tag, 'tail idx')
