@@ -363,3 +363,72 @@ def test_layer_parallel_adaround_equals_single_process(tmp_path):
         for k in (0, 1):
             assert torch.equal(r0['state'][n][k], r1['state'][n][k]), n
             assert torch.equal(r0['state'][n][k], ref_state[n][k]), n
+
+
+# ---- calibration batch smaller than the world: some ranks own an EMPTY shard -------------------------------------------
+def _worker_empty_shard(rank, port, outdir):
+    tq_dist = _setup(rank, port)
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from quantization.quantization_manager import QuantizationManager
+    from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(1, 6, 24, generator=g) * (1 + i) for i in range(2)]        # ONE sample per batch, world 2
+    out = []
+    for method, init, layout, ip in (('asymmetric_uniform', 'running_minmax', None, {}),
+                                     ('symmetric_uniform', 'current_minmax', None, {}),
+                                     ('asymmetric_uniform', 'current_minmax', 'per_embd', {}),
+                                     ('asymmetric_uniform', 'MSE', None, dict(num_candidates=8))):
+        mgr = QuantizationManager(qmethod=QMethods[method], init=RangeEstimators[init],
+                                  qparams=dict(n_bits=4 if init == 'MSE' else 8), init_params=ip)
+        if layout == 'per_embd':
+            set_act_quant_axis_and_groups(mgr, axis=2, n_groups=None)
+        for x in xs:
+            local = tq_dist.shard_batch(x)
+            assert local.shape[0] == (1 if rank == 0 else 0)
+            y = mgr(local)
+            assert y.shape == local.shape
+        out.append((mgr.range_estimator.current_xmin.clone(), mgr.range_estimator.current_xmax.clone(),
+                    mgr.quantizer._delta.clone()))
+    torch.save((out, xs), os.path.join(outdir, f'empty_{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_empty_shards_contribute_the_identity(tmp_path):
+    """A 1-sample calibration batch over 2 ranks (the README recipe's --est-ranges-batch-size 1): rank 1 owns nothing,
+    contributes (+inf, -inf) to the exchanged statistics and zero to the candidate losses, and ends with exactly the
+    ranges rank 0 -- and a single process -- finds."""
+    port = _free_port()
+    mp.spawn(_worker_empty_shard, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    r0, xs = torch.load(os.path.join(tmp_path, 'empty_0.pt'), weights_only=False)
+    r1, _ = torch.load(os.path.join(tmp_path, 'empty_1.pt'), weights_only=False)
+    from quantization import _hip, distributed as tq_dist
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from quantization.quantization_manager import QuantizationManager
+    from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+    from tests._oracle_backend import OracleBackend
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        tq_dist.disable()
+        ref = []
+        for method, init, layout, ip in (('asymmetric_uniform', 'running_minmax', None, {}),
+                                         ('symmetric_uniform', 'current_minmax', None, {}),
+                                         ('asymmetric_uniform', 'current_minmax', 'per_embd', {}),
+                                         ('asymmetric_uniform', 'MSE', None, dict(num_candidates=8))):
+            mgr = QuantizationManager(qmethod=QMethods[method], init=RangeEstimators[init],
+                                      qparams=dict(n_bits=4 if init == 'MSE' else 8), init_params=ip)
+            if layout == 'per_embd':
+                set_act_quant_axis_and_groups(mgr, axis=2, n_groups=None)
+            for x in xs:
+                mgr(x)
+            ref.append((mgr.range_estimator.current_xmin.clone(), mgr.range_estimator.current_xmax.clone(),
+                        mgr.quantizer._delta.clone()))
+        with pytest.raises(Exception):          # not sharded: an empty tensor stays an error, as in the reference
+            QuantizationManager(qmethod=QMethods.asymmetric_uniform, init=RangeEstimators.current_minmax,
+                                qparams=dict(n_bits=8))(torch.zeros(0, 4))
+    finally:
+        _hip.set_backend(prev)
+    for a, b, r in zip(r0, r1, ref):
+        for k in range(3):
+            assert torch.equal(a[k], b[k]) and torch.equal(a[k], r[k])

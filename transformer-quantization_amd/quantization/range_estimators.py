@@ -71,20 +71,32 @@ class RangeEstimatorBase(nn.Module):
         return self._get_name() + '(' + extra + ')'
 
     # ---- shared kernel plumbing --------------------------------------------------------
+    @staticmethod
+    def _local_minmax(x, n_params, inner):
+        """Batch statistics of this rank's shard.  A rank whose shard is EMPTY (calibration batch smaller than the
+        world size, e.g. the README recipe's --est-ranges-batch-size 1 over 8 GPUs) contributes the identity of the
+        MAX all-reduce of [-min | max]; without sharding an empty tensor is an error, as in the reference."""
+        if x.numel() == 0 and tq_dist.is_enabled():
+            dt = torch.float64 if x.dtype == torch.float64 else torch.float32
+            shape = () if n_params == 1 else (n_params,)
+            return (torch.full(shape, float('inf'), dtype=dt, device=x.device),
+                    torch.full(shape, float('-inf'), dtype=dt, device=x.device))
+        return _hip.backend().minmax(x, n_params, inner)
+
     def _axis_stats(self, x):
         """min/max per index of self.axis, all-reduced across ranks if sharded."""
         inner = 1
         for s in x.shape[self.axis + 1:]:
             inner *= s
-        mn, mx = _hip.backend().minmax(x, x.shape[self.axis], inner)
+        mn, mx = self._local_minmax(x, x.shape[self.axis], inner)
         return tq_dist.sync_minmax(mn, mx)
 
     def _channel_stats(self, x):
-        mn, mx = _hip.backend().minmax(x, x.shape[0], x.numel() // x.shape[0])
+        mn, mx = self._local_minmax(x, x.shape[0], x.numel() // max(x.shape[0], 1))
         return tq_dist.sync_minmax(mn, mx)
 
     def _tensor_stats(self, x):
-        mn, mx = _hip.backend().minmax(x, 1, 1)
+        mn, mx = self._local_minmax(x, 1, 1)
         return tq_dist.sync_minmax(mn, mx)
 
 
