@@ -128,10 +128,10 @@ def sync_minmax(mn, mx):
         return mn, mx
     shape = mn.shape
     buf = torch.cat([(-mn).reshape(-1), mx.reshape(-1)])
-    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=_group)
+    # the same exchange as the fused step's (mailbox or RCCL): a rank on the layered path -- e.g. one whose shard is
+    # empty -- must meet its peers in the same collective
+    sync_max_inplace(buf)
     n = buf.numel() // 2
-    _stats['minmax_calls'] += 1
-    _stats['bytes'] += buf.numel() * buf.element_size()
     return (-buf[:n]).reshape(shape), buf[n:].reshape(shape)
 
 
