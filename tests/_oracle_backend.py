@@ -214,6 +214,8 @@ class OracleBackend:
         return self.mse_candidates(xg, n_groups, cand, loss)
 
     def xent_candidates(self, x, cand, loss):
+        if x.numel() == 0:
+            return loss
         xf = x.detach().float().reshape(x.shape[0], -1)
         for ci in range(cand.shape[0]):
             y = self._table_quant(xf, cand[ci])

@@ -378,12 +378,15 @@ def _worker_empty_shard(rank, port, outdir):
     for method, init, layout, ip in (('asymmetric_uniform', 'running_minmax', None, {}),
                                      ('symmetric_uniform', 'current_minmax', None, {}),
                                      ('asymmetric_uniform', 'current_minmax', 'per_embd', {}),
-                                     ('asymmetric_uniform', 'MSE', None, dict(num_candidates=8))):
+                                     ('asymmetric_uniform', 'MSE', None, dict(num_candidates=8)),
+                                     ('asymmetric_uniform', 'cross_entropy', 'logits', dict(num_candidates=8))):
         mgr = QuantizationManager(qmethod=QMethods[method], init=RangeEstimators[init],
                                   qparams=dict(n_bits=4 if init == 'MSE' else 8), init_params=ip)
         if layout == 'per_embd':
             set_act_quant_axis_and_groups(mgr, axis=2, n_groups=None)
         for x in xs:
+            if layout == 'logits':
+                x = x[:, 0, :3].contiguous()
             local = tq_dist.shard_batch(x)
             assert local.shape[0] == (1 if rank == 0 else 0)
             y = mgr(local)
@@ -415,13 +418,14 @@ def test_empty_shards_contribute_the_identity(tmp_path):
         for method, init, layout, ip in (('asymmetric_uniform', 'running_minmax', None, {}),
                                          ('symmetric_uniform', 'current_minmax', None, {}),
                                          ('asymmetric_uniform', 'current_minmax', 'per_embd', {}),
-                                         ('asymmetric_uniform', 'MSE', None, dict(num_candidates=8))):
+                                         ('asymmetric_uniform', 'MSE', None, dict(num_candidates=8)),
+                                         ('asymmetric_uniform', 'cross_entropy', 'logits', dict(num_candidates=8))):
             mgr = QuantizationManager(qmethod=QMethods[method], init=RangeEstimators[init],
                                       qparams=dict(n_bits=4 if init == 'MSE' else 8), init_params=ip)
             if layout == 'per_embd':
                 set_act_quant_axis_and_groups(mgr, axis=2, n_groups=None)
             for x in xs:
-                mgr(x)
+                mgr(x[:, 0, :3].contiguous() if layout == 'logits' else x)
             ref.append((mgr.range_estimator.current_xmin.clone(), mgr.range_estimator.current_xmax.clone(),
                         mgr.quantizer._delta.clone()))
         with pytest.raises(Exception):          # not sharded: an empty tensor stays an error, as in the reference

@@ -789,6 +789,8 @@ class HipBackend:
                           'use min-max or MSE estimators with --double')
         x = x.detach().float().contiguous()
         rows = x.shape[0]
+        if x.numel() == 0:
+            return loss                   # an empty shard adds nothing to the candidate losses
         cols = x.numel() // rows
         rc = self.lib.tq_xent_candidates(_ptr(x), rows, cols, _ptr(cand), cand.shape[0], _ptr(loss),
                                          _stream())
