@@ -436,3 +436,55 @@ def test_empty_shards_contribute_the_identity(tmp_path):
     for a, b, r in zip(r0, r1, ref):
         for k in range(3):
             assert torch.equal(a[k], b[k]) and torch.equal(a[k], r[k])
+
+
+def _one_layer_bert():
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from tests.harness_bert import build_bert_base
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.current_minmax)
+    model, _ = build_bert_base(seed=1000, num_layers=1, **qp)
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(1000, 30000, (1, 16), generator=g)                  # ONE calibration sample
+    return model.eval(), ids
+
+
+def _bert_ranges(model):
+    from tests.harness_bert import quantizer_census
+    act, _ = quantizer_census(model)
+    return torch.stack([torch.stack([m.range_estimator.current_xmin.reshape(()), m.range_estimator.current_xmax.reshape(())])
+                        for _, m in act if m.quantizer.is_initialized])
+
+
+def _worker_bert_one_sample(rank, port, outdir):
+    _setup(rank, port)
+    from utils.utils import pass_data_for_range_estimation
+    model, ids = _one_layer_bert()
+    with torch.no_grad():
+        pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
+    torch.save(_bert_ranges(model), os.path.join(outdir, f'bert1_{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_whole_model_calibration_with_one_sample_over_two_ranks(tmp_path):
+    """The README recipe's calibration (ONE sample, utils.pass_data_for_range_estimation) sharded over 2 ranks: rank 1
+    runs the whole model on an empty batch, and both ranks end with the single-process activation ranges."""
+    port = _free_port()
+    mp.spawn(_worker_bert_one_sample, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    from quantization import _hip, distributed as tq_dist
+    from tests._oracle_backend import OracleBackend
+    from utils.utils import pass_data_for_range_estimation
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        tq_dist.disable()
+        model, ids = _one_layer_bert()
+        with torch.no_grad():
+            pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
+        ref = _bert_ranges(model)
+    finally:
+        _hip.set_backend(prev)
+    r0 = torch.load(os.path.join(tmp_path, 'bert1_0.pt'), weights_only=False)
+    r1 = torch.load(os.path.join(tmp_path, 'bert1_1.pt'), weights_only=False)
+    assert r0.shape == ref.shape and r0.shape[0] > 10
+    assert torch.equal(r0, r1) and torch.equal(r0, ref)

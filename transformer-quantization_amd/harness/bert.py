@@ -89,7 +89,8 @@ class QSelfAttention(QuantizedModel):
                 scores = scores + mask
             probs = self.attn_probs_act_quantizer(torch.softmax(scores, dim=-1))
         ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).contiguous()
-        return self.context_act_quantizer(ctx.view(ctx.shape[0], ctx.shape[1], -1))
+        # explicit width: an empty batch (a rank without calibration samples) has no elements to infer it from
+        return self.context_act_quantizer(ctx.view(ctx.shape[0], ctx.shape[1], self.heads * self.head_dim))
 
 
 class QResidualBlock(QuantizedModel):

@@ -139,7 +139,7 @@ class QMobileSelfAttention(QuantizedModel):
         probs = self.attn_probs_act_quantizer(torch.softmax(scores, dim=-1))
         ctx = self.attn_output_act_quantizer(torch.matmul(probs, v))              # quantized per head, before the merge
         ctx = ctx.permute(0, 2, 1, 3).contiguous()
-        return ctx.view(ctx.shape[0], ctx.shape[1], -1)
+        return ctx.view(ctx.shape[0], ctx.shape[1], self.heads * self.head_dim)
 
 
 class QResidualNoNorm(QuantizedModel):
