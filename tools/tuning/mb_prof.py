@@ -15,9 +15,10 @@ with torch.no_grad():
     mb(ids)
     mb.fix_ranges()
     if mode == 'fast':
-        from harness.mobilebert import QMobileSelfAttention
+        from harness.mobilebert import QBottleneckLayer, QMobileSelfAttention
         QResidualNoNorm.fuse = True
         QMobileSelfAttention.fuse = True
+        QBottleneckLayer.fuse = True
         options.INT8_LINEAR = True
     for _ in range(3):
         mb(ids)
