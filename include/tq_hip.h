@@ -150,6 +150,21 @@ int tq_linear_i8_nonorm_fwd(const int8_t* x_idx, const int8_t* w_idx, const int3
                             uint64_t w_n_params, float w_eps, const tq_quantizer* q_dense,
                             const tq_quantizer* q_sum, const tq_quantizer* q_out, tq_stream_t stream);
 
+/* MobileBERT feed-forward block as ONE launch (reference models/quantized_mobilebert.py:330-352, hijacker.py:66-116):
+ *   y = Q_out( Q_sum( Q_dense( lin2( Q_mid( relu( lin1(x) ) ) ) ) + residual ) * nn_weight + nn_bias )
+ * lin1: [N1, K1] with ReLU and the intermediate quantizer q_mid (per-tensor, asymmetric, <= 8 bit), lin2: [N2, N1], then the
+ * NoNorm tail of tq_linear_i8_nonorm_fwd.  The [M, N1] intermediate never leaves the CU (its int8 indices are written
+ * into LDS in the layout the second GEMM reads).  Built for (K1, N1, N2) = (128, 512, 128), M % 32 == 0; other shapes
+ * return TQ_EINVAL.  Bit-identical to tq_linear_i8_fwd followed by tq_linear_i8_nonorm_fwd.                          */
+int tq_ffn_i8_nonorm_fwd(const int8_t* x_idx, const float* x_delta, const float* x_zero_float, int x_n_bits, float x_eps,
+                         const int8_t* w1_idx, const int32_t* w1_rowsum, const float* bias1, const float* w1_delta,
+                         uint64_t w1_n_params, float w1_eps, const tq_quantizer* q_mid, const int8_t* w2_idx,
+                         const int32_t* w2_rowsum, const float* bias2, const float* w2_delta, uint64_t w2_n_params,
+                         float w2_eps, const float* residual, const float* nn_weight, const float* nn_bias,
+                         const tq_quantizer* q_dense, const tq_quantizer* q_sum, const tq_quantizer* q_out, void* y,
+                         int8_t* y_idx, int y_dtype, uint64_t M, uint64_t K1, uint64_t N1, uint64_t N2,
+                         tq_stream_t stream);
+
 /* Several quantized Linears that share their input, as ONE launch: the weights (and row sums, biases,
  * per-row weight scales w_delta[N]) of n_groups <= 3 layers are stacked along N; group g owns output
  * columns [g N / n_groups, (g+1) N / n_groups) and has its own per-tensor output quantizer q_out[g]

@@ -248,3 +248,60 @@ def test_linear_i8_nonorm_tail_equals_two_launches(shape, with_res, quantizers):
         assert torch.equal(got_i, ref_i)
     yb = be.linear_i8_nonorm(x_i8, w_i8, rs, dev(p['b']), res, nw, nb, xq, wd, 1e-8, q_dense, q_sum, q_out, torch.bfloat16)
     assert torch.equal(yb, ref_y.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize('M', [32, 1024, 4096])
+@pytest.mark.parametrize('quantizers', ['all', 'no_dense', 'no_sum', 'no_out'])
+@pytest.mark.parametrize('per_channel', [False, True])
+def test_ffn_i8_block_equals_two_launches(M, quantizers, per_channel):
+    """tq_ffn_i8_nonorm_fwd -- MobileBERT's feed-forward block (128 -> 512 ReLU quant -> 128, residual NoNorm tail) as one
+    launch with the intermediate kept in LDS -- against tq_linear_i8_fwd followed by tq_linear_i8_nonorm_fwd: bit-identical
+    y and indices (same integer contractions, same element arithmetic)."""
+    from quantization import _hip
+    be = _hip.backend()
+    K1, N1, N2 = 128, 512, 128
+    g = torch.Generator().manual_seed(M + 17 * per_channel)
+    x = torch.randn(M, K1, generator=g) * 1.2 + 0.2
+    w1 = torch.randn(N1, K1, generator=g) * 0.08
+    w2 = torch.randn(N2, N1, generator=g) * 0.06
+    b1, b2 = torch.randn(N1, generator=g) * 0.1, torch.randn(N2, generator=g) * 0.1
+    res = (torch.randn(M, N2, generator=g) * 0.7).cuda()
+    nw, nb = (1 + 0.3 * torch.randn(N2, generator=g)).cuda(), (0.2 * torch.randn(N2, generator=g)).cuda()
+    xd, xz = O.asym_params_from_range(x.min(), x.max(), 4)
+
+    def wq(w, bits):
+        d, _ = O.sym_params_from_range(w.amin(1) if per_channel else w.min(), w.amax(1) if per_channel else w.max(), bits)
+        n = w.shape[0] if per_channel else 1
+        wi = be.quantize_to_int8(w.cuda(), d.cuda(), None, torch.tensor(True).cuda(), bits, True, False, 1e-8, n,
+                                 w.shape[1] if per_channel else 1, minus_128=False)
+        return wi, be.rowsum_i8(wi), d.cuda().reshape(-1)
+    w1i, rs1, w1d = wq(w1, 4)
+    w2i, rs2, w2d = wq(w2, 4)
+    x_i8 = be.quantize_to_int8(x.cuda(), xd.cuda(), xz.cuda(), None, 4, False, False, 1e-8, 1, 1, minus_128=True)
+    xq = (xd.cuda(), xz.cuda(), 4, 1e-8)
+
+    def q7(lo, hi, bits):
+        d, z = O.asym_params_from_range(lo, hi, bits)
+        return (d.cuda(), z.cuda(), None, bits, False, False, 1e-8)
+    pre = be.linear_i8(x_i8, w1i, rs1, b1.cuda(), xq, w1d, 1e-8, _hip.ACT_RELU, None, torch.float32)
+    q_mid = q7(0.0, 0.8 * float(pre.max()), 4)
+    # two launches
+    h, h_idx = be.linear_i8(x_i8, w1i, rs1, b1.cuda(), xq, w1d, 1e-8, _hip.ACT_RELU, q_mid, torch.float32, want_idx=True)
+    mid_q = (q_mid[0], q_mid[1], 4, 1e-8)
+    lin2 = be.linear_i8(h_idx, w2i, rs2, b2.cuda(), mid_q, w2d, 1e-8, _hip.ACT_NONE, None, torch.float32)
+    s = float(lin2.abs().max())
+    q_dense = None if quantizers == 'no_dense' else q7(-0.8 * s, 0.9 * s, 4)
+    q_sum = None if quantizers == 'no_sum' else q7(-1.2 * s - 1, 1.1 * s + 1, 8)
+    q_out = None if quantizers == 'no_out' else q7(-1.5 * s, 1.4 * s, 4)
+    ref = be.linear_i8_nonorm(h_idx, w2i, rs2, b2.cuda(), res, nw, nb, mid_q, w2d, 1e-8, q_dense, q_sum, q_out,
+                              torch.float32, want_idx=q_out is not None)
+    got = be.ffn_i8_nonorm(x_i8, xq, w1i, rs1, b1.cuda(), w1d, 1e-8, q_mid, w2i, rs2, b2.cuda(), w2d, 1e-8, res, nw, nb,
+                           q_dense, q_sum, q_out, torch.float32, want_idx=q_out is not None)
+    ref_y, ref_i = ref if isinstance(ref, tuple) else (ref, None)
+    got_y, got_i = got if isinstance(got, tuple) else (got, None)
+    assert torch.equal(got_y, ref_y)
+    if ref_i is not None:
+        assert torch.equal(got_i, ref_i)
+    yb = be.ffn_i8_nonorm(x_i8, xq, w1i, rs1, b1.cuda(), w1d, 1e-8, q_mid, w2i, rs2, b2.cuda(), w2d, 1e-8, res, nw, nb,
+                          q_dense, q_sum, q_out, torch.bfloat16)
+    assert torch.equal(yb, ref_y.to(torch.bfloat16))

@@ -201,7 +201,7 @@ def test_mobilebert_linear_nonorm_tails_in_gemm_epilogue():
     residual tails of a layer through QResidualNoNorm.fuse, the two bottlenecks through QBottleneckLayer.fuse): the
     logits equal those of the integer Linears followed by separate NoNorm / quantizer launches bit for bit -- same
     integer contraction, same element arithmetic, fewer launches."""
-    from harness.mobilebert import QBottleneckLayer, QResidualNoNorm, build_mobilebert
+    from harness.mobilebert import QBottleneckLayer, QFFN, QResidualNoNorm, build_mobilebert
     from quantization import _hip, options
     from quantization.quantizers import QMethods
     from quantization.range_estimators import RangeEstimators
@@ -224,9 +224,20 @@ def test_mobilebert_linear_nonorm_tails_in_gemm_epilogue():
             be.linear_i8_nonorm = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
             QResidualNoNorm.fuse = QBottleneckLayer.fuse = True
             fused = model(ids)
+            # + the four feed-forward blocks of a layer as one launch each (tq_ffn_i8_nonorm_fwd)
+            ffn_calls = []
+            orig_ffn = be.ffn_i8_nonorm
+            be.ffn_i8_nonorm = lambda *a, **k: (ffn_calls.append(1), orig_ffn(*a, **k))[1]
+            QFFN.fuse = True
+            try:
+                fused_ffn = model(ids)
+            finally:
+                QFFN.fuse = False
+                be.ffn_i8_nonorm = orig_ffn
         finally:
             QResidualNoNorm.fuse = QBottleneckLayer.fuse = False
             options.INT8_LINEAR = False
             be.linear_i8_nonorm = orig
     assert len(calls) >= 2 * 6 - 2, len(calls)        # per layer: 2 bottlenecks + 4 residual tails (the first layer's inputs
     assert torch.equal(fused, separate)               # come from the embeddings without int8 provenance)
+    assert len(ffn_calls) == 2 * 4 and torch.equal(fused_ffn, separate)

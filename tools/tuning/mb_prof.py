@@ -15,10 +15,11 @@ with torch.no_grad():
     mb(ids)
     mb.fix_ranges()
     if mode == 'fast':
-        from harness.mobilebert import QBottleneckLayer, QMobileSelfAttention
+        from harness.mobilebert import QBottleneckLayer, QFFN, QMobileSelfAttention
         QResidualNoNorm.fuse = True
         QMobileSelfAttention.fuse = True
         QBottleneckLayer.fuse = True
+        QFFN.fuse = True
         options.INT8_LINEAR = True
     for _ in range(3):
         mb(ids)

@@ -157,8 +157,11 @@ __device__ __forceinline__ void store_y4(void* y, size_t at, f32x2 lo, f32x2 hi)
 template <int NI, int MI, int YDT, int ACT, bool HASQ, bool STAGED, int TAIL = 0>
 __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
                                                      int kg, const QF& qf, int shift, float sx, int8_t* stage,
-                                                     const float* cst, const QF& qf1 = QF{}, const QF& qf2 = QF{}) {
-  constexpr int JP = STAGED ? 2 : MI;                   // j tiles per pass (staged: 32 token rows)
+                                                     const float* cst, const QF& qf1 = QF{}, const QF& qf2 = QF{},
+                                                     int cs = 2 * NI * 16 /* floats between the arrays of `cst` */,
+                                                     const f32x4 (*res_pre)[MI] = nullptr /* residual fetched early */) {
+  constexpr int JP = STAGED ? (MI >= 2 ? 2 : 1) : MI;   // j tiles per pass (staged: 32 token rows, 16 for a 16-row tile)
+  constexpr int PR = JP * 16;                           // token rows per staged pass
   constexpr int NP = 2 * JP;
   constexpr int WTN = NI * 16;                          // output features of this wave
   constexpr int ES = YDT == TQ_F32 ? 4 : 2;
@@ -169,7 +172,7 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
   const f32x2 zpb = {zfin, zfin};
   const int lane = kg * 16 + r16;
   int8_t* ystage = stage;
-  int8_t* istage = stage + 32 * YP;
+  int8_t* istage = stage + PR * YP;
   const bool want_idx = fin_q && p.y_idx != nullptr;
 #pragma unroll
   for (int h = 0; h < MI / JP; ++h) {
@@ -181,8 +184,8 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
       if (STAGED) {                                        // per-column constants prepared in LDS by the kernel prologue
         const int col = i * 16 + kg * 4;
         const f32x4 s4 = *reinterpret_cast<const f32x4*>(cst + col);
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(cst + 2 * WTN + col);
-        const v4i r4 = *reinterpret_cast<const v4i*>(cst + 4 * WTN + col);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(cst + cs + col);
+        const v4i r4 = *reinterpret_cast<const v4i*>(cst + 2 * cs + col);
         sw[0] = f32x2{s4.x, s4.y}; sw[1] = f32x2{s4.z, s4.w};
         bs[0] = f32x2{b4.x, b4.y}; bs[1] = f32x2{b4.z, b4.w};
         rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
@@ -218,7 +221,8 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
       if (TAIL == 2) {                                      // + residual, then the sum quantizer
 #pragma unroll
         for (int jj = 0; jj < JP; ++jj) {
-          const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(m0 + (h * JP + jj) * 16 + r16) * p.N + n);
+          const f32x4 r4 = res_pre != nullptr ? res_pre[i][h * JP + jj]
+                                              : *reinterpret_cast<const f32x4*>(p.residual + (size_t)(m0 + (h * JP + jj) * 16 + r16) * p.N + n);
           v[2 * jj] = v[2 * jj] + f32x2{r4.x, r4.y};
           v[2 * jj + 1] = v[2 * jj + 1] + f32x2{r4.z, r4.w};
         }
@@ -232,8 +236,8 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
         f32x2 nw[2], nb[2];
         if (STAGED) {
           const int col = i * 16 + kg * 4;
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(cst + 6 * WTN + col);
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(cst + 8 * WTN + col);
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(cst + 3 * cs + col);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(cst + 4 * cs + col);
           nw[0] = f32x2{w4.x, w4.y}; nw[1] = f32x2{w4.z, w4.w};
           nb[0] = f32x2{b4.x, b4.y}; nb[1] = f32x2{b4.z, b4.w};
         } else {
@@ -275,23 +279,25 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
     }
     if (STAGED) {
       // wave-private staging: program order (+ the compiler's lgkmcnt) is all the synchronisation needed
-      const uint32_t mrow0 = m0 + h * 32;
+      const uint32_t mrow0 = m0 + h * PR;
       if (p.y != nullptr) {
         constexpr int LPR = WTN * ES / 16, RPI = 64 / LPR;   // lanes per row, rows per store instruction
 #pragma unroll
-        for (int t = 0; t < 32 / RPI; ++t) {
+        for (int t = 0; t < (PR + RPI - 1) / RPI; ++t) {
           const int row = t * RPI + lane / LPR;
-          const u32x4 d = *reinterpret_cast<const u32x4*>(ystage + row * YP + (lane % LPR) * 16);
-          __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(static_cast<int8_t*>(p.y) + ((size_t)(mrow0 + row) * p.N + n0) * ES +
-                                                                  (lane % LPR) * 16));
+          if (RPI <= PR || row < PR) {
+            const u32x4 d = *reinterpret_cast<const u32x4*>(ystage + row * YP + (lane % LPR) * 16);
+            __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(static_cast<int8_t*>(p.y) +
+                                                                    ((size_t)(mrow0 + row) * p.N + n0) * ES + (lane % LPR) * 16));
+          }
         }
       }
       if (want_idx) {
         constexpr int LPR = WTN / 16, RPI = 64 / LPR;
 #pragma unroll
-        for (int t = 0; t < (32 + RPI - 1) / RPI; ++t) {
+        for (int t = 0; t < (PR + RPI - 1) / RPI; ++t) {
           const int row = t * RPI + lane / LPR;
-          if (RPI <= 32 || row < 32) {
+          if (RPI <= PR || row < PR) {
             const u32x4 d = *reinterpret_cast<const u32x4*>(istage + row * IP + (lane % LPR) * 16);
             *reinterpret_cast<u32x4*>(p.y_idx + (size_t)(mrow0 + row) * p.N + n0 + (lane % LPR) * 16) = d;
           }
@@ -352,34 +358,55 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
   }
 }
 
-template <int NI, int MI, int YDT, bool STAGED, bool WITH_TAIL>
-__device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
-                                                int kg, int8_t* stage = nullptr, const float* cst = nullptr) {
+// Everything the epilogue reads through pointers -- the quantizers' range buffers, the input scale / zero point -- as
+// values.  The LDS kernels build it BEFORE the main loop: the scalar loads (~1 us cold each, partly dependent) then
+// overlap with the operand fetches instead of sitting exposed between the last MFMA and the first store (measured on
+// the feed-forward block kernel: 2.8 us of its 7 us were this epilogue's load latency).
+struct EpiCtx {
+  QP qo;
+  QF qf, qf1, qf2;
+  float sx;
+  int shift;
+  bool fast;
+};
+
+template <bool WITH_TAIL>
+__device__ __forceinline__ EpiCtx epilogue_prepare(const LinArgs& p, uint32_t n0) {
+  EpiCtx c;
   const float dx = p.x_delta[0];
-  const float sx = dx < p.x_eps ? p.x_eps : dx;
+  c.sx = dx < p.x_eps ? p.x_eps : dx;
   const int zx = (int)clamp_nanprop(rintf(p.x_zero_float[0]), 0.0f, grid_top(p.x_n_bits));
-  const int shift = 128 - zx;
-  QP qo = {1.f, 0.f, 0.f, 0.f};
+  c.shift = 128 - zx;
+  c.qo = QP{1.f, 0.f, 0.f, 0.f};
   if (p.has_q) {
     const uint32_t grp = n0 / p.group_cols;             // a block tile never straddles two groups
-    qo = make_qp(grp == 0 ? p.q_out : (grp == 1 ? p.q_out1 : p.q_out2), 0);
+    c.qo = make_qp(grp == 0 ? p.q_out : (grp == 1 ? p.q_out1 : p.q_out2), 0);
   }
-  const QF qf = make_qf(qo);
-  bool fast = p.act != ACT_TANH && (!p.has_q || qf.ok) && p.fast_epi != 0;
+  c.qf = make_qf(c.qo);
+  c.fast = p.act != ACT_TANH && (!p.has_q || c.qf.ok) && p.fast_epi != 0;
+  c.qf1 = c.qf2 = c.qf;
+  if (WITH_TAIL) {
+    c.qf1 = make_qf(p.on_t1 ? make_qp(p.q_t1, 0) : QP{1.f, 0.f, 0.f, 1.f});
+    c.qf2 = make_qf(p.on_t2 ? make_qp(p.q_t2, 0) : QP{1.f, 0.f, 0.f, 1.f});
+    c.fast = c.fast && p.act == ACT_NONE && c.qf1.ok && c.qf2.ok;
+  }
+  return c;
+}
+
+template <int NI, int MI, int YDT, bool STAGED, bool WITH_TAIL>
+__device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
+                                                int kg, const EpiCtx& c, int8_t* stage = nullptr, const float* cst = nullptr,
+                                                int cs = 2 * NI * 16, const f32x4 (*res_pre)[MI] = nullptr) {
+  if (!c.fast) return linear_epilogue_generic<NI, MI, YDT>(p, acc, n0, m0, r16, kg, c.qo, c.shift, c.sx);
   if (WITH_TAIL) {                 // separate kernel instantiation: the plain Linear keeps its register budget
-    const QF qf1 = make_qf(p.on_t1 ? make_qp(p.q_t1, 0) : QP{1.f, 0.f, 0.f, 1.f});
-    const QF qf2 = make_qf(p.on_t2 ? make_qp(p.q_t2, 0) : QP{1.f, 0.f, 0.f, 1.f});
-    fast = fast && p.act == ACT_NONE && qf1.ok && qf2.ok;
-    if (!fast) return linear_epilogue_generic<NI, MI, YDT>(p, acc, n0, m0, r16, kg, qo, shift, sx);
-#define TQ_EPI_T(Q, T) linear_epilogue_fast<NI, MI, YDT, ACT_NONE, Q, STAGED, T>(p, acc, n0, m0, r16, kg, qf, shift, sx, stage, cst, qf1, qf2)
+#define TQ_EPI_T(Q, T) linear_epilogue_fast<NI, MI, YDT, ACT_NONE, Q, STAGED, T>(p, acc, n0, m0, r16, kg, c.qf, c.shift, c.sx, stage, cst, c.qf1, c.qf2, cs, res_pre)
     if (p.tail == 2) { if (p.has_q) TQ_EPI_T(true, 2); else TQ_EPI_T(false, 2); }
     else             { if (p.has_q) TQ_EPI_T(true, 1); else TQ_EPI_T(false, 1); }
 #undef TQ_EPI_T
     return;
   }
-  if (!fast) return linear_epilogue_generic<NI, MI, YDT>(p, acc, n0, m0, r16, kg, qo, shift, sx);
   // wave-uniform dispatch: one straight-line body per (activation, quantizer) combination
-#define TQ_EPI(A, Q) linear_epilogue_fast<NI, MI, YDT, A, Q, STAGED>(p, acc, n0, m0, r16, kg, qf, shift, sx, stage, cst)
+#define TQ_EPI(A, Q) linear_epilogue_fast<NI, MI, YDT, A, Q, STAGED>(p, acc, n0, m0, r16, kg, c.qf, c.shift, c.sx, stage, cst, QF{}, QF{}, cs)
   if (p.has_q) {
     if (p.act == ACT_GELU)      TQ_EPI(ACT_GELU, true);
     else if (p.act == ACT_RELU) TQ_EPI(ACT_RELU, true);
@@ -439,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void linear_i8_k(LinArgs p) {
       for (int j = 0; j < MI; ++j) fx[j] = nx[j];
     }
   }
-  linear_epilogue<NI, MI, YDT, false, WITH_TAIL>(p, acc, n0, m0, r16, kg);
+  linear_epilogue<NI, MI, YDT, false, WITH_TAIL>(p, acc, n0, m0, r16, kg, epilogue_prepare<WITH_TAIL>(p, n0));
 }
 
 // LDS-staged variant (the fast path).  Measured on MI355X: the LDS-free kernel above is bound by the
@@ -454,6 +481,12 @@ __global__ __launch_bounds__(kBlock) void linear_i8_k(LinArgs p) {
 // 8 chunk slots).  Double-buffered: the next slab's loads are in flight while the current slab's 2 * NI * MI MFMAs
 // run; one barrier per slab.  A 4-stage ring of 64-byte slabs with counted vmcnt waits was slower (tools/tuning/
 // i8_glds.hip: more barriers per MFMA; the loop is LDS-bandwidth-, not latency-bound).  M, N % BT == 0, K % 128 == 0.
+// Wait for this wave's LDS-DMA loads explicitly before the barrier that publishes them.  hipcc usually puts an
+// `s_waitcnt vmcnt(0)` in front of the s_barrier of __syncthreads() when global_load_lds is in flight, but that is a
+// property of its memory model pass, not a contract: after an unrelated change to the kernel prologue (epilogue
+// parameters loaded before the loop) the 64 x 64 variant lost the wait inside its K loop and read half-landed slabs.
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 #define TQ_GLDS16(gp, lp)                                                                         \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp),           \
                                    (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
@@ -499,6 +532,7 @@ __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
     for (int j = 0; j < MI; ++j) acc[i][j] = v4i{0, 0, 0, 0};
 
   issue(0, 0);
+  const EpiCtx ectx = epilogue_prepare<WITH_TAIL>(p, n0 + wn);      // range buffers etc. while the first slab is in flight
   // per-column epilogue constants (combined scale, bias, zero-point correction) -> LDS behind the stages, while the
   // first slab is in flight; the loop's first barrier publishes them.  [BT scale | BT bias | BT correction | BT NoNorm
   // weight | BT NoNorm bias]
@@ -516,6 +550,7 @@ __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
   }
   const uint32_t nk = p.K / 128;
   for (uint32_t kb = 0; kb < nk; ++kb) {
+    lds_dma_wait_all();
     __syncthreads();                              // slab kb landed (vmcnt(0) + barrier); slab kb - 1 is no longer read
     if (kb + 1 < nk) issue((kb + 1) & 1, (kb + 1) * 128);
     const int8_t* bw = lds_i8 + (kb & 1) * STB + wn * 128;
@@ -537,7 +572,209 @@ __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
   __syncthreads();                                // the operand stages become the waves' output staging areas
   constexpr int kStageBytes = 32 * (WT * 4 + 16) + 32 * (WT + 16);
   static_assert(4 * kStageBytes <= 2 * STB, "output staging must fit the operand stages");
-  linear_epilogue<NI, MI, YDT, true, WITH_TAIL>(p, acc, n0 + wn, m0 + wm, r16, kg, lds_i8 + wave * kStageBytes, cst + wn);
+  linear_epilogue<NI, MI, YDT, true, WITH_TAIL>(p, acc, n0 + wn, m0 + wm, r16, kg, ectx, lds_i8 + wave * kStageBytes, cst + wn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MobileBERT feed-forward block as ONE launch (reference models/quantized_mobilebert.py:330-352 on top of hijacker.py:
+// 66-116): y = Q_out( Q_sum( Q_dense( lin2( Q_mid( relu( lin1(x) ) ) ) ) + residual ) * nn_w + nn_b )
+//   lin1: K1 -> N1 (128 -> 512) with ReLU and the intermediate activation quantizer Q_mid (asymmetric, <= 8 bit);
+//   lin2: N1 -> N2 (512 -> 128); then the NoNorm tail of tq_linear_i8_nonorm_fwd.
+// At B x T = 1024 tokens these two GEMMs are 32 workgroups of a few K slabs each: pure launch + load latency (5.6 +
+// 8.2 us).  Here a block owns BM = 16 or 32 token rows end to end: the [32, N1] intermediate never leaves the CU -- Q_mid's
+// int8 indices go straight into LDS in the K-slab layout the second GEMM's fragments read.  Every wave works on its own
+// slice of output features in BOTH GEMMs (128 of N1, then 32 of N2), so the weight slices are wave-private LDS regions
+// (no barriers around them) and all three operand fetches (x rows, W1 slice, W2 slice) are in flight from the first
+// instruction on; only the x tile and the intermediate are shared (2 barriers per block).  Same integer contractions,
+// same element arithmetic as the separate launches: bit-identical results.
+struct FfnArgs {
+  const int8_t* x;          // [M, K1] indices - 128 of the block input
+  const int8_t* w1;         // [N1, K1]
+  const int32_t* rs1;
+  const float* b1;          // or null
+  const float* w1_delta;    // [1] or [N1]
+  uint32_t w1_n_params;
+  float w1_eps;
+  const float* x_delta;     // input quantizer (per-tensor asymmetric)
+  const float* x_zero_float;
+  float x_eps;
+  int x_n_bits;
+  tq_quantizer q_mid;       // intermediate activation quantizer (= input quantizer of lin2)
+  const int8_t* w2;         // [N2, N1]
+  const int32_t* rs2;
+  LinArgs lin2;             // second Linear + tail, as tq_linear_i8_nonorm_fwd describes it (x / w / K unused)
+  uint32_t M;
+};
+
+template <int K1, int N1, int N2, int YDT, int BM>
+__global__ __launch_bounds__(kBlock) void ffn_i8_k(FfnArgs p) {
+  static_assert(K1 == 128 && N1 == 512 && N2 == 128, "instantiated for MobileBERT's feed-forward shape");
+  static_assert(BM == 16 || BM == 32, "token rows per block");
+  constexpr int MI = BM / 16;
+  constexpr int NI1 = N1 / 4 / 16;                  // n tiles per wave in GEMM 1 (8)
+  constexpr int NI2 = N2 / 4 / 16;                  // n tiles per wave in GEMM 2 (2)
+  constexpr int SL2 = N1 / 128;                     // K slabs of GEMM 2 (4)
+  // LDS map (bytes): x tile | intermediate indices [SL2][BM][128] | per wave: W1 slice [N1/4][128] | per wave: W2 slice
+  // [SL2][N2/4][128] | column constants of GEMM 1 [3][N1] and of GEMM 2 + tail [5][N2]
+  constexpr int kX = 0, kH = kX + BM * 128, kW1 = kH + SL2 * BM * 128, kW1w = (N1 / 4) * 128;
+  constexpr int kW2 = kW1 + 4 * kW1w, kW2w = SL2 * (N2 / 4) * 128, kC1 = kW2 + 4 * kW2w, kC2 = kC1 + 3 * N1 * 4;
+  extern __shared__ __attribute__((aligned(1024))) int8_t lds_i8[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const uint32_t m0 = blockIdx.x * BM;
+
+  // ---- all operand fetches up front (global_load_lds: 8 rows x 128 B per instruction, XOR chunk swizzle as above)
+  {
+    const int row8 = lane >> 3, slot = lane & 7;
+    if (wave * 8 < BM) {   // x tile: wave w brings rows [8 w, 8 w + 8)
+      const int row = wave * 8 + row8;
+      TQ_GLDS16(p.x + (size_t)(m0 + row) * K1 + ((slot ^ ((row >> 1) & 7)) << 4), lds_i8 + kX + wave * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < N1 / 4 / 8; ++q) {   // own W1 slice: rows n = wave * 128 + 8 q + row8
+      const int row = q * 8 + row8;
+      TQ_GLDS16(p.w1 + (size_t)(wave * (N1 / 4) + row) * K1 + ((slot ^ ((row >> 1) & 7)) << 4), lds_i8 + kW1 + wave * kW1w + q * 1024);
+    }
+#pragma unroll
+    for (int sl = 0; sl < SL2; ++sl)
+#pragma unroll
+      for (int q = 0; q < N2 / 4 / 8; ++q) {   // own W2 slice, slab sl: rows n = wave * 32 + 8 q + row8, k bytes [128 sl, 128 sl + 128)
+        const int row = q * 8 + row8;
+        TQ_GLDS16(p.w2 + (size_t)(wave * (N2 / 4) + row) * N1 + sl * 128 + ((slot ^ ((row >> 1) & 7)) << 4),
+                  lds_i8 + kW2 + wave * kW2w + sl * (N2 / 4) * 128 + q * 1024);
+      }
+  }
+  // ---- everything the second epilogue reads through pointers, now (their latency hides under the fetches)
+  const EpiCtx ectx = epilogue_prepare<true>(p.lin2, wave * (N2 / 4));
+  f32x4 res_pre[NI2][MI];
+#pragma unroll
+  for (int i = 0; i < NI2; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+      res_pre[i][j] = *reinterpret_cast<const f32x4*>(p.lin2.residual + (size_t)(m0 + j * 16 + r16) * N2 + wave * (N2 / 4) + i * 16 + kg * 4);
+  // ---- column constants (combined scale, bias, zero-point correction; NoNorm affine) while the fetches are in flight
+  float* c1 = reinterpret_cast<float*>(lds_i8 + kC1);
+  float* c2 = reinterpret_cast<float*>(lds_i8 + kC2);
+  const QP qm = make_qp(p.q_mid, 0);
+  {
+    const float dx = p.x_delta[0];
+    const float sx = dx < p.x_eps ? p.x_eps : dx;
+    const int zx = (int)clamp_nanprop(rintf(p.x_zero_float[0]), 0.0f, grid_top(p.x_n_bits));
+    for (int n = tid; n < N1; n += kBlock) {
+      const float dw = p.w1_delta[p.w1_n_params == 1 ? 0 : n];
+      c1[n] = sx * (dw < p.w1_eps ? p.w1_eps : dw);
+      c1[N1 + n] = p.b1 ? p.b1[n] : 0.0f;
+      reinterpret_cast<int*>(c1)[2 * N1 + n] = p.rs1[n] * (128 - zx);
+    }
+    const LinArgs& l = p.lin2;
+    const int zm = (int)qm.zp;                       // lin2's input lives on Q_mid's grid
+    for (int n = tid; n < N2; n += kBlock) {
+      const float dw = l.w_delta[l.w_n_params == 1 ? 0 : n];
+      c2[n] = qm.scale * (dw < l.w_eps ? l.w_eps : dw);
+      c2[N2 + n] = l.bias ? l.bias[n] : 0.0f;
+      reinterpret_cast<int*>(c2)[2 * N2 + n] = p.rs2[n] * (128 - zm);
+      c2[3 * N2 + n] = l.nn_w[n];
+      c2[4 * N2 + n] = l.nn_b[n];
+    }
+  }
+  lds_dma_wait_all();
+  __syncthreads();                                   // x tile, weight slices (vmcnt(0)) and constants are in LDS
+
+  const int swz = (r16 >> 1) & 7;
+  const int off[2] = {r16 * 128 + ((kg ^ swz) << 4), r16 * 128 + (((4 + kg) ^ swz) << 4)};
+
+  // ---- GEMM 1: [BM, K1] x [N1 / 4 (own), K1]^T
+  v4i acc1[NI1][MI];
+#pragma unroll
+  for (int i = 0; i < NI1; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc1[i][j] = v4i{0, 0, 0, 0};
+  {
+    const int8_t* bw = lds_i8 + kW1 + wave * kW1w;
+    const int8_t* bx = lds_i8 + kX;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      v4i fx[MI];
+#pragma unroll
+      for (int j = 0; j < MI; ++j) fx[j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s]);
+#pragma unroll
+      for (int i = 0; i < NI1; ++i) {
+        const v4i fw = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw, fx[j], acc1[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue 1: scale + bias, ReLU, Q_mid -> int8(index - 128) into the intermediate's K-slab layout (slab = wave)
+  {
+    const QF qf = make_qf(qm);
+    const f32x2 zpb = {qm.zp, qm.zp};
+    int8_t* hb = lds_i8 + kH + wave * (BM * 128);
+#pragma unroll
+    for (int i = 0; i < NI1; ++i) {
+      const int col = wave * (N1 / 4) + i * 16 + kg * 4;
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(c1 + col);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(c1 + N1 + col);
+      const v4i r4 = *reinterpret_cast<const v4i*>(c1 + 2 * N1 + col);
+      const f32x2 sw[2] = {f32x2{s4.x, s4.y}, f32x2{s4.z, s4.w}}, bs[2] = {f32x2{b4.x, b4.y}, f32x2{b4.z, b4.w}};
+      f32x2 v[2 * MI], hq[2 * MI];
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const f32x2 lo = {(float)(acc1[i][j][0] + r4.x), (float)(acc1[i][j][1] + r4.y)};
+        const f32x2 hi = {(float)(acc1[i][j][2] + r4.z), (float)(acc1[i][j][3] + r4.w)};
+        v[2 * j] = lo * sw[0] + bs[0];
+        v[2 * j + 1] = hi * sw[1] + bs[1];
+      }
+#pragma unroll
+      for (int e = 0; e < 2 * MI; ++e) v[e] = f32x2{v[e].x > 0.0f ? v[e].x : 0.0f, v[e].y > 0.0f ? v[e].y : 0.0f};
+      if (qf.ok) {
+        qf_round2_n<2 * MI>(v, qf, hq);
+#pragma unroll
+        for (int e = 0; e < 2 * MI; ++e) hq[e] = hq[e] + zpb;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 2 * MI; ++e) hq[e] = f32x2{q_index(v[e].x, qm), q_index(v[e].y, qm)};
+      }
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        uint32_t w = 0;
+        w = __builtin_amdgcn_cvt_pk_u8_f32(hq[2 * j].x, 0, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(hq[2 * j].y, 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(hq[2 * j + 1].x, 2, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(hq[2 * j + 1].y, 3, w) ^ 0x80808080u;
+        const int m = j * 16 + r16;                      // chunk i of slab `wave`, swizzled like every operand row
+        *reinterpret_cast<uint32_t*>(hb + m * 128 + ((i ^ ((m >> 1) & 7)) << 4) + kg * 4) = w;
+      }
+    }
+  }
+  __syncthreads();                                   // the whole [BM, N1] intermediate is in LDS
+
+  // ---- GEMM 2: [BM, N1] x [N2 / 4 (own), N1]^T
+  v4i acc2[NI2][MI];
+#pragma unroll
+  for (int i = 0; i < NI2; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc2[i][j] = v4i{0, 0, 0, 0};
+#pragma unroll
+  for (int sl = 0; sl < SL2; ++sl) {
+    const int8_t* bw = lds_i8 + kW2 + wave * kW2w + sl * (N2 / 4) * 128;
+    const int8_t* bh = lds_i8 + kH + sl * (BM * 128);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      v4i fw[NI2], fh[MI];
+#pragma unroll
+      for (int i = 0; i < NI2; ++i) fw[i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
+#pragma unroll
+      for (int j = 0; j < MI; ++j) fh[j] = *reinterpret_cast<const v4i*>(bh + j * 2048 + off[s]);
+#pragma unroll
+      for (int i = 0; i < NI2; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[i], fh[j], acc2[i][j], 0, 0, 0);
+    }
+  }
+  // ---- epilogue 2: the NoNorm tail of the plain kernel; outputs staged through this wave's (now free) W1 region
+  linear_epilogue<NI2, MI, YDT, true, true>(p.lin2, acc2, wave * (N2 / 4), m0, r16, kg, ectx, lds_i8 + kW1 + wave * kW1w,
+                                            c2 + wave * (N2 / 4), N2, res_pre);
 }
 
 // rowsum[n] = sum_k w[n, k]   (once per weight tensor)
@@ -705,4 +942,67 @@ extern "C" int tq_linear_i8_nonorm_fwd(const int8_t* x_idx, const int8_t* w_idx,
   if (q_out) a.q_t2 = *q_out;
   hipStream_t st = static_cast<hipStream_t>(stream);
   return y_dtype == TQ_F32 ? launch_linear<TQ_F32>(a, st) : launch_linear<TQ_BF16>(a, st);
+}
+
+// MobileBERT feed-forward block (intermediate Linear + ReLU + quantizer, output Linear, residual NoNorm tail) as one
+// launch: see ffn_i8_k.  Shapes: (K1, N1, N2) = (128, 512, 128), M % 32 == 0; anything else is TQ_EINVAL and the caller
+// runs tq_linear_i8_fwd + tq_linear_i8_nonorm_fwd (the results are bit-identical either way).
+extern "C" int tq_ffn_i8_nonorm_fwd(const int8_t* x_idx, const float* x_delta, const float* x_zero_float, int x_n_bits, float x_eps,
+                                    const int8_t* w1_idx, const int32_t* w1_rowsum, const float* bias1, const float* w1_delta,
+                                    uint64_t w1_n_params, float w1_eps, const tq_quantizer* q_mid, const int8_t* w2_idx,
+                                    const int32_t* w2_rowsum, const float* bias2, const float* w2_delta, uint64_t w2_n_params,
+                                    float w2_eps, const float* residual, const float* nn_weight, const float* nn_bias,
+                                    const tq_quantizer* q_dense, const tq_quantizer* q_sum, const tq_quantizer* q_out, void* y,
+                                    int8_t* y_idx, int y_dtype, uint64_t M, uint64_t K1, uint64_t N1, uint64_t N2,
+                                    tq_stream_t stream) {
+  if (M == 0) return TQ_OK;
+  TQ_REQUIRE(x_idx && x_delta && x_zero_float && w1_idx && w1_rowsum && w1_delta && q_mid && w2_idx && w2_rowsum && w2_delta &&
+             residual && nn_weight && nn_bias && y, "tq_ffn_i8_nonorm_fwd: NULL pointer");
+  TQ_REQUIRE(K1 == 128 && N1 == 512 && N2 == 128, "tq_ffn_i8_nonorm_fwd: only the (128, 512, 128) feed-forward shape is built");
+  TQ_REQUIRE(M % 32 == 0 && M < (1u << 31), "tq_ffn_i8_nonorm_fwd: M must be a multiple of 32");
+  TQ_REQUIRE(y_dtype == TQ_F32 || y_dtype == TQ_BF16, "tq_ffn_i8_nonorm_fwd: y dtype must be fp32 or bf16");
+  TQ_REQUIRE(x_n_bits >= 1 && x_n_bits <= 8, "tq_ffn_i8_nonorm_fwd: input quantizer must have <= 8 bits");
+  TQ_REQUIRE((w1_n_params == 1 || w1_n_params == N1) && (w2_n_params == 1 || w2_n_params == N2),
+             "tq_ffn_i8_nonorm_fwd: weight scales must be per-tensor or per-output-channel");
+  TQ_REQUIRE(aligned16(x_idx) && aligned16(w1_idx) && aligned16(w2_idx) && aligned16(y) && aligned16(residual),
+             "tq_ffn_i8_nonorm_fwd: 16-byte alignment required");
+  if (int e = check_quantizer(q_mid, M * N1, "tq_ffn_i8_nonorm_fwd")) return e;
+  TQ_REQUIRE(q_mid->n_params == 1 && !q_mid->symmetric && q_mid->n_bits <= 8 && !q_mid->log_domain,
+             "tq_ffn_i8_nonorm_fwd: the intermediate quantizer must be per-tensor, asymmetric, linear, <= 8 bit");
+  TQ_REQUIRE(y_idx == nullptr || (q_out != nullptr && !q_out->symmetric && q_out->n_bits <= 8),
+             "tq_ffn_i8_nonorm_fwd: y_idx needs an asymmetric <= 8-bit output quantizer");
+  FfnArgs f{};
+  f.x = x_idx; f.w1 = w1_idx; f.rs1 = w1_rowsum; f.b1 = bias1; f.w1_delta = w1_delta; f.w1_n_params = (uint32_t)w1_n_params;
+  f.w1_eps = w1_eps; f.x_delta = x_delta; f.x_zero_float = x_zero_float; f.x_eps = x_eps; f.x_n_bits = x_n_bits;
+  f.q_mid = *q_mid; f.w2 = w2_idx; f.rs2 = w2_rowsum; f.M = (uint32_t)M;
+  LinArgs& a = f.lin2;
+  a.w_rowsum = w2_rowsum; a.bias = bias2; a.y = y; a.y_idx = y_idx;
+  a.M = (uint32_t)M; a.N = (uint32_t)N2; a.K = (uint32_t)N1;
+  a.x_delta = q_mid->delta; a.x_zero_float = q_mid->zero_float; a.x_eps = q_mid->eps; a.x_n_bits = q_mid->n_bits;
+  a.w_delta = w2_delta; a.w_n_params = (uint32_t)w2_n_params; a.w_eps = w2_eps; a.act = ACT_NONE;
+  a.group_cols = (uint32_t)N2; a.fast_epi = tuning("TQ_I8_FAST_EPI", 1);
+  a.tail = 2; a.residual = residual; a.nn_w = nn_weight; a.nn_b = nn_bias;
+  const tq_quantizer* qs[3] = {q_dense, q_sum, q_out};
+  for (const tq_quantizer* q : qs)
+    if (q != nullptr) {
+      if (int e = check_quantizer(q, M * N2, "tq_ffn_i8_nonorm_fwd")) return e;
+      TQ_REQUIRE(q->n_params == 1, "tq_ffn_i8_nonorm_fwd: per-tensor quantizers only");
+    }
+  a.has_q = q_dense != nullptr;
+  if (q_dense) a.q_out = *q_dense;
+  a.on_t1 = q_sum != nullptr;
+  if (q_sum) a.q_t1 = *q_sum;
+  a.on_t2 = q_out != nullptr;
+  if (q_out) a.q_t2 = *q_out;
+  // 16 token rows per block while that still leaves every CU at most one block (more, shorter blocks), else 32
+  const int bm = tuning("TQ_FFN_BM", M / 16 <= 256 ? 16 : 32);
+  TQ_REQUIRE(bm == 16 || bm == 32, "TQ_FFN_BM must be 16 or 32");
+  const size_t lds = (size_t)bm * 128 + 4 * (size_t)bm * 128 + 4 * 128 * 128 + 4 * 4 * 32 * 128 + 3 * 512 * 4 + 5 * 128 * 4;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(M / bm));
+#define TQ_FFN(DT, B) hipLaunchKernelGGL((ffn_i8_k<128, 512, 128, DT, B>), grid, dim3(kBlock), lds, st, f)
+  if (y_dtype == TQ_F32) { if (bm == 16) TQ_FFN(TQ_F32, 16); else TQ_FFN(TQ_F32, 32); }
+  else                   { if (bm == 16) TQ_FFN(TQ_BF16, 16); else TQ_FFN(TQ_BF16, 32); }
+#undef TQ_FFN
+  return check_launch("ffn_i8_k");
 }

@@ -169,8 +169,17 @@ class QFFN(QuantizedModel):
         self.intermediate = quantize_model(nn.Sequential(hf.intermediate.dense, nn.ReLU()), **qp)
         self.output = QResidualNoNorm(hf.output, sites['res_ffn_output'], **qp)
 
+    fuse = False   # set True: intermediate + output + NoNorm tail as one integer launch (quantization/fused.py quantized_ffn)
+
     def forward(self, h):
+        if self.fuse:
+            return _ffn(self.intermediate, self.output, h)
         return self.output(self.intermediate(h), h)
+
+
+def _ffn(intermediate, out_block, h):
+    from quantization.fused import quantized_ffn
+    return quantized_ffn(intermediate[0], out_block.dense, out_block.res_act_quantizer, out_block.LayerNorm, h)
 
 
 class QMobileLayer(QuantizedModel):
@@ -194,7 +203,7 @@ class QMobileLayer(QuantizedModel):
         a = self.attention_output(self.attention_self(shared, shared, h, mask), layer_input)
         for f in self.ffn:
             a = f(a)
-        o = self.output(self.intermediate(a), a)
+        o = _ffn(self.intermediate, self.output, a) if QFFN.fuse else self.output(self.intermediate(a), a)
         return self.output_bottleneck(o, h)                       # back to 512, residual = the layer's input
 
 

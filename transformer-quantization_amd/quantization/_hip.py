@@ -68,6 +68,8 @@ SIGNATURES = {
                                         _u64, C.POINTER(_QP), _vp]),
     'tq_scores_softmax_quant_fwd': (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _f, _QP, _QP, _vp]),
     'tq_rowsum_i8': (_int, [_vp, _vp, _u64, _u64, _vp]),
+    'tq_ffn_i8_nonorm_fwd': (_int, [_vp, _vp, _vp, _int, _f, _vp, _vp, _vp, _vp, _u64, _f, _QP, _vp, _vp, _vp, _vp, _u64, _f,
+                                    _vp, _vp, _vp, _QP, _QP, _QP, _vp, _vp, _int, _u64, _u64, _u64, _u64, _vp]),
     'tq_linear_i8_nonorm_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f,
                                        _vp, _u64, _f, _QP, _QP, _QP, _vp]),
     'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
@@ -451,6 +453,27 @@ class HipBackend:
             _ptr(nn_b.detach().float().contiguous()), _ptr(y), _ptr(y_idx), _DTYPES[out_dtype], M, N, K, _ptr(x_q[0]),
             _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(w_delta), w_delta.numel(), float(w_eps), refs[0], refs[1],
             refs[2], _stream())
+        _check(rc, self.lib)
+        return (y, y_idx) if want_idx else y
+
+    FFN_SHAPES = {(128, 512, 128)}          # (K1, N1, N2) tq_ffn_i8_nonorm_fwd is built for
+
+    def ffn_i8_nonorm(self, x_idx, x_q, w1_idx, w1_rowsum, bias1, w1_delta, w1_eps, q_mid, w2_idx, w2_rowsum, bias2, w2_delta,
+                      w2_eps, residual, nn_w, nn_b, q_dense, q_sum, q_out, out_dtype, want_idx=False):
+        """MobileBERT feed-forward block in one launch (see include/tq_hip.h); q_* 7-tuples or None (q_mid required)."""
+        K1 = x_idx.shape[-1]
+        M = x_idx.numel() // K1
+        N1, N2 = w1_idx.shape[0], w2_idx.shape[0]
+        y = torch.empty(x_idx.shape[:-1] + (N2,), dtype=out_dtype, device=x_idx.device)
+        y_idx = torch.empty(y.shape, dtype=torch.int8, device=y.device) if want_idx else None
+        descs = [None if q is None else self._qdesc(*q, 1, 1) for q in (q_mid, q_dense, q_sum, q_out)]
+        refs = [None if d is None else C.byref(d) for d in descs]
+        rc = self.lib.tq_ffn_i8_nonorm_fwd(
+            _ptr(x_idx), _ptr(x_q[0]), _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(w1_idx), _ptr(w1_rowsum), _ptr(bias1),
+            _ptr(w1_delta), w1_delta.numel(), float(w1_eps), refs[0], _ptr(w2_idx), _ptr(w2_rowsum), _ptr(bias2),
+            _ptr(w2_delta), w2_delta.numel(), float(w2_eps), _ptr(residual.detach().float().contiguous()),
+            _ptr(nn_w.detach().float().contiguous()), _ptr(nn_b.detach().float().contiguous()), refs[1], refs[2], refs[3],
+            _ptr(y), _ptr(y_idx), _DTYPES[out_dtype], M, K1, N1, N2, _stream())
         _check(rc, self.lib)
         return (y, y_idx) if want_idx else y
 

@@ -72,25 +72,28 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
             self._int8_cache = (key, w_idx, be.rowsum_i8(w_idx))
         return self._int8_cache[1], self._int8_cache[2], self._int8_signed[1]
 
+    def _int8_weight_side_ok(self):
+        """The weight half of the integer path's preconditions: fixed symmetric <= 8-bit linear-domain weight ranges
+        (per-tensor or per-output-channel), weights quantized, nothing recording this layer's activations."""
+        from quantization.quantization_manager import Qstates
+        wmgr = self.weight_quantizer
+        return bool(self._quant_w and self.activation_save_target is None
+                    and isinstance(wmgr, QuantizationManager) and wmgr.quantizer.is_initialized
+                    and wmgr.quantizer.symmetric and wmgr.quantizer.n_bits <= 8
+                    and wmgr.quantizer.scale_domain == 'linear'
+                    and wmgr.quantizer._delta.numel() in (1, self.out_features)
+                    and wmgr.state == Qstates.fix_ranges and not wmgr.quantizer._delta.requires_grad)
+
     def _int8_plan(self, x, with_output_quantizer=True):
         """Arguments of the integer evaluation of this layer for input `x`, or None when the configuration does not
         allow it (no fixed per-tensor asymmetric <= 8-bit input quantizer known for x, unsupported weight / output
         quantizer, shapes the MFMA kernel does not tile, ...)."""
         src = provenance.quantizer_of(x)                 # the quantizer that produced x (fixed range)
-        wmgr = self.weight_quantizer
         act_code = _ACT_CODES.get(type(self.activation_function))
-        if (src is None or not self._quant_w or act_code is None
-                or not x.is_cuda or x.dtype != torch.float32
-                or self.activation_save_target is not None
-                or not isinstance(wmgr, QuantizationManager) or not wmgr.quantizer.is_initialized
-                or not wmgr.quantizer.symmetric or wmgr.quantizer.n_bits > 8
-                or wmgr.quantizer.scale_domain != 'linear'
-                or wmgr.quantizer._delta.numel() not in (1, self.out_features)
+        if (src is None or act_code is None or not x.is_cuda or x.dtype != torch.float32
+                or not self._int8_weight_side_ok()
                 or src.symmetric or src.n_bits > 8 or src._delta is None or src._delta.numel() != 1
                 or src.scale_domain != 'linear' or src._delta.requires_grad):
-            return None
-        from quantization.quantization_manager import Qstates
-        if wmgr.state != Qstates.fix_ranges or wmgr.quantizer._delta.requires_grad:
             return None
         M = x.numel() // self.in_features
         if self.in_features % 64 or self.out_features % 32 or M % 32 or self.in_features > 16384:

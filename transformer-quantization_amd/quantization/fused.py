@@ -121,6 +121,60 @@ def linear_nonorm_quant(dense, layer_norm, x):
     return layer_norm(dense(x))
 
 
+def quantized_ffn(intermediate, dense, res_quantizer, layer_norm, x):
+    """MobileBERT feed-forward block (reference models/quantized_mobilebert.py:330-352):
+
+        layer_norm(res_quantizer(dense(intermediate(x)) + x))
+
+    with `intermediate` a QuantLinear + ReLU, `dense` a QuantLinear, `layer_norm` a QuantNoNorm -- as ONE integer launch
+    (tq_ffn_i8_nonorm_fwd: the [tokens, 512] intermediate stays in LDS) when options.INT8_LINEAR applies to both Linears,
+    every range involved is fixed and per-tensor and the shape is one the kernel is built for; otherwise the two
+    Linears run on their own (integer or layered) and the tail through residual_layernorm_quant."""
+    def separate():
+        return residual_layernorm_quant(dense, res_quantizer, layer_norm, intermediate(x), x)
+
+    from quantization.autoquant_utils import INT8_STATS, QuantNoNorm
+    be = _hip.backend()
+    if (not options.INT8_LINEAR or not hasattr(be, 'ffn_i8_nonorm') or not isinstance(layer_norm, QuantNoNorm)
+            or not hasattr(intermediate, '_int8_plan') or not hasattr(dense, '_int8_weight_side_ok')
+            or not x.is_cuda or x.dtype != torch.float32 or (torch.is_grad_enabled() and x.requires_grad)
+            or dense.activation_function is not None or layer_norm.activation_function is not None
+            or layer_norm.activation_save_target is not None or not dense._int8_weight_side_ok()):
+        return separate()
+    K1, N1, N2 = intermediate.in_features, intermediate.out_features, dense.out_features
+    if (K1, N1, N2) not in be.FFN_SHAPES or dense.in_features != N1 or (x.numel() // K1) % 32:
+        return separate()
+    plan = intermediate._int8_plan(x, with_output_quantizer=True)
+    q1 = _fixed_per_tensor(dense._quant_a, dense.activation_quantizer)
+    q2 = _fixed_per_tensor(getattr(res_quantizer, '_quant_a', False), getattr(res_quantizer, 'activation_quantizer', res_quantizer))
+    q3 = _fixed_per_tensor(layer_norm._quant_a, layer_norm.activation_quantizer)
+    if plan is None or plan[1] != _hip.ACT_RELU or plan[2] is None or 'no' in (q1, q2, q3):
+        return separate()
+    q_mid = plan[2]
+    if q_mid[4] or q_mid[5] or q_mid[3] > 8:                 # intermediate quantizer: asymmetric, linear, <= 8 bit
+        return separate()
+    ops = intermediate._int8_operands(x, plan)
+    if ops is None:
+        return separate()
+    w2_idx, rs2, w2_signed = dense._int8_weights()
+    if not w2_signed:
+        return separate()
+    arg = lambda q: None if q == 'off' else q
+    ln_w, ln_b = layer_norm.quantized_params()
+    oq = layer_norm.activation_quantizer.quantizer if q3 != 'off' else None
+    want_idx = oq is not None and not oq.symmetric and oq.n_bits <= 8
+    wq2 = dense.weight_quantizer.quantizer
+    bias2 = None if dense.bias is None else dense.bias.detach()
+    INT8_STATS['kernel_calls'] += 2                          # two Linears' worth of integer GEMM
+    out = be.ffn_i8_nonorm(ops[0], ops[4], ops[1], ops[2], ops[3], ops[5], ops[6], q_mid, w2_idx, rs2, bias2,
+                           wq2._delta.reshape(-1), wq2.eps, x, ln_w, ln_b, arg(q1), arg(q2), arg(q3), torch.float32,
+                           want_idx=want_idx)
+    y = out[0] if want_idx else out
+    if oq is not None:
+        provenance.tag(y, oq, out[1] if want_idx else None)
+    return y
+
+
 def scores_softmax_quant(scores_quantizer, probs_quantizer, scores, mask, denom):
     """Equivalent to ``probs_quantizer(softmax(scores_quantizer(scores) / denom + mask, dim=-1))``
     (reference models/quantized_bert.py:153-198) as one kernel when both quantizers are fixed and
