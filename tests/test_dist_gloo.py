@@ -439,14 +439,18 @@ def test_empty_shards_contribute_the_identity(tmp_path):
 
 
 def _one_layer_bert():
+    from transformers import BertConfig, BertForSequenceClassification
     from quantization.quantizers import QMethods
     from quantization.range_estimators import RangeEstimators
-    from tests.harness_bert import build_bert_base
+    from tests.harness_bert import QBertForSequenceClassification
     qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
               weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.current_minmax)
-    model, _ = build_bert_base(seed=1000, num_layers=1, **qp)
+    torch.manual_seed(1000)
+    cfg = BertConfig(num_labels=2, hidden_size=64, num_attention_heads=4, intermediate_size=128, vocab_size=1000,
+                     num_hidden_layers=1, max_position_embeddings=64)
+    model = QBertForSequenceClassification(BertForSequenceClassification(cfg).eval(), **qp)
     g = torch.Generator().manual_seed(11)
-    ids = torch.randint(1000, 30000, (1, 16), generator=g)                  # ONE calibration sample
+    ids = torch.randint(10, 1000, (1, 16), generator=g)                     # ONE calibration sample
     return model.eval(), ids
 
 
