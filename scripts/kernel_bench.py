@@ -141,6 +141,30 @@ def fam_i8():
         run('i8', f'integer Linear+GELU+quant M={M} N={N} K={K}', 'linear_i8_lds_k',
             lambda: be.linear_i8(x, w, rs, b, (xd, xz, 8, 1e-8), wd, 1e-8, _hip.ACT_GELU, qo, torch.float32),
             2.0 * M * N * K, 'mfma_i8', note=f'M={M} N={N} K={K}')
+    # MobileBERT shapes (M = 1024 tokens): Linear 512 -> 128 with the residual NoNorm tail in its epilogue, and a whole
+    # feed-forward block (128 -> 512 ReLU quant -> 128 + tail) as one launch
+    M = 1024
+    g = torch.Generator(device=dev).manual_seed(5)
+    def i8(shape, lo=-127, hi=127):
+        return torch.randint(lo, hi, shape, dtype=torch.int8, device=dev, generator=g)
+    xd, xz = torch.tensor(0.02, device=dev), torch.tensor(117.0, device=dev)
+    wd = torch.tensor(0.001, device=dev).reshape(1)
+    res = torch.randn(M, 128, device=dev)
+    nw, nb = torch.rand(128, device=dev) + 0.5, torch.randn(128, device=dev) * 0.1
+    x5, w5 = i8((M, 512), -128, 127), i8((128, 512))
+    rs5 = be.rowsum_i8(w5)
+    b5 = torch.randn(128, device=dev)
+    qa, qb, qc, qm = q7(0.05, 100.0), q7(0.06, 110.0), q7(0.05, 120.0), q7(0.02, 0.0)
+    run('i8', 'integer Linear 512->128 + residual NoNorm tail M=1024', 'linear_i8_lds_k',
+        lambda: be.linear_i8_nonorm(x5, w5, rs5, b5, res, nw, nb, (xd, xz, 8, 1e-8), wd, 1e-8, qa, qb, qc, torch.float32,
+                                    want_idx=True), 2.0 * M * 128 * 512, 'mfma_i8')
+    x1, w1, w2 = i8((M, 128), -128, 127), i8((512, 128)), i8((128, 512))
+    rs1, rs2 = be.rowsum_i8(w1), be.rowsum_i8(w2)
+    b1 = torch.randn(512, device=dev)
+    run('i8', 'feed-forward block 128->512->128 + tail, one launch M=1024', 'ffn_i8_k',
+        lambda: be.ffn_i8_nonorm(x1, (xd, xz, 8, 1e-8), w1, rs1, b1, wd, 1e-8, qm, w2, rs2, b5, wd, 1e-8, res, nw, nb,
+                                 qa, qb, qc, torch.float32, want_idx=True),
+        2.0 * M * 512 * 128 * 2, 'mfma_i8')
     for B, T, H in ((8, 128, 12), (64, 128, 12)):
         qi, ki, vi = (torch.randint(-128, 128, (B, T, H * 64), dtype=torch.int8, device=dev) for _ in range(3))
         mask = torch.zeros(B, T, device=dev)
