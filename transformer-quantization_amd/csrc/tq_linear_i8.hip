@@ -531,22 +531,23 @@ __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = v4i{0, 0, 0, 0};
 
+  // everything read through pointers first, as independent loads in flight together with the first slab: the
+  // quantizers' range buffers (epilogue parameters) and the per-column scale / bias / row sum this thread turns into
+  // LDS constants [BT scale | BT bias | BT correction | BT NoNorm weight | BT NoNorm bias] (published by the loop's
+  // first barrier)
+  const EpiCtx ectx = epilogue_prepare<WITH_TAIL>(p, n0 + wn);
+  const uint32_t ncol = n0 + (tid & (BT - 1));     // threads >= BT load duplicates and do not write
+  const float ld_dw = p.w_delta[p.w_n_params == 1 ? 0 : ncol], ld_b = p.bias ? p.bias[ncol] : 0.0f;
+  const int ld_rs = p.w_rowsum[ncol];
+  float ld_nw = 0.0f, ld_nb = 0.0f;
+  if (WITH_TAIL) { ld_nw = p.nn_w[ncol]; ld_nb = p.nn_b[ncol]; }
   issue(0, 0);
-  const EpiCtx ectx = epilogue_prepare<WITH_TAIL>(p, n0 + wn);      // range buffers etc. while the first slab is in flight
-  // per-column epilogue constants (combined scale, bias, zero-point correction) -> LDS behind the stages, while the
-  // first slab is in flight; the loop's first barrier publishes them.  [BT scale | BT bias | BT correction | BT NoNorm
-  // weight | BT NoNorm bias]
   float* cst = reinterpret_cast<float*>(lds_i8 + 2 * STB);
   if (tid < BT) {
-    const float dx = p.x_delta[0];
-    const float sx = dx < p.x_eps ? p.x_eps : dx;
-    const int zx = (int)clamp_nanprop(rintf(p.x_zero_float[0]), 0.0f, grid_top(p.x_n_bits));
-    const uint32_t n = n0 + tid;
-    const float dw = p.w_delta[p.w_n_params == 1 ? 0 : n];
-    cst[tid] = sx * (dw < p.w_eps ? p.w_eps : dw);
-    cst[BT + tid] = p.bias ? p.bias[n] : 0.0f;
-    reinterpret_cast<int*>(cst)[2 * BT + tid] = p.w_rowsum[n] * (128 - zx);
-    if (WITH_TAIL) { cst[3 * BT + tid] = p.nn_w[n]; cst[4 * BT + tid] = p.nn_b[n]; }
+    cst[tid] = ectx.sx * (ld_dw < p.w_eps ? p.w_eps : ld_dw);
+    cst[BT + tid] = ld_b;
+    reinterpret_cast<int*>(cst)[2 * BT + tid] = ld_rs * ectx.shift;
+    if (WITH_TAIL) { cst[3 * BT + tid] = ld_nw; cst[4 * BT + tid] = ld_nb; }
   }
   const uint32_t nk = p.K / 128;
   for (uint32_t kb = 0; kb < nk; ++kb) {
