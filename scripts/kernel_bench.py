@@ -112,8 +112,9 @@ def fam_tails():
                 lambda: be.affine_fake_quant(a, w, b, *q3), 2 * es * a.numel(), 'hbm')
     s = torch.randn(64, 12, 128, 128, device=dev)
     mask = torch.zeros(64, 128, device=dev)
+    qs, qp = q7(0.5, 128.0), q7(0.004, 0.0)
     run('tails', 'scores->softmax->probs fp32 [64,12,128,128]', 'softmax_quant_k',
-        lambda: be.scores_softmax_quant(s, mask, 12 * 128, 8.0, q7(0.5, 128.0), q7(0.004, 0.0)), 8 * s.numel(), 'hbm')
+        lambda: be.scores_softmax_quant(s, mask, 12 * 128, 8.0, qs, qp), 8 * s.numel(), 'hbm')
 
 
 def fam_mse():

@@ -99,3 +99,35 @@ def test_fused_attention_in_bert_harness_matches_layered():
         QSelfAttention.fuse = False
     span = float(layered.max() - layered.min())
     assert float((fused - layered).abs().max()) <= 0.10 * span
+
+
+@pytest.mark.parametrize('T,denom', [(32, math.sqrt(32.0)), (128, 8.0), (512, 3.0)])
+def test_branch_free_softmax_is_bit_identical_to_the_division_path(T, denom, monkeypatch):
+    """The exact-quotient body (Markstein x / denom and e / sum, QF quantizers) against the same kernel's IEEE-division
+    body: every output bit, including NaN rows, +-inf scores, -inf / finfo.min masks and a fully masked row."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(7 * T)
+    B, H, Tq = 4, 3, 33
+    s = torch.randn(B, H, Tq, T, generator=g) * 30
+    s[0, 0, 0, 3] = float('nan')
+    s[0, 0, 1, 5] = float('inf')
+    s[0, 0, 2, 7] = -float('inf')
+    s[1, 1, 4] = 0.0
+    mask = torch.zeros(B, T)
+    mask[1, T // 2:] = -float('inf')
+    mask[2, 1:] = torch.finfo(torch.float32).min
+    mask[3, :] = -float('inf')                      # fully masked: NaN rows in the reference too
+    p1 = O.asym_params_from_range(-70.0, 80.0, 8)
+    p2 = O.asym_params_from_range(0.0, 1.0, 8)
+    k = lambda p: (p[0].cuda(), p[1].cuda(), None, 8, False, False, 1e-8)
+    outs = []
+    for fast in ('1', '0'):
+        monkeypatch.setenv('TQ_SM_FAST', fast)
+        for m in (mask.cuda(), None):
+            outs.append(be.scores_softmax_quant(s.cuda(), m, H * Tq, denom, k(p1), k(p2)).cpu())
+    for a, b in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        assert torch.equal(torch.nan_to_num(a, nan=-1.0).view(torch.int32), torch.nan_to_num(b, nan=-1.0).view(torch.int32))
+    assert torch.isnan(outs[0][0, 0, 0]).all() and torch.isnan(outs[0][3]).all()
+    assert not torch.isnan(outs[1][1:]).any()

@@ -62,6 +62,17 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+template <int LPR>
+__device__ __forceinline__ float group_max(float v) {      // fmaxf butterfly on the same paths as group_sum
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  if (LPR >= 8) v = fmaxf(v, dpp_f32<0x141>(v));
+  if (LPR >= 16) v = fmaxf(v, dpp_f32<0x140>(v));
+  if (LPR >= 32) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F)));
+  if (LPR >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
 struct FusedF {
   QF f;
   int on;
@@ -312,45 +323,187 @@ static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, u
 //     p = Q_probs( softmax( Q_scores(scores) / denom + mask , dim=-1 ) )
 // = quantizer, division, mask add, softmax, quantizer: five sweeps of [B, H, T, T] in the reference,
 // here 1 read + 1 write.  LPR lanes own one row of T = LPR * NV * 4 fp32 values.
-template <int LPR, int NV>
+// Branch-free exact variant of the element math (both quantizers on, tq_device.h QF): ~30 VALU issue slots per element
+// instead of ~75 with four IEEE divisions -- the scalar version was VALU-bound at 40 % of the HBM rate.
+//   scores quantizer, probs quantizer: QF pairs (med3 clamp + Markstein quotient);
+//   t / denom: Markstein with rd = RN(1 / denom): the operand is a grid value (>= 2^-60 or 0, < 2^82), so the fma
+//     residual is exact and the quotient correctly rounded -- the same value v_div_* returns;
+//   e / sum: the same with rs = RN(1 / sum), one IEEE division per row.  1 <= sum <= T and e in [0, 1]: the residual
+//     is exact for e >= 2^-62; below that the probability is < scale / 4 and the probs quantizer returns index 0
+//     whatever the last bit of the quotient (which is why this path needs the probs quantizer).
+// NaN: v_med3 does not keep it, so a NaN score poisons the row sum (the reference's row is NaN as a whole) and rows
+// with a NaN sum are patched after the last quantizer.
+__device__ __forceinline__ bool softmax_fast_ok(const tq_quantizer& q1, const tq_quantizer& q2, int on1, int on2, float denom) {
+  if (!on1 || !on2) return false;
+  const QP p1 = make_qp(q1, 0), p2 = make_qp(q2, 0);
+  const float ad = fabsf(denom);
+  return make_qf(p1).ok && make_qf(p2).ok && p1.scale >= 0x1p-60f && p1.scale <= 0x1p60f && p2.scale >= 0x1p-60f &&
+         p2.scale <= 0x1p60f && ad >= 0x1p-20f && ad <= 0x1p20f;
+}
+
+template <int LPR, int NV, int R>
+__device__ __forceinline__ void softmax_fast_body(const f32x4* __restrict__ s, f32x4* __restrict__ y, uint64_t rows,
+                                                  const float* __restrict__ mask, uint64_t rows_per_mask, float denom,
+                                                  const tq_quantizer& q1, const tq_quantizer& q2) {
+  constexpr int RPB = kBlock / LPR;
+  constexpr uint32_t T4 = LPR * NV;
+  constexpr int P = NV * 2;                      // pairs per lane and row
+  const QF f1 = make_qf(make_qp(q1, 0)), f2 = make_qf(make_qp(q2, 0));
+  const float rdv = 1.0f / denom;
+  const f32x2 rd = {rdv, rdv}, nd = {-denom, -denom};
+  const int lane = threadIdx.x % LPR, sub = threadIdx.x / LPR;
+  for (uint64_t row0 = ((uint64_t)blockIdx.x * RPB + sub) * R; row0 < rows; row0 += (uint64_t)gridDim.x * RPB * R) {
+    f32x4 in[R][NV], mk[R][NV];
+    const uint64_t m0 = mask ? row0 / rows_per_mask : 0, rem0 = row0 - m0 * rows_per_mask;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t row = row0 + r < rows ? row0 + r : rows - 1;
+      const uint64_t mi = rem0 + r < rows_per_mask ? m0 : row / rows_per_mask;
+      const f32x4* mrow = mask ? reinterpret_cast<const f32x4*>(mask + mi * (uint64_t)T4 * 4) : nullptr;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        in[r][k] = s[row * T4 + k * LPR + lane];
+        mk[r][k] = mrow ? mrow[k * LPR + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    f32x2 t[R][P];
+    float mx[R], sum[R];
+    bool bad[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      bad[r] = false;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        bad[r] = bad[r] || in[r][k][0] != in[r][k][0] || in[r][k][1] != in[r][k][1] || in[r][k][2] != in[r][k][2] ||
+                 in[r][k][3] != in[r][k][3];
+        t[r][2 * k] = f32x2{in[r][k][0], in[r][k][1]};
+        t[r][2 * k + 1] = f32x2{in[r][k][2], in[r][k][3]};
+      }
+      qf_fake_quant2_n<P>(t[r], f1);
+      f32x2 q0[P], e[P];
+#pragma unroll
+      for (int i = 0; i < P; ++i) q0[i] = t[r][i] * rd;
+#pragma unroll
+      for (int i = 0; i < P; ++i) e[i] = __builtin_elementwise_fma(q0[i], nd, t[r][i]);
+#pragma unroll
+      for (int i = 0; i < P; ++i) t[r][i] = __builtin_elementwise_fma(e[i], rd, q0[i]);
+      if (mask) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          t[r][2 * k] = t[r][2 * k] + f32x2{mk[r][k][0], mk[r][k][1]};
+          t[r][2 * k + 1] = t[r][2 * k + 1] + f32x2{mk[r][k][2], mk[r][k][3]};
+        }
+      }
+      mx[r] = -__builtin_huge_valf();
+#pragma unroll
+      for (int i = 0; i < P; ++i) mx[r] = fmaxf(mx[r], fmaxf(t[r][i].x, t[r][i].y));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) mx[r] = group_max<LPR>(mx[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      sum[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        t[r][i].x = expf(t[r][i].x - mx[r]);
+        t[r][i].y = expf(t[r][i].y - mx[r]);
+        sum[r] += t[r][i].x;             // the scalar kernel's (and the oracle's) left-to-right order
+        sum[r] += t[r][i].y;
+      }
+      if (bad[r]) sum[r] = __builtin_nanf("");
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum[r] = group_sum<LPR>(sum[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float rsv = 1.0f / sum[r];
+      const f32x2 rs = {rsv, rsv}, ns = {-sum[r], -sum[r]};
+      f32x2 q0[P], e[P];
+#pragma unroll
+      for (int i = 0; i < P; ++i) q0[i] = t[r][i] * rs;
+#pragma unroll
+      for (int i = 0; i < P; ++i) e[i] = __builtin_elementwise_fma(q0[i], ns, t[r][i]);
+#pragma unroll
+      for (int i = 0; i < P; ++i) t[r][i] = __builtin_elementwise_fma(e[i], rs, q0[i]);
+      qf_fake_quant2_n<P>(t[r], f2);
+      if (__ballot(sum[r] != sum[r])) {          // rare: a NaN row
+        if (sum[r] != sum[r]) {
+#pragma unroll
+          for (int i = 0; i < P; ++i) t[r][i] = f32x2{__builtin_nanf(""), __builtin_nanf("")};
+        }
+      }
+      if (row0 + r >= rows) continue;
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+        y[(row0 + r) * T4 + k * LPR + lane] = f32x4{t[r][2 * k].x, t[r][2 * k].y, t[r][2 * k + 1].x, t[r][2 * k + 1].y};
+    }
+  }
+}
+
+template <int LPR, int NV, int R>
 __global__ __launch_bounds__(kBlock) void softmax_quant_k(const f32x4* __restrict__ s, f32x4* __restrict__ y, uint64_t rows,
                                                           const float* __restrict__ mask, uint64_t rows_per_mask,
-                                                          float denom, tq_quantizer q1, tq_quantizer q2, int on1, int on2) {
+                                                          float denom, tq_quantizer q1, tq_quantizer q2, int on1, int on2,
+                                                          int allow_fast) {
+  // R rows per lane group and step: R independent load -> reduce -> exp -> reduce -> store chains in flight
+  if (allow_fast && softmax_fast_ok(q1, q2, on1, on2, denom)) {          // wave-uniform
+    softmax_fast_body<LPR, NV, R>(s, y, rows, mask, rows_per_mask, denom, q1, q2);
+    return;
+  }
   constexpr int RPB = kBlock / LPR;
   constexpr uint32_t T4 = LPR * NV;              // float4 vectors per row
   const FusedQ f1 = make_fq(q1, on1), f2 = make_fq(q2, on2);
   const int lane = threadIdx.x % LPR, sub = threadIdx.x / LPR;
-  for (uint64_t row = (uint64_t)blockIdx.x * RPB + sub; row < rows; row += (uint64_t)gridDim.x * RPB) {
-    const f32x4* mrow = mask ? reinterpret_cast<const f32x4*>(mask + (row / rows_per_mask) * (uint64_t)T4 * 4) : nullptr;
-    float v[NV][4];
-    float mx = -__builtin_huge_valf();
+  for (uint64_t row0 = ((uint64_t)blockIdx.x * RPB + sub) * R; row0 < rows; row0 += (uint64_t)gridDim.x * RPB * R) {
+    f32x4 in[R][NV], mk[R][NV];
+    const uint64_t m0 = mask ? row0 / rows_per_mask : 0, rem0 = row0 - m0 * rows_per_mask;   // one 64-bit division per step
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const f32x4 in = s[row * T4 + k * LPR + lane];
-      f32x4 mk = {0.f, 0.f, 0.f, 0.f};
-      if (mrow) mk = mrow[k * LPR + lane];
+    for (int r = 0; r < R; ++r) {
+      const uint64_t row = row0 + r < rows ? row0 + r : rows - 1;        // clamp: tail rows recompute the last one
+      const uint64_t mi = rem0 + r < rows_per_mask ? m0 : row / rows_per_mask;
+      const f32x4* mrow = mask ? reinterpret_cast<const f32x4*>(mask + mi * (uint64_t)T4 * 4) : nullptr;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t = apply_q(in[j], f1) / denom;
-        if (mrow) t = t + mk[j];
-        v[k][j] = t;
-        mx = fmaxf(mx, t);
+      for (int k = 0; k < NV; ++k) {
+        in[r][k] = s[row * T4 + k * LPR + lane];
+        mk[r][k] = mrow ? mrow[k * LPR + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    float v[R][NV][4], mx[R], sum[R];
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, LPR));
-    float sum = 0.f;
+    for (int r = 0; r < R; ++r) {
+      mx[r] = -__builtin_huge_valf();
 #pragma unroll
-    for (int k = 0; k < NV; ++k)
+      for (int k = 0; k < NV; ++k)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v[k][j] = expf(v[k][j] - mx); sum += v[k][j]; }
-    sum = group_sum<LPR>(sum);
+        for (int j = 0; j < 4; ++j) {
+          float t = apply_q(in[r][k][j], f1) / denom;
+          if (mask) t = t + mk[r][k][j];
+          v[r][k][j] = t;
+          mx[r] = fmaxf(mx[r], t);
+        }
+    }
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      f32x4 o;
+    for (int r = 0; r < R; ++r) mx[r] = group_max<LPR>(mx[r]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = apply_q(v[k][j] / sum, f2);
-      y[row * T4 + k * LPR + lane] = o;
+    for (int r = 0; r < R; ++r) {
+      sum[r] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[r][k][j] = expf(v[r][k][j] - mx[r]); sum[r] += v[r][k][j]; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum[r] = group_sum<LPR>(sum[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (row0 + r >= rows) continue;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = apply_q(v[r][k][j] / sum[r], f2);
+        y[(row0 + r) * T4 + k * LPR + lane] = o;
+      }
     }
   }
 }
@@ -418,10 +571,23 @@ extern "C" int tq_scores_softmax_quant_fwd(const float* scores, float* probs, ui
   auto yv = reinterpret_cast<f32x4*>(probs);
 #define TQ_SM(LPR, NV)                                                                                          \
   if (cols == (uint64_t)(LPR) * (NV) * 4) {                                                                     \
-    const unsigned rpb = kBlock / (LPR);                                                                        \
+    static const int r_env = tuning("TQ_SM_R", 0);                                                              \
+    const int allow_fast = tuning("TQ_SM_FAST", 1);      /* read per call: the parity test flips it */            \
+    /* rows in flight per lane group: as many as the registers allow, while the grid still covers the chip twice */ \
+    int want = r_env ? r_env : 4;                                                                               \
+    while (!r_env && want > 1 && rows / (kBlock / (LPR) * want) < 512) want >>= 1;                              \
+    const int R = (want == 4 && (NV) == 1) ? 4 : ((want >= 2 && (NV) <= 2) ? 2 : 1);                            \
+    const unsigned rpb = kBlock / (LPR) * R;                                                                    \
     const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(rows, rpb), 1), 1u << 20);   \
-    hipLaunchKernelGGL((softmax_quant_k<LPR, NV>), dim3(grid), dim3(kBlock), 0, st, sv, yv, rows, mask, rows_per_mask, \
-                       denom, c1, c2, q_scores != nullptr, q_probs != nullptr);                                 \
+    if (R == 4 && (NV) == 1)                                                                                    \
+      hipLaunchKernelGGL((softmax_quant_k<LPR, NV, 4>), dim3(grid), dim3(kBlock), 0, st, sv, yv, rows, mask, rows_per_mask, \
+                         denom, c1, c2, q_scores != nullptr, q_probs != nullptr, allow_fast);                               \
+    else if (R == 2 && (NV) <= 2)                                                                               \
+      hipLaunchKernelGGL((softmax_quant_k<LPR, NV, 2>), dim3(grid), dim3(kBlock), 0, st, sv, yv, rows, mask, rows_per_mask, \
+                         denom, c1, c2, q_scores != nullptr, q_probs != nullptr, allow_fast);                               \
+    else                                                                                                        \
+      hipLaunchKernelGGL((softmax_quant_k<LPR, NV, 1>), dim3(grid), dim3(kBlock), 0, st, sv, yv, rows, mask, rows_per_mask, \
+                         denom, c1, c2, q_scores != nullptr, q_probs != nullptr, allow_fast);                               \
     return check_launch("softmax_quant_k");                                                                     \
   }
   TQ_SM(8, 1) TQ_SM(16, 1) TQ_SM(32, 1) TQ_SM(64, 1) TQ_SM(64, 2) TQ_SM(64, 4)
