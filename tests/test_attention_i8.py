@@ -268,3 +268,68 @@ def test_attention_i8_with_infinite_masks(fill):
     assert torch.isfinite(ctx).all()
     diff = (ctx.cpu() - ref).abs()
     assert float((diff == 0).float().mean()) >= 0.995 and float(diff.max()) <= 2.01 * float(pc[0])
+
+
+@pytest.mark.parametrize('T,dh,denom', [(64, 64, 8.0), (128, 64, 8.0), (128, 32, math.sqrt(32.0)), (256, 64, 3.0), (192, 32, 8.0)])
+def test_branch_free_chain_is_bit_identical_to_the_guarded_one(T, dh, denom, monkeypatch):
+    """T <= 256 runs the exact branch-free quantizer / quotient chain (QF + Markstein); TQ_ATTN_FAST=0 keeps the
+    guarded-reciprocal one.  Same context values and indices bit for bit, with and without the scores quantizer, with
+    -inf masks, and NaN for a fully masked batch row in both."""
+    from quantization import _hip
+    be = _hip.backend()
+    B, H = 3, 2
+    g = torch.Generator().manual_seed(11 * T + dh)
+    qi, ki, vi = (torch.randint(-128, 128, (B, T, H * dh), generator=g, dtype=torch.int8).cuda() for _ in range(3))
+    mask = torch.zeros(B, T)
+    mask[1, T // 3:] = -float('inf')
+    mask[2, :] = -float('inf')
+    pq, pk, pv = _params(-3.0, 2.5), _params(-2.0, 3.0), _params(-1.5, 1.0)
+    ps, pp, pc = _params(-60.0, 70.0), _params(0.0, 0.6), _params(-1.2, 0.9)
+    k7 = lambda p: None if p is None else (p[0].cuda(), p[1].cuda(), None, 8, False, False, 1e-8)
+    for use_s in (True, False):
+        for m in (mask.cuda(), None):
+            outs = []
+            for fast in ('1', '0'):
+                monkeypatch.setenv('TQ_ATTN_FAST', fast)
+                ctx, idx = be.attention_i8(qi, ki, vi, H, m, denom, k7(pq), k7(pk), k7(pv), k7(ps) if use_s else None,
+                                           k7(pp), k7(pc), want_idx=True)
+                outs.append((ctx.cpu(), idx.cpu()))
+            (c1, i1), (c0, i0) = outs
+            assert torch.equal(torch.isnan(c1), torch.isnan(c0))
+            ok = ~torch.isnan(c1)
+            assert torch.equal(c1[ok].view(torch.int32), c0[ok].view(torch.int32))
+            assert torch.equal(i1[ok], i0[ok])
+            if m is not None:
+                assert torch.isnan(c1[2]).all() and not torch.isnan(c1[:2]).any()
+
+
+@pytest.mark.parametrize('T,dh', [(128, 64), (256, 64), (128, 32), (512, 64)])
+def test_key_split_workgroups_match_the_two_wave_form(T, dh, monkeypatch):
+    """Small grids split the keys of a query tile over two waves (row max / row sum / integer partial sums through
+    LDS).  Only the order of the float row sum differs from the two-wave form: probability indices may move by one
+    step on a rounding tie, so >= 99.9 % of the context values are bit-identical and the rest one context step away;
+    the branch-free and the guarded element chains stay bit-identical within each form."""
+    from quantization import _hip
+    be = _hip.backend()
+    B, H = 2, 3
+    g = torch.Generator().manual_seed(5 * T + dh)
+    qi, ki, vi = (torch.randint(-128, 128, (B, T, H * dh), generator=g, dtype=torch.int8).cuda() for _ in range(3))
+    mask = torch.zeros(B, T)
+    mask[1, T // 2:] = -10000.0
+    pq, pk, pv = _params(-3.0, 2.5), _params(-2.0, 3.0), _params(-1.5, 1.0)
+    ps, pp, pc = _params(-60.0, 70.0), _params(0.0, 0.6), _params(-1.2, 0.9)
+    k7 = lambda p: (p[0].cuda(), p[1].cuda(), None, 8, False, False, 1e-8)
+    res = {}
+    for split in ('1', '0'):
+        for fast in ('1', '0'):
+            monkeypatch.setenv('TQ_ATTN_SPLIT', split)
+            monkeypatch.setenv('TQ_ATTN_FAST', fast)
+            ctx, idx = be.attention_i8(qi, ki, vi, H, mask.cuda(), math.sqrt(dh), k7(pq), k7(pk), k7(pv), k7(ps), k7(pp),
+                                       k7(pc), want_idx=True)
+            res[split, fast] = (ctx.cpu(), idx.cpu())
+    for split in ('1', '0'):
+        assert torch.equal(res[split, '1'][0], res[split, '0'][0]) and torch.equal(res[split, '1'][1], res[split, '0'][1])
+    a, b = res['1', '1'], res['0', '1']
+    same = (a[0] == b[0]).float().mean()
+    assert float(same) >= 0.999, float(same)
+    assert int((a[1].int() - b[1].int()).abs().max()) <= 1

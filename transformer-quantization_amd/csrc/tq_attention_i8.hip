@@ -43,6 +43,10 @@ struct AttnArgs {
   tq_quantizer qq, qk, qv;    // per-tensor asymmetric, n_bits <= 8
   tq_quantizer q_scores, q_probs, q_ctx;
   int has_scores, has_ctx;
+#ifdef TQ_ATTN_PROF
+  unsigned long long* prof;   // tools/tuning/attn_prof.py: 8 s_memtime stamps per workgroup
+#endif
+  int fast_ok;                // 0: keep the guarded-reciprocal element math (TQ_ATTN_FAST=0, parity tests)
 };
 
 // position of key (64 s + 16 tt + 4 g + r) inside a V^T row: 64 s + 16 g + 4 tt + r
@@ -50,49 +54,103 @@ __device__ __forceinline__ uint32_t key_slot(uint32_t key) {
   return (key & ~63u) | (((key >> 2) & 3u) << 4) | (((key >> 4) & 3u) << 2) | (key & 3u);
 }
 
-template <int NT, int DH>   // NT = T / 16 key tiles, DH = head dim (32 or 64)
-__global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {   // up to 512 VGPRs per lane at 2 waves
-  constexpr int T = NT * 16, KS = NT / 4;          // KS = 64-key MFMA steps of the second GEMM
-  constexpr int PITCH = T + 32;                    // 32 * odd bytes: conflict-free ds_read_b128 (4 x 16 lane groups, 64 banks)
-  __shared__ __attribute__((aligned(16))) int8_t s_vt[DH * PITCH];
+// RN(x / b) for N pairs given r = RN(1 / b), nb = -b (Markstein: exact fma residual, see tq_device.h); chunks of 8 pairs
+// keep the live stage arrays small
+template <int N>
+__device__ __forceinline__ void quot2_n(f32x2* x, f32x2 r, f32x2 nb) {
+  constexpr int C = N < 8 ? N : 8;
+  static_assert(N % C == 0, "pairs");
+#pragma unroll
+  for (int c = 0; c < N; c += C) {
+    f32x2 q0[C], e[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) q0[i] = x[c + i] * r;
+#pragma unroll
+    for (int i = 0; i < C; ++i) e[i] = __builtin_elementwise_fma(q0[i], nb, x[c + i]);
+#pragma unroll
+    for (int i = 0; i < C; ++i) x[c + i] = __builtin_elementwise_fma(e[i], r, q0[i]);
+  }
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef TQ_ATTN_PROF
+#define TQ_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    unsigned long long t_;                                                                            \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    if (threadIdx.x == 0 && p.prof) p.prof[blockIdx.x * 8 + (k)] = t_;                                \
+  } while (0)
+#else
+#define TQ_STAMP(k)
+#endif
+
+// value of the other key-half wave (same queries) through LDS; one barrier
+__device__ __forceinline__ float pair_exchange(float (*slot)[16], float v, int wave, int kh, int r16, int g) {
+  if (g == 0) slot[kh * 2 + wave][r16] = v;
+  __syncthreads();
+  return slot[(kh ^ 1) * 2 + wave][r16];
+}
+
+// SPLIT: four waves per 32 queries -- wave (qh, kh) owns 16 queries x one half of the keys.  One wave issues one VALU
+// instruction per 4 cycles, and a 16 x T score tile is ~45 T instructions per lane: with B * H * T / 32 workgroups below
+// ~2 waves per SIMD (BERT-base at batch 8: 0.75) the kernel is the latency of that one chain, so halving it pays for
+// the three exchanges through LDS (row max, row sum, the integer partial sums of the second GEMM -- all exact, the
+// float sum a + b is the same value in both waves).
+template <int NT_ALL, int DH, bool SPLIT>   // NT_ALL = T / 16 key tiles, DH = head dim (32 or 64)
+__global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void attention_i8_k(AttnArgs p) {   // <= 512 VGPRs per lane
+  constexpr int T = NT_ALL * 16;
+  constexpr int NT = SPLIT ? NT_ALL / 2 : NT_ALL;  // key tiles of this wave
+  constexpr int KS = NT / 4;                       // its 64-key MFMA steps of the second GEMM
+  constexpr int THREADS = SPLIT ? 2 * kAttnThreads : kAttnThreads;
+  constexpr int PITCH = T + 32;                    // 32 * odd bytes: conflict-free ds_read_b128 (4 x 16 lane groups, 64 banks)
+  constexpr int NPART = 1 + 8 * (DH / 16);         // integers per lane a kh = 1 wave hands to its kh = 0 partner
+  static_assert(!SPLIT || NT_ALL % 8 == 0, "key split needs an even number of 64-key steps");
+  __shared__ __attribute__((aligned(16))) int8_t s_vt[DH * PITCH];
+  __shared__ float s_red[SPLIT ? 2 : 1][4][16];    // [max | sum][wave][query]
+  __shared__ int s_part[SPLIT ? 2 : 1][SPLIT ? NPART : 1][64];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 1, kh = SPLIT ? tid >> 7 : 0;
   const int r16 = lane & 15, g = lane >> 4;
+  const int t0 = kh * NT;                          // first key tile of this wave
   const uint32_t qblocks = T / (16 * kAttnWaves);
   const uint32_t bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
   const uint32_t b = bh / p.H, h = bh % p.H;
   const size_t row_stride = p.in_stride;
   const size_t base = (size_t)b * T * row_stride + (size_t)h * DH;
 
-  // ---- V^T -> LDS with the key permutation of the accumulator layout -------------------------------
-  // One work item = 4 consecutive keys x 16 head dims: four 16-byte loads, 4x4 byte transposes in
-  // registers, sixteen 32-bit LDS stores (keys 4m .. 4m+3 are adjacent slots of one V^T row).
-  constexpr uint32_t PARTS = DH / 16;
-  for (uint32_t c = tid; c < (uint32_t)T / 4 * PARTS; c += kAttnThreads) {
-    const uint32_t key4 = (c / PARTS) * 4, part = c % PARTS;
-    v4i raw[4];
+  TQ_STAMP(0);
+  // ---- V tile: loads first (one work item = 4 consecutive keys x 16 head dims, four 16-byte loads) ----------------
+  constexpr uint32_t PARTS = DH / 16, ITEMS = (uint32_t)T / 4 * PARTS;
+  constexpr int VIT = (ITEMS + THREADS - 1) / THREADS;
+  v4i raw[VIT][4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      raw[kk] = *reinterpret_cast<const v4i*>(p.v + base + (size_t)(key4 + kk) * row_stride + part * 16);
-    const uint32_t slot = key_slot(key4);
+  for (int it = 0; it < VIT; ++it) {
+    const uint32_t c = tid + it * THREADS;
+    if (ITEMS % THREADS == 0 || c < ITEMS) {
+      const uint32_t key4 = (c / PARTS) * 4, part = c % PARTS;
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) word |= (((uint32_t)raw[kk][w] >> (8 * e)) & 0xffu) << (8 * kk);
-        *reinterpret_cast<uint32_t*>(s_vt + (part * 16 + w * 4 + e) * PITCH + slot) = word;
-      }
+      for (int kk = 0; kk < 4; ++kk)
+        raw[it][kk] = *reinterpret_cast<const v4i*>(p.v + base + (size_t)(key4 + kk) * row_stride + part * 16);
+    }
   }
 
-  // ---- S^T = K Q^T for this wave's 16 queries --------------------------------------------------------
+  // ---- quantizer parameters and this wave's queries: two dependent rounds of loads (kernel argument -> pointer ->
+  // value) in flight together with the V tile
   const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
   const v4i zero4 = {0, 0, 0, 0};
   const uint32_t qrow = qb * 16 * kAttnWaves + wave * 16 + r16;
   const bool kin = g * 16 < DH;                     // lane groups beyond the head dim supply zeros
   v4i fq = zero4;
   if (kin) fq = *reinterpret_cast<const v4i*>(p.q + base + (size_t)qrow * row_stride + g * 16);
+  // short rows: the K tiles too -- one exposed memory latency for V, Q, K and the parameters instead of two
+  constexpr bool K_EARLY = NT <= 8;
+  v4i fk_all[K_EARLY ? NT : 1];
+  if (K_EARLY) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      fk_all[t] = zero4;
+      if (kin) fk_all[t] = *reinterpret_cast<const v4i*>(p.k + base + (size_t)((t0 + t) * 16 + r16) * row_stride + g * 16);
+    }
+  }
 
   const QP pq = make_qp(p.qq, 0), pk = make_qp(p.qk, 0), pv = make_qp(p.qv, 0), pp = make_qp(p.q_probs, 0);
   const int cq = 128 - (int)pq.zp, ck = 128 - (int)pk.zp, cv = 128 - (int)pv.zp, cp = 128 - (int)pp.zp;
@@ -107,98 +165,262 @@ __global__ __launch_bounds__(kAttnThreads) void attention_i8_k(AttnArgs p) {   /
   const bool denom_pow2 = (dbits & 0x007fffffu) == 0 && (dbits >> 23) >= 32 && (dbits >> 23) <= 222;
   const float inv_denom = 1.0f / p.denom;
 
+  // ---- V^T -> LDS with the key permutation of the accumulator layout: 4x4 byte transposes in registers, sixteen
+  // 32-bit LDS stores per work item (keys 4m .. 4m+3 are adjacent slots of one V^T row)
+#pragma unroll
+  for (int it = 0; it < VIT; ++it) {
+    const uint32_t c = tid + it * THREADS;
+    if (ITEMS % THREADS == 0 || c < ITEMS) {
+      const uint32_t key4 = (c / PARTS) * 4, part = c % PARTS;
+      const uint32_t slot = key_slot(key4);
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t word = 0;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) word |= (((uint32_t)raw[it][kk][w] >> (8 * e)) & 0xffu) << (8 * kk);
+          *reinterpret_cast<uint32_t*>(s_vt + (part * 16 + w * 4 + e) * PITCH + slot) = word;
+        }
+    }
+  }
+
+  TQ_STAMP(1);
+  // ---- S^T = K Q^T for this wave's 16 queries --------------------------------------------------------
   const int rsq = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fq, zero4, 0, 0, 0)[0];   // sum_d a'_q of column r16
   const int q_const = ck * rsq + DH * cq * ck;
 
+  // Wave-uniform: every quantizer of the score / probability chain admits the exact branch-free path (tq_device.h QF)
+  // and the Markstein quotients below keep their fma residuals exact (scales within 2^+-60, see tq_fused_ln.hip).
+  const QF fs = make_qf(ps), fpq = make_qf(pp);
+  const float adn = fabsf(p.denom);
+  const bool fast = p.fast_ok && fpq.ok && pp.scale >= 0x1p-60f && pp.scale <= 0x1p60f && adn >= 0x1p-20f && adn <= 0x1p20f &&
+                    s_qk >= 0x1p-60f && s_qk <= 0x1p60f &&
+                    (!p.has_scores || (fs.ok && ps.scale >= 0x1p-60f && ps.scale <= 0x1p60f));
+
+  TQ_STAMP(2);
+  const QF fc = make_qf(pc);
+  const bool fast_ctx = p.fast_ok && p.has_ctx && fc.ok;
+
   float sc[NT][4];
-  float mx = -__builtin_huge_valf();
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     v4i fk = zero4;
-    if (kin) fk = *reinterpret_cast<const v4i*>(p.k + base + (size_t)(t * 16 + r16) * row_stride + g * 16);
+    if (K_EARLY) fk = fk_all[t];
+    else if (kin) fk = *reinterpret_cast<const v4i*>(p.k + base + (size_t)((t0 + t) * 16 + r16) * row_stride + g * 16);
     const v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq, zero4, 0, 0, 0);
     const v4i rsk = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, ones, zero4, 0, 0, 0);    // sum_d a'_k of rows 4g + r
-    f32x4 mk = {0.f, 0.f, 0.f, 0.f};
-    if (p.mask) mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)b * T + t * 16 + g * 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = (float)(acc[r] + cq * rsk[r] + q_const) * s_qk;
-      if (p.has_scores) {
-        v = q_dequant(clamp_nanprop(rne_quot1(v, ps.scale, rcp_s) + ps.zp, ps.lo, ps.hi), ps);
-      }
-      v = denom_pow2 ? v * inv_denom : v / p.denom;      // x / 2^k == x * 2^-k exactly (sqrt(64) = 8)
-      if (p.mask) v = v + mk[r];
-      sc[t][r] = v;
-      mx = fmaxf(mx, v);
-    }
+    for (int r = 0; r < 4; ++r) sc[t][r] = (float)(acc[r] + cq * rsk[r] + q_const) * s_qk;
+    // pin the four scores: the scheduler otherwise keeps both integer accumulators of every tile (8 NT registers) alive
+    asm volatile("" : "+v"(sc[t][0]), "+v"(sc[t][1]), "+v"(sc[t][2]), "+v"(sc[t][3]));
   }
-  // ---- softmax over the T keys of this lane's query: in-lane, then across the 4 lane groups ------------
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { sc[t][r] = expf(sc[t][r] - mx); sum += sc[t][r]; }
-  sum += __shfl_xor(sum, 16);
-  sum += __shfl_xor(sum, 32);
-  const float inv_sum = (sum >= 7.888609052210118e-31f && sum <= 1.2676506002282294e30f) ? 1.0f / sum : __builtin_nanf("");
 
-  // ---- probability indices -> B operand of the second GEMM (byte tt * 4 + r of step s = key 64s + 16tt + 4g + r)
+  TQ_STAMP(3);
   v4i fp[KS];
+  bool bad_row;                                      // NaN row sum (fully masked query): the context row is NaN
+  if (NT <= 16 && fast) {       // (longer rows: the stage arrays would spill)
+    // ---- branch-free: NT * 2 register pairs move through every stage side by side ---------------------------------
+    constexpr int P = NT * 2;
+    f32x2 x[P];
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
+    for (int t = 0; t < NT; ++t) { x[2 * t] = f32x2{sc[t][0], sc[t][1]}; x[2 * t + 1] = f32x2{sc[t][2], sc[t][3]}; }
+    if (p.has_scores) {
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      uint32_t word = 0;
+      for (int c = 0; c < P; c += 8) {
+        f32x2 (&xc)[8] = *reinterpret_cast<f32x2(*)[8]>(&x[c]);
+        qf_fake_quant2_n<8>(xc, fs);
+      }
+    }
+    if (denom_pow2) {
+      const f32x2 rd = {inv_denom, inv_denom};
+#pragma unroll
+      for (int i = 0; i < P; ++i) x[i] = x[i] * rd;
+    } else {                                         // RN(x / denom)
+      quot2_n<P>(x, f32x2{inv_denom, inv_denom}, f32x2{-p.denom, -p.denom});
+    }
+    if (p.mask) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)b * T + (t0 + t) * 16 + g * 4);
+        x[2 * t] = x[2 * t] + f32x2{mk[0], mk[1]};
+        x[2 * t + 1] = x[2 * t + 1] + f32x2{mk[2], mk[3]};
+      }
+    }
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int i = 0; i < P; ++i) mx = fmaxf(mx, fmaxf(x[i].x, x[i].y));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (SPLIT) mx = fmaxf(mx, pair_exchange(s_red[0], mx, wave, kh, r16, g));   // (the barrier inside also publishes V^T)
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      x[i].x = expf(x[i].x - mx);
+      x[i].y = expf(x[i].y - mx);
+      sum += x[i].x;
+      sum += x[i].y;
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (SPLIT) sum += pair_exchange(s_red[1], sum, wave, kh, r16, g);
+    bad_row = sum != sum;
+    const float rsv = 1.0f / sum;                    // RN(e / sum), 1 <= sum <= T
+    quot2_n<P>(x, f32x2{rsv, rsv}, f32x2{-sum, -sum});
+    f32x2 hq[P];
+#pragma unroll
+    for (int c = 0; c < P; c += 8) {                 // clamp(rne(p / scale) + zp, lo, hi) - zp
+      f32x2 (&xc)[8] = *reinterpret_cast<f32x2(*)[8]>(&x[c]);
+      f32x2 (&hc)[8] = *reinterpret_cast<f32x2(*)[8]>(&hq[c]);
+      qf_round2_n<8>(xc, fpq, hc);
+    }
+    const f32x2 zp2 = {pp.zp, pp.zp};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const f32x2 i0 = hq[2 * (s * 4 + tt)] + zp2, i1 = hq[2 * (s * 4 + tt) + 1] + zp2;     // indices in [0, 255]
+        uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(i0.x, 0, 0u);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(i0.y, 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(i1.x, 2, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(i1.y, 3, w);
+        fp[s][tt] = (int)(w ^ 0x80808080u);          // int8(index - 128)
+      }
+  } else {
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 mk = {0.f, 0.f, 0.f, 0.f};
+      if (p.mask) mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)b * T + (t0 + t) * 16 + g * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        // rne((e / sum) / scale): e * (1/sum) * (1/scale) carries 4 roundings against the 2 of the exact chain
-        // (<= 6 u apart); a band of 8 u (|h| + 1) around the ties decides which elements redo it exactly
-        const float e = sc[s * 4 + tt][r];
-        const float q0 = (e * inv_sum) * rcp_p;
-        float hq = rintf(q0);
-        if (!(fabsf(q0 - hq) < __builtin_fmaf(fabsf(hq), -2.0f * kTieTol, 0.5f - 2.0f * kTieTol)))   // 4 roundings: 8 u band
-          hq = rintf((e / sum) / pp.scale);
-        const int a = (int)clamp_nanprop(hq + pp.zp, pp.lo, pp.hi) - 128;
-        word |= ((uint32_t)a & 0xffu) << (8 * r);
+        float v = sc[t][r];
+        if (p.has_scores) {
+          v = q_dequant(clamp_nanprop(rne_quot1(v, ps.scale, rcp_s) + ps.zp, ps.lo, ps.hi), ps);
+        }
+        v = denom_pow2 ? v * inv_denom : v / p.denom;      // x / 2^k == x * 2^-k exactly (sqrt(64) = 8)
+        if (p.mask) v = v + mk[r];
+        sc[t][r] = v;
+        mx = fmaxf(mx, v);
       }
-      fp[s][tt] = (int)word;
     }
+    // ---- softmax over the T keys of this lane's query: in-lane, then across the 4 lane groups ------------
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (SPLIT) mx = fmaxf(mx, pair_exchange(s_red[0], mx, wave, kh, r16, g));   // (the barrier inside also publishes V^T)
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sc[t][r] = expf(sc[t][r] - mx); sum += sc[t][r]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (SPLIT) sum += pair_exchange(s_red[1], sum, wave, kh, r16, g);
+    bad_row = sum != sum;
+    const float inv_sum = (sum >= 7.888609052210118e-31f && sum <= 1.2676506002282294e30f) ? 1.0f / sum : __builtin_nanf("");
 
-  __syncthreads();                                   // V^T is in LDS
+    // ---- probability indices -> B operand of the second GEMM (byte tt * 4 + r of step s = key 64s + 16tt + 4g + r)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // rne((e / sum) / scale): e * (1/sum) * (1/scale) carries 4 roundings against the 2 of the exact chain
+          // (<= 6 u apart); a band of 8 u (|h| + 1) around the ties decides which elements redo it exactly
+          const float e = sc[s * 4 + tt][r];
+          const float q0 = (e * inv_sum) * rcp_p;
+          float hq = rintf(q0);
+          if (!(fabsf(q0 - hq) < __builtin_fmaf(fabsf(hq), -2.0f * kTieTol, 0.5f - 2.0f * kTieTol)))   // 4 roundings: 8 u band
+            hq = rintf((e / sum) / pp.scale);
+          const int a = (int)clamp_nanprop(hq + pp.zp, pp.lo, pp.hi) - 128;
+          word |= ((uint32_t)a & 0xffu) << (8 * r);
+        }
+        fp[s][tt] = (int)word;
+      }
+  }
+
+  TQ_STAMP(4);
+  if (!SPLIT) __syncthreads();                       // V^T is in LDS
+  TQ_STAMP(5);
 
   // ---- C^T = V^T P^T -------------------------------------------------------------------------------
   v4i rsp4 = zero4;
 #pragma unroll
   for (int s = 0; s < KS; ++s) rsp4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fp[s], rsp4, 0, 0, 0);
-  const int p_const = cv * rsp4[0] + T * cp * cv;    // sum_k a'_p of column r16
-  const size_t out_row = ((size_t)b * T + qrow) * ((size_t)p.H * DH) + (size_t)h * DH;
+  v4i accs[DH / 16], csvs[DH / 16];
 #pragma unroll
   for (int j = 0; j < DH / 16; ++j) {
     v4i acc = zero4, csv = zero4;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const v4i fv = *reinterpret_cast<const v4i*>(s_vt + (j * 16 + r16) * PITCH + s * 64 + g * 16);
+      const v4i fv = *reinterpret_cast<const v4i*>(s_vt + (j * 16 + r16) * PITCH + (kh * KS + s) * 64 + g * 16);
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv, fp[s], acc, 0, 0, 0);
       csv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv, ones, csv, 0, 0, 0);              // sum_k a'_v of rows 4g + r
     }
-    float o[4];
-    struct alignas(4) { int8_t e[4]; } oi = {{0, 0, 0, 0}};
+    accs[j] = acc;
+    csvs[j] = csv;
+  }
+  int rsp = rsp4[0];                                 // sum_k a'_p of column r16 (this wave's keys)
+  if (SPLIT) {                                       // integer partial sums of the upper key half -> the kh = 0 wave
+    if (kh == 1) {
+      s_part[wave][0][lane] = rsp;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = (float)(acc[r] + cp * csv[r] + p_const) * s_pv;
-      if (p.has_ctx) {
-        const float xi = q_index(v, pc);
-        oi.e[r] = (int8_t)((int)xi - 128);
-        v = q_dequant(xi, pc);
+      for (int j = 0; j < DH / 16; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s_part[wave][1 + 8 * j + r][lane] = accs[j][r];
+          s_part[wave][1 + 8 * j + 4 + r][lane] = csvs[j][r];
+        }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    rsp += s_part[wave][0][lane];
+#pragma unroll
+    for (int j = 0; j < DH / 16; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        accs[j][r] += s_part[wave][1 + 8 * j + r][lane];
+        csvs[j][r] += s_part[wave][1 + 8 * j + 4 + r][lane];
       }
-      o[r] = v;
+  }
+  const int p_const = cv * rsp + T * cp * cv;
+  const size_t out_row = ((size_t)b * T + qrow) * ((size_t)p.H * DH) + (size_t)h * DH;
+#pragma unroll
+  for (int j = 0; j < DH / 16; ++j) {
+    const v4i acc = accs[j], csv = csvs[j];
+    float o[4];
+    uint32_t oi = 0;
+    if (fast_ctx) {                                  // exact branch-free quantizer (tq_device.h QF): no IEEE division
+      f32x2 v2[2], h2[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v2[r >> 1][r & 1] = (float)(acc[r] + cp * csv[r] + p_const) * s_pv;
+      qf_round2_n<2>(v2, fc, h2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hh = h2[r >> 1][r & 1];
+        oi = __builtin_amdgcn_cvt_pk_u8_f32(hh + pc.zp, r, oi);
+        o[r] = bad_row ? __builtin_nanf("") : pc.scale * (hh + 0.0f);
+      }
+      oi ^= 0x80808080u;                             // int8(index - 128)
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = (float)(acc[r] + cp * csv[r] + p_const) * s_pv;
+        if (p.has_ctx) {
+          const float xi = q_index(v, pc);
+          oi |= ((uint32_t)((int)xi - 128) & 0xffu) << (8 * r);
+          v = q_dequant(xi, pc);
+        }
+        o[r] = bad_row ? __builtin_nanf("") : v;       // softmax of a fully masked row is NaN in the reference
+      }
     }
     const size_t off = out_row + j * 16 + g * 4;
     *reinterpret_cast<f32x4*>(p.ctx + off) = f32x4{o[0], o[1], o[2], o[3]};
-    if (p.ctx_idx) *reinterpret_cast<uint32_t*>(p.ctx_idx + off) = __builtin_bit_cast(uint32_t, oi);
+    if (p.ctx_idx) *reinterpret_cast<uint32_t*>(p.ctx_idx + off) = oi;
   }
+  TQ_STAMP(6);
 }
 
 }  // namespace tq
@@ -251,19 +473,36 @@ extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, con
   a.B = (uint32_t)B; a.T = (uint32_t)T; a.H = (uint32_t)H; a.in_stride = (uint32_t)qkv_row_stride; a.denom = denom;
   a.qq = *q_q; a.qk = *q_k; a.qv = *q_v; a.q_probs = *q_probs;
   a.has_scores = q_scores != nullptr; a.has_ctx = q_ctx != nullptr;
+  a.fast_ok = tuning("TQ_ATTN_FAST", 1);
+#ifdef TQ_ATTN_PROF
+  { const char* e = getenv("TQ_ATTN_PROF_PTR"); a.prof = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }
+#endif
   if (q_scores) a.q_scores = *q_scores;
   if (q_ctx) a.q_ctx = *q_ctx;
   const unsigned grid = (unsigned)(B * H * (T / (16 * kAttnWaves)));
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // key split (4 waves per 32 queries) while the plain grid leaves the SIMDs under ~2 waves each: T % 128 == 0 only
+  const int split_env = tuning("TQ_ATTN_SPLIT", -1);     // read per call: the tests flip it
+  const bool split = T % 128 == 0 && (split_env >= 0 ? split_env != 0 : grid <= 1024);
+#define TQ_ATTN_LAUNCH(NTV, DHV, SP)                                                                             \
+  hipLaunchKernelGGL((attention_i8_k<NTV, DHV, SP>), dim3(grid), dim3((SP) ? 2 * kAttnThreads : kAttnThreads), 0, st, a)
 #define TQ_ATTN(NTV)                                                                                             \
   case NTV * 16:                                                                                                 \
-    if (head_dim == 64) hipLaunchKernelGGL((attention_i8_k<NTV, 64>), dim3(grid), dim3(kAttnThreads), 0, st, a); \
-    else hipLaunchKernelGGL((attention_i8_k<NTV, 32>), dim3(grid), dim3(kAttnThreads), 0, st, a);                \
+    if constexpr ((NTV) % 8 == 0) {                                                                              \
+      if (split) {                                                                                               \
+        if (head_dim == 64) TQ_ATTN_LAUNCH(NTV, 64, true);                                                       \
+        else TQ_ATTN_LAUNCH(NTV, 32, true);                                                                      \
+        break;                                                                                                   \
+      }                                                                                                          \
+    }                                                                                                            \
+    if (head_dim == 64) TQ_ATTN_LAUNCH(NTV, 64, false);                                                          \
+    else TQ_ATTN_LAUNCH(NTV, 32, false);                                                                         \
     break
   switch (T) {
     TQ_ATTN(4); TQ_ATTN(8); TQ_ATTN(12); TQ_ATTN(16); TQ_ATTN(20); TQ_ATTN(24); TQ_ATTN(28); TQ_ATTN(32);
     default: return set_error(TQ_EUNSUPPORTED, "tq_attention_i8_fwd: sequence length %llu", (unsigned long long)T);
   }
+#undef TQ_ATTN_LAUNCH
 #undef TQ_ATTN
   return check_launch("attention_i8_k");
 }
