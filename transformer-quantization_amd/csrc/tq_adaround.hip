@@ -43,18 +43,32 @@ __device__ __forceinline__ uint64_t par_index(const tq_quantizer& q, uint64_t i)
   return q.n_params == 1 ? 0 : (i / q.inner) % q.n_params;
 }
 
+// V consecutive elements per thread (16-byte accesses, one parameter look-up per vector); V = 1 for ragged / unaligned /
+// per-channel tensors whose inner extent is not a multiple of 4
+template <int V>
+struct AdaVec { typedef float type __attribute__((ext_vector_type(V))); };
+
+template <int V>
 __global__ __launch_bounds__(kBlock) void ada_fwd_k(const float* __restrict__ w, const float* __restrict__ alpha,
                                                     float* __restrict__ out, uint64_t n, tq_quantizer q, int mode,
                                                     int soft, float temp) {
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    const QP p = make_qp(q, par_index(q, i));
-    const float fl = floorf(w[i] / p.scale);
-    const float a = alpha[i];
-    const float r = soft ? ada_h(a, mode, temp, nullptr) : (a >= 0.0f ? 1.0f : 0.0f);
-    float xi = fl + r;
-    if (!q.symmetric) xi += p.zp;
-    xi = clamp_nanprop(xi, p.lo, p.hi);
-    out[i] = q_dequant(xi, p);
+  typedef typename AdaVec<V>::type vec;
+  const uint64_t nv = n / V;
+  for (uint64_t iv = (uint64_t)blockIdx.x * kBlock + threadIdx.x; iv < nv; iv += (uint64_t)gridDim.x * kBlock) {
+    const QP p = make_qp(q, par_index(q, iv * V));
+    const vec wv = reinterpret_cast<const vec*>(w)[iv], av = reinterpret_cast<const vec*>(alpha)[iv];
+    vec o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float fl = floorf(wv[j] / p.scale);
+      const float a = av[j];
+      const float r = soft ? ada_h(a, mode, temp, nullptr) : (a >= 0.0f ? 1.0f : 0.0f);
+      float xi = fl + r;
+      if (!q.symmetric) xi += p.zp;
+      xi = clamp_nanprop(xi, p.lo, p.hi);
+      o[j] = q_dequant(xi, p);
+    }
+    reinterpret_cast<vec*>(out)[iv] = o;
   }
 }
 
@@ -90,42 +104,64 @@ __global__ __launch_bounds__(kBlock) void ada_bwd_k(const float* __restrict__ w,
   }
 }
 
+template <int V>
 __global__ __launch_bounds__(kBlock) void ada_bwd_adam_k(const float* __restrict__ w, const float* __restrict__ g_wq,
                                                          float* __restrict__ alpha, float* __restrict__ m,
                                                          float* __restrict__ v, float* __restrict__ g_out, uint64_t n,
                                                          tq_quantizer q, int mode, float temp, float reg_w, float beta,
                                                          float lr, float b1, float b2, float adam_eps, float bc1,
                                                          float bc2_sqrt, const float* __restrict__ sched) {
+  typedef typename AdaVec<V>::type vec;
   if (sched != nullptr) {      // per-iteration scalars from device memory (hipGraph replay of the optimisation loop)
     reg_w = sched[0]; beta = sched[1]; bc1 = sched[2]; bc2_sqrt = sched[3];
   }
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    const QP p = make_qp(q, par_index(q, i));
-    const float a = alpha[i];
-    float dh;
-    const float h = ada_h(a, mode, temp, &dh);
-    float xi = floorf(w[i] / p.scale) + h;
-    if (!q.symmetric) xi += p.zp;
-    const bool in = (xi >= p.lo) && (xi <= p.hi);
-    // d loss / d alpha through w_q = s * (x_int - zp)
-    float g = in ? (g_wq[i] * p.scale) * dh : 0.0f;
-    if (reg_w != 0.0f) {
-      // d/dalpha [ reg_w * (1 - (2|h - 0.5|)^beta) ]
-      const float c = h - 0.5f;
-      const float u = fabsf(c) * 2.0f;
-      const float sgn = c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f);
-      const float dpow = (u == 0.0f && beta >= 1.0f) ? 0.0f : beta * powf(u, beta - 1.0f);
-      g += -reg_w * dpow * 2.0f * sgn * dh;
+  const uint64_t nv = n / V;
+  for (uint64_t iv = (uint64_t)blockIdx.x * kBlock + threadIdx.x; iv < nv; iv += (uint64_t)gridDim.x * kBlock) {
+    const QP p = make_qp(q, par_index(q, iv * V));
+    const vec wv = reinterpret_cast<const vec*>(w)[iv], gv = reinterpret_cast<const vec*>(g_wq)[iv];
+    const vec av = reinterpret_cast<const vec*>(alpha)[iv], mv = reinterpret_cast<const vec*>(m)[iv];
+    const vec vv = reinterpret_cast<const vec*>(v)[iv];
+    vec ao, mo, vo, go;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float a = av[j];
+      float dh;
+      const float h = ada_h(a, mode, temp, &dh);
+      float xi = floorf(wv[j] / p.scale) + h;
+      if (!q.symmetric) xi += p.zp;
+      const bool in = (xi >= p.lo) && (xi <= p.hi);
+      // d loss / d alpha through w_q = s * (x_int - zp)
+      float g = in ? (gv[j] * p.scale) * dh : 0.0f;
+      if (reg_w != 0.0f) {
+        // d/dalpha [ reg_w * (1 - (2|h - 0.5|)^beta) ]
+        const float c = h - 0.5f;
+        const float u = fabsf(c) * 2.0f;
+        const float sgn = c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f);
+        const float dpow = (u == 0.0f && beta >= 1.0f) ? 0.0f : beta * powf(u, beta - 1.0f);
+        g += -reg_w * dpow * 2.0f * sgn * dh;
+      }
+      go[j] = g;
+      // torch.optim.Adam (no weight decay / amsgrad)
+      const float mi = mv[j] + (g - mv[j]) * (1.0f - b1);      // exp_avg.lerp_(grad, 1 - beta1)
+      const float vi = vv[j] * b2 + (1.0f - b2) * g * g;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+      const float denom = sqrtf(vi) / bc2_sqrt + adam_eps;
+      ao[j] = a - (lr / bc1) * (mi / denom);
+      mo[j] = mi;
+      vo[j] = vi;
     }
-    if (g_out) g_out[i] = g;
-    // torch.optim.Adam (no weight decay / amsgrad)
-    const float mi = m[i] + (g - m[i]) * (1.0f - b1);       // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = v[i] * b2 + (1.0f - b2) * g * g;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-    const float denom = sqrtf(vi) / bc2_sqrt + adam_eps;
-    alpha[i] = a - (lr / bc1) * (mi / denom);
-    m[i] = mi;
-    v[i] = vi;
+    if (g_out) reinterpret_cast<vec*>(g_out)[iv] = go;
+    reinterpret_cast<vec*>(alpha)[iv] = ao;
+    reinterpret_cast<vec*>(m)[iv] = mo;
+    reinterpret_cast<vec*>(v)[iv] = vo;
   }
+}
+
+// 16-byte vectors when every stream allows it
+static bool ada_vec4(uint64_t n, const tq_quantizer* q, std::initializer_list<const void*> ptrs) {
+  if (n % 4 != 0 || (q->n_params != 1 && q->inner % 4 != 0)) return false;
+  for (const void* p : ptrs)
+    if (p != nullptr && !aligned16(p)) return false;
+  return true;
 }
 
 // block partial sums -> ws[blockIdx.x]; finalize adds/sets out[0]
@@ -200,8 +236,12 @@ extern "C" int tq_adaround_fwd(const float* w, const float* alpha, float* w_q, u
   if (int e = check_quantizer(q, n, "tq_adaround_fwd")) return e;
   if (int e = check_mode(mode, temperature, "tq_adaround_fwd")) return e;
   if (n == 0) return TQ_OK;
-  hipLaunchKernelGGL(ada_fwd_k, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, alpha, w_q, n, *q,
-                     mode, soft, temperature);
+  if (ada_vec4(n, q, {w, alpha, w_q}))
+    hipLaunchKernelGGL(ada_fwd_k<4>, dim3(ew_grid(n / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, alpha, w_q, n,
+                       *q, mode, soft, temperature);
+  else
+    hipLaunchKernelGGL(ada_fwd_k<1>, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, alpha, w_q, n, *q,
+                       mode, soft, temperature);
   return check_launch("ada_fwd_k");
 }
 
@@ -239,9 +279,14 @@ extern "C" int tq_adaround_bwd_adam(const float* w, const float* grad_wq, float*
   // bias corrections in double like python, narrowed once (torch computes them as python floats)
   const double bc1 = 1.0 - pow((double)adam_b1, (double)step);
   const double bc2 = 1.0 - pow((double)adam_b2, (double)step);
-  hipLaunchKernelGGL(ada_bwd_adam_k, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq, alpha,
-                     exp_avg, exp_avg_sq, grad_alpha_out, n, *q, mode, temperature, reg_weight, beta, lr, adam_b1,
-                     adam_b2, adam_eps, (float)bc1, (float)sqrt(bc2), (const float*)nullptr);
+  if (ada_vec4(n, q, {w, grad_wq, alpha, exp_avg, exp_avg_sq, grad_alpha_out}))
+    hipLaunchKernelGGL(ada_bwd_adam_k<4>, dim3(ew_grid(n / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq,
+                       alpha, exp_avg, exp_avg_sq, grad_alpha_out, n, *q, mode, temperature, reg_weight, beta, lr, adam_b1,
+                       adam_b2, adam_eps, (float)bc1, (float)sqrt(bc2), (const float*)nullptr);
+  else
+    hipLaunchKernelGGL(ada_bwd_adam_k<1>, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq, alpha,
+                       exp_avg, exp_avg_sq, grad_alpha_out, n, *q, mode, temperature, reg_weight, beta, lr, adam_b1,
+                       adam_b2, adam_eps, (float)bc1, (float)sqrt(bc2), (const float*)nullptr);
   return check_launch("ada_bwd_adam_k");
 }
 
@@ -256,9 +301,14 @@ extern "C" int tq_adaround_bwd_adam_sched(const float* w, const float* grad_wq, 
   if (int e = check_quantizer(q, n, "tq_adaround_bwd_adam_sched")) return e;
   if (int e = check_mode(mode, temperature, "tq_adaround_bwd_adam_sched")) return e;
   if (n == 0) return TQ_OK;
-  hipLaunchKernelGGL(ada_bwd_adam_k, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq, alpha,
-                     exp_avg, exp_avg_sq, (float*)nullptr, n, *q, mode, temperature, 0.0f, 0.0f, lr, adam_b1, adam_b2, adam_eps,
-                     1.0f, 1.0f, sched);
+  if (ada_vec4(n, q, {w, grad_wq, alpha, exp_avg, exp_avg_sq}))
+    hipLaunchKernelGGL(ada_bwd_adam_k<4>, dim3(ew_grid(n / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq,
+                       alpha, exp_avg, exp_avg_sq, (float*)nullptr, n, *q, mode, temperature, 0.0f, 0.0f, lr, adam_b1, adam_b2,
+                       adam_eps, 1.0f, 1.0f, sched);
+  else
+    hipLaunchKernelGGL(ada_bwd_adam_k<1>, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq, alpha,
+                       exp_avg, exp_avg_sq, (float*)nullptr, n, *q, mode, temperature, 0.0f, 0.0f, lr, adam_b1, adam_b2, adam_eps,
+                       1.0f, 1.0f, sched);
   return check_launch("ada_bwd_adam_k");
 }
 
