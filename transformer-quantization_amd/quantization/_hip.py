@@ -224,6 +224,7 @@ class HipBackend:
     def __init__(self):
         self.lib = load_library()
         self._ws = {}
+        self._qdesc_cache = {}
         self._counters = {}      # zeroed ticket words of tq_calibrate_tensor, one per (device, stream)
 
     # -- helpers -------------------------------------------------------------------------
@@ -248,9 +249,19 @@ class HipBackend:
         return torch.tensor(v, dtype=torch.float64).float().to(dev)
 
     def _qdesc(self, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner):
-        return tq_quantizer(_ptr(delta), _ptr(zero_float), _ptr(signed), int(n_bits),
-                            int(bool(symmetric)), int(bool(log_domain)), float(eps),
-                            int(n_params), int(inner))
+        """The C descriptor of a quantizer.  Building a 9-field ctypes struct is ~4 us of host time -- a quarter of a
+        launch-bound fixed-range call -- so descriptors are memoised by VALUE (pointers and scalars: the key
+        determines every field, nothing can go stale; a struct is never written after construction)."""
+        key = (None if delta is None else delta.data_ptr(), None if zero_float is None else zero_float.data_ptr(),
+               None if signed is None else signed.data_ptr(), n_bits, symmetric, log_domain, eps, n_params, inner)
+        cache = self._qdesc_cache
+        d = cache.get(key)
+        if d is None:
+            if len(cache) > 8192:        # calibration rebinds the range tensors every step: bounded, not LRU
+                cache.clear()
+            d = cache[key] = tq_quantizer(key[0], key[1], key[2], int(n_bits), int(bool(symmetric)),
+                                          int(bool(log_domain)), float(eps), int(n_params), int(inner))
+        return d
 
     # -- FP64 (`--double`) ------------------------------------------------------------------
     @staticmethod

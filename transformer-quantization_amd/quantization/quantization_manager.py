@@ -205,10 +205,15 @@ class QuantizationManager(nn.Module):
         return tuple(bufs)
 
     def forward(self, x):
-        est = self.range_estimator
+        # (sub-modules through the registry: nn.Module.__getattr__ is the slow path of attribute access, and a
+        # fixed-range call is launch-bound)
+        mods = self._modules
+        est = mods.get('range_estimator')
         if est is not None and est.per_group_range_estimation:
             est(x)          # PEG phase 1: only collect per-dimension ranges, pass x through
             return x
+        if self.state == Qstates.fix_ranges:
+            return self._fixed_forward(x, mods['quantizer'])
         if self._estimating():
             if est is None:
                 raise RuntimeError('this manager was built with a fixed range: no estimator to run')
@@ -217,16 +222,19 @@ class QuantizationManager(nn.Module):
                 return y
             cur_xmin, cur_xmax = est(x)
             self.set_quant_range(cur_xmin, cur_xmax)
-        if self.state == Qstates.fix_ranges:
-            y = self._fixed_forward_with_indices(x) if options.INT8_LINEAR else None
-            if y is None:
-                y = self.quantizer(x)
-            # provenance record: lets a consumer (the fused integer Linear, also under autograd in QAT) recover the
-            # exact grid indices of this tensor from the quantizer that produced it (quantization/provenance.py)
-            if options.INT8_LINEAR:          # only the integer fast paths consume the record
-                provenance.tag(y, self.quantizer, provenance.indices_of(y))
-            return y
-        return self.quantizer(x)
+        return mods['quantizer'](x)
+
+    def _fixed_forward(self, x, q):
+        if not options.INT8_LINEAR:
+            return q(x)
+        y = self._fixed_forward_with_indices(x)
+        if y is None:
+            y = q(x)
+        # provenance record: lets a consumer (the fused integer Linear, also under autograd in QAT) recover the
+        # exact grid indices of this tensor from the quantizer that produced it (quantization/provenance.py);
+        # only the integer fast paths consume it
+        provenance.tag(y, q, provenance.indices_of(y))
+        return y
 
     def _fixed_forward_with_indices(self, x):
         """Fixed per-tensor asymmetric <= 8-bit quantizer feeding integer Linears: one launch writes

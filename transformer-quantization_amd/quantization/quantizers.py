@@ -269,15 +269,24 @@ class AsymmetricUniformQuantizer(QuantizerBase):
             self._adjust_params_per_axis(x_float)
         if self.per_channel:
             self._adjust_params_per_channel(x_float)
-        delta = self.delta
-        zf = self._zero_float
-        n_params, inner = self._layout(x_float)
+        # state straight from the registries (a fixed-range call is launch-bound: nn.Module.__getattr__ -- and the
+        # AttributeError it builds for the `_signed` an asymmetric quantizer does not have -- was a quarter of its
+        # host time)
+        bufs = self._buffers
+        delta = bufs.get('_delta')
+        if delta is None:
+            delta = self.delta                  # trainable range (nn.Parameter) or not initialised (raises)
+        zf = bufs.get('_zero_float')
+        if zf is None and not self.symmetric:
+            zf = self._zero_float
+        n = delta.numel()
+        n_params, inner = (1, 1) if n == 1 else param_layout(x_float, n, self.axis, self.per_channel, delta.shape)
         needs_grad = torch.is_grad_enabled() and (
             x_float.requires_grad or delta.requires_grad or (zf is not None and zf.requires_grad))
         if needs_grad:
             return _FakeQuantSTE.apply(x_float, delta, zf, self, n_params, inner)
         y, _ = _hip.backend().fake_quant(
-            x_float, delta, zf, getattr(self, '_signed', None), self.n_bits, self.symmetric,
+            x_float, delta, zf, bufs.get('_signed'), self.n_bits, self.symmetric,
             self.scale_domain == 'log', self.eps, n_params, inner)
         return y
 
