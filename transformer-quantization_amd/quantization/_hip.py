@@ -225,6 +225,7 @@ class HipBackend:
         self.lib = load_library()
         self._ws = {}
         self._qdesc_cache = {}
+        self._ws_bytes = {}
         self._counters = {}      # zeroed ticket words of tq_calibrate_tensor, one per (device, stream)
 
     # -- helpers -------------------------------------------------------------------------
@@ -235,6 +236,17 @@ class HipBackend:
             ws = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
             self._ws[key] = ws
         return ws
+
+    def _calib_ws_bytes(self, n, n_params, inner):
+        """tq_calibrate_workspace_bytes, memoised (a pure function of its arguments; one C call less per calibrating
+        forward of every quantizer)."""
+        key = (n, n_params, inner)
+        v = self._ws_bytes.get(key)
+        if v is None:
+            if len(self._ws_bytes) > 4096:
+                self._ws_bytes.clear()
+            v = self._ws_bytes[key] = self.lib.tq_calibrate_workspace_bytes(n, n_params, inner)
+        return v
 
     def to_device_f32(self, v, like=None):
         """python scalar / numpy / CPU tensor -> fp32 tensor on the active ROCm device."""
@@ -565,11 +577,12 @@ class HipBackend:
             if counter is None:
                 counter = self._counters[key] = torch.zeros(1, dtype=torch.int32, device=dev)
             if out is None:
-                buf = torch.empty(4, dtype=torch.float32, device=dev)    # cur_min, cur_max, delta, zero_float
-                out = (buf[0], buf[1], buf[2], None if symmetric else buf[3],
+                # cur_min, cur_max, delta, zero_float: one allocation, one op for the four 0-D views
+                b0, b1, b2, b3 = torch.empty(4, dtype=torch.float32, device=dev).unbind(0)
+                out = (b0, b1, b2, None if symmetric else b3,
                        torch.empty((), dtype=torch.bool, device=dev) if symmetric else None)
             y = torch.empty_like(x) if want_y else None
-            ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), 1, 1))
+            ws = self._workspace(dev, self._calib_ws_bytes(x.numel(), 1, 1))
             rc = self.lib.tq_calibrate_tensor(
                 x.data_ptr(), x.numel(), _dtype_code(x, 'calibrate_minmax'), mode, _ptr(prev_min), _ptr(prev_max),
                 _ptr(out[0]), _ptr(out[1]), float(momentum), int(n_bits), int(bool(symmetric)), float(eps),
@@ -579,7 +592,7 @@ class HipBackend:
             return (*out, y)
         y = torch.empty_like(x) if want_y else None
         if out is not None:
-            ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), n_params, inner))
+            ws = self._workspace(dev, self._calib_ws_bytes(x.numel(), n_params, inner))
             rc = self.lib.tq_calibrate_minmax(
                 _ptr(x), x.numel(), _dtype_code(x, 'calibrate_minmax'), n_params, inner, mode,
                 _ptr(prev_min), _ptr(prev_max), _ptr(out[0]), _ptr(out[1]), float(momentum), int(n_groups or 0),
@@ -590,7 +603,7 @@ class HipBackend:
         cur = torch.empty(2, n_params, dtype=torch.float32, device=dev)
         par = torch.empty(1 if symmetric else 2, n_params, dtype=torch.float32, device=dev)
         signed = torch.empty((), dtype=torch.bool, device=dev) if symmetric else None
-        ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), n_params, inner))
+        ws = self._workspace(dev, self._calib_ws_bytes(x.numel(), n_params, inner))
         rc = self.lib.tq_calibrate_minmax(
             _ptr(x), x.numel(), _dtype_code(x, 'calibrate_minmax'), n_params, inner, mode,
             _ptr(prev_min), _ptr(prev_max), _ptr(cur[0]), _ptr(cur[1]), float(momentum), int(n_groups or 0),
@@ -616,7 +629,7 @@ class HipBackend:
             counter = self._counters.get(key)
             if counter is None:
                 counter = self._counters[key] = torch.zeros(1, dtype=torch.int32, device=dev)
-        ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), n_params, inner))
+        ws = self._workspace(dev, self._calib_ws_bytes(x.numel(), n_params, inner))
         rc = self.lib.tq_calibrate_stats(x.data_ptr(), x.numel(), _dtype_code(x, 'calibrate_stats'), n_params, inner,
                                          stats.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(counter), st)
         _check(rc, self.lib)
@@ -668,7 +681,7 @@ class HipBackend:
             if counter is None:
                 counter = self._counters[key] = torch.zeros(1, dtype=torch.int32, device=dev)
         y = torch.empty_like(x) if want_y else None
-        ws = self._workspace(dev, self.lib.tq_calibrate_workspace_bytes(x.numel(), n_params, inner))
+        ws = self._workspace(dev, self._calib_ws_bytes(x.numel(), n_params, inner))
         rc = self.lib.tq_calibrate_minmax_mailbox(
             x.data_ptr(), x.numel(), _dtype_code(x, 'calibrate_minmax_mailbox'), n_params, inner, mode, _ptr(prev_min),
             _ptr(prev_max), _ptr(out[0]), _ptr(out[1]), float(momentum), int(n_groups or 0), _ptr(order), int(n_bits),

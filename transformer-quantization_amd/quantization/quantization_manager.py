@@ -118,7 +118,8 @@ class QuantizationManager(nn.Module):
         """estimator(x) -> set_quant_range -> quantizer(x) as one backend call (two around the all-reduce when
         calibration is sharded), or None when the configuration needs the layered path (percentiles, custom
         classes, autograd, CPU tensors, > 4096 ranges).  Leaves exactly the state the layered path leaves."""
-        est, q = self.range_estimator, self.quantizer
+        mods = self._modules
+        est, q = mods.get('range_estimator'), mods['quantizer']
         mode = _FUSED_ESTIMATORS.get(type(est))
         be = _hip.backend()
         sharded = tq_dist.is_enabled()
@@ -148,8 +149,9 @@ class QuantizationManager(nn.Module):
         order = None
         if n_groups and mode == _hip.EST_CURRENT and est.ranges is not None:
             order = be.argsort(est.ranges)
-        prev_min = est.current_xmin if mode != _hip.EST_CURRENT else None
-        prev_max = est.current_xmax if mode != _hip.EST_CURRENT else None
+        ebufs = est._buffers                 # (registered buffers, read through the registry: see forward)
+        prev_min = ebufs['current_xmin'] if mode != _hip.EST_CURRENT else None
+        prev_max = ebufs['current_xmax'] if mode != _hip.EST_CURRENT else None
         if prev_min is not None and (prev_min.dtype != torch.float32 or prev_max.dtype != torch.float32):
             return None                      # state left by a float64 pass: the layered path promotes like torch
         out = None
@@ -174,7 +176,7 @@ class QuantizationManager(nn.Module):
                 q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log', out=out)
         # registered buffers: rebinding through the dict skips nn.Module.__setattr__'s type dispatch
         # (4 rebinds per call x 161 quantizers per calibration batch)
-        est._buffers['current_xmin'], est._buffers['current_xmax'] = cur_min, cur_max
+        ebufs['current_xmin'], ebufs['current_xmax'] = cur_min, cur_max
         object.__setattr__(q, '_range_gen', q._range_gen + 1)          # the dict rebinds below bypass __setattr__
         q._buffers['_delta'] = delta
         if q.symmetric:
