@@ -73,6 +73,30 @@ def test_argument_validation_without_gpu(lib_path):
     assert lib.tq_mse_workspace_bytes(1, 786432, 100) >= 100 * 8
 
 
+def test_quantizer_descriptors_are_memoised_by_value(lib_path):
+    """The C descriptor of a quantizer is memoised on (pointers, scalars): the same operands give the same struct, a
+    rebound range tensor (what every calibration step does) or any changed scalar a different one with the new fields."""
+    import torch
+    from quantization import _hip
+    be = _hip.HipBackend()
+    d1, z1, d2 = torch.tensor(0.1), torch.tensor(3.0), torch.tensor(0.2)
+    a = be._qdesc(d1, z1, None, 8, False, False, 1e-8, 1, 1)
+    assert be._qdesc(d1, z1, None, 8, False, False, 1e-8, 1, 1) is a
+    assert a.delta == d1.data_ptr() and a.zero_float == z1.data_ptr() and not a.signed_flag
+    assert (a.n_bits, a.symmetric, a.log_domain, a.n_params, a.inner) == (8, 0, 0, 1, 1) and abs(a.eps - 1e-8) < 1e-15
+    b = be._qdesc(d2, z1, None, 8, False, False, 1e-8, 1, 1)
+    assert b is not a and b.delta == d2.data_ptr()
+    for changed in ((d1, z1, None, 4, False, False, 1e-8, 1, 1), (d1, z1, None, 8, True, False, 1e-8, 1, 1),
+                    (d1, z1, None, 8, False, True, 1e-8, 1, 1), (d1, z1, None, 8, False, False, 1e-6, 1, 1),
+                    (d1, z1, None, 8, False, False, 1e-8, 768, 1), (d1, z1, None, 8, False, False, 1e-8, 768, 64),
+                    (d1, None, d2, 8, True, False, 1e-8, 1, 1)):
+        c = be._qdesc(*changed)
+        assert c is not a
+        assert (c.n_bits, c.symmetric, c.log_domain, c.n_params, c.inner) == (
+            changed[3], int(changed[4]), int(changed[5]), changed[7], changed[8])
+    assert be._calib_ws_bytes(1 << 20, 1, 1) == be.lib.tq_calibrate_workspace_bytes(1 << 20, 1, 1)
+
+
 def test_product_package_never_imports_oracle():
     bad = []
     for dirpath, _, files in os.walk(PKG):
