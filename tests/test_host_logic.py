@@ -434,3 +434,31 @@ def test_adaround_samples_from_the_cached_rows():
         res = apply_adaround_to_layer(net, getattr(net, name), data, batch_size=4, act_quant=False,
                                       adaround_config=copy.deepcopy(cfg))
         assert np.isfinite(res.loss_hard_after)
+
+
+def test_provenance_records_die_with_any_change():
+    """A provenance record (quantization/provenance.py) vouches for ONE tensor object in ONE state: views and copies
+    have none, an in-place op or a re-set range of the producing quantizer invalidates it."""
+    from quantization import provenance
+    from quantization.quantizers import AsymmetricUniformQuantizer
+    q = AsymmetricUniformQuantizer(n_bits=8)
+    q._delta, q._zero_float = torch.tensor(0.1), torch.tensor(3.0)
+    y = torch.zeros(4, 8)
+    idx = torch.zeros(4, 8, dtype=torch.int8)
+    provenance.tag(y, q, idx)
+    assert provenance.quantizer_of(y) is q and provenance.indices_of(y) is idx
+    assert provenance.of(y.view(8, 4)) is None and provenance.of(y.clone()) is None and provenance.of(y + 0) is None
+    y.add_(1.0)                                  # in-place: same object, other values
+    assert provenance.of(y) is None
+    provenance.tag(y, q, idx)
+    assert provenance.of(y) is not None
+    q._delta = torch.tensor(0.2)                 # producer's grid moved after the record was made
+    assert provenance.of(y) is None
+    provenance.tag(y, q, idx)
+    q._delta.mul_(2.0)                           # ... or was updated in place (learned ranges)
+    assert provenance.of(y) is None
+    z = torch.ones(3)
+    provenance.tag(z, q)
+    key = id(z)
+    del z
+    assert key not in provenance._records        # records die with their tensor

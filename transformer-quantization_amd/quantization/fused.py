@@ -307,7 +307,8 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
             return None
         wq, oq = l.weight_quantizer.quantizer, l.activation_quantizer.quantizer
         if (not wq.symmetric or wq.n_bits > 8 or wq.scale_domain != 'linear' or wq._delta.numel() not in (1, D)
-                or oq.symmetric or oq.n_bits > 8 or oq.scale_domain != 'linear'):
+                or oq.symmetric or oq.n_bits > 8 or oq.scale_domain != 'linear'
+                or wq.eps != query.weight_quantizer.quantizer.eps):     # one eps argument serves the stacked weights
             return None
         outs.append((oq._delta, oq._zero_float, None, oq.n_bits, False, False, oq.eps))
     qs = _fixed_per_tensor(scores_quantizer._quant_a, scores_quantizer.activation_quantizer)

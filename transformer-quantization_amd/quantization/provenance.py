@@ -12,7 +12,9 @@ tensor attributes:
 Records are keyed by tensor OBJECT identity and die with the tensor (weak references).  Anything that makes a new
 tensor object -- a view, `.contiguous()`, dropout, an arithmetic op -- has no record, and the consumer takes the
 layered path (always correct, only slower).  That is the intended safety property, not an accident: values are trusted
-to be on-grid only for the very object the quantizer kernel returned.
+to be on-grid only for the very object the quantizer kernel returned -- and only while that object is UNCHANGED: a
+record also carries the tensor's version counter (any in-place op: `add_`, in-place dropout, `copy_`) and the range
+state of the producing quantizer (a range re-set between producer and consumer), and is ignored once either moved.
 """
 import weakref
 
@@ -25,15 +27,22 @@ def tag(tensor, quantizer, idx=None):
 
     def _drop(_ref, key=key):
         _records.pop(key, None)
-    _records[key] = (weakref.ref(tensor, _drop), quantizer, idx)
+    _records[key] = (weakref.ref(tensor, _drop), quantizer, idx, tensor._version, _range_state(quantizer))
     return tensor
 
 
+def _range_state(quantizer):
+    key = getattr(quantizer, 'range_state_key', None)
+    return key() if key is not None else None
+
+
 def of(tensor):
-    """(quantizer, idx | None) recorded for this tensor object, or None."""
+    """(quantizer, idx | None) recorded for this tensor object, or None (no record, or a stale one)."""
     rec = _records.get(id(tensor))
     if rec is None or rec[0]() is not tensor:
         return None
+    if tensor._version != rec[3] or _range_state(rec[1]) != rec[4]:
+        return None                          # modified in place / producer's grid changed since the record was made
     return rec[1], rec[2]
 
 
