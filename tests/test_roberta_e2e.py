@@ -1,0 +1,131 @@
+"""RoBERTa through the drop-in classes (harness/roberta.py): what the reference's models/quantized_roberta.py adds to
+BERT -- position ids derived from the input ids with real padding, no pooler, the generic-rewriter classification head
+-- against a fixture produced by the reference's own blocks (tests/golden/make_golden_roberta.py; 2 layers, W8A8
+per-tensor, running min/max, one calibration batch, fixed-range forward).
+
+* CPU (oracle-backed backend double): position ids, 31 activation ranges, 22 weight deltas and logits EXACTLY.
+* GPU: through the HIP kernels; weight deltas and the pre-GEMM sites exact, every site bit-equal to the oracle on the
+  tensor it saw, logits within the round-off of hipBLASLt vs CPU GEMMs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import GOLDEN
+
+
+def _fixture():
+    return np.load(os.path.join(GOLDEN, 'roberta_2l_w8a8.npz'))
+
+
+def _build(device):
+    from harness.roberta import build_roberta
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    model, hf = build_roberta(seed=1000, num_layers=2, **qp)
+    return model.to(device).eval(), hf
+
+
+def _check_weights_reproduced(hf, z):
+    got = float(hf.roberta.encoder.layer[0].attention.self.query.weight.detach().double().sum())
+    if got != float(z['first_weight_sum']):
+        pytest.skip('random-init weights differ from the fixture (other torch/transformers build): ' + str(z['versions']))
+
+
+def _calibrate_and_run(model, ids, amask):
+    from utils.utils import pass_data_for_range_estimation
+    dev = next(model.parameters()).device
+    with torch.no_grad():
+        # dict batches reach the model as keyword arguments (reference utils/utils.py:70-73); tuples pass one element
+        pass_data_for_range_estimation([{'input_ids': ids, 'attention_mask': amask}], model, act_quant=True,
+                                       weight_quant=True, max_num_batches=1)
+        model.fix_ranges()
+        return model(ids.to(dev), amask.to(dev))
+
+
+def test_roberta_position_ids_follow_the_reference():
+    z = _fixture()
+    from harness.roberta import QRobertaEmbeddings
+    ids = torch.from_numpy(z['input_ids'])
+    emb = QRobertaEmbeddings.__new__(QRobertaEmbeddings)
+    emb.padding_idx = 1
+    pos = QRobertaEmbeddings.position_ids(emb, ids)
+    assert torch.equal(pos, torch.from_numpy(z['position_ids']))
+    assert int(pos[3, 5]) == 1 and int(pos[3, 4]) == 6 and int(pos[0, 0]) == 2      # pad keeps 1; tokens count from 2
+
+
+def test_roberta_2l_w8a8_cpu_exact():
+    from harness.bert import quantizer_census
+    from quantization import _hip
+    from tests._oracle_backend import OracleBackend
+    z = _fixture()
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        torch.set_num_threads(8)
+        model, hf = _build('cpu')
+        _check_weights_reproduced(hf, z)
+        ids, amask = torch.from_numpy(z['input_ids']), torch.from_numpy(z['attention_mask'])
+        logits = _calibrate_and_run(model, ids, amask)
+        act, wts = quantizer_census(model)
+        assert len(act) == 31 and len(wts) == 22
+        wd = np.array([float(m.quantizer._delta) for _, m in wts], np.float32)
+        assert np.array_equal(wd, z['w_delta'])
+        amin = np.array([float(m.range_estimator.current_xmin) for _, m in act], np.float32)
+        amax = np.array([float(m.range_estimator.current_xmax) for _, m in act], np.float32)
+        assert np.array_equal(amin, z['act_min']) and np.array_equal(amax, z['act_max'])
+        assert np.array_equal(logits.numpy(), z['logits'])
+    finally:
+        _hip.set_backend(prev)
+        torch.set_num_threads(1)
+
+
+@pytest.mark.gpu
+def test_roberta_2l_w8a8_gpu():
+    from harness.bert import quantizer_census
+    from oracle import tq_oracle as O
+    z = _fixture()
+    model, hf = _build('cuda')
+    _check_weights_reproduced(hf, z)
+    ids, amask = torch.from_numpy(z['input_ids']), torch.from_numpy(z['attention_mask'])
+    logits = _calibrate_and_run(model, ids, amask)
+    act, wts = quantizer_census(model)
+    assert len(act) == 31 and len(wts) == 22
+    wd = np.array([float(m.quantizer._delta) for _, m in wts], np.float32)
+    assert np.array_equal(wd, z['w_delta'])                      # weights: no GEMM involved -> exact
+    amin = np.array([float(m.range_estimator.current_xmin) for _, m in act], np.float32)
+    amax = np.array([float(m.range_estimator.current_xmax) for _, m in act], np.float32)
+    span = z['act_max'] - z['act_min']
+    rel = np.maximum(np.abs(amin - z['act_min']), np.abs(amax - z['act_max'])) / span
+    assert rel[0] == 0 and rel[1] == 0                           # embedding sums, before any GEMM: exact
+    assert rel.max() <= 0.15 and np.median(rel) <= 0.02, (rel.max(), np.median(rel))
+    lspan = float(z['logits'].max() - z['logits'].min())
+    assert np.abs(logits.cpu().numpy() - z['logits']).max() <= 0.20 * lspan
+
+    # every site, on the tensor it actually saw: HIP kernel == CPU oracle, bit for bit
+    seen = []
+
+    def hook(mod, inp, out):
+        x = inp[0]
+        seen.append((mod, x.reshape(-1, x.shape[-1])[:256].detach().cpu(),
+                     out.reshape(-1, out.shape[-1])[:256].detach().cpu(), float(x.min()), float(x.max())))
+
+    handles = [m.register_forward_hook(hook) for _, m in act]
+    model.estimate_ranges()
+    for _, m in act:
+        m.range_estimator.reset()
+    with torch.no_grad():
+        model(ids.cuda(), amask.cuda())
+    for h in handles:
+        h.remove()
+    assert len(seen) == 31
+    for mod, x, y, xmin, xmax in seen:
+        q = mod.quantizer
+        assert float(mod.range_estimator.current_xmin) == xmin and float(mod.range_estimator.current_xmax) == xmax
+        delta, zf = O.asym_params_from_range(torch.tensor(xmin), torch.tensor(xmax), 8)
+        assert torch.equal(q._delta.cpu().reshape(()), delta) and torch.equal(q._zero_float.cpu().reshape(()), zf)
+        _, ref = O.fake_quant(x, delta, zf, 8, False)
+        assert torch.equal(y, ref)

@@ -33,9 +33,12 @@ class QEmbeddings(QuantizedModel):
         self.sum_pos_embd_act_quantizer = QuantizedActivation(**qp)
         self.LayerNorm = quantize_model(hf.LayerNorm, **qp)
 
+    def position_ids(self, input_ids):
+        """BERT: 0 .. T-1 whatever the tokens (RoBERTa overrides this, harness/roberta.py)."""
+        return torch.arange(input_ids.shape[1], device=input_ids.device).unsqueeze(0)
+
     def forward(self, input_ids):
-        B, T = input_ids.shape
-        pos = torch.arange(T, device=input_ids.device).unsqueeze(0)
+        pos = self.position_ids(input_ids)
         tok = torch.zeros_like(input_ids)
         x = self.word_embeddings(input_ids) + self.token_type_embeddings(tok)
         x = self.sum_input_token_type_embd_act_quantizer(x)
