@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the oracle against the REFERENCE ITSELF (build container only: needs /root/reference).
+
+Test infrastructure, like everything under oracle/: it pins oracle/tq_oracle.py beyond the committed fixtures by
+running the reference's own classes (quantization/quantizers.py, quantization/range_estimators.py) next to the
+restatement on thousands of random configurations -- bit widths 2..16, symmetric / asymmetric, degenerate and
+one-sided ranges, magnitudes 1e-6..1e6, NaN / +-inf / denormal / -0 data; per-tensor, per-channel, per-axis,
+per-group and range-permuted group statistics through three-batch current / all-time / running min-max traces --
+and demanding bit equality of parameters, indices, dequantised values and estimator state.
+
+    python oracle/fuzz_vs_reference.py [n_quantizer_cases] [n_estimator_cases]      (defaults 4000, 1500)
+
+Run in its own process: the reference's package is also called `quantization`.  tests/test_oracle_golden.py runs a
+short version when /root/reference exists and skips otherwise (the GPU box has no reference).
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = '/root/reference'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REF)
+_u = types.ModuleType('utils')
+_u.__path__ = [os.path.join(REF, 'utils')]
+sys.modules['utils'] = _u
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from quantization.quantizers import AsymmetricUniformQuantizer as RA, SymmetricUniformQuantizer as RS  # noqa: E402
+from quantization.range_estimators import (  # noqa: E402
+    AllMinMaxEstimator as RAll, CurrentMinMaxEstimator as RC, RunningMinMaxEstimator as RRun)
+
+sys.path.insert(0, ROOT)
+from oracle import tq_oracle as O  # noqa: E402
+
+SPECIALS = [0.0, -0.0, float('inf'), -float('inf'), float('nan'), 1e-38, -1e-38, 1e38, -1e38, 3.4e38, 1e-45]
+
+
+def _same(a, b):
+    return torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(
+        torch.nan_to_num(a, nan=7.0).view(torch.int32), torch.nan_to_num(b, nan=7.0).view(torch.int32))
+
+
+def fuzz_quantizers(n_cases, seed=0):
+    rs = np.random.RandomState(seed)
+    bad = 0
+    for _ in range(n_cases):
+        n_bits = int(rs.choice([2, 3, 4, 6, 8, 16]))
+        sym = bool(rs.randint(2))
+        mag = 10.0 ** rs.uniform(-6, 6)
+        shape = tuple(int(v) for v in rs.randint(1, 9, size=rs.randint(1, 4)))
+        x = torch.tensor(rs.randn(*shape).astype(np.float32) * mag)
+        if rs.rand() < 0.3:
+            flat = x.reshape(-1)
+            for _k in range(rs.randint(1, 4)):
+                flat[rs.randint(flat.numel())] = SPECIALS[rs.randint(len(SPECIALS))]
+        kind = rs.randint(5)
+        lo, hi = sorted((rs.randn() * mag, rs.randn() * mag))
+        if kind == 0:
+            lo = 0.0
+        elif kind == 1:
+            hi = 0.0
+        elif kind == 2:
+            lo = hi = 0.0
+        elif kind == 3:
+            lo, hi = abs(lo), abs(lo) + abs(hi)
+        Q = (RS if sym else RA)(n_bits=n_bits)
+        Q.set_quant_range(torch.tensor(lo, dtype=torch.float32), torch.tensor(hi, dtype=torch.float32))
+        yr, ir = Q(x), Q.to_integer_forward(x)
+        if sym:
+            d, signed = O.sym_params_from_range(torch.tensor(lo), torch.tensor(hi), n_bits)
+            io, yo = O.fake_quant(x, d, None, n_bits, True, bool(signed))
+            okp = torch.equal(d.reshape(()), Q._delta.reshape(())) and bool(signed) == bool(Q._signed)
+        else:
+            d, zf = O.asym_params_from_range(torch.tensor(lo), torch.tensor(hi), n_bits)
+            io, yo = O.fake_quant(x, d, zf, n_bits, False)
+            okp = torch.equal(d.reshape(()), Q._delta.reshape(())) and torch.equal(zf.reshape(()), Q._zero_float.reshape(()))
+        if not (okp and _same(yr, yo) and _same(ir, io)):
+            bad += 1
+            if bad <= 8:
+                print('MISMATCH', dict(n_bits=n_bits, sym=sym, lo=lo, hi=hi, shape=shape, params_ok=okp))
+    return bad
+
+
+def fuzz_estimators(n_cases, seed=1):
+    rs = np.random.RandomState(seed)
+    bad = 0
+    for _ in range(n_cases):
+        B, T, D = int(rs.randint(1, 5)), int(rs.randint(1, 9)), int(rs.choice([6, 12, 24]))
+        mode = rs.randint(5)        # 0 per-tensor, 1 per-channel, 2 per-axis, 3 groups, 4 groups ordered by phase-1 ranges
+        axis, n_groups, per_channel = None, None, mode == 1
+        if mode >= 2:
+            axis = 2
+        if mode >= 3:
+            n_groups = int(rs.choice([2, 3, 6]))
+        xs = [torch.tensor((rs.randn(B, T, D) * 10 ** rs.uniform(-2, 2)).astype(np.float32)) for _k in range(3)]
+        kind = rs.randint(3)
+        q = RA(n_bits=8, axis=axis, per_channel=per_channel)
+        kw = dict(per_channel=per_channel, quantizer=q, axis=axis, n_groups=n_groups)
+        mom = float(rs.choice([0.9, 0.5, 0.99]))
+        est = RC(**kw) if kind == 0 else (RAll(**kw) if kind == 1 else RRun(momentum=mom, **kw))
+        ranges = None
+        if mode == 4 and kind == 0:
+            est.per_group_range_estimation = True
+            est(xs[0])
+            est.per_group_range_estimation = False
+            ranges = est.ranges.clone()
+        cur = None
+        for x in xs:
+            rmin, rmax = est(x)
+            if kind == 1:           # AllMinMax ignores axis / groups
+                bm, bM = O.batch_minmax(x, axis=None, n_groups=None, per_channel=per_channel)
+                cur = (bm, bM) if cur is None else O.allminmax_update(cur[0], cur[1], bm, bM)
+            elif kind == 0:
+                cur = O.batch_minmax(x, axis=axis, n_groups=n_groups, per_channel=per_channel, ranges=ranges)
+            else:
+                bm, bM = O.batch_minmax(x, axis=axis, n_groups=n_groups, per_channel=per_channel)
+                cur = (bm, bM) if cur is None else O.running_update(cur[0], cur[1], bm, bM, mom)
+            if not (torch.equal(rmin.reshape(-1), cur[0].reshape(-1)) and torch.equal(rmax.reshape(-1), cur[1].reshape(-1))):
+                bad += 1
+                if bad <= 8:
+                    print('MISMATCH', dict(kind=kind, mode=mode, n_groups=n_groups, shape=(B, T, D)))
+                break
+    return bad
+
+
+if __name__ == '__main__':
+    nq = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+    ne = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+    bq, be_ = fuzz_quantizers(nq), fuzz_estimators(ne)
+    print(f'quantizer cases {nq}: {bq} mismatches; estimator cases {ne}: {be_} mismatches')
+    sys.exit(1 if (bq or be_) else 0)

@@ -211,3 +211,19 @@ def test_aten_sum_restatement():
         assert np.array_equal(A.sum_rows(e.numpy()), ref_rows.numpy()), shape
         assert float(A.loss_sum(e.numpy())) == torch.sum(ref_rows).item(), shape
         assert np.array_equal(A.loss_sum(e.numpy(), per_channel_loss=True), ref_rows.numpy()), shape
+
+
+def test_oracle_fuzz_against_the_reference_itself():
+    """Build container only: oracle/fuzz_vs_reference.py runs the reference's own quantizer / estimator classes next to
+    the restatement on random configurations (bit equality of parameters, indices, values, estimator state).  Its own
+    process, because the reference's package is also called `quantization`; skipped where /root/reference is absent."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    if not os.path.isdir('/root/reference/quantization'):
+        pytest.skip('no /root/reference here (GPU box): the committed fixtures pin the oracle')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_vs_reference.py'), '600', '250'],
+                       capture_output=True, text=True, cwd='/tmp', timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '0 mismatches; estimator' in r.stdout and r.stdout.strip().endswith('0 mismatches')
