@@ -5,10 +5,11 @@ Test infrastructure, like everything under oracle/: it pins oracle/tq_oracle.py 
 running the reference's own classes (quantization/quantizers.py, quantization/range_estimators.py) next to the
 restatement on thousands of random configurations -- bit widths 2..16, symmetric / asymmetric, degenerate and
 one-sided ranges, magnitudes 1e-6..1e6, NaN / +-inf / denormal / -0 data; per-tensor, per-channel, per-axis,
-per-group and range-permuted group statistics through three-batch current / all-time / running min-max traces --
+per-group and range-permuted group statistics through three-batch current / all-time / running min-max traces; MSE and
+cross-entropy searches (1-D / 2-D grids, scipy golden section, per-channel rows) over two batches --
 and demanding bit equality of parameters, indices, dequantised values and estimator state.
 
-    python oracle/fuzz_vs_reference.py [n_quantizer_cases] [n_estimator_cases]      (defaults 4000, 1500)
+    python oracle/fuzz_vs_reference.py [n_quantizer_cases] [n_estimator_cases] [n_search_cases]   (defaults 4000, 1500, 300)
 
 Run in its own process: the reference's package is also called `quantization`.  tests/test_oracle_golden.py runs a
 short version when /root/reference exists and skips otherwise (the GPU box has no reference).
@@ -29,7 +30,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from quantization.quantizers import AsymmetricUniformQuantizer as RA, SymmetricUniformQuantizer as RS  # noqa: E402
 from quantization.range_estimators import (  # noqa: E402
-    AllMinMaxEstimator as RAll, CurrentMinMaxEstimator as RC, RunningMinMaxEstimator as RRun)
+    AllMinMaxEstimator as RAll, CrossEntropyEstimator as RXent, CurrentMinMaxEstimator as RC, MSE_Estimator as RMSE,
+    OptMethod as ROpt, RunningMinMaxEstimator as RRun)
 
 sys.path.insert(0, ROOT)
 from oracle import tq_oracle as O  # noqa: E402
@@ -125,9 +127,48 @@ def fuzz_estimators(n_cases, seed=1):
     return bad
 
 
+def fuzz_searches(n_cases, seed=2):
+    """MSE_Estimator / CrossEntropyEstimator (1-D and 2-D grids, golden section, per-channel rows) over two batches:
+    returned thresholds and the accumulated fp64 loss array, bit for bit."""
+    rs = np.random.RandomState(seed)
+    bad = 0
+    for _ in range(n_cases):
+        n_bits = int(rs.choice([2, 3, 4, 8]))
+        sym = bool(rs.randint(2))
+        per_channel = bool(rs.randint(3) == 0)
+        golden = bool(rs.randint(3) == 0)
+        xent = (not per_channel) and rs.randint(5) == 0
+        C = int(rs.choice([5, 10, 20]))
+        rows, cols = int(rs.randint(2, 7)), int(rs.choice([2, 16, 40]))
+        mag = 10.0 ** rs.uniform(-2, 2)
+        datas = [torch.tensor((rs.randn(rows, cols) * mag).astype(np.float32)) for _k in range(2)]
+        if rs.randint(4) == 0:
+            datas = [d.abs() for d in datas]                 # one-sided
+        q = (RS if sym else RA)(n_bits=n_bits, per_channel=per_channel)
+        opt = ROpt.golden_section if golden else ROpt.grid
+        est = (RXent if xent else RMSE)(per_channel=per_channel, quantizer=q, num_candidates=C, opt_method=opt)
+        o = O.MSESearch(O.QSpec(n_bits, sym), num_candidates=C, opt_method='golden_section' if golden else 'grid',
+                        per_channel=per_channel, loss_value=O.xent_loss_value if xent else O.mse_loss_value)
+        ok = True
+        for d in datas:
+            rmin, rmax = est(d)
+            omin, omax = o.step_batch(d)
+            ok = ok and torch.equal(torch.as_tensor(rmin).reshape(-1).float(), omin.reshape(-1).float()) \
+                and torch.equal(torch.as_tensor(rmax).reshape(-1).float(), omax.reshape(-1).float())
+            if not golden:
+                ok = ok and np.array_equal(np.asarray(est.loss_array), o.loss_array)
+        if not ok:
+            bad += 1
+            if bad <= 8:
+                print('MISMATCH', dict(n_bits=n_bits, sym=sym, per_channel=per_channel, golden=golden, xent=xent, C=C,
+                                       shape=(rows, cols)))
+    return bad
+
+
 if __name__ == '__main__':
     nq = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
     ne = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
-    bq, be_ = fuzz_quantizers(nq), fuzz_estimators(ne)
-    print(f'quantizer cases {nq}: {bq} mismatches; estimator cases {ne}: {be_} mismatches')
-    sys.exit(1 if (bq or be_) else 0)
+    ns = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+    bq, be_, bs = fuzz_quantizers(nq), fuzz_estimators(ne), fuzz_searches(ns)
+    print(f'quantizer cases {nq}: {bq} mismatches; estimator cases {ne}: {be_} mismatches; search cases {ns}: {bs} mismatches')
+    sys.exit(1 if (bq or be_ or bs) else 0)
