@@ -223,7 +223,7 @@ def test_oracle_fuzz_against_the_reference_itself():
     from tests.conftest import ROOT
     if not os.path.isdir('/root/reference/quantization'):
         pytest.skip('no /root/reference here (GPU box): the committed fixtures pin the oracle')
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_vs_reference.py'), '600', '250', '60'],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_vs_reference.py'), '600', '250', '60', '300', '200'],
                        capture_output=True, text=True, cwd='/tmp', timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count(' 0 mismatches') == 3, r.stdout[-500:]
+    assert r.stdout.count(' 0 mismatches') == 5, r.stdout[-500:]
