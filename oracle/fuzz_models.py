@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Module-level differential fuzz: the SAME script drives either the reference's `quantization` package or this
+repository's drop-in (on the CPU, through the oracle-backed backend double of tests/_oracle_backend.py) -- which is the
+drop-in claim itself -- on random small networks and quantization settings, and dumps every observable: calibrated
+estimator state, quantizer parameters, cached weights' fake-quantized values and the outputs of an estimating, a
+fixed-range and a train-mode forward.  tests/test_host_logic.py runs both sides in separate processes (both packages
+are called `quantization`) and demands bit equality; skipped where /root/reference is absent.
+
+    python oracle/fuzz_models.py --impl ref|mine --n 20 --seed 0 --out /tmp/x.npz
+
+Random axes: depth 2-4, widths 8/16/24, ReLU / GELU folded into the Linear or none, LayerNorm in between, weight bits
+4/8 and activation bits 4/8/16, per-channel weights, weight estimator current min-max / MSE grid / MSE golden section,
+activation estimator current / running (momentum) / all-time min-max / MSE grid, 1-3 calibration batches.
+Test infrastructure (like everything under oracle/); needs /root/reference for --impl ref.
+"""
+import argparse
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(impl):
+    if impl == 'ref':
+        ref = '/root/reference'
+        sys.path.insert(0, ref)
+        u = types.ModuleType('utils')
+        u.__path__ = [os.path.join(ref, 'utils')]
+        sys.modules['utils'] = u
+    else:
+        sys.path.insert(0, os.path.join(ROOT, 'transformer-quantization_amd'))
+        sys.path.insert(0, ROOT)
+        from quantization import _hip
+        from tests._oracle_backend import OracleBackend
+        _hip.set_backend(OracleBackend())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--impl', choices=['ref', 'mine'], required=True)
+    ap.add_argument('--n', type=int, default=20)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--out', required=True)
+    args = ap.parse_args()
+    _setup(args.impl)
+
+    import numpy as np
+    import torch
+    from torch import nn
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_classes import QuantizedModule
+    from quantization.quantization_manager import QuantizationManager
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import OptMethod, RangeEstimators
+
+    torch.set_num_threads(1)
+    out = {}
+    for case in range(args.n):
+        rs = np.random.RandomState(1000 * args.seed + case)
+        torch.manual_seed(1000 * args.seed + case)
+        depth = int(rs.randint(2, 5))
+        widths = [int(rs.choice([8, 16, 24])) for _ in range(depth + 1)]
+        layers = []
+        # usually one activation style per network: the rewriter folds the FIRST activation found anywhere after a Linear
+        # into it and skips what lies between (reference autoquant_utils.py get_act / quant_module) -- a mixed network
+        # mostly ends in a shape error on both sides; one case in six keeps the free mix to cover exactly that
+        style = int(rs.randint(3))
+        wild = rs.randint(6) == 0
+        for i in range(depth):
+            layers.append(nn.Linear(widths[i], widths[i + 1], bias=bool(rs.randint(4))))
+            a = rs.randint(3) if wild else style
+            if a == 1:
+                layers.append(nn.ReLU())
+            elif a == 2:
+                layers.append(nn.GELU())
+            if rs.randint(3) == 0:
+                layers.append(nn.LayerNorm(widths[i + 1]))
+        net = nn.Sequential(*layers)
+        w_est = [(RangeEstimators.current_minmax, None), (RangeEstimators.MSE, dict(num_candidates=10)),
+                 (RangeEstimators.MSE, dict(opt_method=OptMethod.golden_section))][rs.randint(3)]
+        a_est = [(RangeEstimators.current_minmax, None), (RangeEstimators.running_minmax, dict(momentum=float(rs.choice([0.9, 0.5])))),
+                 (RangeEstimators.allminmax, None), (RangeEstimators.MSE, dict(num_candidates=6))][rs.randint(4)]
+        n_bits_act = int(rs.choice([4, 8, 16]))
+        if a_est[0] == RangeEstimators.MSE:
+            n_bits_act = 4                     # 2-D grid: 6 x 4 x 2 candidates per batch
+        qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform,
+                  n_bits=int(rs.choice([4, 8])), n_bits_act=n_bits_act,
+                  per_channel_weights=bool(rs.randint(2)),
+                  weight_range_method=w_est[0], act_range_method=a_est[0])
+        if w_est[1]:
+            qp['weight_range_options'] = w_est[1]
+        if a_est[1]:
+            qp['act_range_options'] = a_est[1]
+        tag = f'c{case}_'
+        try:
+            qm = quantize_model(net, **qp)
+            B = int(rs.randint(2, 6))
+            batches = [torch.tensor((rs.randn(B, widths[0]) * 10 ** rs.uniform(-1, 1)).astype(np.float32))
+                       for _ in range(int(rs.randint(1, 4)))]
+            x_eval = torch.tensor(rs.randn(B, widths[0]).astype(np.float32))
+            for m in qm.modules():
+                if isinstance(m, QuantizedModule):
+                    m.quantized()
+            qm.eval()
+            with torch.no_grad():
+                for k, xb in enumerate(batches):
+                    out[tag + f'y_est{k}'] = qm(xb).numpy().copy()
+                mgrs = [(n, m) for n, m in qm.named_modules() if isinstance(m, QuantizationManager)]
+                for n, m in mgrs:
+                    if m.quantizer.is_initialized:
+                        m.fix_ranges()
+                out[tag + 'y_fixed'] = qm(x_eval).numpy().copy()
+            qm.train()                              # train mode: no weight cache, ranges stay fixed
+            out[tag + 'y_train'] = qm(x_eval).detach().numpy().copy()
+            for n, m in mgrs:
+                q = m.quantizer
+                if not q.is_initialized:
+                    continue
+                out[tag + n + '.delta'] = q._delta.detach().numpy().reshape(-1).copy()
+                zf = getattr(q, '_zero_float', None)
+                if zf is not None:
+                    out[tag + n + '.zero_float'] = zf.detach().numpy().reshape(-1).copy()
+                sg = getattr(q, '_signed', None)
+                if sg is not None:
+                    out[tag + n + '.signed'] = np.array(bool(sg))
+                est = m.range_estimator
+                if est is not None and getattr(est, 'current_xmin', None) is not None:
+                    out[tag + n + '.xmin'] = torch.as_tensor(est.current_xmin).detach().numpy().reshape(-1).copy()
+                    out[tag + n + '.xmax'] = torch.as_tensor(est.current_xmax).detach().numpy().reshape(-1).copy()
+        except Exception as e:      # error behaviour is part of the contract: same exception type on both sides
+            for k in [k for k in out if k.startswith(tag)]:
+                del out[k]
+            out[tag + 'raised'] = np.array(type(e).__name__)
+        out[tag + 'cfg'] = np.array(repr({k: str(v) for k, v in qp.items()}) + f' depth={depth} widths={widths}')
+    np.savez_compressed(args.out, **out)
+    print('cases', args.n, 'arrays', len(out))
+
+
+if __name__ == '__main__':
+    main()

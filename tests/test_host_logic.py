@@ -462,3 +462,35 @@ def test_provenance_records_die_with_any_change():
     key = id(z)
     del z
     assert key not in provenance._records        # records die with their tensor
+
+
+def test_drop_in_equals_the_reference_on_random_networks(tmp_path):
+    """Build container only: oracle/fuzz_models.py -- ONE script, run once against the reference's `quantization`
+    package and once against this repository's (oracle-backed backend) -- on random small networks and quantization
+    settings: every calibrated range, quantizer parameter and output (estimating, fixed-range, train-mode forwards) must
+    be bit-identical, and where the reference raises, the same exception type must be raised here."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    if not os.path.isdir('/root/reference/quantization'):
+        pytest.skip('no /root/reference here (GPU box)')
+    outs = {}
+    for impl in ('ref', 'mine'):
+        outs[impl] = str(tmp_path / f'{impl}.npz')
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_models.py'), '--impl', impl, '--n', '24',
+                            '--seed', '11', '--out', outs[impl]], capture_output=True, text=True, cwd=str(tmp_path),
+                           timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    a, b = np.load(outs['ref']), np.load(outs['mine'])
+    assert set(a.keys()) == set(b.keys()), sorted(set(a.keys()) ^ set(b.keys()))[:10]
+    n_ok = 0
+    for k in a.keys():
+        if k.endswith('_cfg'):
+            continue
+        if a[k].dtype.kind in 'US':
+            assert str(a[k]) == str(b[k]), (k, str(a[k]), str(b[k]))
+        else:
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), k
+            n_ok += 1
+    assert n_ok > 200          # most cases are valid networks with ~25 observables each

@@ -349,6 +349,8 @@ class MSE_Estimator(RangeEstimatorBase):
         """Loss of ONE candidate as a host fp32 value (golden-section path; reference :248-256): the same
         bits as the reference's `torch.sum(torch.sum(err.view(len(data), -1), dim=1))` on the CPU, so that
         scipy's iterates -- hence the returned thresholds -- follow the reference's."""
+        len(data)       # reference :250 views the error as [len(data), -1]: a 0-d slice (per-channel golden section on a
+        #                 1-D weight such as LayerNorm's) raises TypeError there, and therefore here
         if not (neg_thr or pos_thr):
             # quirk q7 (reference :292): both thresholds falsy -> the quantizer's current range
             neg_thr, pos_thr = float(self.quantizer.x_min), float(self.quantizer.x_max)
