@@ -2,8 +2,8 @@
 """Module-level differential fuzz: the SAME script drives either the reference's `quantization` package or this
 repository's drop-in (on the CPU, through the oracle-backed backend double of tests/_oracle_backend.py) -- which is the
 drop-in claim itself -- on random small networks and quantization settings, and dumps every observable: calibrated
-estimator state, quantizer parameters, cached weights' fake-quantized values and the outputs of an estimating, a
-fixed-range and a train-mode forward.  tests/test_host_logic.py runs both sides in separate processes (both packages
+estimator state, quantizer parameters, the outputs of an estimating, a fixed-range and a train-mode forward, and -- with
+learnable ranges (QAT) -- the straight-through gradients w.r.t. the input, the weights and every range parameter.  tests/test_host_logic.py runs both sides in separate processes (both packages
 are called `quantization`) and demands bit equality; skipped where /root/reference is absent.
 
     python oracle/fuzz_models.py --impl ref|mine --n 20 --seed 0 --out /tmp/x.npz
@@ -114,6 +114,19 @@ def main():
                 out[tag + 'y_fixed'] = qm(x_eval).numpy().copy()
             qm.train()                              # train mode: no weight cache, ranges stay fixed
             out[tag + 'y_train'] = qm(x_eval).detach().numpy().copy()
+            # learnable ranges (QAT): straight-through backward w.r.t. input, weights and every range parameter
+            for n, m in mgrs:
+                if m.quantizer.is_initialized:
+                    m.learn_ranges()
+            xg = x_eval.clone().requires_grad_(True)
+            yq = qm(xg)
+            gy = torch.tensor(rs.randn(*yq.shape).astype(np.float32))
+            (yq * gy).sum().backward()
+            out[tag + 'y_learn'] = yq.detach().numpy().copy()
+            out[tag + 'gx'] = xg.grad.numpy().copy()
+            for pn, prm in qm.named_parameters():
+                if prm.grad is not None:
+                    out[tag + 'grad.' + pn] = prm.grad.numpy().reshape(-1).copy()
             for n, m in mgrs:
                 q = m.quantizer
                 if not q.is_initialized:
