@@ -10,7 +10,10 @@ are called `quantization`) and demands bit equality; skipped where /root/referen
 
 Random axes: depth 2-4, widths 8/16/24, ReLU / GELU folded into the Linear or none, LayerNorm in between, weight bits
 4/8 and activation bits 4/8/16, per-channel weights, weight estimator current min-max / MSE grid / MSE golden section,
-activation estimator current / running (momentum) / all-time min-max / MSE grid, 1-3 calibration batches.
+activation estimator current / running (momentum) / all-time min-max / MSE grid, 1-3 calibration batches.  A second
+family drives ONE activation site on [B, T, d] hidden states through the transformer granularities of
+utils/per_embd_quant_utils.py (per-embedding, N groups, range-permuted groups incl. the phase-1 range collection, bit
+width overrides, 'fp32') -- shapes of the parameter buffers included.
 Test infrastructure (like everything under oracle/); needs /root/reference for --impl ref.
 """
 import argparse
@@ -147,6 +150,54 @@ def main():
                 del out[k]
             out[tag + 'raised'] = np.array(type(e).__name__)
         out[tag + 'cfg'] = np.array(repr({k: str(v) for k, v in qp.items()}) + f' depth={depth} widths={widths}')
+
+    # ---- second family: one activation site on [B, T, d] hidden states with the transformer-specific granularities
+    # (utils/per_embd_quant_utils.py: per-embedding, N groups, range-permuted groups, quant_dict letter-code values)
+    from quantization.base_quantized_classes import QuantizedActivation
+    from utils.per_embd_quant_utils import hijack_act_quant
+    for case in range(args.n):
+        rs = np.random.RandomState(77000 + 1000 * args.seed + case)
+        tag = f's{case}_'
+        d = int(rs.choice([12, 24, 48]))
+        B, T = int(rs.randint(1, 4)), int(rs.randint(2, 7))
+        code = [None, 'per_embd', 'ng2', 'ng6', 'ngp3', 'ngp6', int(rs.choice([4, 6, 16])), 'fp32'][rs.randint(8)]
+        est = [(RangeEstimators.current_minmax, None), (RangeEstimators.running_minmax, dict(momentum=0.9)),
+               (RangeEstimators.allminmax, None), (RangeEstimators.MSE, dict(num_candidates=5))][rs.randint(4)]
+        if isinstance(code, str) and code.startswith('ngp') and rs.randint(4):
+            est = (RangeEstimators.current_minmax, None)     # the only estimator with a phase 1 (range collection)
+        qp = dict(act_method=QMethods.asymmetric_uniform, n_bits_act=int(rs.choice([4, 8])), act_range_method=est[0])
+        if est[1]:
+            qp['act_range_options'] = est[1]
+        xs = [torch.tensor((rs.randn(B, T, d) * 10 ** rs.uniform(-1, 1)).astype(np.float32)) for _ in range(int(rs.randint(1, 4)))]
+        for x in xs:                        # a few outlier dimensions, as in BERT's residual stream
+            x[..., rs.randint(d)] *= 20.0
+        try:
+            site = QuantizedActivation(**qp)
+            hijack_act_quant({'y': code}, 'y', site)
+            site.quantized_acts()
+            site.eval()
+            mgr = site.activation_quantizer
+            with torch.no_grad():
+                estr = getattr(mgr, 'range_estimator', None)
+                if estr is not None and getattr(estr, 'per_group_range_estimation', False):
+                    out[tag + 'y_phase1'] = site(xs[0]).numpy().copy()        # phase 1: passthrough, collects ranges
+                    out[tag + 'ranges'] = estr.ranges.numpy().reshape(-1).copy()
+                    estr.per_group_range_estimation = False
+                for k, x in enumerate(xs):
+                    out[tag + f'y_est{k}'] = site(x).numpy().copy()
+                if hasattr(mgr, 'fix_ranges'):
+                    mgr.fix_ranges()
+                out[tag + 'y_fixed'] = site(xs[-1] * 1.5).numpy().copy()
+            if hasattr(mgr, 'quantizer'):
+                out[tag + 'delta'] = mgr.quantizer._delta.detach().numpy().copy()
+                out[tag + 'zero_float'] = mgr.quantizer._zero_float.detach().numpy().copy()
+                out[tag + 'xmin'] = torch.as_tensor(mgr.range_estimator.current_xmin).numpy().copy()
+                out[tag + 'xmax'] = torch.as_tensor(mgr.range_estimator.current_xmax).numpy().copy()
+        except Exception as e:
+            for k in [k for k in out if k.startswith(tag)]:
+                del out[k]
+            out[tag + 'raised'] = np.array(type(e).__name__)
+        out[tag + 'cfg'] = np.array(f'code={code} est={est[0]} d={d} B={B} T={T} bits={qp["n_bits_act"]}')
     np.savez_compressed(args.out, **out)
     print('cases', args.n, 'arrays', len(out))
 
