@@ -14,7 +14,9 @@ activation estimator current / running (momentum) / all-time min-max / MSE grid,
 family drives ONE activation site on [B, T, d] hidden states through the transformer granularities of
 utils/per_embd_quant_utils.py (per-embedding, N groups, range-permuted groups incl. the phase-1 range collection, bit
 width overrides, 'fp32') -- shapes of the parameter buffers included.  A third
-family runs AdaRound (apply_adaround_to_layer) on both Linears of a small network: alpha, grid, reported losses, output.
+family runs AdaRound (apply_adaround_to_layer) on both Linears of a small network: alpha, grid, reported losses, output;
+a fourth the calibration driver utils.pass_data_for_range_estimation (switches, batch limits, tuple / dict batches, the
+cross-entropy estimator on a named layer).
 Test infrastructure (like everything under oracle/); needs /root/reference for --impl ref.
 """
 import argparse
@@ -281,6 +283,58 @@ def main():
                 del out[k]
             out[tag + 'raised'] = np.array(type(e).__name__)
         out[tag + 'cfg'] = np.array(f'{cfg.round_mode} {cfg.init} asym={cfg.asym} act={cfg.include_act_func} iters={cfg.iters}')
+
+    # ---- fourth family: the calibration driver utils.pass_data_for_range_estimation on a QuantizedModel -- weight_quant /
+    # act_quant switches, max_num_batches, tuple and dict batches, the cross-entropy estimator installed on a named layer
+    # (reference utils/utils.py:47-79) -- followed by model.fix_ranges() and a forward
+    from utils.utils import pass_data_for_range_estimation
+    for case in range(max(args.n // 2, 1)):
+        rs = np.random.RandomState(33000 + 1000 * args.seed + case)
+        torch.manual_seed(33000 + 1000 * args.seed + case)
+        d0, d1, d2 = int(rs.choice([8, 16])), int(rs.choice([8, 16])), int(rs.choice([2, 3, 5]))
+        a_est = [(RangeEstimators.current_minmax, None), (RangeEstimators.running_minmax, None),
+                 (RangeEstimators.MSE, dict(num_candidates=6))][rs.randint(3)]
+        qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=int(rs.choice([4, 8])),
+                  n_bits_act=4 if a_est[0] == RangeEstimators.MSE else 8, per_channel_weights=bool(rs.randint(2)),
+                  weight_range_method=RangeEstimators.current_minmax, act_range_method=a_est[0])
+        if a_est[1]:
+            qp['act_range_options'] = a_est[1]
+
+        class Head(QuantizedModel):
+            def __init__(self):
+                super().__init__()
+                self.body = quantize_model(nn.Sequential(nn.Linear(d0, d1), nn.ReLU(), nn.Linear(d1, d2)), **qp)
+
+            def forward(self, x=None, scale=None):
+                return self.body(x if scale is None else x * scale)
+
+        tag = f'p{case}_'
+        act_quant, weight_quant = bool(rs.randint(4)), bool(rs.randint(4))
+        xent = [None, 'body.1', 'body.7'][rs.randint(3)] if rs.randint(2) else None      # 'body.7': no such layer
+        n_batches, max_b = int(rs.randint(1, 5)), int(rs.randint(1, 4))
+        as_dict = bool(rs.randint(2))
+        try:
+            model = Head()
+            xs = [torch.tensor((rs.randn(4, d0) * (1 + k)).astype(np.float32)) for k in range(n_batches)]
+            loader = [dict(x=x, scale=torch.tensor(1.5)) for x in xs] if as_dict else [(torch.zeros(1), x) for x in xs]
+            kw = {} if as_dict else dict(inp_idx=1)
+            with torch.no_grad():
+                pass_data_for_range_estimation(loader, model, act_quant, weight_quant, max_num_batches=max_b,
+                                               cross_entropy_layer=xent, **kw)
+                model.fix_ranges()
+                out[tag + 'y'] = model(xs[0]).numpy().copy()
+            for n, m in model.named_modules():
+                if isinstance(m, QuantizationManager) and m.quantizer.is_initialized:
+                    out[tag + n + '.delta'] = m.quantizer._delta.detach().numpy().reshape(-1).copy()
+                    zf = getattr(m.quantizer, '_zero_float', None)
+                    if zf is not None:
+                        out[tag + n + '.zero_float'] = zf.detach().numpy().reshape(-1).copy()
+                    out[tag + n + '.estimator'] = np.array(type(m.range_estimator).__name__)
+        except Exception as e:
+            for k in [k for k in out if k.startswith(tag)]:
+                del out[k]
+            out[tag + 'raised'] = np.array(type(e).__name__)
+        out[tag + 'cfg'] = np.array(f'act={act_quant} w={weight_quant} xent={xent} batches={n_batches}/{max_b} dict={as_dict} est={a_est[0]}')
 
     np.savez_compressed(args.out, **out)
     print('cases', args.n, 'arrays', len(out))
