@@ -16,7 +16,8 @@ utils/per_embd_quant_utils.py (per-embedding, N groups, range-permuted groups in
 width overrides, 'fp32') -- shapes of the parameter buffers included.  A third
 family runs AdaRound (apply_adaround_to_layer) on both Linears of a small network: alpha, grid, reported losses, output;
 a fourth the calibration driver utils.pass_data_for_range_estimation (switches, batch limits, tuple / dict batches, the
-cross-entropy estimator on a named layer).
+cross-entropy estimator on a named layer); a fifth the model-level drivers utils.adaround_utils.apply_adaround_to_model and
+utils.qat_utils.prepare_model_for_quantization (manager states and trainable-parameter names included).
 Test infrastructure (like everything under oracle/); needs /root/reference for --impl ref.
 """
 import argparse
@@ -335,6 +336,69 @@ def main():
                 del out[k]
             out[tag + 'raised'] = np.array(type(e).__name__)
         out[tag + 'cfg'] = np.array(f'act={act_quant} w={weight_quant} xent={xent} batches={n_batches}/{max_b} dict={as_dict} est={a_est[0]}')
+
+    # ---- fifth family: the model-level drivers -- utils.adaround_utils.apply_adaround_to_model (layer selection 'all' /
+    # by name, act_quant_mode post_adaround / no_act_quant with the re-calibration of activation ranges that follows)
+    # and utils.qat_utils.prepare_model_for_quantization (learn_ranges / estimate-in-train / fixed weight and activation
+    # ranges), each followed by a forward
+    from quantization.adaround.utils import AdaRoundActQuantMode
+    from utils.adaround_utils import apply_adaround_to_model
+    from utils.qat_utils import prepare_model_for_quantization
+    for case in range(max(args.n // 4, 1)):
+        rs = np.random.RandomState(21000 + 1000 * args.seed + case)
+        torch.manual_seed(21000 + 1000 * args.seed + case)
+        d0, d1, d2 = int(rs.choice([8, 16])), int(rs.choice([8, 16])), int(rs.choice([2, 4]))
+        qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=4, n_bits_act=8,
+                  weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+
+        class Net(QuantizedModel):
+            def __init__(self):
+                super().__init__()
+                self.body = quantize_model(nn.Sequential(nn.Linear(d0, d1), nn.ReLU(), nn.Linear(d1, d2)), **qp)
+
+            def forward(self, x):
+                return self.body(x)
+
+        tag = f'm{case}_'
+        which = 'adaround' if rs.randint(2) else 'qat'
+        cfg = DotDict(quant=DotDict(act_quant=bool(rs.randint(3)), weight_quant=True),
+                      act_quant=DotDict(num_batches=int(rs.randint(1, 3)), cross_entropy_layer=None),
+                      qat=DotDict(learn_ranges=bool(rs.randint(2)), fix_weight_ranges=bool(rs.randint(2)),
+                                  fix_act_ranges=bool(rs.randint(2))))
+        ada = DotDict(dict(DEFAULT_ADAROUND_CONFIG))
+        ada.iters, ada.lr, ada.num_samples = 12, 1e-2, 24
+        ada.layers = [('all',), ('body.0',), ('body.1', 'body.0')][rs.randint(3)]
+        ada.act_quant_mode = [AdaRoundActQuantMode.post_adaround, AdaRoundActQuantMode.no_act_quant][rs.randint(2)]
+        cfg.adaround = ada
+        try:
+            model = Net()
+            xs = [torch.tensor(rs.randn(8, d0).astype(np.float32)) for _ in range(4)]
+            loader = [(x, torch.zeros(8)) for x in xs]
+            if which == 'adaround':
+                with torch.no_grad():
+                    pass_data_for_range_estimation(loader, model, act_quant=False, weight_quant=True, max_num_batches=1)
+                model.fix_ranges()
+                torch.manual_seed(4242 + case)
+                apply_adaround_to_model(cfg, model, loader, loader, batch_size=8)
+            else:
+                prepare_model_for_quantization(cfg, model, loader)
+                model.train()
+            y = model(xs[0])
+            out[tag + 'y'] = y.detach().numpy().copy()
+            for n, m in model.named_modules():
+                if isinstance(m, QuantizationManager):
+                    out[tag + n + '.state'] = np.array(str(m.state))
+                    if m.quantizer.is_initialized:
+                        out[tag + n + '.delta'] = m.quantizer._delta.detach().numpy().reshape(-1).copy()
+                        al = getattr(m.quantizer, 'alpha', None)
+                        if al is not None:
+                            out[tag + n + '.alpha'] = al.detach().numpy().copy()
+            out[tag + 'trainable'] = np.array(sorted(n for n, p_ in model.named_parameters() if p_.requires_grad))
+        except Exception as e:
+            for k in [k for k in out if k.startswith(tag)]:
+                del out[k]
+            out[tag + 'raised'] = np.array(type(e).__name__)
+        out[tag + 'cfg'] = np.array(f'{which} layers={ada.layers} mode={ada.act_quant_mode} act_quant={cfg.quant.act_quant} qat={dict(cfg.qat)}')
 
     np.savez_compressed(args.out, **out)
     print('cases', args.n, 'arrays', len(out))
