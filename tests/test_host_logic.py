@@ -478,7 +478,7 @@ def test_drop_in_equals_the_reference_on_random_networks(tmp_path):
     outs = {}
     for impl in ('ref', 'mine'):
         outs[impl] = str(tmp_path / f'{impl}.npz')
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_models.py'), '--impl', impl, '--n', '24',
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_models.py'), '--impl', impl, '--n', '16',
                             '--seed', '11', '--out', outs[impl]], capture_output=True, text=True, cwd=str(tmp_path),
                            timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
@@ -493,4 +493,4 @@ def test_drop_in_equals_the_reference_on_random_networks(tmp_path):
         else:
             assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), k
             n_ok += 1
-    assert n_ok > 200          # most cases are valid networks with ~25 observables each
+    assert n_ok > 300          # most cases are valid, with 10-40 observables each
