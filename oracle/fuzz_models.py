@@ -54,8 +54,13 @@ def main():
     ap.add_argument('--n', type=int, default=20)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--out', required=True)
+    ap.add_argument('--inplace-state', action='store_true',
+                    help='(mine) options.INPLACE_CALIBRATION_STATE: calibration updates its state buffers in place')
     args = ap.parse_args()
     _setup(args.impl)
+    if args.inplace_state:
+        from quantization import options
+        options.INPLACE_CALIBRATION_STATE = True
 
     import numpy as np
     import torch

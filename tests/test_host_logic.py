@@ -476,21 +476,26 @@ def test_drop_in_equals_the_reference_on_random_networks(tmp_path):
     if not os.path.isdir('/root/reference/quantization'):
         pytest.skip('no /root/reference here (GPU box)')
     outs = {}
-    for impl in ('ref', 'mine'):
+    # 'mine-inplace': the same with options.INPLACE_CALIBRATION_STATE (state buffers updated in place: the hipGraph-
+    # capturable form of calibration) -- must not change a bit either
+    for impl in ('ref', 'mine', 'mine-inplace'):
         outs[impl] = str(tmp_path / f'{impl}.npz')
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_models.py'), '--impl', impl, '--n', '16',
-                            '--seed', '11', '--out', outs[impl]], capture_output=True, text=True, cwd=str(tmp_path),
-                           timeout=900)
+        extra = ['--inplace-state'] if impl == 'mine-inplace' else []
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_models.py'), '--impl', impl.split('-')[0],
+                            '--n', '16', '--seed', '11', '--out', outs[impl]] + extra, capture_output=True, text=True,
+                           cwd=str(tmp_path), timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    a, b = np.load(outs['ref']), np.load(outs['mine'])
-    assert set(a.keys()) == set(b.keys()), sorted(set(a.keys()) ^ set(b.keys()))[:10]
-    n_ok = 0
-    for k in a.keys():
-        if k.endswith('_cfg'):
-            continue
-        if a[k].dtype.kind in 'US':
-            assert str(a[k]) == str(b[k]), (k, str(a[k]), str(b[k]))
-        else:
-            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), k
-            n_ok += 1
-    assert n_ok > 300          # most cases are valid, with 10-40 observables each
+    a = np.load(outs['ref'])
+    for other in ('mine', 'mine-inplace'):
+        b = np.load(outs[other])
+        assert set(a.keys()) == set(b.keys()), sorted(set(a.keys()) ^ set(b.keys()))[:10]
+        n_ok = 0
+        for k in a.keys():
+            if k.endswith('_cfg'):
+                continue
+            if a[k].dtype.kind in 'US':
+                assert str(a[k]) == str(b[k]), (other, k, str(a[k]), str(b[k]))
+            else:
+                assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), (other, k)
+                n_ok += 1
+        assert n_ok > 300          # most cases are valid, with 10-40 observables each
