@@ -54,6 +54,9 @@ def main():
     ap.add_argument('--n', type=int, default=20)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--out', required=True)
+    ap.add_argument('--double', action='store_true',
+                    help='main.py:227-231 (--double): the first family in float64, parameter caching off (the reference\'s eval '
+                         'cache narrows float64 weights to fp32 and its next forward fails); other families are skipped')
     ap.add_argument('--inplace-state', action='store_true',
                     help='(mine) options.INPLACE_CALIBRATION_STATE: calibration updates its state buffers in place')
     args = ap.parse_args()
@@ -141,6 +144,13 @@ def main():
             for m in qm.modules():
                 if isinstance(m, QuantizedModule):
                     m.quantized()
+            if args.double:
+                qm.double()
+                for m in qm.modules():
+                    if hasattr(m, '_caching'):
+                        m._caching = False
+                if not embed:
+                    batches, x_eval = [b_.double() for b_ in batches], x_eval.double()
             qm.eval()
             with torch.no_grad():
                 for k, xb in enumerate(batches):
@@ -158,7 +168,7 @@ def main():
                     m.learn_ranges()
             xg = x_eval.clone() if embed else x_eval.clone().requires_grad_(True)
             yq = qm(xg)
-            gy = torch.tensor(rs.randn(*yq.shape).astype(np.float32))
+            gy = torch.tensor(rs.randn(*yq.shape).astype(np.float32)).to(yq.dtype)
             (yq * gy).sum().backward()
             out[tag + 'y_learn'] = yq.detach().numpy().copy()
             if not embed:
@@ -186,6 +196,11 @@ def main():
                 del out[k]
             out[tag + 'raised'] = np.array(type(e).__name__)
         out[tag + 'cfg'] = np.array(repr({k: str(v) for k, v in qp.items()}) + f' depth={depth} widths={widths}')
+
+    if args.double:
+        np.savez_compressed(args.out, **out)
+        print('cases', args.n, 'arrays', len(out), '(float64, first family only)')
+        return
 
     # ---- second family: one activation site on [B, T, d] hidden states with the transformer-specific granularities
     # (utils/per_embd_quant_utils.py: per-embedding, N groups, range-permuted groups, quant_dict letter-code values)

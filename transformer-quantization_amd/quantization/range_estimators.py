@@ -346,7 +346,8 @@ class MSE_Estimator(RangeEstimatorBase):
         return candidate_params(neg_thr, pos_thr, q.n_bits, q.symmetric, q.eps)
 
     def loss_fx(self, data, neg_thr, pos_thr, per_channel_loss=False):
-        """Loss of ONE candidate as a host fp32 value (golden-section path; reference :248-256): the same
+        """Loss of ONE candidate as a host value in the precision of the reference's sums (fp32 for fp32 / low-precision
+        data, fp64 under --double; golden-section path; reference :248-256): the same
         bits as the reference's `torch.sum(torch.sum(err.view(len(data), -1), dim=1))` on the CPU, so that
         scipy's iterates -- hence the returned thresholds -- follow the reference's."""
         len(data)       # reference :250 views the error as [len(data), -1]: a 0-d slice (per-channel golden section on a
@@ -358,7 +359,10 @@ class MSE_Estimator(RangeEstimatorBase):
         cand = be.candidate_table(self._cand_table([neg_thr], [pos_thr]), data.device)
         rows = len(data) if per_channel_loss else 1
         loss = self._batch_losses(data, cand, rows, per_row=per_channel_loss)
-        host = loss.cpu().numpy().astype(np.float32)     # exact: the fp64 cell holds one fp32 value
+        host = loss.cpu().numpy()
+        if data.dtype != torch.float64:
+            host = host.astype(np.float32)               # exact: the fp64 cell holds one fp32 value
+        # (--double: the reference's sums are float64 themselves, scipy sees the float64 value)
         return host[:, 0] if per_channel_loss else host[0, 0]
 
     def quantize(self, x_float, x_min=None, x_max=None):
