@@ -123,6 +123,19 @@ def main():
                   n_bits=int(rs.choice([4, 8])), n_bits_act=n_bits_act,
                   per_channel_weights=bool(rs.randint(2)),
                   weight_range_method=w_est[0], act_range_method=a_est[0])
+        # rarer settings of the module kwargs (base_quantized_classes.py:36-47)
+        if rs.randint(6) == 0:
+            qp['method'] = QMethods.asymmetric_uniform            # asymmetric weight grid
+        if rs.randint(6) == 0:
+            qp['act_method'] = QMethods.symmetric_uniform         # symmetric activation grid
+        if rs.randint(5) == 0:
+            qp['percentile'] = float(rs.choice([99.0, 99.9, 90.0]))
+        if rs.randint(8) == 0:
+            qp['scale_domain'] = 'log'
+        if rs.randint(8) == 0:
+            qp['per_channel_acts'] = True
+        if rs.randint(8) == 0:
+            qp['n_bits'] = 16
         if (qp['per_channel_weights'] and w_est[1] and 'opt_method' in w_est[1] and rs.randint(5)
                 and any(isinstance(l, nn.LayerNorm) for l in layers)):
             qp['per_channel_weights'] = False       # per-channel golden section on a 1-D weight raises (both sides): keep 1 in 5

@@ -530,7 +530,7 @@ def ada_combined_loss(pred, tgt, alpha, it, mode='learned_hard_sigmoid', weight=
 
 
 def fake_quant_with_grads(x, delta, zero_float, n_bits, symmetric, signed=False, eps=1e-8,
-                          grad_out=None, axis=None):
+                          grad_out=None, axis=None, scale_domain='linear'):
     """Autograd through the reference op chain with the STE round (quantizers.py:12-19).
     Returns (y, dx, d_delta, d_zero_float) -- a plain torch reference for the float kernel."""
     x = x.detach().clone().requires_grad_(True)
@@ -547,14 +547,18 @@ def fake_quant_with_grads(x, delta, zero_float, n_bits, symmetric, signed=False,
             return g
 
     d = _broadcast_param(delta, x, axis, False)
-    scale = torch.clamp(d, min=eps)
+    # quantizers.py:142-147: `scale` is a property, evaluated once per use (division, de-quantisation): two graph nodes,
+    # whose gradients meet at `delta` -- for exp() that is g1 * e + g2 * e, not (g1 + g2) * e
+    def scale_of(dd):
+        return torch.exp(dd) if scale_domain == 'log' else torch.clamp(dd, min=eps)
+    scale, scale2 = scale_of(d), scale_of(d)
     lo, hi = grid_limits(n_bits, symmetric, signed)
     if symmetric:
         zp = 0.0
     else:
         zp = torch.clamp(_Round.apply(_broadcast_param(zf, x, axis, False)), lo, hi)
     x_int = torch.clamp(_Round.apply(x / scale) + zp, lo, hi)
-    y = scale * (x_int - zp)
+    y = scale2 * (x_int - zp)
     g = torch.ones_like(y) if grad_out is None else grad_out
     y.backward(g)
     return y.detach(), x.grad, delta.grad, (None if zf is None else zf.grad)

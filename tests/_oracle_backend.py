@@ -84,12 +84,14 @@ class OracleBackend:
                        eps, n_params, inner, param_grads=False):
         sgn = bool(signed.item()) if signed is not None else False
         with torch.enable_grad():
-            return self._bwd(x, grad_y, delta, zero_float, sgn, n_bits, symmetric, eps, param_grads)
+            return self._bwd(x, grad_y, delta, zero_float, sgn, n_bits, symmetric, eps, param_grads,
+                             'log' if log_domain else 'linear')
 
-    def _bwd(self, x, grad_y, delta, zero_float, sgn, n_bits, symmetric, eps, param_grads):
+    def _bwd(self, x, grad_y, delta, zero_float, sgn, n_bits, symmetric, eps, param_grads, scale_domain='linear'):
         _, dx, dd, dz = O.fake_quant_with_grads(self._work(x), delta.detach(), None if zero_float is None
                                                 else zero_float.detach(), n_bits, symmetric, sgn, eps,
-                                                grad_out=self._work(grad_y).to(self._work(x).dtype))
+                                                grad_out=self._work(grad_y).to(self._work(x).dtype),
+                                                scale_domain=scale_domain)
         return dx.to(x.dtype), (dd.reshape(-1) if param_grads else None), (
             dz.reshape(-1) if (param_grads and dz is not None) else
             (torch.zeros(delta.numel()) if param_grads else None))

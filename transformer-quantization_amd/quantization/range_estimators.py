@@ -218,10 +218,12 @@ class OptMethod(Enum):
 # --------------------------------------------------------------------------------------
 # candidate tables (host, numpy fp32, reference operation order)
 # --------------------------------------------------------------------------------------
-def candidate_params(neg_thr, pos_thr, n_bits, symmetric, eps=1e-8):
+def candidate_params(neg_thr, pos_thr, n_bits, symmetric, eps=1e-8, log_domain=False):
     """(scale, zero_point, int_min, int_max) of the temporary quantizer the reference builds for
     a pair of thresholds: set_quant_range (quantizers.py:234-282 / :334-344) followed by the
-    scale / zero_point properties (:142-153).  Vectorised over candidates, linear domain."""
+    scale / zero_point properties (:142-153).  Vectorised over candidates.  log_domain: the reference stores
+    log(delta) and quantizes with exp(log(delta)) (no eps clamp, :143-147, :279-282) -- evaluated here with the same
+    fp32 torch-CPU log / exp the reference's host path runs, so the table holds the scale its candidates see."""
     f32 = np.float32
     x_min = np.minimum(np.asarray(neg_thr, dtype=np.float64).astype(f32), f32(0.0))
     x_max = np.maximum(np.asarray(pos_thr, dtype=np.float64).astype(f32), f32(eps))
@@ -237,7 +239,12 @@ def candidate_params(neg_thr, pos_thr, n_bits, symmetric, eps=1e-8):
         delta = ((x_max - x_min) / int_max).astype(f32)
         zero_float = (-x_min / delta).astype(f32)
         zp = np.clip(np.rint(zero_float), f32(0.0), int_max).astype(f32)
-    scale = np.maximum(delta, f32(eps)).astype(f32)
+    if log_domain:
+        # one 0-d tensor per candidate, as upstream: ATen's vectorised and scalar log / exp may differ in the last bit
+        flat = np.ascontiguousarray(delta, dtype=f32).reshape(-1)
+        scale = np.array([float(torch.exp(torch.log(torch.tensor(v)))) for v in flat], dtype=f32).reshape(np.shape(delta))
+    else:
+        scale = np.maximum(delta, f32(eps)).astype(f32)
     return np.stack([scale, zp, int_min, int_max], axis=-1).astype(f32)
 
 
@@ -341,9 +348,7 @@ class MSE_Estimator(RangeEstimatorBase):
 
     def _cand_table(self, neg_thr, pos_thr):
         q = self.quantizer
-        if q.scale_domain != 'linear':
-            raise NotImplementedError('MSE range search is implemented for the linear scale domain')
-        return candidate_params(neg_thr, pos_thr, q.n_bits, q.symmetric, q.eps)
+        return candidate_params(neg_thr, pos_thr, q.n_bits, q.symmetric, q.eps, log_domain=q.scale_domain == 'log')
 
     def loss_fx(self, data, neg_thr, pos_thr, per_channel_loss=False):
         """Loss of ONE candidate as a host value in the precision of the reference's sums (fp32 for fp32 / low-precision
