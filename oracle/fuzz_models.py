@@ -355,6 +355,9 @@ def main():
             with torch.no_grad():
                 pass_data_for_range_estimation(loader, model, act_quant, weight_quant, max_num_batches=max_b,
                                                cross_entropy_layer=xent, **kw)
+                if rs.randint(3) == 0:            # start over: reset the activation ranges, one more calibration batch
+                    model.reset_act_ranges()
+                    pass_data_for_range_estimation(loader[-1:], model, act_quant, weight_quant, max_num_batches=1, **kw)
                 model.fix_ranges()
                 out[tag + 'y'] = model(xs[0]).numpy().copy()
             for n, m in model.named_modules():
