@@ -173,6 +173,8 @@ def main():
                     if m.quantizer.is_initialized:
                         m.fix_ranges()
                 out[tag + 'y_fixed'] = qm(x_eval).numpy().copy()
+            # checkpoint layout: key names, shapes and dtypes of the calibrated model's state_dict
+            out[tag + 'state_dict'] = np.array(sorted(f'{k}:{tuple(v.shape)}:{v.dtype}' for k, v in qm.state_dict().items()))
             qm.train()                              # train mode: no weight cache, ranges stay fixed
             out[tag + 'y_train'] = qm(x_eval).detach().numpy().copy()
             # learnable ranges (QAT): straight-through backward w.r.t. input, weights and every range parameter
@@ -252,6 +254,7 @@ def main():
                 if hasattr(mgr, 'fix_ranges'):
                     mgr.fix_ranges()
                 out[tag + 'y_fixed'] = site(xs[-1] * 1.5).numpy().copy()
+            out[tag + 'state_dict'] = np.array(sorted(f'{k}:{tuple(v.shape)}:{v.dtype}' for k, v in site.state_dict().items()))
             if hasattr(mgr, 'quantizer'):
                 out[tag + 'delta'] = mgr.quantizer._delta.detach().numpy().copy()
                 out[tag + 'zero_float'] = mgr.quantizer._zero_float.detach().numpy().copy()
@@ -430,6 +433,7 @@ def main():
                         if al is not None:
                             out[tag + n + '.alpha'] = al.detach().numpy().copy()
             out[tag + 'trainable'] = np.array(sorted(n for n, p_ in model.named_parameters() if p_.requires_grad))
+            out[tag + 'state_dict'] = np.array(sorted(f'{k}:{tuple(v.shape)}:{v.dtype}' for k, v in model.state_dict().items()))
         except Exception as e:
             for k in [k for k in out if k.startswith(tag)]:
                 del out[k]
