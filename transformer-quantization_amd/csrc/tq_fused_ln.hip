@@ -558,6 +558,7 @@ extern "C" int tq_scores_softmax_quant_fwd(const float* scores, float* probs, ui
   TQ_REQUIRE(aligned16(scores) && aligned16(probs) && (mask == nullptr || aligned16(mask)),
              "tq_scores_softmax_quant_fwd: 16-byte alignment required");
   TQ_REQUIRE(mask == nullptr || (rows_per_mask >= 1 && rows % rows_per_mask == 0), "tq_scores_softmax_quant_fwd: bad mask layout");
+  if (mask == nullptr) rows_per_mask = rows;      // unused without a mask; keeps the kernels' row -> mask arithmetic away from / 0
   TQ_REQUIRE(denom != 0.0f, "tq_scores_softmax_quant_fwd: denom == 0");
   for (const tq_quantizer* q : {q_scores, q_probs})
     if (q != nullptr) {
