@@ -483,7 +483,7 @@ def test_drop_in_equals_the_reference_on_random_networks(tmp_path):
         outs[impl] = str(tmp_path / f'{impl}.npz')
         extra = {'inplace': ['--inplace-state'], 'double': ['--double']}.get(impl.split('-')[-1], [])
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'fuzz_models.py'), '--impl', impl.split('-')[0],
-                            '--n', '12', '--seed', '11', '--out', outs[impl]] + extra, capture_output=True, text=True,
+                            '--n', '10', '--seed', '11', '--out', outs[impl]] + extra, capture_output=True, text=True,
                            cwd=str(tmp_path), timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     for ref_name, other in (('ref', 'mine'), ('ref', 'mine-inplace'), ('ref-double', 'mine-double')):
@@ -498,4 +498,4 @@ def test_drop_in_equals_the_reference_on_random_networks(tmp_path):
             else:
                 assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), (other, k)
                 n_ok += 1
-        assert n_ok > (250 if 'double' not in other else 100)          # most cases are valid, with 10-40 observables each
+        assert n_ok > (200 if 'double' not in other else 80)          # most cases are valid, with 10-40 observables each
