@@ -271,8 +271,8 @@ def main():
         out[tag + 'cfg'] = np.array(f'code={code} est={est[0]} d={d} B={B} T={T} bits={qp["n_bits_act"]}')
 
     # ---- third family: AdaRound of both Linears of a small network through apply_adaround_to_layer (grid inits
-    # range_estimator / mse / mse_out, symmetric or asymmetric input-caching, with / without the activation function,
-    # learned_sigmoid / learned_hard_sigmoid, 15-30 iterations; mini-batch indices come from the global torch RNG on
+    # range_estimator / mse / mse_out / mse_out_asym, symmetric or asymmetric input-caching, with / without the activation function,
+    # learned_sigmoid / learned_hard_sigmoid / sigmoid_temp_decay, 15-30 iterations; mini-batch indices come from the global torch RNG on
     # both sides, reference adaround/adaround.py:236): alpha, grid, the four reported losses and the final output
     from quantization.adaround import apply_adaround_to_layer
     from quantization.adaround.config import DEFAULT_ADAROUND_CONFIG
@@ -298,8 +298,10 @@ def main():
         tag = f'a{case}_'
         cfg = DotDict(dict(DEFAULT_ADAROUND_CONFIG))
         cfg.iters, cfg.lr = int(rs.choice([15, 30])), 1e-2
-        cfg.round_mode = [AdaRoundMode.learned_hard_sigmoid, AdaRoundMode.learned_sigmoid][rs.randint(2)]
-        cfg.init = [AdaRoundInitMode.range_estimator, AdaRoundInitMode.mse, AdaRoundInitMode.mse_out][rs.randint(3)]
+        cfg.round_mode = [AdaRoundMode.learned_hard_sigmoid, AdaRoundMode.learned_sigmoid,
+                          AdaRoundMode.sigmoid_temp_decay][rs.randint(3)]
+        cfg.init = [AdaRoundInitMode.range_estimator, AdaRoundInitMode.mse, AdaRoundInitMode.mse_out,
+                    AdaRoundInitMode.mse_out_asym][rs.randint(4)]
         cfg.asym, cfg.include_act_func = bool(rs.randint(2)), bool(rs.randint(2))
         try:
             model = Toy()
