@@ -41,7 +41,10 @@ def _calibrate_and_run(model, ids):
 
 def _check_weights_reproduced(hf, z):
     got = float(hf.bert.encoder.layer[0].attention.self.query.weight.double().sum())
-    if got != float(z['first_weight_sum']):
+    # (the float64 sum itself depends on the host's thread count in its last bit -- parallel reduction order -- while a
+    # different random init moves it in the second digit: compare with a tolerance, not bit for bit)
+    want = float(z['first_weight_sum'])
+    if abs(got - want) > 1e-9 * max(1.0, abs(want)):
         pytest.skip('random-init weights differ from the fixture (other torch/transformers build): '
                     + str(z['versions']))
 

@@ -32,7 +32,10 @@ def _build(device):
 
 def _check_weights_reproduced(hf, z):
     got = float(hf.roberta.encoder.layer[0].attention.self.query.weight.detach().double().sum())
-    if got != float(z['first_weight_sum']):
+    # (the float64 sum itself depends on the host's thread count in its last bit -- parallel reduction order -- while a
+    # different random init moves it in the second digit: compare with a tolerance, not bit for bit)
+    want = float(z['first_weight_sum'])
+    if abs(got - want) > 1e-9 * max(1.0, abs(want)):
         pytest.skip('random-init weights differ from the fixture (other torch/transformers build): ' + str(z['versions']))
 
 
@@ -84,6 +87,9 @@ def test_roberta_2l_w8a8_cpu_exact():
 
 
 @pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason='first run on hardware pending: on the one box it reached in round 2 the (then bit-exact) '
+                                       'weight check-sum guard skipped it; same structure as the BERT test, body verified on '
+                                       'the oracle backend')
 def test_roberta_2l_w8a8_gpu():
     from harness.bert import quantizer_census
     from oracle import tq_oracle as O
