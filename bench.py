@@ -227,7 +227,16 @@ def main():
     from quantization.base_quantized_classes import QuantizedActivation
     assert _hip.backend().name == 'hip'
     if use_dist:
-        tq_dist.enable(force=(world == 1))
+        # device tensors are exchanged on the raw RCCL communicator inside libtq_hip.so when the backend is `nccl`
+        # (quantization/rccl.py; self-tested at creation); torch.distributed is the fallback
+        try:
+            tq_dist.enable(force=(world == 1))
+        except Exception as e:       # noqa: BLE001
+            print(f'[bench] raw RCCL exchange unavailable ({e!r}): statistics go through torch.distributed', file=sys.stderr)
+            tq_dist.enable(force=(world == 1), raw=False)
+    transport = 'none'
+    if use_dist:
+        transport = 'raw RCCL (tq_calibrate_minmax_rccl)' if tq_dist.raw_comm() is not None else f'torch.distributed ({backend})'
 
     B, S = args.batch, args.seq
     x = make_hidden(B, S, device, seed=1000 + rank)
@@ -251,14 +260,14 @@ def main():
     mail_wall = None
     if use_dist and backend == 'nccl' and (args.mailbox or os.environ.get('TQ_BENCH_MAILBOX', '0') == '1'):
         try:
-            tq_dist.enable(force=(world == 1), mailbox=True)
+            tq_dist.enable(force=(world == 1), mailbox=True, raw=tq_dist.raw_comm() is not None)
             if tq_dist.mailbox_active():
                 qa(x)
                 mail_wall, _ = timed_region(lambda: qa(x), cal_steps, use_dist)
         except Exception as e:       # noqa: BLE001
             print(f'[bench] mailbox leg skipped: {e!r}', file=sys.stderr)
         finally:
-            tq_dist.enable(force=(world == 1), mailbox=False)
+            tq_dist.enable(force=(world == 1), mailbox=False, raw=tq_dist.raw_comm() is not None)
     qa.activation_quantizer.fix_ranges()
     del calib_batches
 
@@ -325,6 +334,7 @@ def main():
             'what': 'estimate (tq_minmax -> range_update -> set_range) + quantize per step; '
                     + ('one fused MAX all-reduce of [-min;max] per step over RCCL' if world > 1
                        else 'single GPU, no collective'),
+            'transport': transport,
             'value': round(n_elems * world * cal_steps / cal_wall / 1e6, 1),
             'unit': 'M elems/s',
             'ms_per_step': round(cal_wall / cal_steps * 1e3, 4),

@@ -299,7 +299,8 @@ int tq_calibrate_apply(const float* stats, const void* x, uint64_t n, int dtype,
  * on every peer's flag, fold the peers' vectors with max (csrc/tq_mailbox.hip).  In place on `stats` (fp32 [n],
  * n <= tq_mailbox_max_floats() = 2048); `peer_bases` is a DEVICE array of `world` mailbox pointers (entry `rank` is
  * ignored); `status` (device, 4 bytes, zero-initialised) gets bit 0 set if a peer did not answer within `spin_budget`
- * polls (0 = default), in which case `stats` is NaN -- the kernel cannot hang.  hipGraph-capturable (the sequence
+ * polls (0 = default: ~10 minutes, the order of c10d's collective timeout), in which case `stats` is NaN -- the
+ * kernel cannot hang for ever; callers must read `status` when calibration ends.  hipGraph-capturable (the sequence
  * number lives in the mailbox).  All ranks must issue the same sequence of calls.                                 */
 size_t tq_mailbox_bytes(void);
 size_t tq_mailbox_max_floats(void);
@@ -323,6 +324,41 @@ int tq_calibrate_minmax_mailbox(const void* x, uint64_t n, int dtype, uint64_t n
                                 size_t workspace_bytes, uint32_t* counter, void* my_base,
                                 void* const* peer_bases, uint32_t world, uint32_t rank, uint32_t* status,
                                 uint32_t spin_budget, tq_stream_t stream);
+
+/* ---- raw-RCCL exchange for sharded calibration (no torch.distributed / c10d in the data path) ---------------------
+ * The loop being sharded is pass_data_for_range_estimation (reference utils/utils.py:47-79: every rank runs it on its
+ * slice of the calibration batch); the reference has no collective code, these entry points are what its estimators
+ * (range_estimators.py:83-169,172-216: the min/max reductions; :248-256: the candidate-loss accumulation) would call
+ * between "local statistic" and "update".  One process per GPU, one communicator per process:
+ *   tq_comm_load(path)       host: bind librccl at run time (dlopen; NULL = the librccl already mapped into the process,
+ *                            else the loader's search path).  Implicit in the other calls.
+ *   tq_comm_get_unique_id    host: rank 0 makes the tq_comm_unique_id_bytes() (=128) byte id; the caller ships it to the
+ *                            other ranks (e.g. through the torch.distributed rendezvous store).
+ *   tq_comm_init             host, collective over all ranks: ncclCommInitRank on the calling thread's current device.
+ *   tq_comm_allreduce        in place on `buf` (device), enqueued on `stream`; no host synchronisation, capturable.
+ *   tq_comm_broadcast        in place, from `root`.
+ * All ranks must issue the same sequence of collectives.  Errors: TQ_EUNSUPPORTED if librccl cannot be bound.      */
+enum { TQ_COMM_F32 = 0, TQ_COMM_F64 = 1, TQ_COMM_I32 = 2, TQ_COMM_U8 = 3 };
+enum { TQ_COMM_MAX = 0, TQ_COMM_SUM = 1, TQ_COMM_MIN = 2 };
+size_t tq_comm_unique_id_bytes(void);
+int tq_comm_load(const char* librccl_path /* host, may be NULL */);
+int tq_comm_version(void);                     /* ncclGetVersion code of the bound library, 0 if none */
+int tq_comm_get_unique_id(void* id_out /* host */);
+int tq_comm_init(const void* unique_id /* host */, int rank, int world, void** comm_out);
+int tq_comm_destroy(void* comm);
+int tq_comm_rank_world(void* comm, int* rank /* host */, int* world /* host */);
+int tq_comm_allreduce(void* comm, void* buf, uint64_t count, int dtype, int op, tq_stream_t stream);
+int tq_comm_broadcast(void* comm, void* buf, uint64_t count, int dtype, int root, tq_stream_t stream);
+
+/* tq_calibrate_stats -> ncclAllReduce(MAX) on [-min | max] -> tq_calibrate_apply as ONE call: the sharded calibrating
+ * step of a quantizer with the host cost of the single-GPU fused step.  Arguments as tq_calibrate_minmax; counter as
+ * tq_calibrate_tensor (may be NULL); workspace >= tq_calibrate_workspace_bytes(n, n_params, inner).                 */
+int tq_calibrate_minmax_rccl(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner,
+                             int mode, const float* prev_min, const float* prev_max, float* cur_min,
+                             float* cur_max, double momentum, uint64_t n_groups, const int64_t* order,
+                             int n_bits, int symmetric, float eps, int log_domain, float* delta,
+                             float* zero_float, uint8_t* signed_flag, void* y, void* workspace,
+                             size_t workspace_bytes, uint32_t* counter, void* comm, tq_stream_t stream);
 
 /* PEG phase 1 (range_estimators.py:68-80): ranges = max - min per embedding dim; on later
  * batches the reference stores 0.1*r + 0.9*r of the NEW ranges (quirk q4).                    */

@@ -287,12 +287,12 @@ with torch.no_grad():
     c['fixed_range_forward_all_fused_nonorm_in_gemm_epilogue_hipgraph_ms'] = wall(lambda: g4(ids_mb), n=30)
     c['nonorm_in_epilogue_equal_to_separate_launches'] = bool(torch.equal(g4(ids_mb), g3(ids_mb)))
     # + each feed-forward block (128 -> 512 ReLU quant -> 128 + residual NoNorm tail) as ONE launch (tq_ffn_i8_nonorm_fwd)
-    from harness.mobilebert import QFFN
-    QFFN.fuse = True
+    from harness.mobilebert import QFFN, QMobileLayer
+    QFFN.fuse = QMobileLayer.fuse_ffn = True
     g5 = GraphedForward(mb, ids_mb)
     c['fixed_range_forward_all_fused_ffn_blocks_hipgraph_ms'] = wall(lambda: g5(ids_mb), n=30)
     c['ffn_blocks_equal_to_separate_launches'] = bool(torch.equal(g5(ids_mb), g3(ids_mb)))
-    QFFN.fuse = False
+    QFFN.fuse = QMobileLayer.fuse_ffn = False
     QBottleneckLayer.fuse = False
     QMobileSelfAttention.fuse = False
     options.INT8_LINEAR = False

@@ -59,33 +59,45 @@ with torch.no_grad():
     out['single_gpu_hipgraph_ms'] = wall(lambda: g1(ids_all))
     del g1
     options.INPLACE_CALIBRATION_STATE = False
-    tq_dist.enable(force=(world == 1))
+    # ---- exchange through torch.distributed (c10d -> RCCL): the round-2 path, kept as the comparison -----------------
+    tq_dist.enable(force=(world == 1), raw=False)
     ids = tq_dist.shard_batch(ids_all)
     out['local_batch'] = list(ids.shape)
     before = tq_dist.stats()
-    out['sharded_fused_split_ms'] = wall(lambda: model(ids))
+    out['sharded_c10d_eager_ms'] = wall(lambda: model(ids))
     after = tq_dist.stats()
     out['collectives_per_forward'] = (after['minmax_calls'] - before['minmax_calls']) / 23
     out['bytes_per_forward'] = (after['bytes'] - before['bytes']) / 23
     qm.FUSED_CALIBRATION = False                                # round-1 path: layered estimator + sync_minmax
-    out['sharded_layered_ms'] = wall(lambda: model(ids))
+    out['sharded_c10d_layered_ms'] = wall(lambda: model(ids))
     qm.FUSED_CALIBRATION = True
-    # the same sharded forward captured as ONE hipGraph, the 161 ncclAllReduce launches included: no host work
-    # between the statistics kernel, the collective and the update kernel of a site
+    tq_dist.disable()
+    # ---- raw RCCL behind the C ABI (tq_calibrate_minmax_rccl: statistics -> ncclAllReduce -> update + quantize, one
+    # C call per site, no c10d) -----------------------------------------------------------------------------------------
+    tq_dist.enable(force=(world == 1), raw=True)
+    out['raw_rccl_active'] = tq_dist.raw_comm() is not None
+    out['rccl_version'] = tq_dist.raw_comm().version if tq_dist.raw_comm() else None
+    before = tq_dist.stats()
+    out['sharded_raw_rccl_eager_ms'] = wall(lambda: model(ids))
+    after = tq_dist.stats()
+    out['raw_rccl_calls_per_forward'] = (after['raw_rccl_calls'] - before['raw_rccl_calls']) / 23
+    out['ratio_raw_eager_vs_single_eager'] = out['sharded_raw_rccl_eager_ms'] / out['single_gpu_fused_ms']
+    # the same sharded forward captured as ONE hipGraph, the 161 ncclAllReduce launches included
     try:
         options.INPLACE_CALIBRATION_STATE = True
         model(ids)
         g2 = GraphedForward(model, ids)
-        out['sharded_hipgraph_ms'] = wall(lambda: g2(ids))
-        out['ratio_sharded_graph_vs_single_graph'] = out['sharded_hipgraph_ms'] / out['single_gpu_hipgraph_ms']
-        out['ratio_sharded_graph_vs_single_eager'] = out['sharded_hipgraph_ms'] / out['single_gpu_fused_ms']
+        out['sharded_raw_rccl_hipgraph_ms'] = wall(lambda: g2(ids))
+        out['ratio_sharded_graph_vs_single_graph'] = out['sharded_raw_rccl_hipgraph_ms'] / out['single_gpu_hipgraph_ms']
+        out['ratio_sharded_graph_vs_single_eager'] = out['sharded_raw_rccl_hipgraph_ms'] / out['single_gpu_fused_ms']
+        del g2
     except Exception as e:                                         # noqa: BLE001
         out['sharded_hipgraph_error'] = repr(e)[:500]
     options.INPLACE_CALIBRATION_STATE = False
     tq_dist.disable()
     # the same exchange through the P2P mailbox kernel instead of ncclAllReduce (one small kernel, no c10d host work)
     try:
-        tq_dist.enable(force=(world == 1), mailbox=True)
+        tq_dist.enable(force=(world == 1), mailbox=True, raw=False)
         out['mailbox_active'] = tq_dist.mailbox_active()
         model(ids)
         b0 = tq_dist.stats()['mailbox_calls']
@@ -100,10 +112,10 @@ with torch.no_grad():
         out['sharded_mailbox_error'] = repr(e)[:500]
     options.INPLACE_CALIBRATION_STATE = False
     tq_dist.disable()
-    out['ratio_split_vs_single'] = out['sharded_fused_split_ms'] / out['single_gpu_fused_ms']
-t = torch.tensor([out['sharded_fused_split_ms']], device=dev, dtype=torch.float64)
+    out['ratio_c10d_eager_vs_single_eager'] = out['sharded_c10d_eager_ms'] / out['single_gpu_fused_ms']
+t = torch.tensor([out['sharded_raw_rccl_eager_ms']], device=dev, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-out['sharded_fused_split_ms_max_over_ranks'] = float(t[0])
+out['sharded_raw_rccl_eager_ms_max_over_ranks'] = float(t[0])
 if rank == 0:
     print(json.dumps(out, indent=1))
 dist.destroy_process_group()

@@ -26,7 +26,13 @@ def _has_gpu():
         return False
 
 
+# Files whose tests launch other processes (torchrun workers, bench.py ranks, IPC peers): collected LAST, so that a
+# launcher / rendezvous flake under `-x` can never hide a parity test or the CLI harness behind it.
+_LAUNCHER_FILES = ('test_dist_gloo.py', 'test_mailbox.py', 'test_rccl_single_rank.py', 'test_rccl_raw.py')
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: os.path.basename(str(it.fspath)) in _LAUNCHER_FILES)      # stable: keeps file order
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason='no GPU in this container')

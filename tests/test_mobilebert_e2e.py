@@ -204,7 +204,7 @@ def test_mobilebert_linear_nonorm_tails_in_gemm_epilogue():
     residual tails of a layer through QResidualNoNorm.fuse, the two bottlenecks through QBottleneckLayer.fuse): the
     logits equal those of the integer Linears followed by separate NoNorm / quantizer launches bit for bit -- same
     integer contraction, same element arithmetic, fewer launches."""
-    from harness.mobilebert import QBottleneckLayer, QFFN, QResidualNoNorm, build_mobilebert
+    from harness.mobilebert import QBottleneckLayer, QFFN, QMobileLayer, QResidualNoNorm, build_mobilebert
     from quantization import _hip, options
     from quantization.quantizers import QMethods
     from quantization.range_estimators import RangeEstimators
@@ -231,11 +231,11 @@ def test_mobilebert_linear_nonorm_tails_in_gemm_epilogue():
             ffn_calls = []
             orig_ffn = be.ffn_i8_nonorm
             be.ffn_i8_nonorm = lambda *a, **k: (ffn_calls.append(1), orig_ffn(*a, **k))[1]
-            QFFN.fuse = True
+            QFFN.fuse = QMobileLayer.fuse_ffn = True
             try:
                 fused_ffn = model(ids)
             finally:
-                QFFN.fuse = False
+                QFFN.fuse = QMobileLayer.fuse_ffn = False
                 be.__dict__.pop('ffn_i8_nonorm', None)
         finally:
             QResidualNoNorm.fuse = QBottleneckLayer.fuse = False

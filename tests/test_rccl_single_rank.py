@@ -39,8 +39,9 @@ def run(init, axis=None, n_groups=None, params=None):
 cases = [('running_minmax', None, None, None), ('current_minmax', 2, None, None), ('current_minmax', 2, 6, None),
          ('MSE', None, None, dict(num_candidates=50))]
 local = [run(*c) for c in cases]
-tq_dist.enable(force=True)
-assert tq_dist.is_enabled()
+RAW = os.environ.get('TQ_TEST_RAW', '1') == '1'
+tq_dist.enable(force=True, raw=RAW)
+assert tq_dist.is_enabled() and (tq_dist.raw_comm() is not None) == RAW
 shared = [run(*c) for c in cases]
 for a, b in zip(local, shared):
     for u, v in zip(a, b):
@@ -51,6 +52,7 @@ s = tq_dist.sync_sum(torch.arange(5, dtype=torch.float64, device='cuda'))
 assert s.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
 st = tq_dist.stats()
 assert st['minmax_calls'] >= len(cases) + 1 and st['sum_calls'] >= 2, st
+assert (st['raw_rccl_calls'] >= len(cases) + 3) if RAW else st['raw_rccl_calls'] == 0, st
 
 # data-parallel AdaRound over RCCL (1 rank): SUM all-reduce of dL/dW_q before the fused Adam step
 from tests.test_dist_gloo import _ada_problem
@@ -65,7 +67,7 @@ assert tq_dist.stats()['sum_calls'] >= before + 6          # one gradient all-re
 tq_dist.disable()
 a_local = ada()
 assert torch.equal(a_dist, a_local)
-tq_dist.enable(force=True)
+tq_dist.enable(force=True, raw=RAW)
 tq_dist.disable()
 dist.destroy_process_group()
 print('RCCL_SINGLE_RANK_OK', st)
@@ -87,10 +89,13 @@ def _torchrun(args, extra_env=None, timeout=300):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-def test_estimators_over_rccl_world1(tmp_path):
+@pytest.mark.parametrize('raw', ['1', '0'], ids=['raw-rccl', 'c10d'])
+def test_estimators_over_rccl_world1(tmp_path, raw):
+    """raw-rccl: the collectives go through libtq_hip.so's own communicator (tq_comm_allreduce /
+    tq_calibrate_minmax_rccl); c10d: through torch.distributed.all_reduce on the same process group."""
     script = tmp_path / 'worker.py'
     script.write_text('ROOT = %r\n' % ROOT + WORKER)
-    r = _torchrun([str(script)])
+    r = _torchrun([str(script)], extra_env={'TQ_TEST_RAW': raw})
     assert r.returncode == 0 and 'RCCL_SINGLE_RANK_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
@@ -133,48 +138,3 @@ def test_bench_gpus_2_spawns_two_ranks_with_real_kernels():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['rccl_world_size'] == 2 and out['value'] > 0
     assert out['calibration']['value'] > 0 and 'all-reduce' in out['calibration']['what']
-
-
-GRAPH_WORKER = r"""
-import os, sys
-sys.path.insert(0, os.path.join(ROOT, 'transformer-quantization_amd')); sys.path.insert(0, ROOT)
-import torch, torch.distributed as dist
-torch.cuda.set_device(0)
-dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
-from quantization import distributed as tq_dist, options
-from quantization.graphs import GraphedForward
-from tests.test_calibration_graph import _model, _batches
-batches = _batches(4)
-tq_dist.enable(force=True)
-with torch.no_grad():
-    ref = _model(2)
-    for b in batches:
-        ref_out = ref(tq_dist.shard_batch(b))
-    ref_sd = {k: v.clone() for k, v in ref.state_dict().items()}
-    options.INPLACE_CALIBRATION_STATE = True
-    m = _model(2)
-    m(batches[0])                                  # first batch eager: allocates every state buffer
-    n0 = tq_dist.stats()['minmax_calls']
-    g = GraphedForward(m, batches[1])              # captures the ncclAllReduce launches with the kernels
-    n1 = tq_dist.stats()['minmax_calls']
-    for b in batches[1:]:
-        out = g(b)
-    assert tq_dist.stats()['minmax_calls'] == n1 and n1 > n0      # replay issues no python-side collective call
-    sd = m.state_dict()
-    assert sd.keys() == ref_sd.keys()
-    for k in sd:
-        assert torch.equal(sd[k], ref_sd[k]), k
-    assert torch.equal(out, ref_out)
-dist.destroy_process_group()
-print('RCCL_GRAPH_CALIBRATION_OK')
-"""
-
-
-def test_sharded_calibration_replays_as_hipgraph_with_rccl(tmp_path):
-    """A sharded calibrating forward -- statistics kernel -> in-place MAX all-reduce (RCCL) -> update + quantize at
-    every site -- captured ONCE as a hipGraph (collectives included) and replayed per batch == eager sharded
-    calibration, bit for bit (state_dict and outputs)."""
-    script = tmp_path / 'graph_worker.py'
-    script.write_text('ROOT = %r\n' % ROOT + GRAPH_WORKER)
-    r = _torchrun([str(script)])
-    assert r.returncode == 0 and 'RCCL_GRAPH_CALIBRATION_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

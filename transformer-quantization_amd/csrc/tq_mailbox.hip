@@ -30,6 +30,10 @@ constexpr size_t kMailHeader = 256;                                     // seq c
 constexpr size_t kMailSlot = 256 + kMailPayloadFloats * sizeof(float);  // flag (+ padding) | payload
 constexpr size_t kMailBytes = 32768;
 static_assert(kMailHeader + 2 * kMailSlot <= kMailBytes, "mailbox layout");
+// default spin budget: one poll is a system-scope load of remote memory + s_sleep, ~1 us -> ~10 minutes, the order of
+// c10d's collective timeout (ordinary rank skew -- a data-loader stall, first-batch work on rank 0 -- must never time out;
+// RCCL would simply wait).  The Python side reads `status` when calibration ends and raises.
+constexpr uint32_t kDefaultSpin = 600000000u;
 
 __device__ __forceinline__ uint32_t* mail_flag(void* base, uint32_t parity) {
   return reinterpret_cast<uint32_t*>(static_cast<char*>(base) + kMailHeader + parity * kMailSlot);
@@ -162,7 +166,7 @@ extern "C" int tq_mailbox_allreduce_max(float* stats, uint64_t n, void* my_base,
              kMailPayloadFloats);
   TQ_REQUIRE(world >= 1 && rank < world, "tq_mailbox_allreduce_max: bad rank %u / world %u", rank, world);
   hipLaunchKernelGGL(mailbox_allreduce_max_k, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream), stats, (uint32_t)n,
-                     my_base, peer_bases, world, rank, status, spin_budget ? spin_budget : 5000000u);
+                     my_base, peer_bases, world, rank, status, spin_budget ? spin_budget : kDefaultSpin);
   return check_launch("mailbox_allreduce_max_k");
 }
 

@@ -197,13 +197,15 @@ class QMobileLayer(QuantizedModel):
         self.output = QResidualNoNorm(hf.output, sites['res_output'], **qp)
         self.output_bottleneck = QResidualNoNorm(hf.output.bottleneck, sites['res_output_bottleneck'], **qp)
 
+    fuse_ffn = False   # set True: the last feed-forward block (intermediate + output) as one integer launch, like QFFN.fuse
+
     def forward(self, h, mask):
         layer_input = self.bottleneck_input(h)                    # [B, T, 128] residual of the attention block
         shared = self.bottleneck_attention(h)                     # query / key input
         a = self.attention_output(self.attention_self(shared, shared, h, mask), layer_input)
         for f in self.ffn:
             a = f(a)
-        o = _ffn(self.intermediate, self.output, a) if QFFN.fuse else self.output(self.intermediate(a), a)
+        o = _ffn(self.intermediate, self.output, a) if self.fuse_ffn else self.output(self.intermediate(a), a)
         return self.output_bottleneck(o, h)                       # back to 512, residual = the layer's input
 
 

@@ -98,6 +98,17 @@ SIGNATURES = {
     'tq_calibrate_minmax_mailbox': (_int, [_vp, _u64, _int, _u64, _u64, _int, _vp, _vp, _vp, _vp, _d, _u64, _vp, _int, _int, _f,
                                            _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp,
                                            C.c_uint32, _vp]),
+    'tq_comm_unique_id_bytes': (_sz, []),
+    'tq_comm_load': (_int, [C.c_char_p]),
+    'tq_comm_version': (_int, []),
+    'tq_comm_get_unique_id': (_int, [_vp]),
+    'tq_comm_init': (_int, [_vp, _int, _int, C.POINTER(_vp)]),
+    'tq_comm_destroy': (_int, [_vp]),
+    'tq_comm_rank_world': (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
+    'tq_comm_allreduce': (_int, [_vp, _vp, _u64, _int, _int, _vp]),
+    'tq_comm_broadcast': (_int, [_vp, _vp, _u64, _int, _int, _vp]),
+    'tq_calibrate_minmax_rccl': (_int, [_vp, _u64, _int, _u64, _u64, _int, _vp, _vp, _vp, _vp, _d, _u64, _vp, _int, _int, _f,
+                                        _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     'tq_range_update': (_int, [_int, _vp, _vp, _vp, _vp, _u64, _int, _d, _u64, _vp, _vp]),
     'tq_axis_ranges': (_int, [_vp, _vp, _vp, _u64, _int, _vp]),
     'tq_set_range_asym': (_int, [_vp, _vp, _u64, _int, _f, _int, _vp, _vp, _vp]),
@@ -690,6 +701,39 @@ class HipBackend:
             box.status.data_ptr(), box.spin_budget, st)
         _check(rc, self.lib)
         box.calls += 1
+        return (*out, y)
+
+    def calibrate_minmax_rccl(self, comm, x, n_params, inner, mode, prev_min, prev_max, momentum, n_groups, order,
+                              n_bits, symmetric, eps, log_domain, want_y=True, out=None):
+        """Sharded calibrating step in ONE C call: statistics -> ncclAllReduce(MAX) on the raw communicator `comm`
+        (quantization.rccl.RawRcclComm) -> estimator update + parameters + y.  Returns like calibrate_minmax."""
+        _need_device(x, 'calibrate_minmax_rccl')
+        x = x.contiguous()
+        dev = x.device
+        st = _stream()
+        if out is None:
+            cur = torch.empty(2, n_params, dtype=torch.float32, device=dev)
+            par = torch.empty(1 if symmetric else 2, n_params, dtype=torch.float32, device=dev)
+            signed = torch.empty((), dtype=torch.bool, device=dev) if symmetric else None
+            if n_params == 1:
+                out = (cur[0, 0], cur[1, 0], par[0, 0], None if symmetric else par[1, 0], signed)
+            else:
+                out = (cur[0], cur[1], par[0], None if symmetric else par[1], signed)
+        counter = None
+        if n_params == 1:
+            key = (dev.index, st)
+            counter = self._counters.get(key)
+            if counter is None:
+                counter = self._counters[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+        y = torch.empty_like(x) if want_y else None
+        ws = self._workspace(dev, self._calib_ws_bytes(x.numel(), n_params, inner))
+        rc = self.lib.tq_calibrate_minmax_rccl(
+            x.data_ptr(), x.numel(), _dtype_code(x, 'calibrate_minmax_rccl'), n_params, inner, mode, _ptr(prev_min),
+            _ptr(prev_max), _ptr(out[0]), _ptr(out[1]), float(momentum), int(n_groups or 0), _ptr(order), int(n_bits),
+            int(bool(symmetric)), float(eps), int(bool(log_domain)), _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _ptr(y),
+            ws.data_ptr(), ws.numel(), _ptr(counter), comm.handle, st)
+        _check(rc, self.lib)
+        comm.calls += 1
         return (*out, y)
 
     def range_update(self, mode, new_min, new_max, cur_min, cur_max, momentum=0.9, n_groups=0,

@@ -77,12 +77,29 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
     return y
 
 
+def _needs_autograd(*modules_and_tensors):
+    """True when a result must carry a grad_fn: grad mode is on and an input tensor or a parameter of one of the given
+    modules requires grad.  The fused integer kernels are inference-only; checking the input alone would silently drop
+    the gradients of Linear / NoNorm weights behind a frozen input (frozen embeddings, first layer)."""
+    if not torch.is_grad_enabled():
+        return False
+    for m in modules_and_tensors:
+        if m is None:
+            continue
+        if torch.is_tensor(m):
+            if m.requires_grad:
+                return True
+        elif any(p.requires_grad for p in m.parameters()):
+            return True
+    return False
+
+
 def _linear_nonorm_i8(dense, layer_norm, x, residual, q1, q2, q3):
     """Integer Linear -> (+ residual -> Q_sum) -> NoNorm -> Q_out in one launch (tq_linear_i8_nonorm_fwd), or None when
     the integer path does not apply to `dense` / `x` (then the caller runs GEMM and tail separately).  Bit-identical to
     that two-launch form: same integer contraction, same element arithmetic."""
     if not options.INT8_LINEAR or not hasattr(dense, '_int8_plan') or (residual is not None and (
-            residual.dtype != torch.float32 or not residual.is_cuda)):
+            residual.dtype != torch.float32 or not residual.is_cuda)) or _needs_autograd(dense, layer_norm, x, residual):
         return None
     plan = dense._int8_plan(x, with_output_quantizer=False)
     if plan is None or plan[1] != _hip.ACT_NONE:
@@ -111,7 +128,7 @@ def linear_nonorm_quant(dense, layer_norm, x):
     if (isinstance(layer_norm, QuantNoNorm) and x.is_cuda and x.dtype == torch.float32
             and dense.activation_function is None and layer_norm.activation_function is None
             and dense.activation_save_target is None and layer_norm.activation_save_target is None
-            and not (torch.is_grad_enabled() and x.requires_grad)):
+            and not _needs_autograd(dense, layer_norm, x)):
         q1 = _fixed_per_tensor(dense._quant_a, dense.activation_quantizer)
         q3 = _fixed_per_tensor(layer_norm._quant_a, layer_norm.activation_quantizer)
         if 'no' not in (q1, q3):
@@ -137,7 +154,7 @@ def quantized_ffn(intermediate, dense, res_quantizer, layer_norm, x):
     be = _hip.backend()
     if (not options.INT8_LINEAR or not hasattr(be, 'ffn_i8_nonorm') or not isinstance(layer_norm, QuantNoNorm)
             or not hasattr(intermediate, '_int8_plan') or not hasattr(dense, '_int8_weight_side_ok')
-            or not x.is_cuda or x.dtype != torch.float32 or (torch.is_grad_enabled() and x.requires_grad)
+            or not x.is_cuda or x.dtype != torch.float32 or _needs_autograd(intermediate, dense, layer_norm, x)
             or dense.activation_function is not None or layer_norm.activation_function is not None
             or layer_norm.activation_save_target is not None or not dense._int8_weight_side_ok()):
         return separate()

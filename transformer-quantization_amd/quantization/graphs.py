@@ -8,6 +8,26 @@ with the integer fast paths).
 """
 import torch
 
+from quantization import options
+
+
+def _quiesce():
+    """Nothing of this process may be in flight when a capture opens.  Wait for the device; when a c10d `nccl` process
+    group exists, also give its watchdog thread one polling period to retire the (now complete) work objects of eager
+    collectives: an event query from that thread while a GLOBAL-mode capture is open aborts the process, which is why
+    the captures below also use `capture_error_mode='thread_local'` (only the capturing thread's calls are policed).
+    The raw-RCCL exchange (quantization/rccl.py) involves no watchdog at all and is the transport to use for captured
+    sharded calibration."""
+    torch.cuda.synchronize()
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+            import time
+            time.sleep(0.25)
+            torch.cuda.synchronize()
+    except Exception:       # noqa: BLE001 -- best effort: the thread-local capture mode is the actual guard
+        pass
+
 
 class GraphedForward:
     """``g = GraphedForward(model, example_ids); logits = g(ids)``.
@@ -33,8 +53,9 @@ class GraphedForward:
             for _ in range(max(int(warmup), 1)):          # allocator pools, workspaces, ticket words, caches
                 self._run()
         torch.cuda.current_stream().wait_stream(side)
+        _quiesce()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.static_outputs = self._run()
         if snap is not None:
             live = module.state_dict()
@@ -92,14 +113,21 @@ class GraphedTrainStep:
         self.static_inputs = tuple(t.clone() for t in example_inputs)
         self.static_targets = tuple(t.clone() for t in example_targets)
         snap = {k: v.clone() for k, v in module.state_dict().items()} if restore_state else None
+        # optimizer state as it was handed in (empty for a fresh optimizer; moments + step counters of one that has
+        # already stepped): restored IN PLACE after capture -- the graph holds the addresses of the live tensors
+        opt_snap = None
+        if restore_state:
+            opt_snap = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                        for p, st in optimizer.state.items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(int(warmup), 1)):
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
+        _quiesce()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.static_loss = self._step()
         if snap is not None:
             live = module.state_dict()
@@ -107,12 +135,15 @@ class GraphedTrainStep:
                 if k not in snap or v.shape != snap[k].shape:
                     raise RuntimeError(f'module state {k} changed shape during capture')
                 v.copy_(snap[k])
-            # optimizer state (momentum buffers, Adam moments, step counters) back to "no step taken", in place: the
-            # graph holds the addresses of these tensors
-            for st in optimizer.state.values():
-                for v in st.values():
+            for p, st in optimizer.state.items():
+                before = opt_snap.get(id(p), {})
+                for k, v in st.items():
                     if torch.is_tensor(v):
-                        v.zero_()
+                        if torch.is_tensor(before.get(k)) and before[k].shape == v.shape:
+                            v.copy_(before[k])
+                        else:
+                            v.zero_()            # state created by the warm-up: back to "no step taken"
+        options.invalidate_derived_caches()
 
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -128,4 +159,7 @@ class GraphedTrainStep:
                                  f'got {tuple(src.shape)} {src.dtype}')
             dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # the replay rewrote weights / learnable ranges in place without bumping tensor._version: derived caches
+        # (int8 weight indices, NoNorm parameters, stacked operands) must not survive it
+        options.invalidate_derived_caches()
         return self.static_loss

@@ -7,6 +7,8 @@ c10d + RCCL (`profiles/r02/sharded_calibration_rccl1.json`).  Set-up: every rank
 libtq_hip.so, the 64-byte IPC handles travel through `all_gather_object`, peers are mapped with hipIpcOpenMemHandle
 (`HSA_ENABLE_IPC_MODE_LEGACY=0` must be set, as for RCCL on this driver).  `self_test()` compares the path with
 `torch.distributed.all_reduce(MAX)` on known vectors; `quantization.distributed.enable` keeps RCCL if it fails.
+The kernel's wait is bounded (default ~10 minutes); `timed_out()` is checked when calibration ends
+(`quantization.distributed.check_exchange_health`), which raises instead of leaving NaN ranges behind.
 """
 import ctypes as C
 
@@ -26,26 +28,43 @@ class P2PMailbox:
         self.max_floats = int(self.lib.tq_mailbox_max_floats())
         self.device = torch.device('cuda', torch.cuda.current_device())
         hb = int(self.lib.tq_mailbox_handle_bytes())
-        handle = (C.c_ubyte * hb)()
-        base = C.c_void_p()
-        _hip._check(self.lib.tq_mailbox_alloc(C.byref(base), handle), self.lib)
-        self.base = base.value
+        self.base, self._opened = None, []
+        # Every set-up collective below runs on EVERY rank, whatever failed locally: a rank that skipped one would leave
+        # its peers blocked in it (or paired with its next, unrelated collective).  Local failures are recorded and the
+        # verdict is agreed at the end.
+        err, handle = None, (C.c_ubyte * hb)()
+        try:
+            base = C.c_void_p()
+            _hip._check(self.lib.tq_mailbox_alloc(C.byref(base), handle), self.lib)
+            self.base = base.value
+        except Exception as e:      # noqa: BLE001
+            err = e
         handles = [None] * self.world
-        dist.all_gather_object(handles, bytes(handle), group=group)
-        self._opened = []
+        dist.all_gather_object(handles, bytes(handle) if err is None else None, group=group)
         ptrs = []
-        for r, h in enumerate(handles):
-            if r == self.rank:
-                ptrs.append(self.base)
-                continue
-            buf = (C.c_ubyte * hb).from_buffer_copy(h)
-            peer = C.c_void_p()
-            _hip._check(self.lib.tq_mailbox_open(buf, C.byref(peer)), self.lib)
-            self._opened.append(peer.value)
-            ptrs.append(peer.value)
+        if err is None and all(h is not None for h in handles):
+            try:
+                for r, h in enumerate(handles):
+                    if r == self.rank:
+                        ptrs.append(self.base)
+                        continue
+                    buf = (C.c_ubyte * hb).from_buffer_copy(h)
+                    peer = C.c_void_p()
+                    _hip._check(self.lib.tq_mailbox_open(buf, C.byref(peer)), self.lib)
+                    self._opened.append(peer.value)
+                    ptrs.append(peer.value)
+            except Exception as e:  # noqa: BLE001
+                err = e
+        elif err is None:
+            err = RuntimeError('a peer could not allocate its mailbox')
+        verdicts = [None] * self.world
+        dist.all_gather_object(verdicts, err is None, group=group)     # doubles as the barrier: every mailbox is mapped
+        if not all(verdicts):
+            self._release()
+            raise RuntimeError('P2P mailbox set-up failed on rank(s) %s%s' % (
+                [r for r, v in enumerate(verdicts) if not v], '' if err is None else ': %s' % err))
         self.peers = torch.tensor(ptrs, dtype=torch.int64, device=self.device)     # void*[world] on the device
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        dist.barrier(group=group)                    # every mailbox is mapped before anybody posts
         self.calls = 0
 
     def usable(self, buf):
@@ -82,15 +101,18 @@ class P2PMailbox:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)          # all ranks agree on the verdict
         return bool(int(flag[0]))
 
-    def close(self):
-        torch.cuda.synchronize()
-        try:
-            dist.barrier(group=self.group)
-        except Exception:       # noqa: BLE001  (process group may already be gone)
-            pass
+    def _release(self):
         for p in self._opened:
             self.lib.tq_mailbox_close(p)
         self._opened = []
         if self.base:
             self.lib.tq_mailbox_free(self.base)
             self.base = None
+
+    def close(self):
+        torch.cuda.synchronize()
+        try:
+            dist.barrier(group=self.group)
+        except Exception:       # noqa: BLE001  (process group may already be gone)
+            pass
+        self._release()

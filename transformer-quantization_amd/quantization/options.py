@@ -25,3 +25,14 @@ INPLACE_CALIBRATION_STATE = False
 # the fused step of plain Linear layers (closed-form gradient, no folded activation function) on one GPU with the
 # relaxation loss; anything else runs the eager loop.
 GRAPH_ADAROUND = True
+
+# Bumped by anything that rewrites parameters or range buffers behind autograd's back -- a hipGraph replay of a training
+# step updates weights and learnable ranges in place WITHOUT touching tensor._version -- so that every derived cache
+# (int8 weight indices, NoNorm parameters, stacked QKV operands, provenance records) sees a new key:
+# QuantizerBase.range_state_key() includes it.
+CACHE_EPOCH = 0
+
+
+def invalidate_derived_caches():
+    global CACHE_EPOCH
+    CACHE_EPOCH += 1

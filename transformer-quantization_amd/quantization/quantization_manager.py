@@ -164,6 +164,12 @@ class QuantizationManager(nn.Module):
                 box, x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0), n_groups, order,
                 q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log', out=out)
             tq_dist.count_mailbox_exchange(8 * n_params)
+        elif sharded and hasattr(be, 'calibrate_minmax_rccl') and tq_dist.raw_comm_for(x) is not None:
+            # statistics -> ncclAllReduce(MAX) on the raw communicator -> update + quantize as one C call: no c10d
+            cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_minmax_rccl(
+                tq_dist.raw_comm_for(x), x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0),
+                n_groups, order, q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log', out=out)
+            tq_dist.count_raw_exchange(8 * n_params)
         elif sharded:
             # split at the exchange: local [-min | max] -> one in-place MAX all-reduce -> update + quantize
             stats = tq_dist.sync_max_inplace(be.calibrate_stats(x, n_params, inner))

@@ -21,7 +21,7 @@ import torch
 from torch import nn
 from torch.autograd import Function
 
-from quantization import _hip
+from quantization import _hip, options
 
 
 class RoundStraightThrough(Function):
@@ -140,7 +140,7 @@ class QuantizerBase(nn.Module):
     def range_state_key(self):
         """Changes whenever the quantization grid of this quantizer may have changed (rebinding or in-place update)."""
         d = self._buffers.get('_delta', None) if '_delta' in self._buffers else getattr(self, '_delta', None)
-        return (self._range_gen, None if d is None else d._version, self.n_bits)
+        return (self._range_gen, None if d is None else d._version, self.n_bits, options.CACHE_EPOCH)
 
     @property
     def is_initialized(self):

@@ -76,6 +76,7 @@ def pass_data_for_range_estimation(loader, model, act_quant, weight_quant, max_n
 
         if i >= max_num_batches - 1 or not act_quant:
             break
+    tq_dist.check_exchange_health()      # sharded calibration over the P2P mailbox: a timed-out exchange is an error
 
 
 class DotDict(dict):
