@@ -1,0 +1,144 @@
+"""AdaRound on the non-Linear layer kinds of the reference's `'all'` selection (utils/adaround_utils.py:60-75: every
+QuantizedModule with a `weight`): `QuantEmbedding [30522, 768]` (93.8 MB of alpha) and `QuantLayerNorm [768]`, whole
+`apply_adaround_to_layer` runs (quantization/adaround/adaround.py:27-136) at BERT-base's real shapes against results of
+the imported reference (tests/golden/make_golden_adaround_layers.py -> adaround_layers.npz).  The parameters are
+regenerated from numpy's legacy Mersenne-Twister stream on both sides (the table itself is too big for a fixture).
+
+Same body on the CPU (oracle-backed backend double: host logic, ATen arithmetic == the reference's) and on the GPU (HIP
+kernels: fused forward / fused backward + regulariser + Adam step through the generic autograd branch)."""
+import copy
+import json
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from tests.conftest import load_golden
+
+
+@pytest.fixture(scope='module')
+def layers_fx():
+    z, _ = load_golden('adaround_layers')
+    return z, json.loads(str(z['meta']))
+
+
+def _weights(meta):
+    rs = np.random.RandomState(meta['w_seed'])
+    V, D, O = meta['vocab'], meta['dim'], meta['out_features']
+    emb = (rs.standard_normal((V, D)) * 0.02).astype(np.float32)
+    ln_w = (1.0 + 0.25 * rs.standard_normal(D)).astype(np.float32)
+    ln_b = (0.05 * rs.standard_normal(D)).astype(np.float32)
+    fc_w = (rs.standard_normal((O, D)) * 0.02).astype(np.float32)
+    return emb, ln_w, ln_b, fc_w, np.zeros(O, np.float32)
+
+
+def _model(meta, ids, device):
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.quantization_manager import QuantizationManager
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+
+    V, D, O = meta['vocab'], meta['dim'], meta['out_features']
+    emb, ln, fc = nn.Embedding(V, D), nn.LayerNorm(D, eps=1e-12), nn.Linear(D, O)
+    with torch.no_grad():
+        for p, w in zip((emb.weight, ln.weight, ln.bias, fc.weight, fc.bias), _weights(meta)):
+            p.copy_(torch.from_numpy(w))
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=4, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+
+    class QEmbNet(QuantizedModel):
+        def __init__(self):
+            super().__init__()
+            self.emb = quantize_model(emb, **qp)
+            self.ln = quantize_model(ln, **qp)
+            self.fc = quantize_model(fc, **qp)
+
+        def forward(self, x):
+            return self.fc(self.ln(self.emb(x)))
+
+    m = QEmbNet().to(device)
+    m.eval()
+    m.set_quant_state(weight_quant=True, act_quant=False)
+    with torch.no_grad():
+        m(ids[:8])
+    for mod in m.modules():
+        if isinstance(mod, QuantizationManager) and mod.quantizer.is_initialized:
+            mod.fix_ranges()
+    return m
+
+
+def _run(z, meta, device, exact):
+    from quantization.adaround import apply_adaround_to_layer
+    from quantization.adaround.config import DEFAULT_ADAROUND_CONFIG
+    ids = torch.from_numpy(z['ids']).to(device)
+    for c in meta['cases']:
+        k, lname = c['k'], c['layer']
+        model = _model(meta, ids, device)
+        layer = getattr(model, lname)
+        cfg = copy.deepcopy(DEFAULT_ADAROUND_CONFIG)
+        cfg.iters, cfg.lr = c['iters'], c['lr']
+        model.full_precision()
+        layer.quantized_weights()
+        torch.manual_seed(c['seed'])                           # quirk q11: the batch indices come from the global RNG
+        res = apply_adaround_to_layer(model, layer, ids, batch_size=c['bs'], act_quant=False, adaround_config=cfg)
+        wq = layer.weight_quantizer.quantizer
+        assert np.array_equal(wq._delta.detach().cpu().numpy().reshape(-1), z[f'l{k}_delta'].reshape(-1)), lname
+        alpha = wq.alpha.detach()
+        assert alpha.shape == layer.weight.shape
+        with torch.no_grad():
+            idx = wq.to_integer_forward(layer.weight)
+        got = np.array([res.loss_soft_before, res.loss_hard_before, res.loss_soft_after, res.loss_hard_after])
+        ref = z[f'l{k}_losses']
+        # (soft loss before optimisation is round-off of an exact zero: h(alpha_0) == frac(w / s))
+        assert np.allclose(got[1:], ref[1:], rtol=1e-6 if exact else 2e-2), (lname, got, ref)
+        assert got[0] <= max(4 * ref[0], 1e-12), (lname, got[0], ref[0])
+        lr = c['lr']
+        if lname == 'emb':
+            rows = torch.from_numpy(z[f'l{k}_rows'])
+            a_rows, a_ref = alpha[rows.to(device)].cpu(), torch.from_numpy(z[f'l{k}_alpha_rows'])
+            n_up, ref_up = int((alpha >= 0).sum()), int(z[f'l{k}_ups'])
+            rowsum = idx.sum(1).to(torch.int64).cpu().numpy()
+            bad_rows = int((rowsum != z[f'l{k}_hard_rowsum']).sum())
+            if exact:
+                assert torch.allclose(a_rows, a_ref, rtol=2e-4, atol=2e-5), lname
+                assert n_up == ref_up and bad_rows == 0
+            else:
+                dev = (a_rows - a_ref).abs()
+                # untouched rows (second half of the sample) only see the regulariser: a deterministic trajectory
+                assert torch.allclose(a_rows[48:], a_ref[48:], rtol=1e-3, atol=2e-4), float(dev[48:].max())
+                assert float((dev <= 3 * lr).float().mean()) >= 0.95 and float(dev.max()) <= 12 * lr, (
+                    float((dev <= 3 * lr).float().mean()), float(dev.max()))
+                # round-ups: only entries whose alpha ends within round-off of 0 may differ, out of 23.4 M
+                assert abs(n_up - ref_up) <= 64 and bad_rows <= 64, (n_up, ref_up, bad_rows)
+        else:
+            a_ref = torch.from_numpy(z[f'l{k}_alpha'])
+            dev = (alpha.cpu() - a_ref).abs()
+            flips = int((idx.cpu() != torch.from_numpy(z[f'l{k}_hard_idx'])).sum())
+            if exact:
+                assert torch.allclose(alpha.cpu(), a_ref, rtol=2e-4, atol=2e-5), float(dev.max())
+                assert flips == 0
+            else:
+                assert float((dev <= 3 * lr).float().mean()) >= 0.95 and float(dev.max()) <= 12 * lr, (
+                    float((dev <= 3 * lr).float().mean()), float(dev.max()))
+                assert flips <= 8, flips
+
+
+def test_adaround_embedding_and_layernorm_cpu(layers_fx):
+    from quantization import _hip
+    from tests._oracle_backend import OracleBackend
+    z, meta = layers_fx
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        torch.set_num_threads(8)
+        _run(z, meta, 'cpu', exact=True)
+    finally:
+        _hip.set_backend(prev)
+        torch.set_num_threads(1)
+
+
+@pytest.mark.gpu
+def test_adaround_embedding_and_layernorm_gpu(layers_fx):
+    z, meta = layers_fx
+    _run(z, meta, 'cuda', exact=False)

@@ -21,6 +21,50 @@ constexpr float kStretch = (float)(1.1 - (-0.1));   // zeta - gamma evaluated in
 
 __device__ __forceinline__ float sigmoidf_(float a) { return 1.0f / (1.0f + expf(-a)); }
 
+// ---- hardware-rate transcendentals for the per-iteration kernels (K10 soft forward, K11 fused step) ----------------
+// The optimisation loop's relaxation h(alpha), its derivative, the regulariser gradient and the Adam update are
+// compared with the reference at a tolerance (they run through torch's vectorised CPU exp / pow there, which no GPU
+// kernel matches bit for bit anyway); what IS contractual -- floor(w / s), the clamp, the hard rounding [alpha >= 0] --
+// stays exact below.  v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32 are 1-ulp, quarter-rate instructions: a sigmoid is
+// ~10 issue slots instead of ~26 (expf + IEEE division), |2h-1|^(beta-1) ~10 instead of ~60 (powf), the Adam quotient
+// ~11 instead of ~30 (IEEE sqrt + two IEEE divisions).  K11 drops from ~390 to ~80 issue slots per element and becomes
+// what SURVEY 8(d) says it is: a 28 B/element streaming kernel.
+constexpr float kLog2e = 1.44269504088896340736f;
+__device__ __forceinline__ float fast_sigmoid(float a) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * -kLog2e));
+}
+// u^e for u >= 0 (u = 0 -> 0 for e > 0; callers handle e == 0)
+__device__ __forceinline__ float fast_pow(float u, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(u)); }
+
+// h(alpha) and dh/dalpha with the fast sigmoid; inv_temp = 1 / temp
+__device__ __forceinline__ float ada_h_fast(float a, int mode, float inv_temp, float& dh) {
+  if (mode == TQ_ADA_HARD_SIGMOID) {
+    const float s = fast_sigmoid(a);
+    const float u = s * kStretch + kGamma;
+    dh = (u >= 0.0f && u <= 1.0f) ? kStretch * (s * (1.0f - s)) : 0.0f;
+    return clamp_nanprop(u, 0.0f, 1.0f);
+  }
+  if (mode == TQ_ADA_SIGMOID) {
+    const float s = fast_sigmoid(a);
+    dh = s * (1.0f - s);
+    return s;
+  }
+  const float s = fast_sigmoid(a * inv_temp);
+  dh = (s * (1.0f - s)) * inv_temp;
+  return s;
+}
+
+// floor(RN(w / scale)) without the IEEE division: Markstein's correctly rounded quotient from the correctly rounded
+// reciprocal r = RN(1 / scale) (tq_device.h, identity (1); exact-rational proof in tests/test_exact_quotient.py), with
+// the true division for the operands the identity does not cover (huge / non-finite quotients, scales outside
+// [2^-100, 2^100]: rcp = NaN makes the comparison fail).  Bit-identical to floorf(w / scale) for every input.
+__device__ __forceinline__ float floor_quot(float w, float scale, float rcp) {
+  const float q0 = w * rcp;
+  float q1 = __builtin_fmaf(__builtin_fmaf(-q0, scale, w), rcp, q0);
+  if (!(fabsf(q0) < 4194304.0f)) q1 = w / scale;
+  return floorf(q1);
+}
+
 // h(alpha) and dh/dalpha
 __device__ __forceinline__ float ada_h(float a, int mode, float temp, float* dh) {
   if (mode == TQ_ADA_SIGMOID) {
@@ -54,15 +98,18 @@ __global__ __launch_bounds__(kBlock) void ada_fwd_k(const float* __restrict__ w,
                                                     int soft, float temp) {
   typedef typename AdaVec<V>::type vec;
   const uint64_t nv = n / V;
+  const float inv_temp = mode == TQ_ADA_SIGMOID_TEMP ? 1.0f / temp : 1.0f;
   for (uint64_t iv = (uint64_t)blockIdx.x * kBlock + threadIdx.x; iv < nv; iv += (uint64_t)gridDim.x * kBlock) {
     const QP p = make_qp(q, par_index(q, iv * V));
+    const float rcp = guarded_rcp(p.scale);
     const vec wv = reinterpret_cast<const vec*>(w)[iv], av = reinterpret_cast<const vec*>(alpha)[iv];
     vec o;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const float fl = floorf(wv[j] / p.scale);
+      const float fl = floor_quot(wv[j], p.scale, rcp);
       const float a = av[j];
-      const float r = soft ? ada_h(a, mode, temp, nullptr) : (a >= 0.0f ? 1.0f : 0.0f);
+      float dh_unused;
+      const float r = soft ? ada_h_fast(a, mode, inv_temp, dh_unused) : (a >= 0.0f ? 1.0f : 0.0f);
       float xi = fl + r;
       if (!q.symmetric) xi += p.zp;
       xi = clamp_nanprop(xi, p.lo, p.hi);
@@ -96,8 +143,8 @@ __global__ __launch_bounds__(kBlock) void ada_bwd_k(const float* __restrict__ w,
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     const QP p = make_qp(q, par_index(q, i));
     float dh;
-    const float h = ada_h(alpha[i], mode, temp, &dh);
-    float xi = floorf(w[i] / p.scale) + h;
+    const float h = ada_h_fast(alpha[i], mode, mode == TQ_ADA_SIGMOID_TEMP ? 1.0f / temp : 1.0f, dh);
+    float xi = floor_quot(w[i], p.scale, guarded_rcp(p.scale)) + h;
     if (!q.symmetric) xi += p.zp;
     const bool in = (xi >= p.lo) && (xi <= p.hi);
     g_alpha[i] = in ? (g_wq[i] * p.scale) * dh : 0.0f;
@@ -116,8 +163,15 @@ __global__ __launch_bounds__(kBlock) void ada_bwd_adam_k(const float* __restrict
     reg_w = sched[0]; beta = sched[1]; bc1 = sched[2]; bc2_sqrt = sched[3];
   }
   const uint64_t nv = n / V;
+  // uniform scalars of the step, hoisted: every division below is on SGPR values, once per wave
+  const float inv_temp = mode == TQ_ADA_SIGMOID_TEMP ? 1.0f / temp : 1.0f;
+  const float one_m_b1 = 1.0f - b1, one_m_b2 = 1.0f - b2;
+  const float inv_bc2_sqrt = 1.0f / bc2_sqrt, step_size = lr / bc1;
+  const float reg_k = -2.0f * reg_w * beta, bm1 = beta - 1.0f;
+  const bool reg_on = reg_w != 0.0f;
   for (uint64_t iv = (uint64_t)blockIdx.x * kBlock + threadIdx.x; iv < nv; iv += (uint64_t)gridDim.x * kBlock) {
     const QP p = make_qp(q, par_index(q, iv * V));
+    const float rcp = guarded_rcp(p.scale);
     const vec wv = reinterpret_cast<const vec*>(w)[iv], gv = reinterpret_cast<const vec*>(g_wq)[iv];
     const vec av = reinterpret_cast<const vec*>(alpha)[iv], mv = reinterpret_cast<const vec*>(m)[iv];
     const vec vv = reinterpret_cast<const vec*>(v)[iv];
@@ -126,26 +180,26 @@ __global__ __launch_bounds__(kBlock) void ada_bwd_adam_k(const float* __restrict
     for (int j = 0; j < V; ++j) {
       const float a = av[j];
       float dh;
-      const float h = ada_h(a, mode, temp, &dh);
-      float xi = floorf(wv[j] / p.scale) + h;
+      const float h = ada_h_fast(a, mode, inv_temp, dh);
+      float xi = floor_quot(wv[j], p.scale, rcp) + h;
       if (!q.symmetric) xi += p.zp;
       const bool in = (xi >= p.lo) && (xi <= p.hi);
       // d loss / d alpha through w_q = s * (x_int - zp)
       float g = in ? (gv[j] * p.scale) * dh : 0.0f;
-      if (reg_w != 0.0f) {
-        // d/dalpha [ reg_w * (1 - (2|h - 0.5|)^beta) ]
+      if (reg_on) {
+        // d/dalpha [ reg_w * (1 - (2|h - 0.5|)^beta) ] = -2 reg_w beta u^(beta-1) sgn(h - 0.5) dh
         const float c = h - 0.5f;
         const float u = fabsf(c) * 2.0f;
-        const float sgn = c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f);
-        const float dpow = (u == 0.0f && beta >= 1.0f) ? 0.0f : beta * powf(u, beta - 1.0f);
-        g += -reg_w * dpow * 2.0f * sgn * dh;
+        float pw = fast_pow(u, bm1);                                   // u = 0: log2 = -inf -> 0 for beta > 1
+        if (u == 0.0f) pw = 0.0f;                                      // (beta == 1: 0 * -inf; the derivative at the kink is 0)
+        g = __builtin_fmaf(reg_k * __builtin_copysignf(pw, c), dh, g);
       }
       go[j] = g;
       // torch.optim.Adam (no weight decay / amsgrad)
-      const float mi = mv[j] + (g - mv[j]) * (1.0f - b1);      // exp_avg.lerp_(grad, 1 - beta1)
-      const float vi = vv[j] * b2 + (1.0f - b2) * g * g;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-      const float denom = sqrtf(vi) / bc2_sqrt + adam_eps;
-      ao[j] = a - (lr / bc1) * (mi / denom);
+      const float mi = __builtin_fmaf(g - mv[j], one_m_b1, mv[j]);     // exp_avg.lerp_(grad, 1 - beta1)
+      const float vi = __builtin_fmaf(one_m_b2 * g, g, vv[j] * b2);    // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+      const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(vi), inv_bc2_sqrt, adam_eps);
+      ao[j] = __builtin_fmaf(-step_size * mi, __builtin_amdgcn_rcpf(denom), a);
       mo[j] = mi;
       vo[j] = vi;
     }
