@@ -176,19 +176,22 @@ def fam_i8():
 
 
 def fam_ada():
-    n_out, n_in = 3072, 768
-    w = torch.randn(n_out, n_in, device=dev) * 0.05
-    alpha = torch.randn(n_out, n_in, device=dev)
-    g = torch.randn(n_out, n_in, device=dev)
-    m, v = torch.zeros_like(w), torch.zeros_like(w)
-    qargs = (torch.tensor(0.01, device=dev), None, torch.tensor(True, device=dev), 4, True, False, 1e-8, 1, 1)
-    n = w.numel()
-    run('ada', 'K10 adaround soft forward [3072,768]', 'ada_fwd_k',
-        lambda: be.adaround_fwd(w, alpha, qargs, _hip.ADA_HARD_SIGMOID, True, None), 12 * n, 'hbm',
-        note='9.4 MB tensors: L2/MALL resident')
-    run('ada', 'K11 backward+regulariser+Adam [3072,768]', 'ada_bwd_adam_k',
-        lambda: be.adaround_bwd_adam(w, g, alpha, m, v, qargs, _hip.ADA_HARD_SIGMOID, None, 0.01, 10.0, 1e-3, 0.9,
-                                     0.999, 1e-8, 5), 28 * n, 'hbm', note='9.4 MB tensors: L2/MALL resident')
+    # [3072,768] / [768,768]: BERT-base Linear weights (28 B/elem x 2.36 M = 66 MB of streams: L2/MALL resident);
+    # [30522,768]: the word-embedding table, 23.4 M elements = 656 MB of streams per step: genuinely HBM-bound
+    for n_out, n_in in ((3072, 768), (768, 768), (30522, 768)):
+        w = torch.randn(n_out, n_in, device=dev) * 0.05
+        alpha = torch.randn(n_out, n_in, device=dev)
+        g = torch.randn(n_out, n_in, device=dev)
+        m, v = torch.zeros_like(w), torch.zeros_like(w)
+        qargs = (torch.tensor(0.01, device=dev), None, torch.tensor(True, device=dev), 4, True, False, 1e-8, 1, 1)
+        n = w.numel()
+        note = 'streams exceed the 256 MB MALL: HBM-bound' if n > (1 << 23) else 'tensors L2/MALL resident'
+        run('ada', f'K10 adaround soft forward [{n_out},{n_in}]', 'ada_fwd_k',
+            lambda: be.adaround_fwd(w, alpha, qargs, _hip.ADA_HARD_SIGMOID, True, None), 12 * n, 'hbm', note=note)
+        run('ada', f'K11 backward+regulariser+Adam [{n_out},{n_in}]', 'ada_bwd_adam_k',
+            lambda: be.adaround_bwd_adam(w, g, alpha, m, v, qargs, _hip.ADA_HARD_SIGMOID, None, 0.01, 10.0, 1e-3, 0.9,
+                                         0.999, 1e-8, 5), 28 * n, 'hbm', note=note)
+        del w, alpha, g, m, v
     a, b = torch.randn(64, 128, 3072, device=dev), torch.randn(64, 128, 3072, device=dev)
     run('ada', 'K13 reconstruction loss [64,128,3072]', 'sqdiff', lambda: be.recon_loss(a, b), 8 * a.numel(), 'hbm')
 

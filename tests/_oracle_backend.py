@@ -70,7 +70,76 @@ class OracleBackend:
             v = u * ln_weight.float() + ln_bias.float()
         else:
             v = torch.nn.functional.layer_norm(u, (u.shape[-1],), ln_weight.float(), ln_bias.float(), ln_eps)
+        if want_idx:
+            idx, y = self._quant(v, *q_out, 1, 1)
+            return y.to(dense_out.dtype), (idx - 128).to(torch.int8)
         return q(v, q_out).to(dense_out.dtype)
+
+    # ---- integer evaluation of fixed-range layers (oracle/tq_int_oracle.c): the CPU twin of tq_linear_i8_fwd & co ----
+    FFN_SHAPES = {(128, 512, 128)}
+
+    @staticmethod
+    def _q7(q):
+        """7-tuple with scalar tensors -> python scalars (None stays None)"""
+        if q is None:
+            return None
+        d, z, sg, nb, sym, logd, eps = q
+        return (float(d), None if z is None else float(z), None if sg is None else bool(sg), nb, sym, logd, eps)
+
+    def fake_quant_int8(self, x, delta, zero_float, n_bits, eps):
+        idx, y = self._quant(x, delta, zero_float, None, n_bits, False, False, eps, 1, 1)
+        return y.to(x.dtype), (idx - 128).to(torch.int8)
+
+    def quantize_to_int8(self, x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner,
+                         minus_128):
+        idx, _ = self._quant(x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner)
+        return (idx - 128 if minus_128 else idx).to(torch.int8)
+
+    def rowsum_i8(self, w_idx):
+        return w_idx.to(torch.int32).sum(1, dtype=torch.int32)
+
+    def linear_i8(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta, w_eps, activation, q_out, out_dtype, want_idx=False):
+        from oracle import int_oracle
+        y, yi = int_oracle.linear_i8(x_idx, w_idx, bias, tuple(float(v) for v in x_q), w_delta, w_eps, activation,
+                                     self._q7(q_out))
+        return (y.to(out_dtype), yi) if want_idx else y.to(out_dtype)
+
+    def linear_i8_nonorm(self, x_idx, w_idx, w_rowsum, bias, residual, nn_w, nn_b, x_q, w_delta, w_eps, q_dense, q_sum,
+                         q_out, out_dtype, want_idx=False):
+        from oracle import int_oracle
+        y, yi = int_oracle.linear_i8(x_idx, w_idx, bias, tuple(float(v) for v in x_q), w_delta, w_eps, 0,
+                                     self._q7(q_dense), tail=1 if residual is None else 2, residual=residual,
+                                     nn_w=nn_w, nn_b=nn_b, q_t1=self._q7(q_sum), q_t2=self._q7(q_out))
+        return (y.to(out_dtype), yi) if want_idx else y.to(out_dtype)
+
+    def ffn_i8_nonorm(self, x_idx, x_q, w1_idx, w1_rowsum, bias1, w1_delta, w1_eps, q_mid, w2_idx, w2_rowsum, bias2, w2_delta,
+                      w2_eps, residual, nn_w, nn_b, q_dense, q_sum, q_out, out_dtype, want_idx=False):
+        from oracle import int_oracle
+        y, yi = int_oracle.ffn_i8(x_idx, tuple(float(v) for v in x_q), w1_idx, bias1, w1_delta, w1_eps, self._q7(q_mid),
+                                  w2_idx, bias2, w2_delta, w2_eps, residual, nn_w, nn_b, self._q7(q_dense),
+                                  self._q7(q_sum), self._q7(q_out))
+        return (y.to(out_dtype), yi) if want_idx else y.to(out_dtype)
+
+    def attention_i8(self, q_idx, k_idx, v_idx, num_heads, mask, denom, q_q, q_k, q_v, q_scores, q_probs, q_ctx,
+                     want_idx=False):
+        from oracle import int_oracle
+        ctx, ci = int_oracle.attention_i8(q_idx.contiguous(), k_idx.contiguous(), v_idx.contiguous(), num_heads, mask, denom,
+                                          *[self._q7(q) for q in (q_q, q_k, q_v, q_scores, q_probs, q_ctx)])
+        return (ctx, ci) if want_idx else ctx
+
+    def linear_i8_grouped(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta_rows, w_eps, activation, q_outs,
+                          want_y=False, want_idx=True, out_dtype=torch.float32):
+        from oracle import int_oracle
+        G, N = len(q_outs), w_idx.shape[0]
+        ys, yis = [], []
+        for g in range(G):
+            sl = slice(g * N // G, (g + 1) * N // G)
+            y, yi = int_oracle.linear_i8(x_idx, w_idx[sl], None if bias is None else bias[sl],
+                                         tuple(float(v) for v in x_q), w_delta_rows[sl], w_eps, activation,
+                                         self._q7(q_outs[g]))
+            ys.append(y)
+            yis.append(yi)
+        return (torch.cat(ys, -1).to(out_dtype) if want_y else None), (torch.cat(yis, -1) if want_idx else None)
 
     def scores_softmax_quant(self, scores, mask, rows_per_mask, denom, q_scores, q_probs):
         def q(v, a):

@@ -36,15 +36,17 @@ __device__ __forceinline__ float fast_sigmoid(float a) {
 // u^e for u >= 0 (u = 0 -> 0 for e > 0; callers handle e == 0)
 __device__ __forceinline__ float fast_pow(float u, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(u)); }
 
-// h(alpha) and dh/dalpha with the fast sigmoid; inv_temp = 1 / temp
-__device__ __forceinline__ float ada_h_fast(float a, int mode, float inv_temp, float& dh) {
-  if (mode == TQ_ADA_HARD_SIGMOID) {
+// h(alpha) and dh/dalpha with the fast sigmoid; inv_temp = 1 / temp.  MODE is a template parameter of the
+// per-iteration kernels: the element body is then branch-free and the V element chains of a thread interleave.
+template <int MODE>
+__device__ __forceinline__ float ada_h_fast(float a, float inv_temp, float& dh) {
+  if (MODE == TQ_ADA_HARD_SIGMOID) {
     const float s = fast_sigmoid(a);
     const float u = s * kStretch + kGamma;
     dh = (u >= 0.0f && u <= 1.0f) ? kStretch * (s * (1.0f - s)) : 0.0f;
     return clamp_nanprop(u, 0.0f, 1.0f);
   }
-  if (mode == TQ_ADA_SIGMOID) {
+  if (MODE == TQ_ADA_SIGMOID) {
     const float s = fast_sigmoid(a);
     dh = s * (1.0f - s);
     return s;
@@ -52,6 +54,11 @@ __device__ __forceinline__ float ada_h_fast(float a, int mode, float inv_temp, f
   const float s = fast_sigmoid(a * inv_temp);
   dh = (s * (1.0f - s)) * inv_temp;
   return s;
+}
+__device__ __forceinline__ float ada_h_fast(float a, int mode, float inv_temp, float& dh) {
+  if (mode == TQ_ADA_HARD_SIGMOID) return ada_h_fast<TQ_ADA_HARD_SIGMOID>(a, inv_temp, dh);
+  if (mode == TQ_ADA_SIGMOID) return ada_h_fast<TQ_ADA_SIGMOID>(a, inv_temp, dh);
+  return ada_h_fast<TQ_ADA_SIGMOID_TEMP>(a, inv_temp, dh);
 }
 
 // floor(RN(w / scale)) without the IEEE division: Markstein's correctly rounded quotient from the correctly rounded
@@ -63,6 +70,29 @@ __device__ __forceinline__ float floor_quot(float w, float scale, float rcp) {
   float q1 = __builtin_fmaf(__builtin_fmaf(-q0, scale, w), rcp, q0);
   if (!(fabsf(q0) < 4194304.0f)) q1 = w / scale;
   return floorf(q1);
+}
+// V quotients of one parameter: the Markstein chains side by side, ONE (practically never taken) branch per vector for
+// the operands outside the identity's domain instead of one per element
+template <int V, class VEC>
+__device__ __forceinline__ void floor_quot_n(const VEC& w, float scale, float rcp, float (&fl)[V]) {
+  float q0[V], q1[V];
+  bool odd = false;
+#pragma unroll
+  for (int j = 0; j < V; ++j) q0[j] = w[j] * rcp;
+#pragma unroll
+  for (int j = 0; j < V; ++j) q1[j] = __builtin_fmaf(-q0[j], scale, w[j]);
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    q1[j] = __builtin_fmaf(q1[j], rcp, q0[j]);
+    odd = odd || !(fabsf(q0[j]) < 4194304.0f);
+  }
+  if (__builtin_expect(odd, 0)) {
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      if (!(fabsf(q0[j]) < 4194304.0f)) q1[j] = w[j] / scale;
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) fl[j] = floorf(q1[j]);
 }
 
 // h(alpha) and dh/dalpha
@@ -92,27 +122,30 @@ __device__ __forceinline__ uint64_t par_index(const tq_quantizer& q, uint64_t i)
 template <int V>
 struct AdaVec { typedef float type __attribute__((ext_vector_type(V))); };
 
-template <int V>
+template <int V, int MODE, bool SOFT>
 __global__ __launch_bounds__(kBlock) void ada_fwd_k(const float* __restrict__ w, const float* __restrict__ alpha,
-                                                    float* __restrict__ out, uint64_t n, tq_quantizer q, int mode,
-                                                    int soft, float temp) {
+                                                    float* __restrict__ out, uint64_t n, tq_quantizer q, float temp) {
   typedef typename AdaVec<V>::type vec;
   const uint64_t nv = n / V;
-  const float inv_temp = mode == TQ_ADA_SIGMOID_TEMP ? 1.0f / temp : 1.0f;
+  const float inv_temp = MODE == TQ_ADA_SIGMOID_TEMP ? 1.0f / temp : 1.0f;
+  const bool one = q.n_params == 1;
+  QP p = make_qp(q, 0);                              // per-tensor grid: loop-invariant
+  float rcp = guarded_rcp(p.scale);
   for (uint64_t iv = (uint64_t)blockIdx.x * kBlock + threadIdx.x; iv < nv; iv += (uint64_t)gridDim.x * kBlock) {
-    const QP p = make_qp(q, par_index(q, iv * V));
-    const float rcp = guarded_rcp(p.scale);
+    if (!one) {
+      p = make_qp(q, par_index(q, iv * V));
+      rcp = guarded_rcp(p.scale);
+    }
     const vec wv = reinterpret_cast<const vec*>(w)[iv], av = reinterpret_cast<const vec*>(alpha)[iv];
+    float fl[V];
+    floor_quot_n<V>(wv, p.scale, rcp, fl);
     vec o;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const float fl = floor_quot(wv[j], p.scale, rcp);
       const float a = av[j];
       float dh_unused;
-      const float r = soft ? ada_h_fast(a, mode, inv_temp, dh_unused) : (a >= 0.0f ? 1.0f : 0.0f);
-      float xi = fl + r;
-      if (!q.symmetric) xi += p.zp;
-      xi = clamp_nanprop(xi, p.lo, p.hi);
+      const float r = SOFT ? ada_h_fast<MODE>(a, inv_temp, dh_unused) : (a >= 0.0f ? 1.0f : 0.0f);
+      const float xi = clamp_nanprop((fl[j] + r) + p.zp, p.lo, p.hi);      // zp = 0 on a symmetric grid
       o[j] = q_dequant(xi, p);
     }
     reinterpret_cast<vec*>(out)[iv] = o;
@@ -151,11 +184,11 @@ __global__ __launch_bounds__(kBlock) void ada_bwd_k(const float* __restrict__ w,
   }
 }
 
-template <int V>
+template <int V, int MODE>
 __global__ __launch_bounds__(kBlock) void ada_bwd_adam_k(const float* __restrict__ w, const float* __restrict__ g_wq,
                                                          float* __restrict__ alpha, float* __restrict__ m,
                                                          float* __restrict__ v, float* __restrict__ g_out, uint64_t n,
-                                                         tq_quantizer q, int mode, float temp, float reg_w, float beta,
+                                                         tq_quantizer q, float temp, float reg_w, float beta,
                                                          float lr, float b1, float b2, float adam_eps, float bc1,
                                                          float bc2_sqrt, const float* __restrict__ sched) {
   typedef typename AdaVec<V>::type vec;
@@ -164,36 +197,41 @@ __global__ __launch_bounds__(kBlock) void ada_bwd_adam_k(const float* __restrict
   }
   const uint64_t nv = n / V;
   // uniform scalars of the step, hoisted: every division below is on SGPR values, once per wave
-  const float inv_temp = mode == TQ_ADA_SIGMOID_TEMP ? 1.0f / temp : 1.0f;
+  const float inv_temp = MODE == TQ_ADA_SIGMOID_TEMP ? 1.0f / temp : 1.0f;
   const float one_m_b1 = 1.0f - b1, one_m_b2 = 1.0f - b2;
   const float inv_bc2_sqrt = 1.0f / bc2_sqrt, step_size = lr / bc1;
-  const float reg_k = -2.0f * reg_w * beta, bm1 = beta - 1.0f;
   const bool reg_on = reg_w != 0.0f;
+  const float reg_k = reg_on ? -2.0f * reg_w * beta : 0.0f, bm1 = reg_on ? beta - 1.0f : 1.0f;
+  const bool one = q.n_params == 1;
+  QP p = make_qp(q, 0);                              // per-tensor grid: loop-invariant
+  float rcp = guarded_rcp(p.scale);
   for (uint64_t iv = (uint64_t)blockIdx.x * kBlock + threadIdx.x; iv < nv; iv += (uint64_t)gridDim.x * kBlock) {
-    const QP p = make_qp(q, par_index(q, iv * V));
-    const float rcp = guarded_rcp(p.scale);
+    if (!one) {
+      p = make_qp(q, par_index(q, iv * V));
+      rcp = guarded_rcp(p.scale);
+    }
     const vec wv = reinterpret_cast<const vec*>(w)[iv], gv = reinterpret_cast<const vec*>(g_wq)[iv];
     const vec av = reinterpret_cast<const vec*>(alpha)[iv], mv = reinterpret_cast<const vec*>(m)[iv];
     const vec vv = reinterpret_cast<const vec*>(v)[iv];
+    float fl[V];
+    floor_quot_n<V>(wv, p.scale, rcp, fl);
     vec ao, mo, vo, go;
+    // branch-free element body: the V chains (7 quarter-rate transcendentals each) interleave
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const float a = av[j];
       float dh;
-      const float h = ada_h_fast(a, mode, inv_temp, dh);
-      float xi = floor_quot(wv[j], p.scale, rcp) + h;
-      if (!q.symmetric) xi += p.zp;
+      const float h = ada_h_fast<MODE>(a, inv_temp, dh);
+      const float xi = (fl[j] + h) + p.zp;                             // zp = 0 on a symmetric grid
       const bool in = (xi >= p.lo) && (xi <= p.hi);
       // d loss / d alpha through w_q = s * (x_int - zp)
       float g = in ? (gv[j] * p.scale) * dh : 0.0f;
-      if (reg_on) {
-        // d/dalpha [ reg_w * (1 - (2|h - 0.5|)^beta) ] = -2 reg_w beta u^(beta-1) sgn(h - 0.5) dh
-        const float c = h - 0.5f;
-        const float u = fabsf(c) * 2.0f;
-        float pw = fast_pow(u, bm1);                                   // u = 0: log2 = -inf -> 0 for beta > 1
-        if (u == 0.0f) pw = 0.0f;                                      // (beta == 1: 0 * -inf; the derivative at the kink is 0)
-        g = __builtin_fmaf(reg_k * __builtin_copysignf(pw, c), dh, g);
-      }
+      // d/dalpha [ reg_w * (1 - (2|h - 0.5|)^beta) ] = -2 reg_w beta u^(beta-1) sgn(h - 0.5) dh     (reg_k = 0 when off)
+      const float c = h - 0.5f;
+      const float u = fabsf(c) * 2.0f;
+      float pw = fast_pow(u, bm1);                                     // u = 0: log2 = -inf -> 0 for beta > 1
+      pw = (u == 0.0f) ? 0.0f : pw;                                    // (beta == 1: 0 * -inf; the derivative at the kink is 0)
+      g = __builtin_fmaf(reg_k * __builtin_copysignf(pw, c), dh, g);
       go[j] = g;
       // torch.optim.Adam (no weight decay / amsgrad)
       const float mi = __builtin_fmaf(g - mv[j], one_m_b1, mv[j]);     // exp_avg.lerp_(grad, 1 - beta1)
@@ -284,18 +322,32 @@ static int check_mode(int mode, float temp, const char* who) {
 
 using namespace tq;
 
+// dispatch of the templated per-iteration kernels over (vector width, relaxation)
+#define TQ_ADA_MODES(LAUNCH)                                               \
+  switch (mode) {                                                          \
+    case TQ_ADA_SIGMOID: LAUNCH(TQ_ADA_SIGMOID); break;                    \
+    case TQ_ADA_HARD_SIGMOID: LAUNCH(TQ_ADA_HARD_SIGMOID); break;          \
+    default: LAUNCH(TQ_ADA_SIGMOID_TEMP); break;                           \
+  }
+
 extern "C" int tq_adaround_fwd(const float* w, const float* alpha, float* w_q, uint64_t n, const tq_quantizer* q,
                                int mode, int soft, float temperature, tq_stream_t stream) {
   TQ_REQUIRE(w && alpha && w_q, "tq_adaround_fwd: NULL pointer");
   if (int e = check_quantizer(q, n, "tq_adaround_fwd")) return e;
   if (int e = check_mode(mode, temperature, "tq_adaround_fwd")) return e;
   if (n == 0) return TQ_OK;
-  if (ada_vec4(n, q, {w, alpha, w_q}))
-    hipLaunchKernelGGL(ada_fwd_k<4>, dim3(ew_grid(n / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, alpha, w_q, n,
-                       *q, mode, soft, temperature);
-  else
-    hipLaunchKernelGGL(ada_fwd_k<1>, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, alpha, w_q, n, *q,
-                       mode, soft, temperature);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool v4 = ada_vec4(n, q, {w, alpha, w_q});
+  const unsigned grid = ew_grid(v4 ? n / 4 : n);
+#define TQ_ADA_FWD(M)                                                                                                  \
+  do {                                                                                                                 \
+    if (v4 && soft) hipLaunchKernelGGL((ada_fwd_k<4, M, true>), dim3(grid), dim3(kBlock), 0, st, w, alpha, w_q, n, *q, temperature);       \
+    else if (v4) hipLaunchKernelGGL((ada_fwd_k<4, TQ_ADA_SIGMOID, false>), dim3(grid), dim3(kBlock), 0, st, w, alpha, w_q, n, *q, temperature); \
+    else if (soft) hipLaunchKernelGGL((ada_fwd_k<1, M, true>), dim3(grid), dim3(kBlock), 0, st, w, alpha, w_q, n, *q, temperature);        \
+    else hipLaunchKernelGGL((ada_fwd_k<1, TQ_ADA_SIGMOID, false>), dim3(grid), dim3(kBlock), 0, st, w, alpha, w_q, n, *q, temperature);    \
+  } while (0)
+  TQ_ADA_MODES(TQ_ADA_FWD)
+#undef TQ_ADA_FWD
   return check_launch("ada_fwd_k");
 }
 
@@ -321,6 +373,22 @@ extern "C" int tq_adaround_bwd(const float* w, const float* alpha, const float* 
   return check_launch("ada_bwd_k");
 }
 
+static void launch_bwd_adam(bool v4, int mode, hipStream_t st, const float* w, const float* grad_wq, float* alpha,
+                            float* exp_avg, float* exp_avg_sq, float* g_out, uint64_t n, const tq_quantizer* q, float temperature,
+                            float reg_weight, float beta, float lr, float b1, float b2, float adam_eps, float bc1, float bc2_sqrt,
+                            const float* sched) {
+  const unsigned grid = ew_grid(v4 ? n / 4 : n);
+#define TQ_ADA_STEP(M)                                                                                                     \
+  do {                                                                                                                     \
+    if (v4) hipLaunchKernelGGL((ada_bwd_adam_k<4, M>), dim3(grid), dim3(kBlock), 0, st, w, grad_wq, alpha, exp_avg, exp_avg_sq, g_out, n, \
+                               *q, temperature, reg_weight, beta, lr, b1, b2, adam_eps, bc1, bc2_sqrt, sched);            \
+    else hipLaunchKernelGGL((ada_bwd_adam_k<1, M>), dim3(grid), dim3(kBlock), 0, st, w, grad_wq, alpha, exp_avg, exp_avg_sq, g_out, n,   \
+                            *q, temperature, reg_weight, beta, lr, b1, b2, adam_eps, bc1, bc2_sqrt, sched);               \
+  } while (0)
+  TQ_ADA_MODES(TQ_ADA_STEP)
+#undef TQ_ADA_STEP
+}
+
 extern "C" int tq_adaround_bwd_adam(const float* w, const float* grad_wq, float* alpha, float* exp_avg,
                                     float* exp_avg_sq, float* grad_alpha_out, uint64_t n, const tq_quantizer* q,
                                     int mode, float temperature, float reg_weight, float beta, float lr,
@@ -333,14 +401,9 @@ extern "C" int tq_adaround_bwd_adam(const float* w, const float* grad_wq, float*
   // bias corrections in double like python, narrowed once (torch computes them as python floats)
   const double bc1 = 1.0 - pow((double)adam_b1, (double)step);
   const double bc2 = 1.0 - pow((double)adam_b2, (double)step);
-  if (ada_vec4(n, q, {w, grad_wq, alpha, exp_avg, exp_avg_sq, grad_alpha_out}))
-    hipLaunchKernelGGL(ada_bwd_adam_k<4>, dim3(ew_grid(n / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq,
-                       alpha, exp_avg, exp_avg_sq, grad_alpha_out, n, *q, mode, temperature, reg_weight, beta, lr, adam_b1,
-                       adam_b2, adam_eps, (float)bc1, (float)sqrt(bc2), (const float*)nullptr);
-  else
-    hipLaunchKernelGGL(ada_bwd_adam_k<1>, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq, alpha,
-                       exp_avg, exp_avg_sq, grad_alpha_out, n, *q, mode, temperature, reg_weight, beta, lr, adam_b1,
-                       adam_b2, adam_eps, (float)bc1, (float)sqrt(bc2), (const float*)nullptr);
+  launch_bwd_adam(ada_vec4(n, q, {w, grad_wq, alpha, exp_avg, exp_avg_sq, grad_alpha_out}), mode,
+                  static_cast<hipStream_t>(stream), w, grad_wq, alpha, exp_avg, exp_avg_sq, grad_alpha_out, n, q, temperature,
+                  reg_weight, beta, lr, adam_b1, adam_b2, adam_eps, (float)bc1, (float)sqrt(bc2), nullptr);
   return check_launch("ada_bwd_adam_k");
 }
 
@@ -355,14 +418,9 @@ extern "C" int tq_adaround_bwd_adam_sched(const float* w, const float* grad_wq, 
   if (int e = check_quantizer(q, n, "tq_adaround_bwd_adam_sched")) return e;
   if (int e = check_mode(mode, temperature, "tq_adaround_bwd_adam_sched")) return e;
   if (n == 0) return TQ_OK;
-  if (ada_vec4(n, q, {w, grad_wq, alpha, exp_avg, exp_avg_sq}))
-    hipLaunchKernelGGL(ada_bwd_adam_k<4>, dim3(ew_grid(n / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq,
-                       alpha, exp_avg, exp_avg_sq, (float*)nullptr, n, *q, mode, temperature, 0.0f, 0.0f, lr, adam_b1, adam_b2,
-                       adam_eps, 1.0f, 1.0f, sched);
-  else
-    hipLaunchKernelGGL(ada_bwd_adam_k<1>, dim3(ew_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w, grad_wq, alpha,
-                       exp_avg, exp_avg_sq, (float*)nullptr, n, *q, mode, temperature, 0.0f, 0.0f, lr, adam_b1, adam_b2, adam_eps,
-                       1.0f, 1.0f, sched);
+  launch_bwd_adam(ada_vec4(n, q, {w, grad_wq, alpha, exp_avg, exp_avg_sq}), mode, static_cast<hipStream_t>(stream), w, grad_wq,
+                  alpha, exp_avg, exp_avg_sq, nullptr, n, q, temperature, 0.0f, 0.0f, lr, adam_b1, adam_b2, adam_eps, 1.0f, 1.0f,
+                  sched);
   return check_launch("ada_bwd_adam_k");
 }
 

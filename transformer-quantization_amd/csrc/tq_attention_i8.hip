@@ -253,17 +253,26 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     if (SPLIT) mx = fmaxf(mx, pair_exchange(s_red[0], mx, wave, kh, r16, g));   // (the barrier inside also publishes V^T)
-    float sum = 0.f;
+    // The denominator's summation order is part of the contract (oracle/tq_int_oracle.c restates it): per key half,
+    // a lane group adds its exponentials sequentially (tile-major), groups combine as (s0 + s1) + (s2 + s3), the two
+    // halves are added last -- the same tree whether one wave owns the whole row or two waves own a half each.
+    float sum = 0.f, sum_hi = 0.f;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-      x[i].x = expf(x[i].x - mx);
-      x[i].y = expf(x[i].y - mx);
-      sum += x[i].x;
-      sum += x[i].y;
+      x[i].x = exp_neg_ieee(x[i].x - mx);
+      x[i].y = exp_neg_ieee(x[i].y - mx);
+      if (SPLIT || i < P / 2) { sum += x[i].x; sum += x[i].y; }
+      else { sum_hi += x[i].x; sum_hi += x[i].y; }
     }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-    if (SPLIT) sum += pair_exchange(s_red[1], sum, wave, kh, r16, g);
+    if (SPLIT) {
+      sum += pair_exchange(s_red[1], sum, wave, kh, r16, g);
+    } else {
+      sum_hi += __shfl_xor(sum_hi, 16);
+      sum_hi += __shfl_xor(sum_hi, 32);
+      sum += sum_hi;
+    }
     bad_row = sum != sum;
     const float rsv = 1.0f / sum;                    // RN(e / sum), 1 <= sum <= T
     quot2_n<P>(x, f32x2{rsv, rsv}, f32x2{-sum, -sum});
@@ -308,14 +317,24 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     if (SPLIT) mx = fmaxf(mx, pair_exchange(s_red[0], mx, wave, kh, r16, g));   // (the barrier inside also publishes V^T)
-    float sum = 0.f;
+    float sum = 0.f, sum_hi = 0.f;                     // same summation tree as the branch-free form above
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { sc[t][r] = expf(sc[t][r] - mx); sum += sc[t][r]; }
+      for (int r = 0; r < 4; ++r) {
+        sc[t][r] = exp_neg_ieee(sc[t][r] - mx);
+        if (SPLIT || t < NT / 2) sum += sc[t][r];
+        else sum_hi += sc[t][r];
+      }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-    if (SPLIT) sum += pair_exchange(s_red[1], sum, wave, kh, r16, g);
+    if (SPLIT) {
+      sum += pair_exchange(s_red[1], sum, wave, kh, r16, g);
+    } else {
+      sum_hi += __shfl_xor(sum_hi, 16);
+      sum_hi += __shfl_xor(sum_hi, 32);
+      sum += sum_hi;
+    }
     bad_row = sum != sum;
     const float inv_sum = (sum >= 7.888609052210118e-31f && sum <= 1.2676506002282294e30f) ? 1.0f / sum : __builtin_nanf("");
 

@@ -187,6 +187,30 @@ __device__ __forceinline__ float q_dequant(float xi, const QP& p) {
   return p.scale * (xi - p.zp);
 }
 
+// ------------------------------------------------------------------ exp(x), x <= 0, from IEEE operations only
+// The softmax of the integer attention core is specified by THIS function (and its plain-C twin tq_exp_neg in
+// oracle/tq_int_oracle.c) rather than by libm's expf, whose v_exp_f32 core no CPU reproduces: Cephes-style range
+// reduction x = k ln2 + r (two fma with a split ln2), degree-5 polynomial for e^r - 1 - r, exact scaling by 2^k.
+// mul / rndne / fma / add / ldexp are all correctly rounded, so kernel and oracle agree bit for bit and the whole
+// attention core (exact integer contractions around it) is testable at zero tolerance.  x < -86 (incl. -inf) -> 0:
+// keeps 2^k y in the normal range; NaN -> NaN.  < 2 ulp on [-86, 0]; ~16 issue slots (libm's expf: ~14).
+__device__ __forceinline__ float exp_neg_ieee(float x) {
+  const float k = rintf(x * 1.44269504088896341f);
+  float r = __builtin_fmaf(k, -0.693359375f, x);
+  r = __builtin_fmaf(k, 2.12194440e-4f, r);
+  const float z = r * r;
+  float y = __builtin_fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+  y = __builtin_fmaf(y, r, 8.3334519073e-3f);
+  y = __builtin_fmaf(y, r, 4.1665795894e-2f);
+  y = __builtin_fmaf(y, r, 1.6666665459e-1f);
+  y = __builtin_fmaf(y, r, 5.0000001201e-1f);
+  y = __builtin_fmaf(y, z, r);
+  y = y + 1.0f;
+  y = ldexpf(y, (int)k);
+  y = x < -86.0f ? 0.0f : y;
+  return x != x ? x : y;
+}
+
 // ------------------------------------------------------------------ storage <-> fp32
 // NB: always bit-cast a by-value scalar.  clang (ROCm 7.2) mis-compiles
 // __builtin_bit_cast(T, vec[i]) on an ext_vector element lvalue: every i reads element 0.

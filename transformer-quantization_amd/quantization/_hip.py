@@ -712,13 +712,13 @@ class HipBackend:
         dev = x.device
         st = _stream()
         if out is None:
-            cur = torch.empty(2, n_params, dtype=torch.float32, device=dev)
-            par = torch.empty(1 if symmetric else 2, n_params, dtype=torch.float32, device=dev)
             signed = torch.empty((), dtype=torch.bool, device=dev) if symmetric else None
             if n_params == 1:
-                out = (cur[0, 0], cur[1, 0], par[0, 0], None if symmetric else par[1, 0], signed)
+                # cur_min, cur_max, delta, zero_float: one allocation, one op for the four 0-D views
+                b0, b1, b2, b3 = torch.empty(4, dtype=torch.float32, device=dev).unbind(0)
             else:
-                out = (cur[0], cur[1], par[0], None if symmetric else par[1], signed)
+                b0, b1, b2, b3 = torch.empty(4, n_params, dtype=torch.float32, device=dev).unbind(0)
+            out = (b0, b1, b2, None if symmetric else b3, signed)
         counter = None
         if n_params == 1:
             key = (dev.index, st)
@@ -1006,6 +1006,13 @@ def backend():
     if _backend is None:
         _backend = HipBackend()
     return _backend
+
+
+def on_device(t):
+    """True when the active backend can take `t` where it lives: ROCm tensors for the HIP backend (there is no CPU
+    fallback); a test double that declares `accepts_cpu` (tests/_oracle_backend.py) also takes host tensors, so that the
+    host logic of the fused / integer paths can be replayed against the CPU oracle."""
+    return t.is_cuda or getattr(backend(), 'accepts_cpu', False)
 
 
 def set_backend(b):

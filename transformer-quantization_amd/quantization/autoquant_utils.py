@@ -90,7 +90,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         quantizer, shapes the MFMA kernel does not tile, ...)."""
         src = provenance.quantizer_of(x)                 # the quantizer that produced x (fixed range)
         act_code = _ACT_CODES.get(type(self.activation_function))
-        if (src is None or act_code is None or not x.is_cuda or x.dtype != torch.float32
+        if (src is None or act_code is None or not _hip.on_device(x) or x.dtype != torch.float32
                 or not self._int8_weight_side_ok()
                 or src.symmetric or src.n_bits > 8 or src._delta is None or src._delta.numel() != 1
                 or src.scale_domain != 'linear' or src._delta.requires_grad):
@@ -271,7 +271,7 @@ class QuantNoNorm(QuantizationHijacker):
             q = self.activation_quantizer.quantizer
             # feeding integer Linears (MobileBERT's bottlenecks -> query / key): emit the int8 indices in the same launch
             want_idx = (options.INT8_LINEAR and not q.symmetric and q.n_bits <= 8 and q.scale_domain == 'linear'
-                        and x.is_cuda and x.dtype == torch.float32)
+                        and _hip.on_device(x) and x.dtype == torch.float32)
             out = _hip.backend().affine_fake_quant(
                 x, weight, bias, q._delta, q._zero_float, getattr(q, '_signed', None), q.n_bits,
                 q.symmetric, q.scale_domain == 'log', q.eps, **({'want_idx': True} if want_idx else {}))

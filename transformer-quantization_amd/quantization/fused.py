@@ -44,7 +44,7 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
     from quantization.autoquant_utils import QuantNoNorm
     is_nonorm = isinstance(layer_norm, QuantNoNorm)
     fusable = ('no' not in (q1, q2, q3) and dense.activation_function is None
-               and layer_norm.activation_function is None and x.is_cuda and x.dtype != torch.float64
+               and layer_norm.activation_function is None and _hip.on_device(x) and x.dtype != torch.float64
                and not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad))
                and (is_nonorm or len(layer_norm.normalized_shape) == 1)
                and dense.activation_save_target is None and layer_norm.activation_save_target is None)
@@ -99,7 +99,7 @@ def _linear_nonorm_i8(dense, layer_norm, x, residual, q1, q2, q3):
     the integer path does not apply to `dense` / `x` (then the caller runs GEMM and tail separately).  Bit-identical to
     that two-launch form: same integer contraction, same element arithmetic."""
     if not options.INT8_LINEAR or not hasattr(dense, '_int8_plan') or (residual is not None and (
-            residual.dtype != torch.float32 or not residual.is_cuda)) or _needs_autograd(dense, layer_norm, x, residual):
+            residual.dtype != torch.float32 or not _hip.on_device(residual))) or _needs_autograd(dense, layer_norm, x, residual):
         return None
     plan = dense._int8_plan(x, with_output_quantizer=False)
     if plan is None or plan[1] != _hip.ACT_NONE:
@@ -125,7 +125,7 @@ def linear_nonorm_quant(dense, layer_norm, x):
     """MobileBERT bottleneck: ``layer_norm(dense(x))`` with a QuantLinear and a QuantNoNorm, fixed per-tensor ranges:
     one integer launch when options.INT8_LINEAR applies, the layered modules otherwise."""
     from quantization.autoquant_utils import QuantNoNorm
-    if (isinstance(layer_norm, QuantNoNorm) and x.is_cuda and x.dtype == torch.float32
+    if (isinstance(layer_norm, QuantNoNorm) and _hip.on_device(x) and x.dtype == torch.float32
             and dense.activation_function is None and layer_norm.activation_function is None
             and dense.activation_save_target is None and layer_norm.activation_save_target is None
             and not _needs_autograd(dense, layer_norm, x)):
@@ -154,7 +154,7 @@ def quantized_ffn(intermediate, dense, res_quantizer, layer_norm, x):
     be = _hip.backend()
     if (not options.INT8_LINEAR or not hasattr(be, 'ffn_i8_nonorm') or not isinstance(layer_norm, QuantNoNorm)
             or not hasattr(intermediate, '_int8_plan') or not hasattr(dense, '_int8_weight_side_ok')
-            or not x.is_cuda or x.dtype != torch.float32 or _needs_autograd(intermediate, dense, layer_norm, x)
+            or not _hip.on_device(x) or x.dtype != torch.float32 or _needs_autograd(intermediate, dense, layer_norm, x)
             or dense.activation_function is not None or layer_norm.activation_function is not None
             or layer_norm.activation_save_target is not None or not dense._int8_weight_side_ok()):
         return separate()
@@ -201,7 +201,7 @@ def scores_softmax_quant(scores_quantizer, probs_quantizer, scores, mask, denom)
     Tk = scores.shape[-1]
     ok_mask = mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1
                                and mask.shape[0] == scores.shape[0] and mask.shape[3] == Tk)
-    if ('no' in (q1, q2) or not scores.is_cuda or scores.dtype != torch.float32 or scores.dim() != 4
+    if ('no' in (q1, q2) or not _hip.on_device(scores) or scores.dtype != torch.float32 or scores.dim() != 4
             or not ok_mask or Tk not in (32, 64, 128, 256, 512, 1024)
             or (torch.is_grad_enabled() and scores.requires_grad)):
         s = scores_quantizer(scores) / denom
@@ -236,7 +236,7 @@ def quantized_attention(query, key, value, mask, num_heads, scores_quantizer, pr
     carry their int8 grid indices, every quantizer involved is fixed, per-tensor (asymmetric <= 8 bit
     for Q, K, V and the probabilities), T a multiple of 64 up to 512 and d in (32, 64).  Returns None otherwise: the
     caller then runs the layered modules."""
-    if not options.INT8_LINEAR or query.dim() != 3 or not query.is_cuda:
+    if not options.INT8_LINEAR or query.dim() != 3 or not _hip.on_device(query):
         return None
     if torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad):
         return None
@@ -303,7 +303,7 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
     when any of that does not hold (run the layered modules then)."""
     from quantization.autoquant_utils import QuantLinear, _fixed_per_tensor_manager
     layers = (query, key, value)
-    if not options.INT8_LINEAR or x.dim() != 3 or not x.is_cuda or x.dtype != torch.float32:
+    if not options.INT8_LINEAR or x.dim() != 3 or not _hip.on_device(x) or x.dtype != torch.float32:
         return None
     if torch.is_grad_enabled() and (x.requires_grad or any(l.weight.requires_grad for l in layers)):
         return None

@@ -249,7 +249,7 @@ class QuantizationManager(nn.Module):
         the dequantised tensor AND its int8 indices (minus 128), saving the consumer's re-quantisation."""
         q = self.quantizer
         if (type(q) is not AsymmetricUniformQuantizer or q.n_bits > 8 or q._delta.numel() != 1
-                or q.scale_domain != 'linear' or not x.is_cuda or x.dtype != torch.float32
+                or q.scale_domain != 'linear' or not _hip.on_device(x) or x.dtype != torch.float32
                 or (torch.is_grad_enabled() and x.requires_grad)):
             return None
         be = _hip.backend()
