@@ -373,11 +373,17 @@ extern "C" int tq_adaround_bwd(const float* w, const float* alpha, const float* 
   return check_launch("ada_bwd_k");
 }
 
+// one block per 256 vectors (one-shot tiling, like K1): the capped grid-stride form lost ~10 % on the 656 MB embedding step
+static unsigned ada_grid(uint64_t work) {
+  const int cap = tuning("TQ_ADA_GRID", 0);           // 0 = one-shot; > 0 caps the grid (grid-stride loop): A/B only
+  return (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(work, kBlock), 1), cap > 0 ? (uint64_t)cap : (1u << 30));
+}
+
 static void launch_bwd_adam(bool v4, int mode, hipStream_t st, const float* w, const float* grad_wq, float* alpha,
                             float* exp_avg, float* exp_avg_sq, float* g_out, uint64_t n, const tq_quantizer* q, float temperature,
                             float reg_weight, float beta, float lr, float b1, float b2, float adam_eps, float bc1, float bc2_sqrt,
                             const float* sched) {
-  const unsigned grid = ew_grid(v4 ? n / 4 : n);
+  const unsigned grid = ada_grid(v4 ? n / 4 : n);
 #define TQ_ADA_STEP(M)                                                                                                     \
   do {                                                                                                                     \
     if (v4) hipLaunchKernelGGL((ada_bwd_adam_k<4, M>), dim3(grid), dim3(kBlock), 0, st, w, grad_wq, alpha, exp_avg, exp_avg_sq, g_out, n, \

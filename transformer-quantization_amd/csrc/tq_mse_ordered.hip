@@ -175,31 +175,55 @@ __global__ __launch_bounds__(kBlock) void mse_ord_unit_k(const void* __restrict_
       f32x2 s2[NP];
 #pragma unroll
       for (int c = 0; c < NP; ++c) s2[c] = f32x2{a[0][2 * c], a[0][2 * c + 1]};
-      // step-major, candidate pairs side by side: NP independent dependency chains per step in source order (a
-      // dependent packed op needs a wait state; one chain per element made the scheduler emit an s_nop after every
-      // packed instruction)
+      // JB steps x NP candidate pairs = 4 independent dependency chains side by side, stage by stage in source order
+      // (a dependent packed op needs a wait state; one chain per element made the scheduler emit an s_nop after every
+      // packed instruction).  Narrow candidate tiles (NC = 4 / 2: few rows x few candidates, where 8 candidates per
+      // wave leave most SIMDs idle) get their chains from consecutive steps instead; the accumulation into s2 keeps
+      // its sequential step order either way.
+      constexpr int JB = NP >= 4 ? 1 : 4 / NP;
+      // (groups of 4 steps: a short last chunk -- rows of 768 elements are 16 + 8 steps -- skips its zero padding)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float xv = xs[j];
-        const f32x2 x2 = {xv, xv};
-        f32x2 xc[NP], q0[NP], e[NP], q1[NP], h[NP], dl[NP];
+      for (int j0 = 0; j0 < 16; j0 += JB) {
+        if ((j0 & 3) == 0 && j0 > 0 && (uint32_t)j0 >= n) break;
+        f32x2 x2[JB], xc[JB][NP], q0[JB][NP], e[JB][NP], h[JB][NP], dl[JB][NP];
 #pragma unroll
-        for (int c = 0; c < NP; ++c) {
-          xc[c].x = __builtin_amdgcn_fmed3f(xv, ylo[2 * c], yhi[2 * c]);
-          xc[c].y = __builtin_amdgcn_fmed3f(xv, ylo[2 * c + 1], yhi[2 * c + 1]);
+        for (int jj = 0; jj < JB; ++jj) {
+          const float xv = xs[j0 + jj];
+          x2[jj] = f32x2{xv, xv};
+#pragma unroll
+          for (int c = 0; c < NP; ++c) {
+            xc[jj][c].x = __builtin_amdgcn_fmed3f(xv, ylo[2 * c], yhi[2 * c]);
+            xc[jj][c].y = __builtin_amdgcn_fmed3f(xv, ylo[2 * c + 1], yhi[2 * c + 1]);
+          }
         }
 #pragma unroll
-        for (int c = 0; c < NP; ++c) q0[c] = xc[c] * rc2[c];
+        for (int jj = 0; jj < JB; ++jj)
 #pragma unroll
-        for (int c = 0; c < NP; ++c) e[c] = __builtin_elementwise_fma(q0[c], ns2[c], xc[c]);
+          for (int c = 0; c < NP; ++c) q0[jj][c] = xc[jj][c] * rc2[c];
 #pragma unroll
-        for (int c = 0; c < NP; ++c) q1[c] = __builtin_elementwise_fma(e[c], rc2[c], q0[c]);
+        for (int jj = 0; jj < JB; ++jj)
 #pragma unroll
-        for (int c = 0; c < NP; ++c) h[c] = f32x2{rintf(q1[c].x), rintf(q1[c].y)};
+          for (int c = 0; c < NP; ++c) e[jj][c] = __builtin_elementwise_fma(q0[jj][c], ns2[c], xc[jj][c]);
 #pragma unroll
-        for (int c = 0; c < NP; ++c) dl[c] = x2 - sc2[c] * h[c];
+        for (int jj = 0; jj < JB; ++jj)
 #pragma unroll
-        for (int c = 0; c < NP; ++c) s2[c] = s2[c] + dl[c] * dl[c];
+          for (int c = 0; c < NP; ++c) q0[jj][c] = __builtin_elementwise_fma(e[jj][c], rc2[c], q0[jj][c]);
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+          for (int c = 0; c < NP; ++c) h[jj][c] = f32x2{rintf(q0[jj][c].x), rintf(q0[jj][c].y)};
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+          for (int c = 0; c < NP; ++c) dl[jj][c] = x2[jj] - sc2[c] * h[jj][c];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+          for (int c = 0; c < NP; ++c) dl[jj][c] = dl[jj][c] * dl[jj][c];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)                       // sequential in step order, like the reference's sum
+#pragma unroll
+          for (int c = 0; c < NP; ++c) s2[c] = s2[c] + dl[jj][c];
       }
 #pragma unroll
       for (int c = 0; c < NP; ++c) { a[0][2 * c] = s2[c].x; a[0][2 * c + 1] = s2[c].y; }
@@ -329,6 +353,7 @@ static OrdPlan plan_ord(uint64_t rows, uint64_t row_len, uint64_t n_cand) {
   pl.p = level_power(pl.steps);
   pl.nc = n_cand < 4 ? 2 : kOrdNC;
   pl.n_ctiles = (uint32_t)ceil_div(n_cand, pl.nc);
+  const int forced_nc = tuning("TQ_ORD_NC", 0);            // tests / tuning: 2, 4 or 8
   const uint64_t L = 1ull << pl.p;
   // Largest unit that still gives >= 4 waves per SIMD (1024 SIMDs): splitting rows costs state traffic + the fold
   // kernel ([8,128,768] x 12800 candidates: 1.88 ms unsplit vs 2.11 ms split into 12 units per row).
@@ -350,6 +375,14 @@ static OrdPlan plan_ord(uint64_t rows, uint64_t row_len, uint64_t n_cand) {
     pl.units_per_row = (uint32_t)upr;
     if (forced ? (int)k <= forced : ceil_div(rows * upr, 2) * pl.n_ctiles >= 4096) break;
   }
+  // Few rows x few candidates (the config shape [8, 98304] x 100: 624 waves of 8 candidates = 0.6 per SIMD, each a
+  // serial chain of 256 steps x 8 candidates): narrower candidate tiles until there are ~2 waves per SIMD.  x is
+  // re-read once per tile from L2 (3 MB tensor); the results do not depend on the tile width.
+  const uint64_t items = ceil_div(rows * pl.units_per_row, 2);
+  if (forced_nc == 2 || forced_nc == 4 || forced_nc == 8) pl.nc = (uint32_t)forced_nc;
+  else
+    while (pl.nc > 2 && items * ceil_div(n_cand, pl.nc) < 2048) pl.nc /= 2;
+  pl.n_ctiles = (uint32_t)ceil_div(n_cand, pl.nc);
   pl.state_bytes = pl.k_top < 4 ? (size_t)rows * pl.units_per_row * n_cand * 32 * sizeof(float4) : 0;
   pl.row_loss_bytes = ((size_t)rows * n_cand * sizeof(float) + 15) & ~(size_t)15;
   return pl;
@@ -370,6 +403,9 @@ static int launch_ord(const void* x, uint64_t rows, uint64_t row_len, const floa
   const dim3 grid((unsigned)ceil_div(waves, kBlock / kWave));
   if (pl.nc == 2)
     hipLaunchKernelGGL((mse_ord_unit_k<DT, 2>), grid, dim3(kBlock), 0, st, x, row_len, pl.steps, pl.p,
+                       pl.k_top, pl.span, pl.units_per_row, n_ru, c4, (uint32_t)n_cand, pl.n_ctiles, state, row_loss);
+  else if (pl.nc == 4)
+    hipLaunchKernelGGL((mse_ord_unit_k<DT, 4>), grid, dim3(kBlock), 0, st, x, row_len, pl.steps, pl.p,
                        pl.k_top, pl.span, pl.units_per_row, n_ru, c4, (uint32_t)n_cand, pl.n_ctiles, state, row_loss);
   else
     hipLaunchKernelGGL((mse_ord_unit_k<DT, kOrdNC>), grid, dim3(kBlock), 0, st, x, row_len, pl.steps,
