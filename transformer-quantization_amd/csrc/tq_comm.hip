@@ -66,10 +66,16 @@ static int load_rccl(const char* path) {
   }
   RcclApi a;
   a.handle = h;
-  bool ok = bind(h, "ncclGetUniqueId", a.GetUniqueId) & bind(h, "ncclCommInitRank", a.CommInitRank) &
-            bind(h, "ncclCommDestroy", a.CommDestroy) & bind(h, "ncclAllReduce", a.AllReduce) &
-            bind(h, "ncclGetErrorString", a.GetErrorString) & bind(h, "ncclCommCount", a.CommCount) &
-            bind(h, "ncclCommUserRank", a.CommUserRank) & bind(h, "ncclBroadcast", a.Broadcast);
+  int missing = 0;
+  missing += !bind(h, "ncclGetUniqueId", a.GetUniqueId);
+  missing += !bind(h, "ncclCommInitRank", a.CommInitRank);
+  missing += !bind(h, "ncclCommDestroy", a.CommDestroy);
+  missing += !bind(h, "ncclAllReduce", a.AllReduce);
+  missing += !bind(h, "ncclGetErrorString", a.GetErrorString);
+  missing += !bind(h, "ncclCommCount", a.CommCount);
+  missing += !bind(h, "ncclCommUserRank", a.CommUserRank);
+  missing += !bind(h, "ncclBroadcast", a.Broadcast);
+  const bool ok = missing == 0;
   bind(h, "ncclCommAbort", a.CommAbort);
   bind(h, "ncclGetVersion", a.GetVersion);
   if (!ok) return set_error(TQ_EUNSUPPORTED, "tq_comm_load: %s lacks the nccl* entry points", tried ? tried : "librccl");

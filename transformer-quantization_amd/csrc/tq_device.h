@@ -170,6 +170,16 @@ __device__ __forceinline__ void qf_round2_n(const f32x2 (&x)[N], const QF& q, f3
 #pragma unroll
   for (int i = 0; i < N; ++i) h[i] = f32x2{rintf(q0[i].x), rintf(q0[i].y)};
 }
+// The same without the "+ 0": for a quantizer whose output only feeds ANOTHER quantizer (through additions /
+// multiplications), where a -0 instead of +0 cannot reach the final result (x + (-0) == x + 0 for x != 0, and a zero
+// that survives to the last quantizer is normalised there).  Saves one packed add per pair in the fused layer tails.
+template <int N>
+__device__ __forceinline__ void qf_fake_quant2_n_signed_zero(f32x2 (&x)[N], const QF& q) {
+  f32x2 h[N];
+  qf_round2_n<N>(x, q, h);
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = q.scale * h[i];
+}
 template <int N>
 __device__ __forceinline__ void qf_fake_quant2_n(f32x2 (&x)[N], const QF& q) {
   f32x2 h[N];

@@ -155,10 +155,14 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
         f32x2 t[H];
 #pragma unroll
         for (int j = 0; j < H; ++j) t[j] = f32x2{fa[2 * j], fa[2 * j + 1]};
-        if (f1.on) qf_fake_quant2_n<H>(t, f1.f);
+        // ALLON: Q3 follows, so a -0 out of Q1 / Q2 cannot reach y (Q1(a) + r, the statistics and the affine map treat
+        // -0 like +0 unless every term is a zero, and Q3 normalises a surviving zero): skip their "+ 0"
+        if (ALLON) qf_fake_quant2_n_signed_zero<H>(t, f1.f);
+        else if (f1.on) qf_fake_quant2_n<H>(t, f1.f);
 #pragma unroll
         for (int j = 0; j < H; ++j) t[j] = t[j] + f32x2{fr[2 * j], fr[2 * j + 1]};
-        if (f2.on) qf_fake_quant2_n<H>(t, f2.f);
+        if (ALLON) qf_fake_quant2_n_signed_zero<H>(t, f2.f);
+        else if (f2.on) qf_fake_quant2_n<H>(t, f2.f);
         if (affine_only) {        // NoNorm: a NaN input is an element-local NaN output
 #pragma unroll
           for (int j = 0; j < H; ++j) {
