@@ -165,29 +165,12 @@ __global__ __launch_bounds__(kBlock) void mse_ord_unit_k(const void* __restrict_
     else { sc2[c / 2].x = f.scale.x; ns2[c / 2].x = f.nscale.x; rc2[c / 2].x = f.rcp.x; }
   }
 
-  // Software pipeline: the 16 loads of chunk i + 1 are in flight while chunk i is computed.  With few waves per SIMD
-  // (the config shape runs ~2) the exposed L2 latency of 16 chunks per unit was 2/3 of the kernel.
-  // padding with zeros is exact: 0 quantizes to 0 for every candidate, and s + 0 = s
-  // The loads are UNCONDITIONAL (index clamped into the row, value replaced by 0 afterwards): predicated loads sit in
-  // their own basic blocks, and the compiler then waits for all of them -- the prefetch included -- with vmcnt(0).
-  const uint64_t e_last = row_len - 1;
-  float xn[16];
-  {
-    const uint32_t n0 = (uint32_t)min((uint64_t)16, t1 > t0 ? t1 - t0 : 0);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) xn[j] = view(min((t0 + j) * 32 + col, e_last));
-#pragma unroll
-    for (int j = 0; j < 16; ++j) xn[j] = (uint32_t)j < n0 ? xn[j] : 0.0f;
-  }
   for (uint64_t t = t0; t < t1;) {
     const uint32_t n = (uint32_t)min((uint64_t)16, t1 - t);
     float xs[16];
+    // padding with zeros is exact: 0 quantizes to 0 for every candidate, and s + 0 = s
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xs[j] = xn[j];
-    const uint64_t tn = t + n;
-    const uint32_t nn = tn < t1 ? (uint32_t)min((uint64_t)16, t1 - tn) : 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) xn[j] = view(min((tn + j) * 32 + col, e_last));
+    for (int j = 0; j < 16; ++j) xs[j] = (uint32_t)j < n ? view((t + j) * 32 + col) : 0.0f;
     if (fast) {
       f32x2 s2[NP];
 #pragma unroll
@@ -251,8 +234,6 @@ __global__ __launch_bounds__(kBlock) void mse_ord_unit_k(const void* __restrict_
         for (int c = 0; c < NC; ++c) a[0][c] += sq_err(xs[j], cp[c]);
       }
     }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) xn[j] = (uint32_t)j < nn ? xn[j] : 0.0f;      // (first use of the prefetched values)
     t += n;
     if ((t & (L - 1)) == 0) TQ_ORD_DUMP(a, t, p, L, k_top, NC);
   }

@@ -39,6 +39,9 @@ FUSED_CALIBRATION = True
 _FUSED_ESTIMATORS = {CurrentMinMaxEstimator: _hip.EST_CURRENT, AllMinMaxEstimator: _hip.EST_ALL,
                      RunningMinMaxEstimator: _hip.EST_RUNNING}
 _FUSED_QUANTIZERS = (AsymmetricUniformQuantizer, SymmetricUniformQuantizer)
+# Fixed-range forwards of per-tensor quantizers skip the generic Python route (QuantizationManager._fixed_fast)
+FAST_FIXED_FORWARD = True
+_FAST_DTYPES = _hip._DTYPES
 
 
 class Qstates(Enum):
@@ -66,6 +69,7 @@ class QuantizationManager(nn.Module):
                  per_channel=False, axis=None, n_groups=None, x_min=None, x_max=None, qparams=None,
                  init_params=None):
         super().__init__()
+        object.__setattr__(self, '_fast_plan', None)      # launch plan of the fixed-range fast path (never copied / pickled)
         self.state = Qstates.estimate_ranges
         self.qmethod = qmethod
         self.init = init
@@ -232,9 +236,46 @@ class QuantizationManager(nn.Module):
             self.set_quant_range(cur_xmin, cur_xmax)
         return mods['quantizer'](x)
 
+    def __getstate__(self):
+        # the launch plan holds ctypes references into this process's descriptor cache: rebuilt on demand, never copied
+        state = self.__dict__.copy()
+        state['_fast_plan'] = None
+        return state
+
+    def _fixed_fast(self, x, q):
+        """Fixed per-tensor range, plain ROCm tensor, no autograd: torch.empty_like + one foreign call.  Bit-identical to
+        q(x) -- it IS the same entry point with the same descriptor, minus ~6 us of Python (module dispatch, argument
+        marshalling, layout checks) per call.  Returns None whenever anything is out of the ordinary (hooks on the
+        quantizer, per-axis / per-channel ranges, trainable or missing ranges, another device than the current one,
+        non-contiguous input, a backend double): the caller then takes the generic route."""
+        bufs = q._buffers
+        delta, zf = bufs.get('_delta'), bufs.get('_zero_float')
+        if (delta is None or not x.is_cuda or not x.is_contiguous() or x.dtype not in _FAST_DTYPES
+                or q._forward_hooks or q._forward_pre_hooks or type(q) not in _FUSED_QUANTIZERS
+                or (torch.is_grad_enabled() and x.requires_grad) or x.device.index != torch.cuda.current_device()):
+            return None
+        sg = bufs.get('_signed')
+        key = (q._range_gen, delta.data_ptr(), None if zf is None else zf.data_ptr(), None if sg is None else sg.data_ptr(),
+               q.n_bits, q.eps, x.device.index)
+        plan = self._fast_plan
+        if plan is None or plan[0] != key:
+            be = _hip.backend()
+            if (delta.numel() != 1 or q.axis is not None or q.per_channel or not hasattr(be, 'fixed_quant_plan')
+                    or (q.symmetric and sg is None) or (not q.symmetric and zf is None) or delta.requires_grad):
+                return None
+            plan = (key,) + be.fixed_quant_plan(delta, zf, sg, q.n_bits, q.symmetric,
+                                             q.scale_domain == 'log', q.eps) + (be.lib,)
+            object.__setattr__(self, '_fast_plan', plan)
+        y = torch.empty_like(x)
+        rc = plan[1](x.data_ptr(), y.data_ptr(), None, 0, x.numel(), _FAST_DTYPES[x.dtype], plan[2], _hip._stream())
+        if rc != 0:
+            _hip._check(rc, plan[4])
+        return y
+
     def _fixed_forward(self, x, q):
         if not options.INT8_LINEAR:
-            return q(x)
+            y = self._fixed_fast(x, q) if FAST_FIXED_FORWARD else None
+            return q(x) if y is None else y
         y = self._fixed_forward_with_indices(x)
         if y is None:
             y = q(x)
