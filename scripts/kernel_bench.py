@@ -28,8 +28,9 @@ import torch
 from quantization import _hip
 
 HBM = 8000.0                 # GB/s
-VALU_PACKED = 157.0e3        # GFLOP/s fp32 packed FMA peak (256 CU x 128 lanes x 2 x 2.4 GHz)
-MFMA_I8 = 5.0e6              # GOP/s dense int8 MFMA (MI355X_MICROARCH.md: ~5 POP/s fp8/int8 class)
+VALU_PACKED = 157.0e3        # GFLOP/s fp32 vector peak (256 CU x 4 SIMD-32 x 2 flop x 2.4 GHz; reached by plain v_fma_f32 --
+                             # v_pk_fma_f32 is the same rate per element, v_med3 / v_rndne half: tools/tuning/valu_probe.hip)
+MFMA_I8 = 3.944e6            # GOP/s dense int8 MFMA: the MEASURED v_mfma_i32_16x16x64_i8 rate of MI355X_MICROARCH.md (>= 3944 TOPS)
 
 be = _hip.backend()
 dev = 'cuda'

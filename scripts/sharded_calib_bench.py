@@ -113,6 +113,26 @@ with torch.no_grad():
     options.INPLACE_CALIBRATION_STATE = False
     tq_dist.disable()
     out['ratio_c10d_eager_vs_single_eager'] = out['sharded_c10d_eager_ms'] / out['single_gpu_fused_ms']
+    # ---- at which GLOBAL batch does sharding over 8 GPUs start to pay?  t_1(B): one GPU calibrates the whole batch;
+    # t_8(B): a rank calibrates B / 8 samples through the sharded path (measured here on the 1-rank communicator: all
+    # launches + the ncclAllReduce enqueue of every site; on 8 ranks each of the 161 collectives additionally waits for
+    # the slowest peer, `allreduce_us_assumed` per site, added below as a model term, not a measurement).
+    if os.environ.get('TQ_BREAK_EVEN', '1') == '1' and world == 1:
+        be_rows = []
+        g = torch.Generator(device=dev).manual_seed(11)
+        tq_dist.enable(force=True, raw=True)
+        for B in (8, 32, 128, 512):
+            ids_B = torch.randint(1000, 30000, (B, 128), device=dev, generator=g)
+            ids_loc = ids_B[:max(B // 8, 1)]
+            tq_dist_was = tq_dist.suspended()
+            with tq_dist_was:
+                t1 = wall(lambda: model(ids_B), n=8, w=2)
+            t8 = wall(lambda: model(ids_loc), n=8, w=2)
+            be_rows.append({'global_batch': B, 'single_gpu_eager_ms': t1, 'per_rank_batch': int(ids_loc.shape[0]),
+                            'sharded_rank_eager_ms': t8})
+        tq_dist.disable()
+        out['break_even'] = {'rows': be_rows, 'allreduce_us_assumed': 20.0, 'collectives_per_forward': 161,
+                             'note': 't_8 = sharded_rank_eager_ms + 161 x allreduce_us_assumed / 1000'}
 t = torch.tensor([out['sharded_raw_rccl_eager_ms']], device=dev, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 out['sharded_raw_rccl_eager_ms_max_over_ranks'] = float(t[0])
