@@ -161,17 +161,21 @@ class QuantizationManager(nn.Module):
         out = None
         if options.INPLACE_CALIBRATION_STATE:
             out = self._inplace_state(est, q, n_params, x.device)
-        box = tq_dist.mailbox_for(2 * n_params) if (sharded and hasattr(be, 'calibrate_minmax_mailbox')) else None
+        box = comm = None
+        if sharded:
+            box = tq_dist.mailbox_for(2 * n_params) if hasattr(be, 'calibrate_minmax_mailbox') else None
+            if box is None and hasattr(be, 'calibrate_minmax_rccl'):
+                comm = tq_dist.raw_comm_for(x)
         if box is not None:
             # statistics -> P2P mailbox all-reduce -> update + quantize as one C call (3-4 launches, no host work between)
             cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_minmax_mailbox(
                 box, x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0), n_groups, order,
                 q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log', out=out)
             tq_dist.count_mailbox_exchange(8 * n_params)
-        elif sharded and hasattr(be, 'calibrate_minmax_rccl') and tq_dist.raw_comm_for(x) is not None:
+        elif comm is not None:
             # statistics -> ncclAllReduce(MAX) on the raw communicator -> update + quantize as one C call: no c10d
             cur_min, cur_max, delta, zero_float, signed, y = be.calibrate_minmax_rccl(
-                tq_dist.raw_comm_for(x), x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0),
+                comm, x, n_params, inner, mode, prev_min, prev_max, getattr(est, 'momentum', 0.0),
                 n_groups, order, q.n_bits, q.symmetric, q.eps, q.scale_domain == 'log', out=out)
             tq_dist.count_raw_exchange(8 * n_params)
         elif sharded:
