@@ -123,7 +123,9 @@ int tq_residual_nonorm_quant_fwd(const void* dense_out, const void* residual, vo
  *   w_idx   int8 [N, K]  weight indices of a symmetric quantizer (TQ_IDX_I8), w_rowsum int32 [N]
  *                         their row sums (tq_rowsum_i8, once per weight), w_delta [1] or [N]
  *   activation 0 none, 1 ReLU, 2 GELU (erf), 3 Tanh;  q_out NULL or a per-tensor quantizer
- *   y       [M, N] fp32 or bf16.   M, N multiples of 32; K multiple of 64, <= 16384.
+ *   y       [M, N] fp32 or bf16, or NULL with y_idx given (index-only output: the consumer is another integer
+ *           Linear, e.g. BERT's intermediate -> output pair; saves the fp32 store, 4/5 of the kernel's HBM writes).
+ *           M, N multiples of 32; K multiple of 64, <= 16384.
  * The accumulation is exact (i32); it differs from the reference's fp32 simulation by that
  * simulation's own accumulation round-off (~1e-6 relative).                                       */
 enum { TQ_ACT_NONE = 0, TQ_ACT_RELU = 1, TQ_ACT_GELU = 2, TQ_ACT_TANH = 3 };

@@ -90,6 +90,14 @@ with torch.no_grad():
     graphed('fixed_range_forward_fused_tails_int8_linear')
     QSelfAttention.fuse = True
     graphed('fixed_range_forward_fused_tails_int8_linear_fused_attention')
+    o_fast = model(ids)
+    # + the feed-forward pair with an index-only intermediate (tq_linear_i8_fwd, y = NULL: the [B, T, 3072] fp32 tensor
+    # is never stored)
+    from tests.harness_bert import QLayer
+    QLayer.fuse_ffn = True
+    graphed('fixed_range_forward_all_fused_index_only_ffn')
+    c['index_only_ffn_equal_to_separate_launches'] = bool(torch.equal(model(ids), o_fast))
+    QLayer.fuse_ffn = False
     QResidualBlock.fuse = QSelfAttention.fuse = False
     options.INT8_LINEAR = False
     c['logit_span'] = float(o.max() - o.min())

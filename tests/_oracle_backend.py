@@ -98,11 +98,13 @@ class OracleBackend:
     def rowsum_i8(self, w_idx):
         return w_idx.to(torch.int32).sum(1, dtype=torch.int32)
 
-    def linear_i8(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta, w_eps, activation, q_out, out_dtype, want_idx=False):
+    def linear_i8(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta, w_eps, activation, q_out, out_dtype, want_idx=False,
+                  want_y=True):
         from oracle import int_oracle
         y, yi = int_oracle.linear_i8(x_idx, w_idx, bias, tuple(float(v) for v in x_q), w_delta, w_eps, activation,
                                      self._q7(q_out))
-        return (y.to(out_dtype), yi) if want_idx else y.to(out_dtype)
+        y = y.to(out_dtype) if want_y else None
+        return (y, yi) if want_idx else y
 
     def linear_i8_nonorm(self, x_idx, w_idx, w_rowsum, bias, residual, nn_w, nn_b, x_q, w_delta, w_eps, q_dense, q_sum,
                          q_out, out_dtype, want_idx=False):

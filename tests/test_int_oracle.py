@@ -107,6 +107,10 @@ def test_linear_i8_equals_integer_oracle_bit_for_bit(shape, act, o_bits):
                          _dev(q_out), torch.float32, want_idx=True)
     assert torch.equal(yi.cpu(), ref_i)
     assert torch.equal(y.cpu(), ref_y)
+    # index-only output (y = NULL): the same indices
+    _, yi2 = be.linear_i8(x_idx.to(DEV), wi, be.rowsum_i8(wi), bias.to(DEV), _xq_dev(x_q), w_delta.to(DEV), 1e-8, act,
+                          _dev(q_out), torch.float32, want_idx=True, want_y=False)
+    assert _ is None and torch.equal(yi2.cpu(), ref_i)
     # without an output quantizer: the raw fp32 pre-activation
     ref0, _ = IO.linear_i8(x_idx, w_idx, bias, x_q, w_delta, 1e-8, act, None)
     y0 = be.linear_i8(x_idx.to(DEV), wi, be.rowsum_i8(wi), bias.to(DEV), _xq_dev(x_q), w_delta.to(DEV), 1e-8, act, None,

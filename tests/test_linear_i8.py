@@ -305,3 +305,37 @@ def test_ffn_i8_block_equals_two_launches(M, quantizers, per_channel):
     yb = be.ffn_i8_nonorm(x_i8, xq, w1i, rs1, b1.cuda(), w1d, 1e-8, q_mid, w2i, rs2, b2.cuda(), w2d, 1e-8, res, nw, nb,
                           q_dense, q_sum, q_out, torch.bfloat16)
     assert torch.equal(yb, ref_y.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+def test_bert_ffn_with_index_only_intermediate_equals_separate_launches():
+    """quantized_bert_ffn: the intermediate Linear (768 -> 3072, GELU, 8-bit quantizer) runs INDEX-ONLY
+    (tq_linear_i8_fwd with y = NULL), the output Linear consumes the int8 indices, then the residual + LayerNorm tail:
+    bit-identical to the separate calls (which store and never re-read the [B, T, 3072] fp32 tensor), layer by layer
+    and for the whole BERT-base forward; and the producer really skipped its fp32 output."""
+    from tests.test_bert_e2e import _build, _fixture, _calibrate_and_run
+    from tests.harness_bert import QResidualBlock, QSelfAttention
+    from harness.bert import QLayer
+    from quantization import _hip, options
+    z = _fixture()
+    model, _ = _build('cuda')
+    ids = torch.from_numpy(z['input_ids']).cuda()
+    _calibrate_and_run(model, ids)
+    be = _hip.backend()
+    seen = []
+    orig = be.linear_i8
+    options.INT8_LINEAR = True
+    QResidualBlock.fuse = QSelfAttention.fuse = True
+    try:
+        with torch.no_grad():
+            separate = model(ids)
+            be.linear_i8 = lambda *a, **k: (seen.append(k.get('want_y', True)), orig(*a, **k))[1]
+            QLayer.fuse_ffn = True
+            chained = model(ids)
+    finally:
+        QLayer.fuse_ffn = False
+        QResidualBlock.fuse = QSelfAttention.fuse = False
+        options.INT8_LINEAR = False
+        be.__dict__.pop('linear_i8', None)
+    assert seen.count(False) == 12, seen           # one index-only intermediate per encoder layer
+    assert torch.equal(chained, separate)

@@ -894,7 +894,7 @@ extern "C" int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const 
                                 uint64_t w_n_params, float w_eps, int activation, const tq_quantizer* q_out,
                                 tq_stream_t stream) {
   if (M == 0 || N == 0) return TQ_OK;
-  TQ_REQUIRE(x_idx && w_idx && w_rowsum && y && x_delta && x_zero_float && w_delta, "tq_linear_i8_fwd: NULL pointer");
+  TQ_REQUIRE(x_idx && w_idx && w_rowsum && (y || y_idx) && x_delta && x_zero_float && w_delta, "tq_linear_i8_fwd: NULL pointer");
   TQ_REQUIRE(y_dtype == TQ_F32 || y_dtype == TQ_BF16, "tq_linear_i8_fwd: y dtype must be fp32 or bf16");
   TQ_REQUIRE(M % 32 == 0 && N % 32 == 0 && K % 64 == 0 && K >= 64 && K <= 16384 && M < (1u << 31) && N < (1u << 31),
              "tq_linear_i8_fwd: unsupported shape M=%llu N=%llu K=%llu (M,N %% 32, K %% 64)", (unsigned long long)M,
@@ -902,7 +902,7 @@ extern "C" int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const 
   TQ_REQUIRE(x_n_bits >= 1 && x_n_bits <= 8, "tq_linear_i8_fwd: input quantizer must have <= 8 bits");
   TQ_REQUIRE(w_n_params == 1 || w_n_params == N, "tq_linear_i8_fwd: weight scales must be per-tensor or per-output-channel");
   TQ_REQUIRE(activation >= ACT_NONE && activation <= ACT_TANH, "tq_linear_i8_fwd: unknown activation %d", activation);
-  TQ_REQUIRE(aligned16(x_idx) && aligned16(w_idx) && aligned16(y), "tq_linear_i8_fwd: 16-byte alignment required");
+  TQ_REQUIRE(aligned16(x_idx) && aligned16(w_idx) && (y == nullptr || aligned16(y)), "tq_linear_i8_fwd: 16-byte alignment required");
   LinArgs a{};
   a.x = x_idx; a.w = w_idx; a.w_rowsum = w_rowsum; a.bias = bias; a.y = y; a.y_idx = y_idx;
   a.M = (uint32_t)M; a.N = (uint32_t)N; a.K = (uint32_t)K;

@@ -122,8 +122,15 @@ class QLayer(QuantizedModel):
         self.intermediate = quantize_model(nn.Sequential(hf.intermediate.dense, nn.GELU()), **qp)
         self.output = QResidualBlock(hf.output, **qp)
 
+    fuse_ffn = False   # set True (with options.INT8_LINEAR): intermediate runs index-only, its [B, T, 3072] fp32 output is
+                       # never stored (quantization/fused.py quantized_bert_ffn)
+
     def forward(self, h, mask):
         a = self.attention_output(self.attention_self(h, mask), h)
+        if self.fuse_ffn:
+            from quantization.fused import quantized_bert_ffn
+            out = self.output
+            return quantized_bert_ffn(self.intermediate[0], out.dense, out.res_act_quantizer, out.LayerNorm, a, a)
         return self.output(self.intermediate(a), a)
 
 

@@ -462,14 +462,16 @@ class HipBackend:
         return out
 
     def linear_i8(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta, w_eps, activation, q_out, out_dtype,
-                  want_idx=False):
+                  want_idx=False, want_y=True):
         """x_idx int8 [..., K]; x_q = (delta, zero_float, n_bits, eps) of the input quantizer;
-        q_out None or the 7-tuple of a per-tensor quantizer.  -> y [..., N]."""
+        q_out None or the 7-tuple of a per-tensor quantizer.  -> y [..., N] (, y_idx); want_y=False (needs want_idx):
+        index-only output, y is None."""
         K = x_idx.shape[-1]
         M = x_idx.numel() // K
         N = w_idx.shape[0]
-        y = torch.empty(x_idx.shape[:-1] + (N,), dtype=out_dtype, device=x_idx.device)
-        y_idx = torch.empty(y.shape, dtype=torch.int8, device=y.device) if want_idx else None
+        shape = x_idx.shape[:-1] + (N,)
+        y = torch.empty(shape, dtype=out_dtype, device=x_idx.device) if want_y else None
+        y_idx = torch.empty(shape, dtype=torch.int8, device=x_idx.device) if want_idx else None
         qd = None if q_out is None else self._qdesc(*q_out, 1, 1)
         rc = self.lib.tq_linear_i8_fwd(
             _ptr(x_idx), _ptr(w_idx), _ptr(w_rowsum), _ptr(bias), _ptr(y), _ptr(y_idx), _DTYPES[out_dtype], M, N, K,

@@ -89,13 +89,18 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         allow it (no fixed per-tensor asymmetric <= 8-bit input quantizer known for x, unsupported weight / output
         quantizer, shapes the MFMA kernel does not tile, ...)."""
         src = provenance.quantizer_of(x)                 # the quantizer that produced x (fixed range)
+        if not _hip.on_device(x) or x.dtype != torch.float32:
+            return None
+        return self._int8_plan_from(src, x.numel() // self.in_features, with_output_quantizer)
+
+    def _int8_plan_from(self, src, M, with_output_quantizer=True):
+        """_int8_plan for an input that is known only by the quantizer `src` that produced it and its row count `M`
+        (index-only producers: the fp32 tensor never exists)."""
         act_code = _ACT_CODES.get(type(self.activation_function))
-        if (src is None or act_code is None or not _hip.on_device(x) or x.dtype != torch.float32
-                or not self._int8_weight_side_ok()
+        if (src is None or act_code is None or not self._int8_weight_side_ok()
                 or src.symmetric or src.n_bits > 8 or src._delta is None or src._delta.numel() != 1
                 or src.scale_domain != 'linear' or src._delta.requires_grad):
             return None
-        M = x.numel() // self.in_features
         if self.in_features % 64 or self.out_features % 32 or M % 32 or self.in_features > 16384:
             return None
         q_out = None
@@ -108,17 +113,19 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
                      oq.scale_domain == 'log', oq.eps)
         return src, act_code, q_out
 
-    def _int8_operands(self, x, plan):
+    def _int8_operands(self, x, plan, x_idx=None):
         """Kernel operands of the integer evaluation: (x_idx, w_idx, rowsum, bias, x_q, w_delta, w_eps), or None when
-        the weight grid is unsigned (indices do not fit int8: the layered path runs, counted in INT8_STATS)."""
+        the weight grid is unsigned (indices do not fit int8: the layered path runs, counted in INT8_STATS).
+        x_idx given (index-only producer): `x` is not touched."""
         src = plan[0]
         be = _hip.backend()
         w_idx, rowsum, w_signed = self._int8_weights()
         if not w_signed:
             INT8_STATS['unsigned_weight_fallbacks'] += 1
             return None
-        x_idx = provenance.indices_of(x)           # emitted by the producing quantizer in the same launch
-        if x_idx is None or x_idx.shape != x.shape:
+        if x_idx is None:
+            x_idx = provenance.indices_of(x)       # emitted by the producing quantizer in the same launch
+        if x_idx is None or (x is not None and x_idx.shape != x.shape):
             x_idx = be.quantize_to_int8(x.detach(), src._delta, src._zero_float, None, src.n_bits, False, False,
                                         src.eps, 1, 1, minus_128=True)
         wq = self.weight_quantizer.quantizer
@@ -126,15 +133,21 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         return (x_idx, w_idx, rowsum, bias, (src._delta, src._zero_float, src.n_bits, src.eps), wq._delta.reshape(-1),
                 wq.eps)
 
-    def _int8_compute(self, x, plan):
-        """The fused integer Linear itself (no autograd): y [, its int8 indices] or None (unsigned weight grid)."""
+    def _int8_compute(self, x, plan, x_idx=None, index_only=False):
+        """The fused integer Linear itself (no autograd): y [, its int8 indices] or None (unsigned weight grid).
+        index_only: only the int8 indices of the output are produced and returned (the consumer is another integer
+        Linear; needs an asymmetric <= 8-bit output quantizer in the plan)."""
         _, act_code, q_out = plan
-        ops = self._int8_operands(x, plan)
+        ops = self._int8_operands(x, plan, x_idx)
         if ops is None:
             return None
         amgr = self.activation_quantizer
         want_idx = q_out is not None and not amgr.quantizer.symmetric and amgr.quantizer.n_bits <= 8
         INT8_STATS['kernel_calls'] += 1
+        if index_only:
+            assert want_idx, 'index-only output needs an asymmetric <= 8-bit output quantizer'
+            return _hip.backend().linear_i8(*ops[:5], ops[5], ops[6], act_code, q_out, torch.float32, want_idx=True,
+                                            want_y=False)[1]
         out = _hip.backend().linear_i8(*ops[:5], ops[5], ops[6], act_code, q_out, torch.float32, want_idx=want_idx)
         y = out[0] if want_idx else out
         if q_out is not None:

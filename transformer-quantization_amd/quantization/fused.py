@@ -33,9 +33,12 @@ def _fixed_per_tensor(enabled, mgr):
             q.scale_domain == 'log', q.eps)
 
 
-def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
+def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual, _gemm=None):
     """dense: QuantLinear, res_quantizer: QuantizedActivation, layer_norm: QuantLayerNorm or MobileBERT's
-    QuantNoNorm (tq_residual_nonorm_quant_fwd).  Equivalent to ``layer_norm(res_quantizer(dense(x) + residual))``."""
+    QuantNoNorm (tq_residual_nonorm_quant_fwd).  Equivalent to ``layer_norm(res_quantizer(dense(x) + residual))``.
+    (_gemm: the pre-quantizer output of `dense`, already computed by quantized_bert_ffn from int8 indices.)"""
+    if _gemm is not None:
+        x = _gemm
     q1 = _fixed_per_tensor(dense._quant_a and dense.activation_function is None, dense.activation_quantizer)
     q2 = _fixed_per_tensor(getattr(res_quantizer, '_quant_a', False),
                            getattr(res_quantizer, 'activation_quantizer', res_quantizer))   # FP32Acts: site switched off
@@ -49,13 +52,15 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
                and (is_nonorm or len(layer_norm.normalized_shape) == 1)
                and dense.activation_save_target is None and layer_norm.activation_save_target is None)
     if not fusable:
+        if _gemm is not None:
+            raise RuntimeError('residual_layernorm_quant: pre-computed GEMM handed to a tail that is not fusable')
         return layer_norm(res_quantizer(dense(x) + residual))
-    if is_nonorm:
+    if is_nonorm and _gemm is None:
         y = _linear_nonorm_i8(dense, layer_norm, x, residual, q1, q2, q3)      # GEMM + whole tail as ONE integer launch
         if y is not None:
             return y
-    gemm = None
-    if options.INT8_LINEAR and hasattr(dense, '_int8_forward'):
+    gemm = _gemm
+    if gemm is None and options.INT8_LINEAR and hasattr(dense, '_int8_forward'):
         gemm = dense._int8_forward(x, with_output_quantizer=False)     # exact integer GEMM (MFMA i8)
     if gemm is None:
         w, b = dense.get_params()
@@ -75,6 +80,50 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual):
     if oq is not None:
         provenance.tag(y, oq, out[1] if want_idx else None)
     return y
+
+
+def quantized_bert_ffn(intermediate, dense, res_quantizer, layer_norm, x, residual):
+    """BERT feed-forward block (reference models/quantized_bert.py:252-280 behind hijacker.py:66-116):
+
+        layer_norm(res_quantizer(dense(intermediate(x)) + residual))
+
+    with `intermediate` a QuantLinear + GELU whose 8-bit output ONLY feeds `dense`.  With options.INT8_LINEAR and fixed
+    per-tensor ranges everywhere, the intermediate Linear runs index-only (tq_linear_i8_fwd with y = NULL: the
+    [tokens, 3072] fp32 activation -- 12.6 MB per layer at B = 8, 4/5 of that kernel's HBM writes -- is never stored),
+    `dense` consumes the int8 indices, and the residual + LayerNorm tail follows as one kernel.  Same integer
+    contractions and element arithmetic as the separate calls: bit-identical result.  Anything else: the layered
+    modules / the tail helper."""
+    def separate():
+        return residual_layernorm_quant(dense, res_quantizer, layer_norm, intermediate(x), residual)
+
+    if (not options.INT8_LINEAR or not hasattr(intermediate, '_int8_plan') or not hasattr(dense, '_int8_plan_from')
+            or not _hip.on_device(x) or x.dtype != torch.float32 or dense.activation_function is not None
+            or _needs_autograd(intermediate, dense, layer_norm, x, residual)):
+        return separate()
+    from quantization.autoquant_utils import QuantNoNorm
+    q1 = _fixed_per_tensor(dense._quant_a, dense.activation_quantizer)
+    q2 = _fixed_per_tensor(getattr(res_quantizer, '_quant_a', False), getattr(res_quantizer, 'activation_quantizer', res_quantizer))
+    q3 = _fixed_per_tensor(layer_norm._quant_a and layer_norm.activation_function is None, layer_norm.activation_quantizer)
+    if ('no' in (q1, q2, q3) or isinstance(layer_norm, QuantNoNorm) or layer_norm.activation_function is not None
+            or len(layer_norm.normalized_shape) != 1 or dense.activation_save_target is not None
+            or layer_norm.activation_save_target is not None or intermediate.activation_save_target is not None
+            or residual.dtype != torch.float32):
+        return separate()                                  # (the same conditions the tail helper checks)
+    plan1 = intermediate._int8_plan(x, with_output_quantizer=True)
+    if plan1 is None or plan1[2] is None or plan1[2][4] or plan1[2][5] or plan1[2][3] > 8:
+        return separate()                                  # intermediate quantizer: asymmetric, linear domain, <= 8 bit
+    mid_q = intermediate.activation_quantizer.quantizer
+    M = x.numel() // intermediate.in_features
+    plan2 = dense._int8_plan_from(mid_q, M, with_output_quantizer=False)
+    if plan2 is None or not dense._int8_weights()[2]:
+        return separate()
+    mid_idx = intermediate._int8_compute(x, plan1, index_only=True)
+    if mid_idx is None:
+        return separate()
+    gemm = dense._int8_compute(None, plan2, x_idx=mid_idx)
+    if gemm is None:
+        return separate()
+    return residual_layernorm_quant(dense, res_quantizer, layer_norm, None, residual, _gemm=gemm)
 
 
 def _needs_autograd(*modules_and_tensors):
