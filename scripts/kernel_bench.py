@@ -143,6 +143,12 @@ def fam_i8():
         run('i8', f'integer Linear+GELU+quant M={M} N={N} K={K}', 'linear_i8_lds_k',
             lambda: be.linear_i8(x, w, rs, b, (xd, xz, 8, 1e-8), wd, 1e-8, _hip.ACT_GELU, qo, torch.float32),
             2.0 * M * N * K, 'mfma_i8', note=f'M={M} N={N} K={K}')
+        if M == 8192 or N == 3072:
+            # index-only output (y = NULL): what BERT's intermediate Linear runs inside quantized_bert_ffn
+            run('i8', f'integer Linear+GELU+quant INDEX-ONLY M={M} N={N} K={K}', 'linear_i8_lds_k',
+                lambda: be.linear_i8(x, w, rs, b, (xd, xz, 8, 1e-8), wd, 1e-8, _hip.ACT_GELU, qo, torch.float32,
+                                     want_idx=True, want_y=False),
+                2.0 * M * N * K, 'mfma_i8', note=f'M={M} N={N} K={K}, int8 indices only')
     # MobileBERT shapes (M = 1024 tokens): Linear 512 -> 128 with the residual NoNorm tail in its epilogue, and a whole
     # feed-forward block (128 -> 512 ReLU quant -> 128 + tail) as one launch
     M = 1024

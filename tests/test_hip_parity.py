@@ -362,6 +362,34 @@ def test_ste_backward_matches_autograd(q):
             assert torch.allclose(qz._zero_float.grad.cpu(), ref_dz, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize('symmetric', [False, True], ids=['asym', 'sym'])
+def test_ste_backward_log_scale_domain(symmetric):
+    """scale_domain='log' (scale = exp(delta), reference quantizers.py:142-147): tq_fake_quant_bwd's range gradients
+    d/d log(delta) against autograd through the oracle's op chain.  expf on the device and torch's CPU exp agree to
+    1 ulp only, so an index can flip where x / scale sits on a rounding tie: the element gradient is compared where the
+    forward index agrees (all but a handful), the parameter gradients at the tolerance of the linear-domain test."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(48, 96, generator=g) * 2.5
+    go = torch.randn(48, 96, generator=g)
+    log_delta = torch.log(torch.tensor(0.21))
+    zf = None if symmetric else torch.tensor(7.3)
+    sgn = torch.tensor(True) if symmetric else None
+    ref_y, ref_dx, ref_dd, ref_dz = O.fake_quant_with_grads(x, log_delta, zf, 4, symmetric, signed=True, grad_out=go,
+                                                            scale_domain='log')
+    y, _ = be.fake_quant(x.to(DEV), log_delta.to(DEV), None if zf is None else zf.to(DEV), None if sgn is None else
+                         sgn.to(DEV), 4, symmetric, True, 1e-8, 1, 1)
+    same = (y.cpu() - ref_y).abs() <= 1e-6 * ref_y.abs().clamp(min=1.0)
+    assert float(same.float().mean()) >= 0.999
+    gx, gd, gz = be.fake_quant_bwd(x.to(DEV), go.to(DEV), log_delta.to(DEV), None if zf is None else zf.to(DEV),
+                                   None if sgn is None else sgn.to(DEV), 4, symmetric, True, 1e-8, 1, 1, param_grads=True)
+    assert torch.allclose(gx.cpu()[same], ref_dx[same], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(gd.cpu().reshape(()), ref_dd, rtol=2e-3, atol=2e-2), (float(gd), float(ref_dd))
+    if not symmetric:
+        assert torch.allclose(gz.cpu().reshape(()), ref_dz, rtol=2e-3, atol=2e-2), (float(gz), float(ref_dz))
+
+
 # ------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE.json's full size: [B, S, 768] bf16 hidden states
 # ------------------------------------------------------------------------------------------
