@@ -280,7 +280,9 @@ int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mode, const fl
  * finalize otherwise); the caller all-reduces `stats` IN PLACE with MAX over RCCL (min and max fused into one
  * collective; exact, min/max are associative); tq_calibrate_apply then performs the estimator update +
  * range -> parameters (one launch) and, if y != NULL, the quantizer: 3 launches + 1 collective per
- * calibrating call.  Arguments as tq_calibrate_minmax; counter as tq_calibrate_tensor (may be NULL: always
+ * calibrating call -- 2 launches for a single range with FRESH output buffers (cur_* not aliasing prev_*) and
+ * 16-byte aligned x / y: every block of the quantizer launch re-derives the parameters from `stats`, block 0
+ * stores the new state (in-place state keeps the separate update launch: a block might still read prev_*).  Arguments as tq_calibrate_minmax; counter as tq_calibrate_tensor (may be NULL: always
  * the two-launch statistics); workspace tq_calibrate_workspace_bytes(n, n_params, inner).                  */
 int tq_calibrate_stats(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner,
                        float* stats, void* workspace, size_t workspace_bytes, uint32_t* counter,

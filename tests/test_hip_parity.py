@@ -722,3 +722,48 @@ def test_percentile_ranges_on_gpu(q):
         d, s = O.sym_params_from_range(torch.Tensor(r_lo), torch.Tensor(r_hi), 4)
         _, ref = O.fake_quant(w, d, None, 4, True, bool(s), per_channel=True)
         assert torch.equal(y.cpu(), ref)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('symmetric', [False, True], ids=['asym', 'sym'])
+@pytest.mark.parametrize('mode', [0, 1, 2], ids=['current', 'all', 'running'])
+def test_split_calibration_step_equals_the_single_gpu_step(mode, symmetric, dtype):
+    """tq_calibrate_stats + tq_calibrate_apply (the sharded step: statistics | exchange | update + quantize) against
+    tq_calibrate_minmax / tq_calibrate_tensor (one GPU) on the same tensor, over three batches: estimator state,
+    parameters and y bit-equal.  Fresh output buffers take the ONE-launch apply (fq_tensor_calib: every block re-derives
+    the parameters from the statistics), in-place state the separate update launch: both are checked, on a vectorised
+    tensor, a ragged one (scalar tail) and an unaligned view."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(5 + mode)
+    base = [torch.randn(3 * 128 * 96 + 8, generator=g) * (1.0 + i) for i in range(3)]
+    for view in ('vec', 'ragged', 'unaligned'):
+        def cut(t):
+            t = t.to(dtype).to(DEV)
+            if view == 'vec':
+                return t[:3 * 128 * 96].reshape(3, 128, 96)
+            if view == 'ragged':
+                return t[:3 * 128 * 96 + 5]
+            return t[1:3 * 128 * 96 + 1]
+        ref = [None, None]
+        fresh = [None, None]
+        inplace = None
+        for i, t in enumerate(base):
+            x = cut(t)
+            r = be.calibrate_minmax(x, 1, 1, mode, ref[0], ref[1], 0.9, 0, None, 8, symmetric, 1e-8, False)
+            ref = [r[0], r[1]]
+            f = be.calibrate_apply(be.calibrate_stats(x, 1, 1), x, 1, 1, mode, fresh[0], fresh[1], 0.9, 0, None, 8,
+                                   symmetric, 1e-8, False)
+            fresh = [f[0], f[1]]
+            if inplace is None:
+                inplace = tuple(None if v is None else v.clone() for v in f[:5])
+                ip = f
+            else:
+                ip = be.calibrate_apply(be.calibrate_stats(x, 1, 1), x, 1, 1, mode, inplace[0], inplace[1], 0.9, 0, None, 8,
+                                        symmetric, 1e-8, False, out=inplace)
+            for a, b, c in zip(r, f, ip):
+                if a is None:
+                    assert b is None and c is None
+                else:
+                    assert torch.equal(a, b), (view, i)
+                    assert torch.equal(a, c), (view, i)

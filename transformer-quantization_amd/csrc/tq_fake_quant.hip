@@ -167,6 +167,61 @@ __global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x,
   }
 }
 
+// ------------------------------------------------------------------------------ per tensor, parameters from statistics
+// The second half of a sharded per-tensor calibrating step (tq_calibrate_apply) without its own update launch: the
+// estimator rule (range_estimators.py:83-216) and range -> parameters (quantizers.py:258-259, 276-277, 335-339) are a
+// dozen scalar operations, so every block redoes them from the all-reduced [-min, max] and the previous state, in the
+// exact operation order of calib_update_k (tq_stats.hip), and quantizes its tile; block 0 stores the new state.
+template <int DT, bool NT, int U>
+__global__ __launch_bounds__(kBlock) void fq_tensor_calib(const u32x4* __restrict__ x, u32x4* __restrict__ y, uint64_t n,
+                                                          CalibApplyArgs c) {
+  constexpr int V = Store<DT>::kVec;
+  float a = -c.stats[0], b = c.stats[1];
+  if (!(c.mode == TQ_EST_CURRENT || c.prev_min == nullptr)) {
+    const float pa = c.prev_min[0], pb = c.prev_max[0];
+    if (c.mode == TQ_EST_ALL) { a = min_nanprop(pa, a); b = max_nanprop(pb, b); }
+    else { a = c.om * a + c.mom * pa; b = c.om * b + c.mom * pb; }
+  }
+  const float lo = min_nanprop(a, 0.0f), hi = max_nanprop(b, c.eps);
+  QP p;
+  float d_store, zf_store = 0.0f;
+  bool sgn = false;
+  if (c.symmetric) {
+    sgn = lo < 0.0f;
+    const float d = max_nanprop(fabsf(lo), hi) / grid_top(c.n_bits - (sgn ? 1 : 0));
+    d_store = c.log_domain ? logf(d) : d;
+    p.zp = 0.0f;
+    p.lo = sgn ? -(float)ldexp(1.0, c.n_bits - 1) : 0.0f;
+    p.hi = grid_top(c.n_bits - (sgn ? 1 : 0));
+  } else {
+    const float d = (hi - lo) / grid_top(c.n_bits);
+    zf_store = (-lo) / d;
+    d_store = c.log_domain ? logf(d) : d;
+    p.lo = 0.0f;
+    p.hi = grid_top(c.n_bits);
+    p.zp = clamp_nanprop(rintf(zf_store), p.lo, p.hi);
+  }
+  p.scale = c.log_domain ? expf(d_store) : (d_store < c.eps ? c.eps : d_store);      // make_qp on the stored values
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    c.cur_min[0] = a;
+    c.cur_max[0] = b;
+    c.delta[0] = d_store;
+    if (c.symmetric) c.signed_flag[0] = sgn ? 1 : 0;
+    else c.zero_float[0] = zf_store;
+  }
+  const QF qf = make_qf(p);
+  const uint64_t n_vec = n / V;
+  if (qf.ok) fq_tensor_tiles<DT, false, NT, U, true>(x, y, nullptr, TQ_IDX_NONE, n_vec, p, qf);
+  else fq_tensor_tiles<DT, false, NT, U, false>(x, y, nullptr, TQ_IDX_NONE, n_vec, p, qf);
+  const uint64_t tail0 = n_vec * V;
+  if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
+    typedef typename Store<DT>::elem_t E;
+    const uint64_t k = tail0 + threadIdx.x;
+    const float xi = q_index(Store<DT>::load1(reinterpret_cast<const E*>(x) + k), p);
+    Store<DT>::store1(reinterpret_cast<E*>(y) + k, q_dequant(xi, p));
+  }
+}
+
 // ------------------------------------------------------------------------------ last axis
 // x viewed as [rows, d]; d % V == 0.  LDS: scale[d], zp[d].  Same tiling as fq_tensor, but a block
 // owns TPB consecutive tiles so that the table fill (6 KB for d = 768) is paid once per 64 KiB of
@@ -525,6 +580,33 @@ static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t 
   const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, kBlock), 1), kMaxGrid);
   hipLaunchKernelGGL((fq_scalar<DT, HAS_IDX>), dim3(grid), dim3(kBlock), 0, st, x, y, idx, idx_dtype, n, q);
   return check_launch("fq_scalar");
+}
+
+template <int DT>
+static int launch_calib_fq(const void* x, void* y, uint64_t n, const CalibApplyArgs& c, hipStream_t st) {
+  constexpr int V = Store<DT>::kVec;
+  static const int nt_min_mb = tuning("TQ_NT_MIN_MB", 64);
+  const bool nt = (n * elem_size(DT)) >= ((uint64_t)nt_min_mb << 20);
+  const uint64_t n_vec_all = n / V;
+  const bool big = n_vec_all >= (uint64_t)kBlock * 4 * 2048;
+  const auto xv = static_cast<const u32x4*>(x);
+  auto yv = static_cast<u32x4*>(y);
+#define TQ_LAUNCH_CALIB(NTV, UV)                                                                           \
+  hipLaunchKernelGGL((fq_tensor_calib<DT, NTV, UV>),                                                        \
+                     dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n_vec_all, kBlock * UV), 1), kMaxTiles)), \
+                     dim3(kBlock), 0, st, xv, yv, n, c)
+  if (big) { if (nt) TQ_LAUNCH_CALIB(true, 4); else TQ_LAUNCH_CALIB(false, 4); }
+  else     { if (nt) TQ_LAUNCH_CALIB(true, 1); else TQ_LAUNCH_CALIB(false, 1); }
+#undef TQ_LAUNCH_CALIB
+  return check_launch("fq_tensor_calib");
+}
+
+int launch_fq_from_stats(const void* x, void* y, uint64_t n, int dtype, const CalibApplyArgs& c, hipStream_t st) {
+  switch (dtype) {
+    case TQ_F32: return launch_calib_fq<TQ_F32>(x, y, n, c, st);
+    case TQ_BF16: return launch_calib_fq<TQ_BF16>(x, y, n, c, st);
+    default: return launch_calib_fq<TQ_F16>(x, y, n, c, st);
+  }
 }
 
 // ------------------------------------------------------------------------------ STE backward

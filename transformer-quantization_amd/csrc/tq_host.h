@@ -30,6 +30,20 @@ inline int check_launch(const char* what) {
 
 int check_quantizer(const tq_quantizer* q, uint64_t n, const char* who);
 
+// Sharded per-tensor calibration, second half as ONE launch (tq_fake_quant.hip): every block derives the estimator
+// update and the quantizer parameters from the all-reduced statistics stats = [-min, max] in registers and quantizes its
+// tile with them; block 0 also writes the new state.  Requires fresh outputs (cur_* / delta / zero_float / signed_flag
+// must not alias prev_*: another block may still be reading the previous state) and 16-byte aligned x / y.
+struct CalibApplyArgs {
+  const float* stats;
+  const float *prev_min, *prev_max;
+  float *cur_min, *cur_max, *delta, *zero_float;
+  uint8_t* signed_flag;
+  int mode, n_bits, symmetric, log_domain;
+  float eps, om, mom;
+};
+int launch_fq_from_stats(const void* x, void* y, uint64_t n, int dtype, const CalibApplyArgs& c, hipStream_t st);
+
 }  // namespace tq
 
 #define TQ_REQUIRE(cond, ...)                                   \

@@ -767,6 +767,16 @@ extern "C" int tq_calibrate_apply(const float* stats, const void* x, uint64_t n,
   TQ_REQUIRE(n_params >= 1 && n_params <= kCalibMaxN, "tq_calibrate_apply: n_params=%llu > %u", (unsigned long long)n_params, kCalibMaxN);
   TQ_REQUIRE(n_groups == 0 || n_params % n_groups == 0, "tq_calibrate_apply: n_params %% n_groups != 0");
   TQ_REQUIRE(n_bits >= 1 && n_bits <= 24, "tq_calibrate_apply: n_bits=%d", n_bits);
+  // one range, fresh output buffers, vectorisable tensor: update + parameters + quantize as ONE launch (every block
+  // re-derives the dozen scalars; in-place state -- the hipGraph mode -- keeps the separate update launch below, since
+  // block 0's store could race another block's read of the previous state)
+  static const int fused_apply = tuning("TQ_CALIB_FUSED_APPLY", 1);
+  if (fused_apply && n_params == 1 && n_groups == 0 && y != nullptr && x != nullptr && aligned16(x) && aligned16(y) &&
+      cur_min != prev_min && cur_max != prev_max && (dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16)) {
+    CalibApplyArgs c{stats, prev_min, prev_max, cur_min, cur_max, delta, zero_float, signed_flag, mode, n_bits, symmetric,
+                     log_domain, eps, (float)(1.0 - momentum), (float)momentum};
+    return launch_fq_from_stats(x, y, n, dtype, c, static_cast<hipStream_t>(stream));
+  }
   const size_t lds = (2 * n_params + 2 * n_groups) * sizeof(float);
   hipLaunchKernelGGL(calib_update_k, dim3(1), dim3(n_params >= 256 ? 1024 : 256), lds, static_cast<hipStream_t>(stream), mode,
                      stats, stats + n_params, prev_min, prev_max, cur_min, cur_max, (uint32_t)n_params, momentum,
