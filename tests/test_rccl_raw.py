@@ -122,6 +122,6 @@ def test_raw_comm_without_a_process_group(tmp_path):
     script.write_text('ROOT = %r\n' % ROOT + NO_PG_WORKER)
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
-               MASTER_PORT=str(port))
+               MASTER_PORT=str(port), TQ_RCCL_STORE_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'RAW_RCCL_NO_PG_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
