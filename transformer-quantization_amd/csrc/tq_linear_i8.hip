@@ -58,6 +58,7 @@ struct LinArgs {
   tq_quantizer q_out1, q_out2;   // groups 1, 2 of a grouped launch (Q | K | V stacked along N)
   uint32_t group_cols;    // output columns per group (N for a plain launch); multiple of 64
   int fast_epi;           // 0 forces the generic epilogue (TQ_I8_FAST_EPI=0: A/B and tests)
+  int dbg;                // tools/tuning only (TQ_I8_DBG): 1 no epilogue, 2 no operand loads, 4 no MFMA
   // optional NoNorm tail fused behind the output quantizer (MobileBERT; models/quantized_mobilebert.py:58-72, 287-352):
   //   tail 1:  y = Q_t2( Q_out(v) * nn_w + nn_b )                       bottleneck Linear -> NoNorm
   //   tail 2:  y = Q_t2( Q_t1( Q_out(v) + residual ) * nn_w + nn_b )    Linear -> + residual -> NoNorm
@@ -498,82 +499,111 @@ __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
   constexpr int OPB = BT * 128, STB = 2 * OPB;    // bytes per operand tile / per stage
   extern __shared__ __attribute__((aligned(1024))) int8_t lds_i8[];   // [2 stages][W | X][BT rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t tiles_m = p.M / BT;
-  const uint32_t n0 = (blockIdx.x / tiles_m) * BT, m0 = (blockIdx.x % tiles_m) * BT;
+  const uint32_t tiles_m = p.M / BT, n_tiles = tiles_m * (p.N / BT);
   const int wn = (wave >> 1) * WT, wm = (wave & 1) * WT;
   const int r16 = lane & 15, kg = lane >> 4;
-
-  // loader: wave w moves rows [w WT / 2, (w + 1) WT / 2) of both tiles, 8 rows per instruction
-  const int8_t* wsrc[LPW];
-  const int8_t* xsrc[LPW];
-#pragma unroll
-  for (int q = 0; q < LPW; ++q) {
-    const int row = wave * (WT / 2) + q * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    wsrc[q] = p.w + (size_t)(n0 + row) * p.K + chunk * 16;
-    xsrc[q] = p.x + (size_t)(m0 + row) * p.K + chunk * 16;
-  }
-  auto issue = [&](int stage, uint32_t k) {
-    int8_t* bw = lds_i8 + stage * STB + wave * (WT / 2) * 128;
-#pragma unroll
-    for (int q = 0; q < LPW; ++q) {
-      TQ_GLDS16(wsrc[q] + k, bw + q * 1024);
-      TQ_GLDS16(xsrc[q] + k, bw + OPB + q * 1024);
-    }
-  };
   // reader: k chunk c = 4 s + kg of row (16-aligned base) + r16 sits in slot c ^ ((r16 >> 1) & 7)
   const int swz = (r16 >> 1) & 7;
   const int off[2] = {r16 * 128 + ((kg ^ swz) << 4), r16 * 128 + (((4 + kg) ^ swz) << 4)};
-
-  v4i acc[NI][MI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j) acc[i][j] = v4i{0, 0, 0, 0};
-
-  // everything read through pointers first, as independent loads in flight together with the first slab: the
-  // quantizers' range buffers (epilogue parameters) and the per-column scale / bias / row sum this thread turns into
-  // LDS constants [BT scale | BT bias | BT correction | BT NoNorm weight | BT NoNorm bias] (published by the loop's
-  // first barrier)
-  const EpiCtx ectx = epilogue_prepare<WITH_TAIL>(p, n0 + wn);
-  const uint32_t ncol = n0 + (tid & (BT - 1));     // threads >= BT load duplicates and do not write
-  const float ld_dw = p.w_delta[p.w_n_params == 1 ? 0 : ncol], ld_b = p.bias ? p.bias[ncol] : 0.0f;
-  const int ld_rs = p.w_rowsum[ncol];
-  float ld_nw = 0.0f, ld_nb = 0.0f;
-  if (WITH_TAIL) { ld_nw = p.nn_w[ncol]; ld_nb = p.nn_b[ncol]; }
-  issue(0, 0);
   float* cst = reinterpret_cast<float*>(lds_i8 + 2 * STB);
-  if (tid < BT) {
-    cst[tid] = ectx.sx * (ld_dw < p.w_eps ? p.w_eps : ld_dw);
-    cst[BT + tid] = ld_b;
-    reinterpret_cast<int*>(cst)[2 * BT + tid] = ld_rs * ectx.shift;
-    if (WITH_TAIL) { cst[3 * BT + tid] = ld_nw; cst[4 * BT + tid] = ld_nb; }
-  }
   const uint32_t nk = p.K / 128;
-  for (uint32_t kb = 0; kb < nk; ++kb) {
-    lds_dma_wait_all();
-    __syncthreads();                              // slab kb landed (vmcnt(0) + barrier); slab kb - 1 is no longer read
-    if (kb + 1 < nk) issue((kb + 1) & 1, (kb + 1) * 128);
-    const int8_t* bw = lds_i8 + (kb & 1) * STB + wn * 128;
-    const int8_t* bx = lds_i8 + (kb & 1) * STB + OPB + wm * 128;
+
+  // PERSISTENT tiles: a block owns a contiguous run of output tiles (consecutive token tiles of one feature tile, so
+  // the per-column constants and the quantizer parameters are loaded once per run).  Launching one workgroup per
+  // 128 x 128 tile cost ~4 us of dispatch + dependent parameter loads + first-slab latency per tile -- more than the 6
+  // K slabs of MFMA work at K = 768 (tools/tuning/i8_dbg.py: the barrier / LDS-read skeleton alone was 17 of 50 us at
+  // M = 8192).  Two such blocks are resident per CU; one's epilogue (VALU) runs against the other's main loop.
+  const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const uint32_t t_begin = blockIdx.x * per, t_end = min(n_tiles, t_begin + per);
+  uint32_t cur_n0 = 0xffffffffu;
+  EpiCtx ectx{};
+  for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+    const uint32_t n0 = (tile / tiles_m) * BT, m0 = (tile % tiles_m) * BT;
+    // loader: wave w moves rows [w WT / 2, (w + 1) WT / 2) of both tiles, 8 rows per instruction
+    const int8_t* wsrc[LPW];
+    const int8_t* xsrc[LPW];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      v4i fw[NI], fx[MI];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) fw[i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
-#pragma unroll
-      for (int j = 0; j < MI; ++j) fx[j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s]);
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[i], fx[j], acc[i][j], 0, 0, 0);
+    for (int q = 0; q < LPW; ++q) {
+      const int row = wave * (WT / 2) + q * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      wsrc[q] = p.w + (size_t)(n0 + row) * p.K + chunk * 16;
+      xsrc[q] = p.x + (size_t)(m0 + row) * p.K + chunk * 16;
     }
+    auto issue = [&](int stage, uint32_t k) {
+      int8_t* bw = lds_i8 + stage * STB + wave * (WT / 2) * 128;
+#pragma unroll
+      for (int q = 0; q < LPW; ++q) {
+        TQ_GLDS16(wsrc[q] + k, bw + q * 1024);
+        TQ_GLDS16(xsrc[q] + k, bw + OPB + q * 1024);
+      }
+    };
+
+    v4i acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+    // the previous tile's epilogue used the operand stages as output staging and read the column constants: everybody
+    // must be done with both before the next slab / the next constants land
+    if (tile != t_begin) __syncthreads();
+    const bool new_cols = n0 != cur_n0;
+    float ld_dw = 0.0f, ld_b = 0.0f, ld_nw = 0.0f, ld_nb = 0.0f;
+    int ld_rs = 0;
+    if (new_cols) {
+      // everything read through pointers first, as independent loads in flight together with the first slab: the
+      // quantizers' range buffers (epilogue parameters) and the per-column scale / bias / row sum this thread turns into
+      // LDS constants [BT scale | BT bias | BT correction | BT NoNorm weight | BT NoNorm bias] (published by the loop's
+      // first barrier)
+      ectx = epilogue_prepare<WITH_TAIL>(p, n0 + wn);
+      const uint32_t ncol = n0 + (tid & (BT - 1));     // threads >= BT load duplicates and do not write
+      ld_dw = p.w_delta[p.w_n_params == 1 ? 0 : ncol];
+      ld_b = p.bias ? p.bias[ncol] : 0.0f;
+      ld_rs = p.w_rowsum[ncol];
+      if (WITH_TAIL) { ld_nw = p.nn_w[ncol]; ld_nb = p.nn_b[ncol]; }
+      cur_n0 = n0;
+    }
+    issue(0, 0);
+    if (new_cols && tid < BT) {
+      cst[tid] = ectx.sx * (ld_dw < p.w_eps ? p.w_eps : ld_dw);
+      cst[BT + tid] = ld_b;
+      reinterpret_cast<int*>(cst)[2 * BT + tid] = ld_rs * ectx.shift;
+      if (WITH_TAIL) { cst[3 * BT + tid] = ld_nw; cst[4 * BT + tid] = ld_nb; }
+    }
+    for (uint32_t kb = 0; kb < nk; ++kb) {
+      lds_dma_wait_all();
+      __syncthreads();                              // slab kb landed (vmcnt(0) + barrier); slab kb - 1 is no longer read
+      if (kb + 1 < nk && !(p.dbg & 2)) issue((kb + 1) & 1, (kb + 1) * 128);
+      const int8_t* bw = lds_i8 + (kb & 1) * STB + wn * 128;
+      const int8_t* bx = lds_i8 + (kb & 1) * STB + OPB + wm * 128;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        v4i fw[NI], fx[MI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fw[i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) fx[j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s]);
+        if (p.dbg & 4) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) acc[i][0] = acc[i][0] + fw[i] + fx[i % MI];
+          continue;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < MI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[i], fx[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                // the operand stages become the waves' output staging areas
+    if (p.dbg & 1) {
+      if (acc[0][0][0] == 0x7fffffff) p.y_idx[0] = 1;   // keep the accumulators alive
+      continue;
+    }
+    constexpr int kStageBytes = 32 * (WT * 4 + 16) + 32 * (WT + 16);
+    static_assert(4 * kStageBytes <= 2 * STB, "output staging must fit the operand stages");
+    linear_epilogue<NI, MI, YDT, true, WITH_TAIL>(p, acc, n0 + wn, m0 + wm, r16, kg, ectx, lds_i8 + wave * kStageBytes, cst + wn);
   }
-  __syncthreads();                                // the operand stages become the waves' output staging areas
-  constexpr int kStageBytes = 32 * (WT * 4 + 16) + 32 * (WT + 16);
-  static_assert(4 * kStageBytes <= 2 * STB, "output staging must fit the operand stages");
-  linear_epilogue<NI, MI, YDT, true, WITH_TAIL>(p, acc, n0 + wn, m0 + wm, r16, kg, ectx, lds_i8 + wave * kStageBytes, cst + wn);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -822,9 +852,16 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
   if (a.K % 128 == 0 && a.M % 64 == 0 && a.N % 64 == 0 && tuning("TQ_I8_LDS", 1)) {
     // 128 x 128 block tiles once they still give >= 4 blocks per CU, else 64 x 64
     const bool big = a.M % 128 == 0 && a.N % 128 == 0 && (uint64_t)(a.M / 128) * (a.N / 128) >= (uint64_t)tuning("TQ_I8_BIG_MIN", 1024);
-    if (big) hipLaunchKernelGGL((linear_i8_lds_k<64, YDT, WITH_TAIL>), dim3((a.M / 128) * (a.N / 128)), dim3(kBlock),
-                                2 * 2 * 128 * 128 + 5 * 128 * 4, st, a);
-    else     hipLaunchKernelGGL((linear_i8_lds_k<32, YDT, WITH_TAIL>), dim3((a.M / 64) * (a.N / 64)), dim3(kBlock),
+    // persistent blocks: as many as are resident at once (128 x 128: 2 per CU by registers; 64 x 64: 4), each
+    // working through a contiguous run of tiles; TQ_I8_PERSIST=0 launches one block per tile (A/B)
+    static const int persist = tuning("TQ_I8_PERSIST", 1);
+    const uint64_t tiles = big ? (uint64_t)(a.M / 128) * (a.N / 128) : (uint64_t)(a.M / 64) * (a.N / 64);
+    const uint64_t resident = 256ull * (big ? 2 : 4);
+    uint64_t grid = persist ? std::min<uint64_t>(tiles, resident) : tiles;
+    if (persist && tiles > resident) grid = ceil_div(tiles, ceil_div(tiles, resident));   // equal runs, no idle tail blocks
+    if (big) hipLaunchKernelGGL((linear_i8_lds_k<64, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock),
+                                2 * 2 * 128 * 128 + 5 * 128 * 4 + (size_t)tuning("TQ_I8_LDS_PAD", 0), st, a);
+    else     hipLaunchKernelGGL((linear_i8_lds_k<32, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock),
                                 2 * 2 * 64 * 128 + 5 * 64 * 4, st, a);
     return check_launch("linear_i8_lds_k");
   }
@@ -837,6 +874,7 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
 template <int YDT>
 static int launch_linear(LinArgs a, hipStream_t st) {
   a.fast_epi = tuning("TQ_I8_FAST_EPI", 1);
+  a.dbg = tuning("TQ_I8_DBG", 0);
   return a.tail ? launch_linear_t<YDT, true>(a, st) : launch_linear_t<YDT, false>(a, st);
 }
 
