@@ -493,7 +493,8 @@ __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmc
                                    (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 
 template <int WT, int YDT, bool WITH_TAIL>
-__global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
+__global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinArgs p) {   // 2 (128 x 128 tiles) / 4 waves per SIMD
+  constexpr bool PERSIST = WT == 64;              // 64 x 64 tiles: one tile per block (the run loop cost it 70 VGPRs)
   constexpr int BT = 2 * WT, NI = WT / 16, MI = WT / 16;
   constexpr int LPW = WT / 16;                    // 1 KB load instructions per wave, operand and slab
   constexpr int OPB = BT * 128, STB = 2 * OPB;    // bytes per operand tile / per stage
@@ -513,8 +514,8 @@ __global__ __launch_bounds__(kBlock) void linear_i8_lds_k(LinArgs p) {
   // 128 x 128 tile cost ~4 us of dispatch + dependent parameter loads + first-slab latency per tile -- more than the 6
   // K slabs of MFMA work at K = 768 (tools/tuning/i8_dbg.py: the barrier / LDS-read skeleton alone was 17 of 50 us at
   // M = 8192).  Two such blocks are resident per CU; one's epilogue (VALU) runs against the other's main loop.
-  const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
-  const uint32_t t_begin = blockIdx.x * per, t_end = min(n_tiles, t_begin + per);
+  const uint32_t per = PERSIST ? (n_tiles + gridDim.x - 1) / gridDim.x : 1u;
+  const uint32_t t_begin = blockIdx.x * per, t_end = PERSIST ? min(n_tiles, t_begin + per) : t_begin + 1;
   uint32_t cur_n0 = 0xffffffffu;
   EpiCtx ectx{};
   for (uint32_t tile = t_begin; tile < t_end; ++tile) {
@@ -852,13 +853,13 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
   if (a.K % 128 == 0 && a.M % 64 == 0 && a.N % 64 == 0 && tuning("TQ_I8_LDS", 1)) {
     // 128 x 128 block tiles once they still give >= 4 blocks per CU, else 64 x 64
     const bool big = a.M % 128 == 0 && a.N % 128 == 0 && (uint64_t)(a.M / 128) * (a.N / 128) >= (uint64_t)tuning("TQ_I8_BIG_MIN", 1024);
-    // persistent blocks: as many as are resident at once (128 x 128: 2 per CU by registers; 64 x 64: 4), each
-    // working through a contiguous run of tiles; TQ_I8_PERSIST=0 launches one block per tile (A/B)
+    // 128 x 128 tiles: persistent blocks, as many as are resident at once (2 per CU by registers), each working
+    // through a contiguous run of tiles; TQ_I8_PERSIST=0 launches one block per tile (A/B).  64 x 64: one per tile.
     static const int persist = tuning("TQ_I8_PERSIST", 1);
     const uint64_t tiles = big ? (uint64_t)(a.M / 128) * (a.N / 128) : (uint64_t)(a.M / 64) * (a.N / 64);
-    const uint64_t resident = 256ull * (big ? 2 : 4);
-    uint64_t grid = persist ? std::min<uint64_t>(tiles, resident) : tiles;
-    if (persist && tiles > resident) grid = ceil_div(tiles, ceil_div(tiles, resident));   // equal runs, no idle tail blocks
+    const uint64_t resident = 256ull * 2;
+    uint64_t grid = (persist && big) ? std::min<uint64_t>(tiles, resident) : tiles;
+    if (persist && big && tiles > resident) grid = ceil_div(tiles, ceil_div(tiles, resident));   // equal runs, no idle tail blocks
     if (big) hipLaunchKernelGGL((linear_i8_lds_k<64, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock),
                                 2 * 2 * 128 * 128 + 5 * 128 * 4 + (size_t)tuning("TQ_I8_LDS_PAD", 0), st, a);
     else     hipLaunchKernelGGL((linear_i8_lds_k<32, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock),
