@@ -71,12 +71,19 @@ def enable(group=None, force=False, mailbox=None, raw=None):
     active = force or dist.get_world_size(group) > 1
     if active and _want_raw(group, raw):
         from quantization.rccl import RawRcclComm
-        comm = RawRcclComm()                    # collective: every rank takes this branch (same env, same backend)
-        if comm.self_test():
-            _raw = comm
-        else:
-            logger.warning('raw RCCL self-test failed: statistics go through torch.distributed')
-            comm.close()
+        try:
+            comm = RawRcclComm()                # collective: every rank takes this branch (same env, same backend)
+        except Exception as e:      # noqa: BLE001 -- librccl not loadable / communicator refused: the same on every rank
+            if raw:                 # explicitly requested: do not hide it
+                raise
+            logger.warning('raw RCCL exchange unavailable (%s): statistics go through torch.distributed', e)
+            comm = None
+        if comm is not None:
+            if comm.self_test():
+                _raw = comm
+            else:
+                logger.warning('raw RCCL self-test failed: statistics go through torch.distributed')
+                comm.close()
     if mailbox and torch.cuda.is_available() and active:
         box = None
         try:
