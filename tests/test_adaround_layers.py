@@ -92,7 +92,7 @@ def _run(z, meta, device, exact):
         got = np.array([res.loss_soft_before, res.loss_hard_before, res.loss_soft_after, res.loss_hard_after])
         ref = z[f'l{k}_losses']
         # (soft loss before optimisation is round-off of an exact zero: h(alpha_0) == frac(w / s))
-        assert np.allclose(got[1:], ref[1:], rtol=1e-6 if exact else 2e-2), (lname, got, ref)
+        assert np.allclose(got[1:], ref[1:], rtol=1e-6 if exact else 1e-4), (lname, got, ref)
         assert got[0] <= max(4 * ref[0], 1e-12), (lname, got[0], ref[0])
         lr = c['lr']
         if lname == 'emb':
@@ -106,12 +106,12 @@ def _run(z, meta, device, exact):
                 assert n_up == ref_up and bad_rows == 0
             else:
                 dev = (a_rows - a_ref).abs()
-                # untouched rows (second half of the sample) only see the regulariser: a deterministic trajectory
-                assert torch.allclose(a_rows[48:], a_ref[48:], rtol=1e-3, atol=2e-4), float(dev[48:].max())
-                assert float((dev <= 3 * lr).float().mean()) >= 0.95 and float(dev.max()) <= 12 * lr, (
-                    float((dev <= 3 * lr).float().mean()), float(dev.max()))
+                # measured on MI355X: max deviation 1.2e-4 lr on the touched rows (embedding backward = atomics, the
+                # step kernel's 1-ulp transcendentals), 5e-6 on the untouched ones, identical round-ups
+                assert torch.allclose(a_rows[48:], a_ref[48:], rtol=1e-4, atol=2e-5), float(dev[48:].max())
+                assert float(dev.max()) <= 0.05 * lr, float(dev.max())
                 # round-ups: only entries whose alpha ends within round-off of 0 may differ, out of 23.4 M
-                assert abs(n_up - ref_up) <= 64 and bad_rows <= 64, (n_up, ref_up, bad_rows)
+                assert abs(n_up - ref_up) <= 4 and bad_rows <= 4, (n_up, ref_up, bad_rows)
         else:
             a_ref = torch.from_numpy(z[f'l{k}_alpha'])
             dev = (alpha.cpu() - a_ref).abs()
@@ -120,9 +120,8 @@ def _run(z, meta, device, exact):
                 assert torch.allclose(alpha.cpu(), a_ref, rtol=2e-4, atol=2e-5), float(dev.max())
                 assert flips == 0
             else:
-                assert float((dev <= 3 * lr).float().mean()) >= 0.95 and float(dev.max()) <= 12 * lr, (
-                    float((dev <= 3 * lr).float().mean()), float(dev.max()))
-                assert flips <= 8, flips
+                assert float(dev.max()) <= 0.05 * lr, float(dev.max())           # measured: 1e-4 lr
+                assert flips <= 2, flips
 
 
 def test_adaround_embedding_and_layernorm_cpu(layers_fx):
