@@ -1,5 +1,6 @@
 """Where the time of the fused integer Linear goes at M = 8192 (768 -> 3072, GELU + quantizer, index-only):
-TQ_I8_DBG bit 1 = no epilogue, 2 = no operand loads, 4 = no MFMA (tq_linear_i8.hip, read per call)."""
+TQ_I8_DBG bit 1 = no epilogue, 2 = no operand loads, 4 = no MFMA (tq_linear_i8.hip, read per call).
+Needs a breakdown build:  TQ_EXTRA_HIPCC_FLAGS=-DTQ_I8_DBG_BUILD python transformer-quantization_amd/build.py --force"""
 import os, sys, time
 sys.path.insert(0, '/root/repo/transformer-quantization_amd'); sys.path.insert(0, '/root/repo')
 import torch

@@ -41,6 +41,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    extra = os.environ.get('TQ_EXTRA_HIPCC_FLAGS', '').split()      # e.g. -DTQ_I8_DBG_BUILD for tools/tuning/i8_dbg.py
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hdrs = _headers()
@@ -49,7 +50,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+            cmd = [hipcc] + FLAGS + extra + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

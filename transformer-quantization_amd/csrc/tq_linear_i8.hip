@@ -58,7 +58,7 @@ struct LinArgs {
   tq_quantizer q_out1, q_out2;   // groups 1, 2 of a grouped launch (Q | K | V stacked along N)
   uint32_t group_cols;    // output columns per group (N for a plain launch); multiple of 64
   int fast_epi;           // 0 forces the generic epilogue (TQ_I8_FAST_EPI=0: A/B and tests)
-  int dbg;                // tools/tuning only (TQ_I8_DBG): 1 no epilogue, 2 no operand loads, 4 no MFMA
+  int dbg;                // breakdown builds only (-DTQ_I8_DBG_BUILD, env TQ_I8_DBG): 1 no epilogue, 2 no operand loads, 4 no MFMA
   // optional NoNorm tail fused behind the output quantizer (MobileBERT; models/quantized_mobilebert.py:58-72, 287-352):
   //   tail 1:  y = Q_t2( Q_out(v) * nn_w + nn_b )                       bottleneck Linear -> NoNorm
   //   tail 2:  y = Q_t2( Q_t1( Q_out(v) + residual ) * nn_w + nn_b )    Linear -> + residual -> NoNorm
@@ -574,7 +574,11 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
     for (uint32_t kb = 0; kb < nk; ++kb) {
       lds_dma_wait_all();
       __syncthreads();                              // slab kb landed (vmcnt(0) + barrier); slab kb - 1 is no longer read
+#ifdef TQ_I8_DBG_BUILD
       if (kb + 1 < nk && !(p.dbg & 2)) issue((kb + 1) & 1, (kb + 1) * 128);
+#else
+      if (kb + 1 < nk) issue((kb + 1) & 1, (kb + 1) * 128);
+#endif
       const int8_t* bw = lds_i8 + (kb & 1) * STB + wn * 128;
       const int8_t* bx = lds_i8 + (kb & 1) * STB + OPB + wm * 128;
 #pragma unroll
@@ -584,11 +588,13 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
         for (int i = 0; i < NI; ++i) fw[i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
 #pragma unroll
         for (int j = 0; j < MI; ++j) fx[j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s]);
+#ifdef TQ_I8_DBG_BUILD
         if (p.dbg & 4) {
 #pragma unroll
           for (int i = 0; i < NI; ++i) acc[i][0] = acc[i][0] + fw[i] + fx[i % MI];
           continue;
         }
+#endif
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -597,10 +603,12 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
       }
     }
     __syncthreads();                                // the operand stages become the waves' output staging areas
+#ifdef TQ_I8_DBG_BUILD
     if (p.dbg & 1) {
       if (acc[0][0][0] == 0x7fffffff) p.y_idx[0] = 1;   // keep the accumulators alive
       continue;
     }
+#endif
     constexpr int kStageBytes = 32 * (WT * 4 + 16) + 32 * (WT + 16);
     static_assert(4 * kStageBytes <= 2 * STB, "output staging must fit the operand stages");
     linear_epilogue<NI, MI, YDT, true, WITH_TAIL>(p, acc, n0 + wn, m0 + wm, r16, kg, ectx, lds_i8 + wave * kStageBytes, cst + wn);
