@@ -494,7 +494,8 @@ __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmc
 
 template <int WT, int YDT, bool WITH_TAIL>
 __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinArgs p) {   // 2 (128 x 128 tiles) / 4 waves per SIMD
-  constexpr bool PERSIST = WT == 64;              // 64 x 64 tiles: one tile per block (the run loop cost it 70 VGPRs)
+  constexpr bool PERSIST = false;                 // tile runs per block: measured +3 % for +50 VGPRs; the registers go to
+                                                  // the fragment pipeline below instead (launcher: TQ_I8_PERSIST)
   constexpr int BT = 2 * WT, NI = WT / 16, MI = WT / 16;
   constexpr int LPW = WT / 16;                    // 1 KB load instructions per wave, operand and slab
   constexpr int OPB = BT * 128, STB = 2 * OPB;    // bytes per operand tile / per stage
@@ -581,17 +582,25 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
 #endif
       const int8_t* bw = lds_i8 + (kb & 1) * STB + wn * 128;
       const int8_t* bx = lds_i8 + (kb & 1) * STB + OPB + wm * 128;
+      // Fragment pipeline: the 8 LDS reads of k-step s + 1 are in flight under the 16 MFMAs of k-step s (two fragment
+      // sets in registers).  Left to itself the scheduler issued one ds_read, waited for it with lgkmcnt(0), ran four
+      // MFMAs, and repeated: eight exposed LDS latencies per slab, the matrix cores idle in between.
+      v4i fw[2][NI], fx[2][MI];
+      auto load_frags = [&](int s2) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fw[s2][i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s2]);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) fx[s2][j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s2]);
+      };
+      load_frags(0);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        v4i fw[NI], fx[MI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) fw[i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
-#pragma unroll
-        for (int j = 0; j < MI; ++j) fx[j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s]);
+        if (s == 0) load_frags(1);
+        __builtin_amdgcn_sched_barrier(0);          // keep the reads above, the MFMAs below
 #ifdef TQ_I8_DBG_BUILD
         if (p.dbg & 4) {
 #pragma unroll
-          for (int i = 0; i < NI; ++i) acc[i][0] = acc[i][0] + fw[i] + fx[i % MI];
+          for (int i = 0; i < NI; ++i) acc[i][0] = acc[i][0] + fw[s][i] + fx[s][i % MI];
           continue;
         }
 #endif
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < MI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[i], fx[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[s][i], fx[s][j], acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();                                // the operand stages become the waves' output staging areas
@@ -863,7 +872,7 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     const bool big = a.M % 128 == 0 && a.N % 128 == 0 && (uint64_t)(a.M / 128) * (a.N / 128) >= (uint64_t)tuning("TQ_I8_BIG_MIN", 1024);
     // 128 x 128 tiles: persistent blocks, as many as are resident at once (2 per CU by registers), each working
     // through a contiguous run of tiles; TQ_I8_PERSIST=0 launches one block per tile (A/B).  64 x 64: one per tile.
-    static const int persist = tuning("TQ_I8_PERSIST", 1);
+    static const int persist = 0;   // (kernel built with PERSIST = false)
     const uint64_t tiles = big ? (uint64_t)(a.M / 128) * (a.N / 128) : (uint64_t)(a.M / 64) * (a.N / 64);
     const uint64_t resident = 256ull * 2;
     uint64_t grid = (persist && big) ? std::min<uint64_t>(tiles, resident) : tiles;
