@@ -213,8 +213,10 @@ def _device_guarded(fn):
         # hot path (launch-bound calibration makes 263 such calls per batch): one pass over the positional operands
         idx = -1
         for a in args:
-            if isinstance(a, _Tensor) and a.is_cuda:
-                i = a.device.index
+            if isinstance(a, _Tensor):
+                i = a.get_device()              # device index, -1 for host tensors: one call instead of is_cuda + device.index
+                if i < 0:
+                    continue
                 if idx < 0:
                     idx = i
                 elif i != idx:
