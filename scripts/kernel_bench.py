@@ -111,11 +111,14 @@ def fam_tails():
                 note=f'dtype code {code}, NoNorm (affine_only)')
             run('tails', f'NoNorm affine+quant {name} [{rows},{d}]', f'fq_affine<{code}',
                 lambda: be.affine_fake_quant(a, w, b, *q3), 2 * es * a.numel(), 'hbm')
-    s = torch.randn(64, 12, 128, 128, device=dev)
-    mask = torch.zeros(64, 128, device=dev)
     qs, qp = q7(0.5, 128.0), q7(0.004, 0.0)
-    run('tails', 'scores->softmax->probs fp32 [64,12,128,128]', 'softmax_quant_k',
-        lambda: be.scores_softmax_quant(s, mask, 12 * 128, 8.0, qs, qp), 8 * s.numel(), 'hbm')
+    # [64,...]: 100 MB of traffic, MALL-sized and short (ramp-up / tail are ~15 % of 22 us); [256,...]: 403 MB, HBM-bound
+    for B in (64, 256):
+        s = torch.randn(B, 12, 128, 128, device=dev)
+        mask = torch.zeros(B, 128, device=dev)
+        run('tails', f'scores->softmax->probs fp32 [{B},12,128,128]', 'softmax_quant_k',
+            lambda: be.scores_softmax_quant(s, mask, 12 * 128, 8.0, qs, qp), 8 * s.numel(), 'hbm')
+        del s, mask
 
 
 def fam_mse():
