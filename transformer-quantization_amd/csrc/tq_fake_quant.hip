@@ -176,7 +176,28 @@ template <int DT, bool NT, int U>
 __global__ __launch_bounds__(kBlock) void fq_tensor_calib(const u32x4* __restrict__ x, u32x4* __restrict__ y, uint64_t n,
                                                           CalibApplyArgs c) {
   constexpr int V = Store<DT>::kVec;
-  float a = -c.stats[0], b = c.stats[1];
+  float a, b;
+  if (c.partials != nullptr) {
+    // single-GPU step: the statistics launch left one (min, max) pair per block; every block folds the <= 512 pairs
+    // itself (4 KB from L2) -- no last-block ticket, no device-scope fence in the statistics kernel
+    __shared__ float s_mm[2][kBlock / kWave];
+    float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
+    for (uint32_t t = threadIdx.x; t < c.n_partials; t += kBlock) {
+      mn = min_nanprop(mn, c.partials[2 * t]);
+      mx = max_nanprop(mx, c.partials[2 * t + 1]);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((threadIdx.x & (kWave - 1)) == 0) { s_mm[0][threadIdx.x / kWave] = mn; s_mm[1][threadIdx.x / kWave] = mx; }
+    __syncthreads();
+    a = s_mm[0][0];
+    b = s_mm[1][0];
+#pragma unroll
+    for (int k = 1; k < kBlock / kWave; ++k) { a = min_nanprop(a, s_mm[0][k]); b = max_nanprop(b, s_mm[1][k]); }
+  } else {
+    a = -c.stats[0];
+    b = c.stats[1];
+  }
   if (!(c.mode == TQ_EST_CURRENT || c.prev_min == nullptr)) {
     const float pa = c.prev_min[0], pb = c.prev_max[0];
     if (c.mode == TQ_EST_ALL) { a = min_nanprop(pa, a); b = max_nanprop(pb, b); }

@@ -32,10 +32,13 @@ int check_quantizer(const tq_quantizer* q, uint64_t n, const char* who);
 
 // Sharded per-tensor calibration, second half as ONE launch (tq_fake_quant.hip): every block derives the estimator
 // update and the quantizer parameters from the all-reduced statistics stats = [-min, max] in registers and quantizes its
-// tile with them; block 0 also writes the new state.  Requires fresh outputs (cur_* / delta / zero_float / signed_flag
-// must not alias prev_*: another block may still be reading the previous state) and 16-byte aligned x / y.
+// tile with them; block 0 also writes the new state.  Requires 16-byte aligned x / y, and that no block reads memory
+// block 0 writes: cur_* / delta / zero_float / signed_flag must not alias prev_* (the single-GPU step hands over a COPY
+// of the previous state that its statistics launch made, so in-place state is fine there).
 struct CalibApplyArgs {
-  const float* stats;
+  const float* stats;             // [-min, max] (sharded step: all-reduced), or NULL with `partials`
+  const float* partials;          // single-GPU step: per-block (min, max) pairs of the statistics launch, [n_partials][2]
+  uint32_t n_partials;
   const float *prev_min, *prev_max;
   float *cur_min, *cur_max, *delta, *zero_float;
   uint8_t* signed_flag;
