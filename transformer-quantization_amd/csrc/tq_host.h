@@ -47,6 +47,16 @@ struct CalibApplyArgs {
 };
 int launch_fq_from_stats(const void* x, void* y, uint64_t n, int dtype, const CalibApplyArgs& c, hipStream_t st);
 
+// halves of the one-call sharded steps (tq_stats.hip); `stats` scratch of >= 4 floats
+int calibrate_stats_for_exchange(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner, float* stats,
+                                 void* workspace, size_t workspace_bytes, uint32_t* counter, const float* prev_min,
+                                 const float* prev_max, int* prev_in_stats, tq_stream_t stream);
+int calibrate_apply_after_exchange(const float* stats, const void* x, uint64_t n, int dtype, uint64_t n_params,
+                                   uint64_t inner, int mode, const float* prev_min, const float* prev_max, float* cur_min,
+                                   float* cur_max, double momentum, uint64_t n_groups, const int64_t* order, int n_bits,
+                                   int symmetric, float eps, int log_domain, float* delta, float* zero_float,
+                                   uint8_t* signed_flag, void* y, int prev_in_stats, tq_stream_t stream);
+
 }  // namespace tq
 
 #define TQ_REQUIRE(cond, ...)                                   \

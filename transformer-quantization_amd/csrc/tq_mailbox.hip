@@ -187,8 +187,11 @@ extern "C" int tq_calibrate_minmax_mailbox(const void* x, uint64_t n, int dtype,
   TQ_REQUIRE(workspace && workspace_bytes >= stats_bytes, "tq_calibrate_minmax_mailbox: workspace too small");
   float* stats = static_cast<float*>(workspace);
   char* rest = static_cast<char*>(workspace) + stats_bytes;
-  if (int e = tq_calibrate_stats(x, n, dtype, n_params, inner, stats, rest, workspace_bytes - stats_bytes, counter, stream)) return e;
+  int prev_in_stats = 0;
+  if (int e = calibrate_stats_for_exchange(x, n, dtype, n_params, inner, stats, rest, workspace_bytes - stats_bytes, counter,
+                                           prev_min, prev_max, &prev_in_stats, stream)) return e;
   if (int e = tq_mailbox_allreduce_max(stats, 2 * n_params, my_base, peer_bases, world, rank, status, spin_budget, stream)) return e;
-  return tq_calibrate_apply(stats, x, n, dtype, n_params, inner, mode, prev_min, prev_max, cur_min, cur_max, momentum, n_groups,
-                            order, n_bits, symmetric, eps, log_domain, delta, zero_float, signed_flag, y, stream);
+  return calibrate_apply_after_exchange(stats, x, n, dtype, n_params, inner, mode, prev_min, prev_max, cur_min, cur_max, momentum,
+                                        n_groups, order, n_bits, symmetric, eps, log_domain, delta, zero_float, signed_flag, y,
+                                        prev_in_stats, stream);
 }

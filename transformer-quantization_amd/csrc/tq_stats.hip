@@ -529,6 +529,10 @@ __global__ __launch_bounds__(kBlock) void calib_tensor_k(const void* __restrict_
   if (stats_out != nullptr) {            // sharded calibration: the exchange happens between this and the update
     stats_out[0] = -mn;
     stats_out[1] = mx;
+    if (prev_min != nullptr) {           // one-call sharded steps: a copy of the previous state behind the statistics, so
+      stats_out[2] = prev_min[0];        // that the quantizer launch (whose block 0 stores the new state, possibly in
+      stats_out[3] = prev_max[0];        // place) never reads the live buffers
+    }
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
@@ -790,8 +794,12 @@ extern "C" int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mod
 // ---- sharded calibration: the fused step split at the exchange ---------------------------------------------
 // stats: fp32 [2 * n_params] = [-min | max] of the LOCAL shard, written by the statistics kernel itself; the
 // caller all-reduces it in place with MAX (one collective: min and max fused) and hands it to tq_calibrate_apply.
-extern "C" int tq_calibrate_stats(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner, float* stats,
-                                  void* workspace, size_t workspace_bytes, uint32_t* counter, tq_stream_t stream) {
+// copy_prev_*: non-NULL (one range, ticket path only) -> stats[2], stats[3] receive the previous state; returns 1 in
+// *copied when that happened
+static int calibrate_stats_impl(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner, float* stats,
+                                void* workspace, size_t workspace_bytes, uint32_t* counter, tq_stream_t stream,
+                                const float* copy_prev_min, const float* copy_prev_max, int* copied) {
+  if (copied) *copied = 0;
   TQ_REQUIRE(x && n > 0 && stats, "tq_calibrate_stats: empty tensor / NULL output");
   TQ_REQUIRE(n_params >= 1 && n_params <= kCalibMaxN, "tq_calibrate_stats: n_params=%llu > %u", (unsigned long long)n_params, kCalibMaxN);
   TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_calibrate_stats: bad dtype %d", dtype);
@@ -805,7 +813,8 @@ extern "C" int tq_calibrate_stats(const void* x, uint64_t n, int dtype, uint64_t
       const bool vec = aligned16(x);
       float* stats_out = stats;
       const int mode = TQ_EST_CURRENT, n_bits = 8, symmetric = 0, log_domain = 0;
-      const float *prev_min = nullptr, *prev_max = nullptr;
+      const float *prev_min = copy_prev_min, *prev_max = copy_prev_max;     // (stats-only mode: copied, not applied)
+      if (copied) *copied = copy_prev_min != nullptr;
       float *cur_min = nullptr, *cur_max = nullptr, *delta = nullptr, *zero_float = nullptr;
       uint8_t* signed_flag = nullptr;
       const double momentum = 0.0;
@@ -829,12 +838,56 @@ extern "C" int tq_calibrate_stats(const void* x, uint64_t n, int dtype, uint64_t
 }
 #undef TQ_CALIB
 
+extern "C" int tq_calibrate_stats(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner, float* stats,
+                                  void* workspace, size_t workspace_bytes, uint32_t* counter, tq_stream_t stream) {
+  return calibrate_stats_impl(x, n, dtype, n_params, inner, stats, workspace, workspace_bytes, counter, stream, nullptr,
+                              nullptr, nullptr);
+}
+
+// The one-call sharded steps (tq_calibrate_minmax_rccl / _mailbox): statistics into a scratch `stats` of >= 4 floats,
+// with the previous state copied behind them when the single-range ticket path runs; *prev_in_stats tells the second
+// half (calibrate_apply_after_exchange) to read that copy -- the fused update + quantize launch is then safe for
+// in-place state, i.e. inside a captured hipGraph.
+int tq::calibrate_stats_for_exchange(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner, float* stats,
+                                     void* workspace, size_t workspace_bytes, uint32_t* counter, const float* prev_min,
+                                     const float* prev_max, int* prev_in_stats, tq_stream_t stream) {
+  const bool one = n_params == 1 && prev_min != nullptr;
+  return calibrate_stats_impl(x, n, dtype, n_params, inner, stats, workspace, workspace_bytes, counter, stream,
+                              one ? prev_min : nullptr, one ? prev_max : nullptr, prev_in_stats);
+}
+
 // stats: [-min | max] over ALL ranks -> estimator update + range -> parameters (one launch) [-> quantize x].
+static int calibrate_apply_impl(const float* stats, const void* x, uint64_t n, int dtype, uint64_t n_params,
+                                uint64_t inner, int mode, const float* prev_min, const float* prev_max, float* cur_min,
+                                float* cur_max, double momentum, uint64_t n_groups, const int64_t* order, int n_bits,
+                                int symmetric, float eps, int log_domain, float* delta, float* zero_float,
+                                uint8_t* signed_flag, void* y, tq_stream_t stream, int prev_in_stats);
+
+int tq::calibrate_apply_after_exchange(const float* stats, const void* x, uint64_t n, int dtype, uint64_t n_params,
+                                       uint64_t inner, int mode, const float* prev_min, const float* prev_max,
+                                       float* cur_min, float* cur_max, double momentum, uint64_t n_groups,
+                                       const int64_t* order, int n_bits, int symmetric, float eps, int log_domain,
+                                       float* delta, float* zero_float, uint8_t* signed_flag, void* y, int prev_in_stats,
+                                       tq_stream_t stream) {
+  return calibrate_apply_impl(stats, x, n, dtype, n_params, inner, mode, prev_min, prev_max, cur_min, cur_max, momentum,
+                              n_groups, order, n_bits, symmetric, eps, log_domain, delta, zero_float, signed_flag, y, stream,
+                              prev_in_stats);
+}
+
 extern "C" int tq_calibrate_apply(const float* stats, const void* x, uint64_t n, int dtype, uint64_t n_params,
                                   uint64_t inner, int mode, const float* prev_min, const float* prev_max, float* cur_min,
                                   float* cur_max, double momentum, uint64_t n_groups, const int64_t* order, int n_bits,
                                   int symmetric, float eps, int log_domain, float* delta, float* zero_float,
                                   uint8_t* signed_flag, void* y, tq_stream_t stream) {
+  return calibrate_apply_impl(stats, x, n, dtype, n_params, inner, mode, prev_min, prev_max, cur_min, cur_max, momentum,
+                              n_groups, order, n_bits, symmetric, eps, log_domain, delta, zero_float, signed_flag, y, stream, 0);
+}
+
+static int calibrate_apply_impl(const float* stats, const void* x, uint64_t n, int dtype, uint64_t n_params,
+                                uint64_t inner, int mode, const float* prev_min, const float* prev_max, float* cur_min,
+                                float* cur_max, double momentum, uint64_t n_groups, const int64_t* order, int n_bits,
+                                int symmetric, float eps, int log_domain, float* delta, float* zero_float,
+                                uint8_t* signed_flag, void* y, tq_stream_t stream, int prev_in_stats) {
   TQ_REQUIRE(stats && cur_min && cur_max && delta, "tq_calibrate_apply: NULL pointer");
   TQ_REQUIRE((prev_min == nullptr) == (prev_max == nullptr), "tq_calibrate_apply: prev_min / prev_max mismatch");
   TQ_REQUIRE(symmetric ? signed_flag != nullptr : zero_float != nullptr, "tq_calibrate_apply: missing parameter output");
@@ -846,8 +899,13 @@ extern "C" int tq_calibrate_apply(const float* stats, const void* x, uint64_t n,
   // re-derives the dozen scalars; in-place state -- the hipGraph mode -- keeps the separate update launch below, since
   // block 0's store could race another block's read of the previous state)
   static const int fused_apply = tuning("TQ_CALIB_FUSED_APPLY", 1);
+  if (prev_in_stats) {                  // the statistics launch left a copy of the previous state behind the statistics
+    prev_min = stats + 2;
+    prev_max = stats + 3;
+  }
   if (fused_apply && n_params == 1 && n_groups == 0 && y != nullptr && x != nullptr && aligned16(x) && aligned16(y) &&
-      cur_min != prev_min && cur_max != prev_max && (dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16)) {
+      (prev_in_stats || (cur_min != prev_min && cur_max != prev_max)) &&
+      (dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16)) {
     CalibApplyArgs c{stats, nullptr, 0u, prev_min, prev_max, cur_min, cur_max, delta, zero_float, signed_flag, mode, n_bits,
                      symmetric, log_domain, eps, (float)(1.0 - momentum), (float)momentum};
     return launch_fq_from_stats(x, y, n, dtype, c, static_cast<hipStream_t>(stream));
