@@ -267,7 +267,11 @@ int tq_calibrate_minmax(const void* x, uint64_t n, int dtype, uint64_t n_params,
  * last-finishing block (ticket in *counter) also applies the estimator rule and writes cur_min / cur_max
  * / delta / zero_float | signed_flag (each [1]); then the quantizer runs if y != NULL.  *counter
  * (device, 4 bytes) must be 0 on entry and is 0 again when the kernel has finished; workspace as
- * tq_calibrate_workspace_bytes(n, 1, 1).  The result does not depend on which block finishes last.  */
+ * tq_calibrate_workspace_bytes(n, 1, 1).  The result does not depend on which block finishes last.
+ * With y != NULL and 16-byte aligned x / y the step is ticket-free (round 3): launch 1 leaves one (min, max) pair per
+ * block plus a copy of the previous state in the workspace, launch 2 folds the pairs in every block, applies the rule,
+ * derives the parameters and quantizes (block 0 stores the new state; in-place state is safe, the live buffers are not
+ * read by launch 2): 3.7 + 4.3 us instead of 8.3 + 3.8 us for a [8, 128, 768] tensor; *counter is then not touched.  */
 int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mode, const float* prev_min,
                         const float* prev_max, float* cur_min, float* cur_max, double momentum,
                         int n_bits, int symmetric, float eps, int log_domain, float* delta,
