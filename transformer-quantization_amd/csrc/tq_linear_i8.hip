@@ -494,14 +494,12 @@ __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmc
 
 template <int WT, int YDT, bool WITH_TAIL>
 __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinArgs p) {   // 2 (128 x 128 tiles) / 4 waves per SIMD
-  constexpr bool PERSIST = false;                 // tile runs per block: measured +3 % for +50 VGPRs; the registers go to
-                                                  // the fragment pipeline below instead (launcher: TQ_I8_PERSIST)
   constexpr int BT = 2 * WT, NI = WT / 16, MI = WT / 16;
   constexpr int LPW = WT / 16;                    // 1 KB load instructions per wave, operand and slab
   constexpr int OPB = BT * 128, STB = 2 * OPB;    // bytes per operand tile / per stage
   extern __shared__ __attribute__((aligned(1024))) int8_t lds_i8[];   // [2 stages][W | X][BT rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t tiles_m = p.M / BT, n_tiles = tiles_m * (p.N / BT);
+  const uint32_t tiles_m = p.M / BT;
   const int wn = (wave >> 1) * WT, wm = (wave & 1) * WT;
   const int r16 = lane & 15, kg = lane >> 4;
   // reader: k chunk c = 4 s + kg of row (16-aligned base) + r16 sits in slot c ^ ((r16 >> 1) & 7)
@@ -510,16 +508,10 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
   float* cst = reinterpret_cast<float*>(lds_i8 + 2 * STB);
   const uint32_t nk = p.K / 128;
 
-  // PERSISTENT tiles: a block owns a contiguous run of output tiles (consecutive token tiles of one feature tile, so
-  // the per-column constants and the quantizer parameters are loaded once per run).  Launching one workgroup per
-  // 128 x 128 tile cost ~4 us of dispatch + dependent parameter loads + first-slab latency per tile -- more than the 6
-  // K slabs of MFMA work at K = 768 (tools/tuning/i8_dbg.py: the barrier / LDS-read skeleton alone was 17 of 50 us at
-  // M = 8192).  Two such blocks are resident per CU; one's epilogue (VALU) runs against the other's main loop.
-  const uint32_t per = PERSIST ? (n_tiles + gridDim.x - 1) / gridDim.x : 1u;
-  const uint32_t t_begin = blockIdx.x * per, t_end = PERSIST ? min(n_tiles, t_begin + per) : t_begin + 1;
-  uint32_t cur_n0 = 0xffffffffu;
-  EpiCtx ectx{};
-  for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+  // One block per output tile.  (Round 3 tried persistent blocks working through runs of tiles -- parameters loaded
+  // once per run, no per-tile dispatch: +3 % for +50 VGPRs, dropped; the main loop is LDS-bandwidth bound)
+  {
+    const uint32_t tile = blockIdx.x;
     const uint32_t n0 = (tile / tiles_m) * BT, m0 = (tile % tiles_m) * BT;
     // loader: wave w moves rows [w WT / 2, (w + 1) WT / 2) of both tiles, 8 rows per instruction
     const int8_t* wsrc[LPW];
@@ -546,27 +538,18 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = v4i{0, 0, 0, 0};
 
-    // the previous tile's epilogue used the operand stages as output staging and read the column constants: everybody
-    // must be done with both before the next slab / the next constants land
-    if (tile != t_begin) __syncthreads();
-    const bool new_cols = n0 != cur_n0;
-    float ld_dw = 0.0f, ld_b = 0.0f, ld_nw = 0.0f, ld_nb = 0.0f;
-    int ld_rs = 0;
-    if (new_cols) {
-      // everything read through pointers first, as independent loads in flight together with the first slab: the
-      // quantizers' range buffers (epilogue parameters) and the per-column scale / bias / row sum this thread turns into
-      // LDS constants [BT scale | BT bias | BT correction | BT NoNorm weight | BT NoNorm bias] (published by the loop's
-      // first barrier)
-      ectx = epilogue_prepare<WITH_TAIL>(p, n0 + wn);
-      const uint32_t ncol = n0 + (tid & (BT - 1));     // threads >= BT load duplicates and do not write
-      ld_dw = p.w_delta[p.w_n_params == 1 ? 0 : ncol];
-      ld_b = p.bias ? p.bias[ncol] : 0.0f;
-      ld_rs = p.w_rowsum[ncol];
-      if (WITH_TAIL) { ld_nw = p.nn_w[ncol]; ld_nb = p.nn_b[ncol]; }
-      cur_n0 = n0;
-    }
+    // everything read through pointers first, as independent loads in flight together with the first slab: the
+    // quantizers' range buffers (epilogue parameters) and the per-column scale / bias / row sum this thread turns into
+    // LDS constants [BT scale | BT bias | BT correction | BT NoNorm weight | BT NoNorm bias] (published by the loop's
+    // first barrier)
+    const EpiCtx ectx = epilogue_prepare<WITH_TAIL>(p, n0 + wn);
+    const uint32_t ncol = n0 + (tid & (BT - 1));       // threads >= BT load duplicates and do not write
+    const float ld_dw = p.w_delta[p.w_n_params == 1 ? 0 : ncol], ld_b = p.bias ? p.bias[ncol] : 0.0f;
+    const int ld_rs = p.w_rowsum[ncol];
+    float ld_nw = 0.0f, ld_nb = 0.0f;
+    if (WITH_TAIL) { ld_nw = p.nn_w[ncol]; ld_nb = p.nn_b[ncol]; }
     issue(0, 0);
-    if (new_cols && tid < BT) {
+    if (tid < BT) {
       cst[tid] = ectx.sx * (ld_dw < p.w_eps ? p.w_eps : ld_dw);
       cst[BT + tid] = ld_b;
       reinterpret_cast<int*>(cst)[2 * BT + tid] = ld_rs * ectx.shift;
@@ -615,7 +598,7 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
 #ifdef TQ_I8_DBG_BUILD
     if (p.dbg & 1) {
       if (acc[0][0][0] == 0x7fffffff) p.y_idx[0] = 1;   // keep the accumulators alive
-      continue;
+      return;
     }
 #endif
     constexpr int kStageBytes = 32 * (WT * 4 + 16) + 32 * (WT + 16);
@@ -870,13 +853,7 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
   if (a.K % 128 == 0 && a.M % 64 == 0 && a.N % 64 == 0 && tuning("TQ_I8_LDS", 1)) {
     // 128 x 128 block tiles once they still give >= 4 blocks per CU, else 64 x 64
     const bool big = a.M % 128 == 0 && a.N % 128 == 0 && (uint64_t)(a.M / 128) * (a.N / 128) >= (uint64_t)tuning("TQ_I8_BIG_MIN", 1024);
-    // 128 x 128 tiles: persistent blocks, as many as are resident at once (2 per CU by registers), each working
-    // through a contiguous run of tiles; TQ_I8_PERSIST=0 launches one block per tile (A/B).  64 x 64: one per tile.
-    static const int persist = 0;   // (kernel built with PERSIST = false)
-    const uint64_t tiles = big ? (uint64_t)(a.M / 128) * (a.N / 128) : (uint64_t)(a.M / 64) * (a.N / 64);
-    const uint64_t resident = 256ull * 2;
-    uint64_t grid = (persist && big) ? std::min<uint64_t>(tiles, resident) : tiles;
-    if (persist && big && tiles > resident) grid = ceil_div(tiles, ceil_div(tiles, resident));   // equal runs, no idle tail blocks
+    const uint64_t grid = big ? (uint64_t)(a.M / 128) * (a.N / 128) : (uint64_t)(a.M / 64) * (a.N / 64);   // one block per tile
     if (big) hipLaunchKernelGGL((linear_i8_lds_k<64, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock),
                                 2 * 2 * 128 * 128 + 5 * 128 * 4 + (size_t)tuning("TQ_I8_LDS_PAD", 0), st, a);
     else     hipLaunchKernelGGL((linear_i8_lds_k<32, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock),
