@@ -177,3 +177,55 @@ def _graphed_vs_eager(model, twin, make_opt, opt, loss_fn, batches, labels, int8
         assert torch.equal(a.detach(), b.detach()), n
         moved += int(a.requires_grad)
     assert moved > (30 if int8 else 100)
+
+
+def test_graph_replays_invalidate_derived_caches_and_keep_optimizer_state():
+    """a hipGraph replay rewrites weights in place without bumping tensor._version; caches keyed on the
+    version (int8 weight indices of the integer Linears, NoNorm parameters, stacked operands) must not survive it.
+    Sequence: graphed QAT steps -> eval (fills the caches) -> more replays -> eval again: the second eval must see the
+    NEW weights (== an eval with every cache dropped by hand), and must differ from the first.  Also: capturing with an
+    optimizer that has already stepped keeps its moments / step count (they are snapshot and restored, not zeroed)."""
+    from quantization import options
+    from quantization.autoquant_utils import QuantLinear
+    from quantization.graphs import GraphedTrainStep
+    model, batches, labels = _setup(learn_ranges=False, fix_act=True)
+    model.fix_ranges()
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=5e-2, momentum=0.9)
+    loss_fn = torch.nn.functional.cross_entropy
+    # an optimizer with history: two eager steps first
+    for i in range(2):
+        opt.zero_grad(set_to_none=True)
+        loss_fn(model(batches[i][0]), labels).backward()
+        opt.step()
+    mom_before = {id(p): opt.state[p]['momentum_buffer'].clone() for p in params if p in opt.state}
+    assert mom_before and any(float(v.abs().max()) > 0 for v in mom_before.values())
+    options.INT8_LINEAR = True
+    try:
+        step = GraphedTrainStep(model, loss_fn, opt, (batches[0][0],), (labels,))
+        for p in params:                                           # restored, not zeroed
+            if id(p) in mom_before:
+                assert torch.equal(opt.state[p]['momentum_buffer'], mom_before[id(p)])
+        step((batches[0][0],), (labels,))
+        model.eval()
+        with torch.no_grad():
+            out1 = model(batches[1][0]).clone()                    # fills the int8 weight caches
+        assert any(m._int8_cache is not None for m in model.modules() if isinstance(m, QuantLinear))
+        model.train()
+        for i in range(3):
+            step((batches[i % 3][0],), (labels,))
+        model.eval()
+        with torch.no_grad():
+            out2 = model(batches[1][0]).clone()
+            for m in model.modules():                              # ground truth: every derived cache dropped by hand
+                if isinstance(m, QuantLinear):
+                    m._int8_cache = None
+            out3 = model(batches[1][0]).clone()
+    finally:
+        options.INT8_LINEAR = False
+    assert torch.equal(out2, out3)
+    assert not torch.equal(out2, out1)
