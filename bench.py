@@ -205,7 +205,10 @@ def relaunch_under_torchrun(n):
 
 def dry_run(args, rank, world):
     """TQ_BENCH_DRY_RUN=1: launcher / rendezvous / reporting control flow WITHOUT a GPU and without any kernel
-    (CPU test of `--gpus N`, tests/test_dist_gloo.py).  The line it prints is labelled and carries no measurement."""
+    (CPU test of `--gpus N`, tests/test_dist_gloo.py).  The line it prints is labelled and carries no measurement; it has
+    the keys of the real line, and the raw communicator's agreement round (quantization/rccl.py `agree`) runs for real
+    over the rendezvous store."""
+    agreed = None
     if world > 1 or 'RANK' in os.environ:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo')
@@ -213,11 +216,288 @@ def dry_run(args, rank, world):
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert float(t[0]) == world
+        from quantization import rccl
+        from torch.distributed import distributed_c10d as c10d
+        agreed = rccl.agree(c10d._get_default_store(), 'tq_bench_dry_run', rank, world, True, timeout_s=60) == []
         dist.destroy_process_group()
     if rank == 0:
+        blocks = {k: None for k in ('calibration', 'config_shape', 'calibration_model', 'adaround_dp', 'qat_dp', 'cpu_baseline',
+                                    'roofline')}
         print(json.dumps({'metric': 'DRY RUN (no kernels launched, not a measurement)', 'value': None, 'dry_run': True,
-                          'n_gpus': world, 'rccl_world_size': world, 'steps': args.steps, 'warmup': args.warmup}),
+                          'n_gpus': world, 'rccl_world_size': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'bring_up_agreement_round': agreed, **blocks}),
               flush=True)
+
+
+# ---- optional blocks of the JSON line (after the headline measurement; a failure or a stall in any of them never
+# ---- costs the headline: see _Watchdog) ---------------------------------------------------------------------------------
+class _Watchdog:
+    """The blocks below contain collectives that have never met more than one rank on this pool (raw RCCL bring-up, a
+    captured ncclAllReduce, ...).  If they stall, every rank's timer fires: rank 0 prints the line it has -- headline
+    complete, the unfinished block marked -- and all ranks leave through os._exit, so the driver's record survives."""
+
+    def __init__(self, out, rank, seconds):
+        import threading
+        self.out, self.rank, self.stage = out, rank, 'start'
+        self._done = threading.Event()
+        self._t = threading.Thread(target=self._run, args=(float(seconds),), daemon=True)
+        self._t.start()
+
+    def _run(self, seconds):
+        if self._done.wait(seconds):
+            return
+        if self.rank == 0:
+            self.out.setdefault('incomplete', []).append(f'optional block stalled in stage {self.stage!r} '
+                                                         f'(watchdog, {seconds:.0f} s); headline fields are complete')
+            print(json.dumps(self.out), flush=True)
+        else:
+            time.sleep(2.0)                  # let rank 0 print first
+        os._exit(0)
+
+    def cancel(self):
+        self._done.set()
+
+
+def _max_over_ranks(values, device, use_dist):
+    if not use_dist:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
+def _wall_ms(fn, n, warm, use_dist):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def calibration_model_block(device, rank, world, use_dist, wd):
+    """The latency-bound path of sharded calibration: a whole BERT-base calibrating forward (reference utils/utils.py:47-79
+    is the loop, quantization_manager.py:99-106 is why every site's exchange is inline): 161 activation sites, each
+    statistics -> all-reduce -> update -> quantize, through the harness model (harness/bert.py).
+
+    * weak: every rank calibrates its own [8, 128] batch (per-GPU work fixed);
+    * strong: a GLOBAL [128, 128] batch sharded over the ranks (16 samples per rank on 8 GPUs);
+    each eager and -- on the raw-RCCL transport (or with no exchange at all) -- replayed as ONE hipGraph, collectives
+    included.  Times are the MAX over ranks.  `exchange_latency_us`: the measured device time of one back-to-back
+    all-reduce of 8 B / 6 KB (per-tensor / per-embedding statistics) / 103 KB (2-D MSE loss grid) / 9.4 MB (AdaRound
+    gradient) on the transport in use."""
+    from harness.bert import build_bert_base
+    from quantization import distributed as tq_dist, options
+    from quantization.graphs import GraphedForward
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    wd.stage = 'calibration_model: build'
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    model, _ = build_bert_base(seed=1000, **qp)
+    model = model.to(device).eval()
+    g = torch.Generator(device=device).manual_seed(4000)
+    ids_global = torch.randint(1000, 30000, (128, 128), device=device, generator=g)      # the same on every rank
+    g.manual_seed(5000 + rank)
+    ids_weak = torch.randint(1000, 30000, (8, 128), device=device, generator=g)
+    active = use_dist and tq_dist.is_enabled()
+    raw = tq_dist.raw_comm()
+    blk = {
+        'model': 'BERT-base harness, W8A8 per-tensor, running min/max (BASELINE configs[1]), random init',
+        'world_size': world,
+        'transport': ('raw RCCL (tq_calibrate_minmax_rccl, one C call per site)' if raw is not None else
+                      ('torch.distributed' if active else 'none (single GPU, no exchange)')),
+    }
+    with torch.no_grad():
+        model.set_quant_state(True, True)
+        model.estimate_ranges()
+        legs = {'weak': ids_weak, 'strong': tq_dist.shard_batch(ids_global) if active else ids_global}
+        for name, ids in legs.items():
+            wd.stage = f'calibration_model: {name} eager'
+            leg = {'per_rank_batch': list(ids.shape), 'global_batch': [ids.shape[0] * world if name == 'weak' else 128, 128]}
+            model(ids)                   # untimed: the 102 weight quantizers estimate (and exchange) once, on the first forward
+            before = tq_dist.stats()
+            n_eager = 10
+            eager = _wall_ms(lambda: model(ids), n_eager, 2, use_dist)
+            after = tq_dist.stats()
+            leg['collectives_per_forward'] = (after['minmax_calls'] + after['sum_calls'] - before['minmax_calls']
+                                              - before['sum_calls']) / (n_eager + 2)
+            leg['exchanged_bytes_per_forward'] = (after['bytes'] - before['bytes']) / (n_eager + 2)
+            graph_ms = None
+            if not active or raw is not None:          # c10d collectives cannot be captured (graphs.CaptureRefused)
+                wd.stage = f'calibration_model: {name} hipGraph'
+                try:
+                    options.INPLACE_CALIBRATION_STATE = True
+                    model(ids)
+                    gf = GraphedForward(model, ids)
+                    graph_ms = _wall_ms(lambda: gf(ids), 20, 3, use_dist)
+                    del gf
+                except Exception as e:       # noqa: BLE001
+                    leg['hipgraph_error'] = repr(e)[:300]
+                finally:
+                    options.INPLACE_CALIBRATION_STATE = False
+            eager, graph_ms = _max_over_ranks([eager, graph_ms if graph_ms is not None else -1.0], device, use_dist)
+            leg['eager_ms'] = round(eager, 4)
+            leg['hipgraph_ms'] = round(graph_ms, 4) if graph_ms >= 0 else None
+            best = min(eager, graph_ms) if graph_ms >= 0 else eager
+            leg['tokens_per_s'] = round(leg['global_batch'][0] * 128 / best * 1e3, 1)
+            blk[name] = leg
+        model.fix_ranges()
+        # the calibrated model's fixed-range forward at the config shape (collective-free: configs[1]'s inference pass)
+        wd.stage = 'calibration_model: fixed-range forward'
+        fx = {'per_rank_batch': [8, 128]}
+        fx_eager = _wall_ms(lambda: model(ids_weak), 20, 3, use_dist)
+        fx_graph = None
+        try:
+            with tq_dist.suspended():
+                gf = GraphedForward(model, ids_weak)
+            fx_graph = _wall_ms(lambda: gf(ids_weak), 30, 3, use_dist)
+            del gf
+        except Exception as e:       # noqa: BLE001
+            fx['hipgraph_error'] = repr(e)[:300]
+        fx_eager, fx_graph = _max_over_ranks([fx_eager, fx_graph if fx_graph is not None else -1.0], device, use_dist)
+        fx['eager_ms'] = round(fx_eager, 4)
+        fx['hipgraph_ms'] = round(fx_graph, 4) if fx_graph >= 0 else None
+        blk['fixed_range_forward'] = fx
+    # ---- per-exchange latency on the transport in use, measured (not assumed) -------------------------------------------
+    wd.stage = 'calibration_model: exchange latency'
+    lat = None
+    if active:
+        lat = {}
+        for label, nbytes in (('8B', 8), ('6KB', 6144), ('103KB', 103424), ('9.4MB', 3072 * 768 * 4)):
+            if raw is not None:
+                us = raw.latency_us(nbytes)
+            else:
+                buf = torch.zeros(max(1, nbytes // 4), device=device)
+                us = _wall_ms(lambda: dist.all_reduce(buf), 100, 10, True) * 1e3
+            lat[label] = round(_max_over_ranks([us], device, use_dist)[0], 2)
+    blk['exchange_latency_us'] = lat
+    blk['exchange_latency_method'] = ('median over 20 groups of 10 back-to-back in-place fp32 SUM all-reduces, HIP events '
+                                      'around each group, max over ranks' if raw is not None else
+                                      ('wall clock of 100 back-to-back torch.distributed.all_reduce, max over ranks'
+                                       if active else None))
+    del model
+    return blk
+
+
+def adaround_dp_block(device, rank, world, use_dist, wd):
+    """BASELINE configs[3]: data-parallel AdaRound of one BERT-base FFN layer, W4, weight [3072, 768]: every iteration draws
+    a GLOBAL batch of 8 cached samples (128 tokens each), each rank evaluates its share and the 9.44 MB gradient dL/dW_q
+    is SUM-all-reduced (quantization/adaround/adaround.py).  ms per iteration = (t(120 iterations) - t(20)) / 100, so
+    the caching / initialisation cost cancels; max over ranks."""
+    import copy
+    from quantization import distributed as tq_dist
+    from quantization.adaround import apply_adaround_to_layer
+    from quantization.adaround.config import DEFAULT_ADAROUND_CONFIG
+    from quantization.adaround.utils import AdaRoundMode, AdaRoundInitMode
+    from quantization.autoquant_utils import quantize_model
+    from quantization.base_quantized_model import QuantizedModel
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from quantization import options
+    wd.stage = 'adaround_dp'
+    fin, fout, n, t = 768, 3072, 64, 128
+
+    class Net(QuantizedModel):
+        def __init__(self):
+            super().__init__()
+            self.fc = quantize_model(torch.nn.Linear(fin, fout), method=QMethods.symmetric_uniform, n_bits=4,
+                                     weight_range_method=RangeEstimators.current_minmax)
+
+        def forward(self, x):
+            return self.fc(x)
+
+    g = torch.Generator(device=device).manual_seed(1000)
+    data = torch.randn(n, t, fin, generator=g, device=device)
+    times = {}
+    graph_was = options.GRAPH_ADAROUND
+    try:
+        for iters in (20, 20, 120):                     # the first run is the warm-up (allocator, first-touch, capture set-up)
+            torch.manual_seed(1000)                     # same layer and same sample sequence on every rank
+            net = Net().to(device).eval()
+            net.set_quant_state(True, False)
+            with torch.no_grad():
+                net(data[:8])
+            net.fix_ranges()
+            cfg = copy.deepcopy(DEFAULT_ADAROUND_CONFIG)
+            cfg.iters, cfg.round_mode, cfg.init = iters, AdaRoundMode.learned_hard_sigmoid, AdaRoundInitMode.range_estimator
+            net.full_precision()
+            net.fc.quantized_weights()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            t0 = time.perf_counter()
+            apply_adaround_to_layer(net, net.fc, data, batch_size=8, act_quant=False, adaround_config=cfg)
+            torch.cuda.synchronize()
+            times[iters] = time.perf_counter() - t0
+            del net
+    finally:
+        options.GRAPH_ADAROUND = graph_was
+    ms = (times[120] - times[20]) / 100 * 1e3
+    ms = _max_over_ranks([ms], device, use_dist)[0]
+    active = use_dist and tq_dist.is_enabled()
+    return {'layer': [fout, fin], 'bits': 4, 'global_batch': 8, 'tokens_per_sample': t,
+            'per_rank_samples_per_iter': 8 / world if active else 8,
+            'gradient_allreduce_bytes': fout * fin * 4 if active else 0,
+            'ms_per_iter': round(ms, 4), 'iters_per_s': round(1e3 / ms, 1),
+            'note': 'hipGraph replay of the loop is single-GPU only; with an active exchange the loop runs eagerly'}
+
+
+def qat_dp_block(device, rank, world, use_dist, wd):
+    """BASELINE configs[4] shape of work, at BERT-base scale: one data-parallel QAT step (forward, STE backward, bucketed
+    gradient all-reduce of weights + learnable ranges overlapped with backward, SGD) of the 2-layer W8A8 harness model,
+    per-rank batch [8, 128]; eager and as ONE hipGraph (quantization.graphs.GraphedTrainStep with grad_sync)."""
+    from harness.bert import build_bert_base
+    from quantization import distributed as tq_dist
+    from quantization.data_parallel import GradientBuckets, train_step
+    from quantization.graphs import GraphedTrainStep
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    wd.stage = 'qat_dp: build'
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    model, _ = build_bert_base(seed=1000, num_layers=2, **qp)
+    model = model.to(device)
+    g = torch.Generator(device=device).manual_seed(6000 + rank)
+    ids = torch.randint(1000, 30000, (8, 128), device=device, generator=g)
+    labels = torch.randint(0, 2, (8,), device=device, generator=g)
+    with torch.no_grad(), tq_dist.suspended():
+        model.eval()
+        model.set_quant_state(True, True)
+        model.estimate_ranges()
+        model(ids)
+    model.learn_ranges()
+    model.set_quant_state(True, True)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-4)
+    gb = GradientBuckets(params)
+    loss_fn = torch.nn.functional.cross_entropy
+    active = use_dist and tq_dist.is_enabled()
+    wd.stage = 'qat_dp: eager'
+    eager = _wall_ms(lambda: train_step(model, loss_fn, opt, gb, (ids,), (labels,)), 10, 3, use_dist)
+    graph_ms, err = None, None
+    if not active or tq_dist.raw_comm() is not None:
+        wd.stage = 'qat_dp: hipGraph'
+        try:
+            step = GraphedTrainStep(model, loss_fn, opt, (ids,), (labels,), grad_sync=gb)
+            graph_ms = _wall_ms(lambda: step((ids,), (labels,)), 20, 3, use_dist)
+        except Exception as e:       # noqa: BLE001
+            err = repr(e)[:300]
+    eager, graph_ms = _max_over_ranks([eager, graph_ms if graph_ms is not None else -1.0], device, use_dist)
+    blk = {'model': 'BERT harness, 2 encoder layers, W8A8, learnable ranges, SGD', 'per_rank_batch': [8, 128],
+           'trainable_tensors': len(params), 'gradient_bytes': sum(gb.bucket_sizes()), 'buckets': gb.n_buckets,
+           'allreduces_per_step': gb.n_buckets if active else 0,
+           'eager_ms': round(eager, 4), 'hipgraph_ms': round(graph_ms, 4) if graph_ms >= 0 else None,
+           'samples_per_s': round(8 * world / (min(eager, graph_ms) if graph_ms >= 0 else eager) * 1e3, 1)}
+    if err:
+        blk['hipgraph_error'] = err
+    gb.close()
+    return blk
 
 
 def main():
@@ -229,6 +509,8 @@ def main():
     ap.add_argument('--seq', type=int, default=512)
     ap.add_argument('--sweep', action='store_true', help='also time the SURVEY.md 8d shape sweep')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--headline-only', action='store_true',
+                    help='skip the whole-model calibration / AdaRound / QAT blocks and the CPU baseline')
     ap.add_argument('--mailbox', action='store_true', help='also time calibration with the P2P mailbox exchange')
     args = ap.parse_args()
 
@@ -264,52 +546,26 @@ def main():
     from quantization.range_estimators import RangeEstimators
     from quantization.base_quantized_classes import QuantizedActivation
     assert _hip.backend().name == 'hip'
-    if use_dist:
-        # device tensors are exchanged on the raw RCCL communicator inside libtq_hip.so when the backend is `nccl`
-        # (quantization/rccl.py; self-tested at creation); torch.distributed is the fallback
-        try:
-            tq_dist.enable(force=(world == 1))
-        except Exception as e:       # noqa: BLE001
-            print(f'[bench] raw RCCL exchange unavailable ({e!r}): statistics go through torch.distributed', file=sys.stderr)
-            tq_dist.enable(force=(world == 1), raw=False)
-    transport = 'none'
-    if use_dist:
-        transport = 'raw RCCL (tq_calibrate_minmax_rccl)' if tq_dist.raw_comm() is not None else f'torch.distributed ({backend})'
 
     B, S = args.batch, args.seq
     x = make_hidden(B, S, device, seed=1000 + rank)
     n_elems = x.numel()
 
-    qa = QuantizedActivation(act_method=QMethods.asymmetric_uniform, n_bits_act=8,
-                             act_range_method=RangeEstimators.running_minmax).to(device)
-    qa.quantized_acts()
-    qa.eval()
+    def new_quantizer():
+        q = QuantizedActivation(act_method=QMethods.asymmetric_uniform, n_bits_act=8,
+                                act_range_method=RangeEstimators.running_minmax).to(device)
+        q.quantized_acts()
+        q.eval()
+        return q
 
-    # ---- calibration (untimed for `value`; reported separately): estimate + quantize ----------
-    calib_batches = [x, make_hidden(B, S, device, seed=2000 + rank)]
-    for xb in calib_batches:
+    # ---- the hot path: fixed-range fake-quant forward -----------------------------------------------------------------
+    # Measured FIRST and with no statistics exchange configured: every rank calibrates on its own two batches, fixes the
+    # range and runs the collective-free forward on its own shard (weak scaling).  Nothing that has not yet run on more
+    # than one rank on this pool (raw communicator bring-up, captured collectives) can cost the headline number.
+    qa = new_quantizer()
+    for xb in (x, make_hidden(B, S, device, seed=2000 + rank)):
         qa(xb)
-    cal_wall, cal_ms = timed_region(lambda: qa(x), max(4, min(args.steps, 20)), use_dist)
-    cal_steps = max(4, min(args.steps, 20))
-    # --mailbox / TQ_BENCH_MAILBOX=1: the same step with the statistics exchanged through the P2P mailbox kernel instead
-    # of ncclAllReduce (reported next to the RCCL figure, never instead of it; skipped if the set-up or the self-test
-    # against RCCL fails).  Opt-in: the path has been validated with two processes on one device and with a 1-rank RCCL
-    # group only (no multi-GPU box was available to the build), and the headline run must not depend on it.
-    mail_wall = None
-    if use_dist and backend == 'nccl' and (args.mailbox or os.environ.get('TQ_BENCH_MAILBOX', '0') == '1'):
-        try:
-            tq_dist.enable(force=(world == 1), mailbox=True, raw=tq_dist.raw_comm() is not None)
-            if tq_dist.mailbox_active():
-                qa(x)
-                mail_wall, _ = timed_region(lambda: qa(x), cal_steps, use_dist)
-        except Exception as e:       # noqa: BLE001
-            print(f'[bench] mailbox leg skipped: {e!r}', file=sys.stderr)
-        finally:
-            tq_dist.enable(force=(world == 1), mailbox=False, raw=tq_dist.raw_comm() is not None)
     qa.activation_quantizer.fix_ranges()
-    del calib_batches
-
-    # ---- the hot path: fixed-range fake-quant forward -------------------------------------------
     with torch.no_grad():
         # untimed: let the power management settle (the first ~100 ms after an idle period run at a
         # lower clock: 280-340 us per launch vs 255-265 us steady state for this kernel)
@@ -321,13 +577,7 @@ def main():
         for _ in range(args.warmup):
             qa(x)
         wall, ev_ms = timed_region(lambda: qa(x), args.steps, use_dist)
-
-    if use_dist:
-        tmax = torch.tensor([wall, cal_wall, mail_wall if mail_wall is not None else -1.0], device=device,
-                            dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall, cal_wall = float(tmax[0]), float(tmax[1])
-        mail_wall = float(tmax[2]) if mail_wall is not None else None
+    wall = _max_over_ranks([wall], device, use_dist)[0]
 
     total_elems = n_elems * world * args.steps
     value = total_elems / wall / 1e6
@@ -339,7 +589,7 @@ def main():
         'value': round(value, 1),
         'unit': 'M elems/s',
         'n_gpus': world,
-        'rccl_world_size': dist.get_world_size() if use_dist else 1,
+        'rccl_world_size': None,           # filled from the communicator below
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': round(wall / args.steps * 1e3, 4),
@@ -369,21 +619,20 @@ def main():
             'kernel_ms': round(ev_ms, 4),
             'algorithmic_bytes_per_launch': n_elems * BYTES_PER_ELEM,
         },
-        'calibration': {
-            'what': 'estimate (tq_minmax -> range_update -> set_range) + quantize per step; '
-                    + ('one fused MAX all-reduce of [-min;max] per step over RCCL' if world > 1
-                       else 'single GPU, no collective'),
-            'transport': transport,
-            'value': round(n_elems * world * cal_steps / cal_wall / 1e6, 1),
-            'unit': 'M elems/s',
-            'ms_per_step': round(cal_wall / cal_steps * 1e3, 4),
-        },
+        'cpu_baseline': None,
     }
-    if mail_wall is not None:
-        out['calibration']['p2p_mailbox'] = {
-            'what': 'same step, [-min;max] exchanged by the P2P mailbox kernel (tq_mailbox_allreduce_max) instead of RCCL',
-            'value': round(n_elems * world * cal_steps / mail_wall / 1e6, 1), 'unit': 'M elems/s',
-            'ms_per_step': round(mail_wall / cal_steps * 1e3, 4)}
+
+    # the config shape [8, 128, 768] ("report both"): one launch per activation site of a B=8 forward --
+    # launch-latency bound, 3 MB of traffic
+    xs = make_hidden(8, 128, device, seed=7)
+    with torch.no_grad():
+        for _ in range(10):
+            qa(xs)
+        _, ms_small = timed_region(lambda: qa(xs), 200, False)
+    out['config_shape'] = {'shape': [8, 128, 768], 'kernel_us': round(ms_small * 1e3, 3),
+                           'M_elems_s': round(xs.numel() / ms_small / 1e3, 1),
+                           'GBps': round(xs.numel() * BYTES_PER_ELEM / ms_small / 1e6, 1),
+                           'note': 'HIP-event span of 200 back-to-back calls / 200 (launch boundaries included)'}
 
     if args.sweep and rank == 0:
         sweep = []
@@ -397,16 +646,91 @@ def main():
                           'M_elems_s': round(xs.numel() / ms / 1e3, 1),
                           'GBps': round(xs.numel() * BYTES_PER_ELEM / ms / 1e6, 1)})
         out['sweep'] = sweep
+    del xs
 
-    if rank == 0 and world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline()
-    elif rank == 0:
-        out['cpu_baseline'] = None
+    # ---- everything below runs under the watchdog -----------------------------------------------------------------------
+    wd = _Watchdog(out, rank, float(os.environ.get('TQ_BENCH_WATCHDOG_S', '480')))
+
+    # statistics exchange: the raw RCCL communicator inside libtq_hip.so when the backend is `nccl` (quantization/rccl.py:
+    # two-phase bring-up agreed through the rendezvous store, self-tested); torch.distributed is the fallback
+    transport = 'none'
+    if use_dist:
+        wd.stage = 'exchange bring-up'
+        try:
+            tq_dist.enable(force=(world == 1))
+        except Exception as e:       # noqa: BLE001
+            print(f'[bench] raw RCCL exchange unavailable ({e!r}): statistics go through torch.distributed', file=sys.stderr)
+            tq_dist.enable(force=(world == 1), raw=False)
+        raw = tq_dist.raw_comm()
+        transport = 'raw RCCL (tq_calibrate_minmax_rccl)' if raw is not None else f'torch.distributed ({backend})'
+        # the size of the communicator the data path actually uses (ncclCommCount), not the launcher's environment
+        out['rccl_world_size'] = raw.rank_world()[1] if raw is not None else dist.get_world_size()
+        assert out['rccl_world_size'] == world, f'communicator spans {out["rccl_world_size"]} ranks, WORLD_SIZE is {world}'
+    else:
+        out['rccl_world_size'] = 1
+
+    # ---- calibration of ONE quantizer on the large tensor: estimate + quantize, one fused MAX all-reduce per step ------
+    wd.stage = 'calibration (one quantizer)'
+    qc = new_quantizer()
+    for xb in (x, make_hidden(B, S, device, seed=2000 + rank)):
+        qc(xb)
+    cal_steps = max(4, min(args.steps, 20))
+    cal_wall, _ = timed_region(lambda: qc(x), cal_steps, use_dist)
+    # --mailbox / TQ_BENCH_MAILBOX=1: the same step with the statistics exchanged through the P2P mailbox kernel instead
+    # of ncclAllReduce (reported next to the RCCL figure, never instead of it; skipped if the set-up or the self-test
+    # against RCCL fails).  Opt-in: validated with two processes on one device and with a 1-rank RCCL group only.
+    mail_wall = None
+    if use_dist and backend == 'nccl' and (args.mailbox or os.environ.get('TQ_BENCH_MAILBOX', '0') == '1'):
+        wd.stage = 'calibration (mailbox)'
+        try:
+            tq_dist.enable(force=(world == 1), mailbox=True, raw=tq_dist.raw_comm() is not None)
+            if tq_dist.mailbox_active():
+                qc(x)
+                mail_wall, _ = timed_region(lambda: qc(x), cal_steps, use_dist)
+        except Exception as e:       # noqa: BLE001
+            print(f'[bench] mailbox leg skipped: {e!r}', file=sys.stderr)
+        finally:
+            tq_dist.enable(force=(world == 1), mailbox=False, raw=tq_dist.raw_comm() is not None)
+    cal_wall, mw = _max_over_ranks([cal_wall, mail_wall if mail_wall is not None else -1.0], device, use_dist)
+    mail_wall = mw if mail_wall is not None else None
+    out['calibration'] = {
+        'what': 'estimate (tq_minmax -> range_update -> set_range) + quantize per step; '
+                + ('one fused MAX all-reduce of [-min;max] per step over RCCL' if world > 1
+                   else ('1-rank communicator, collectives forced on' if use_dist else 'single GPU, no collective')),
+        'transport': transport,
+        'value': round(n_elems * world * cal_steps / cal_wall / 1e6, 1),
+        'unit': 'M elems/s',
+        'ms_per_step': round(cal_wall / cal_steps * 1e3, 4),
+    }
+    if mail_wall is not None:
+        out['calibration']['p2p_mailbox'] = {
+            'what': 'same step, [-min;max] exchanged by the P2P mailbox kernel (tq_mailbox_allreduce_max) instead of RCCL',
+            'value': round(n_elems * world * cal_steps / mail_wall / 1e6, 1), 'unit': 'M elems/s',
+            'ms_per_step': round(mail_wall / cal_steps * 1e3, 4)}
+    del x, qc, qa
+
+    # ---- whole-model sharded calibration, data-parallel AdaRound / QAT steps, CPU baseline ------------------------------
+    if not args.headline_only:
+        for key, fn in (('calibration_model', calibration_model_block), ('adaround_dp', adaround_dp_block),
+                        ('qat_dp', qat_dp_block)):
+            torch.cuda.empty_cache()
+            try:
+                out[key] = fn(device, rank, world, use_dist, wd)
+            except Exception as e:       # noqa: BLE001 -- with N > 1 a one-rank failure may stall the peers: the watchdog ends it
+                out[key] = {'error': repr(e)[:500]}
+                print(f'[bench] rank {rank}: block {key} failed: {e!r}', file=sys.stderr)
+        wd.stage = 'cpu_baseline'
+        if rank == 0 and world == 1 and not args.no_cpu:
+            out['cpu_baseline'] = cpu_baseline()
+    wd.cancel()
 
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
-        dist.destroy_process_group()
+        try:
+            tq_dist.disable()
+        finally:
+            dist.destroy_process_group()
 
 
 if __name__ == '__main__':

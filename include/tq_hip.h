@@ -354,6 +354,7 @@ int tq_comm_version(void);                     /* ncclGetVersion code of the bou
 int tq_comm_get_unique_id(void* id_out /* host */);
 int tq_comm_init(const void* unique_id /* host */, int rank, int world, void** comm_out);
 int tq_comm_destroy(void* comm);
+int tq_comm_abort(void* comm);                 /* ncclCommAbort: tear down without waiting for the peers (rejected set-up) */
 int tq_comm_rank_world(void* comm, int* rank /* host */, int* world /* host */);
 int tq_comm_allreduce(void* comm, void* buf, uint64_t count, int dtype, int op, tq_stream_t stream);
 int tq_comm_broadcast(void* comm, void* buf, uint64_t count, int dtype, int root, tq_stream_t stream);

@@ -274,6 +274,9 @@ def test_bench_gpus_flag_spawns_ranks():
     assert len(lines) == 1                                           # rank 0 only
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['rccl_world_size'] == 2 and out['dry_run'] is True and out['value'] is None
+    assert out['bring_up_agreement_round'] is True                  # rccl.agree over the gloo rendezvous store, 2 ranks
+    for k in ('calibration', 'config_shape', 'calibration_model', 'adaround_dp', 'qat_dp'):
+        assert k in out                                             # the keys of the real line (round 4)
 
 
 # ---- layer-parallel AdaRound (asym=False: independent per-layer problems, layers shard over ranks) -------------------
@@ -492,3 +495,132 @@ def test_whole_model_calibration_with_one_sample_over_two_ranks(tmp_path):
     r1 = torch.load(os.path.join(tmp_path, 'bert1_1.pt'), weights_only=False)
     assert r0.shape == ref.shape and r0.shape[0] > 10
     assert torch.equal(r0, r1) and torch.equal(r0, ref)
+
+
+# ---- data-parallel QAT step: bucketed gradient all-reduce (BASELINE configs[4]) ---------------------
+def _qat_problem():
+    """Toy quantized model, calibrated on the GLOBAL batches with the exchange off (identical on every rank), ranges
+    learnable (reference utils/qat_utils.py:26-28: learn_ranges after range estimation)."""
+    from quantization import distributed as tq_dist
+    from utils.utils import pass_data_for_range_estimation
+    torch.manual_seed(5)
+    model = _quant_toy(_Toy())
+    batches = _batches(n=4, B=8, seed=3)
+    with tq_dist.suspended():
+        pass_data_for_range_estimation([(b,) for b in batches[:2]], model, act_quant=True, weight_quant=True,
+                                       max_num_batches=2)
+    model.learn_ranges()
+    model.set_quant_state(True, True)
+    model.train()
+    g = torch.Generator().manual_seed(9)
+    targets = [torch.randn(8, 6, 24, generator=g) for _ in batches]
+    return model, batches, targets
+
+
+def _qat_run(model, batches, targets, shard, opt_name, bucket_bytes, steps=6, first=0, accumulate_over=None):
+    """accumulate_over=N: ONE process walks the N shards of every batch, accumulating their gradients in the buckets and
+    averaging -- arithmetically the data-parallel step (same per-shard GEMM shapes, g0 + g1 is commutative)."""
+    from quantization.data_parallel import GradientBuckets, train_step
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = (torch.optim.SGD(params, lr=0.05, momentum=0.9) if opt_name == 'sgd'
+           else torch.optim.Adam(params, lr=1e-2))
+    gb = GradientBuckets(params, bucket_bytes=bucket_bytes)
+    losses, grads = [], None
+    for i in range(first, first + steps):
+        xb, tb = batches[i % len(batches)], targets[i % len(batches)]
+        if accumulate_over:
+            gb.zero_()
+            per = xb.shape[0] // accumulate_over
+            ls = []
+            for r in range(accumulate_over):
+                loss = torch.nn.functional.mse_loss(model(xb[r * per:(r + 1) * per]), tb[r * per:(r + 1) * per])
+                loss.backward()
+                ls.append(float(loss.detach()))
+            for f in gb._flats:
+                f.mul_(1.0 / accumulate_over)
+            opt.step()
+            losses.append(ls)
+        else:
+            losses.append(float(train_step(model, torch.nn.functional.mse_loss, opt, gb, (shard(xb),), (shard(tb),))))
+        if grads is None:
+            grads = {k: v.grad.detach().clone() for k, v in model.named_parameters()}
+    out = {k: v.detach().clone() for k, v in model.named_parameters()}
+    return out, losses, gb.n_buckets, gb.launched, grads
+
+
+_QAT_CASES = [('sgd', 1 << 30, 6, 0), ('sgd', 2048, 1, 1), ('adam', 2048, 6, 2)]
+
+
+def _worker_qat(rank, port, outdir):
+    tq_dist = _setup(rank, port)
+    res = []
+    for opt_name, bucket_bytes, steps, first in _QAT_CASES:
+        model, batches, targets = _qat_problem()
+        res.append(_qat_run(model, batches, targets, tq_dist.shard_batch, opt_name, bucket_bytes, steps, first))
+    torch.save(res, os.path.join(outdir, f'qat_{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_qat_equals_single_rank_on_the_concatenated_batch(tmp_path):
+    """Two ranks, each on its half of every batch, gradients of weights AND learnable ranges summed in flat buckets and
+    averaged.
+
+    * BIT-EXACT over six optimizer steps (SGD-momentum with one bucket, Adam with many small buckets) against ONE process
+      that accumulates the gradients of the same two half-batches and averages them -- the same arithmetic, so any
+      difference would be a bug in bucketing / hook order / the exchange, not round-off;
+    * against one process on the WHOLE batch (mean-reduced loss) the first-step gradients agree to the round-off a
+      different GEMM shape causes in a discontinuous network: the 8-row and the 4-row products differ in the last bit,
+      a few activations land on the other side of a rounding boundary and their idx-weighted terms move the range
+      gradients by up to a few 1e-3 relative (weights 1e-4); trajectories are not compared beyond that point."""
+    port = _free_port()
+    mp.spawn(_worker_qat, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    from quantization import _hip, distributed as tq_dist
+    from tests._oracle_backend import OracleBackend
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        tq_dist.disable()
+        got = [torch.load(os.path.join(tmp_path, f'qat_{r}.pt'), weights_only=False) for r in range(WORLD)]
+        for ci, (opt_name, bucket_bytes, steps, first) in enumerate(_QAT_CASES):
+            model, batches, targets = _qat_problem()
+            start = {k: v.detach().clone() for k, v in model.named_parameters()}
+            acc, acc_losses, n_buckets, launched, acc_g = _qat_run(model, batches, targets, None, opt_name, bucket_bytes,
+                                                                   steps, first, accumulate_over=WORLD)
+            assert launched == 0                                  # single process: storage only, no collective
+            ranges = [k for k in acc if k.endswith('_delta') or k.endswith('_zero_float')]
+            assert len(ranges) >= 6, 'learnable ranges must be among the trained parameters'
+            p0, l0, nb0, launched0, g0 = got[0][ci]
+            p1, l1, nb1, launched1, g1 = got[1][ci]
+            assert nb0 == nb1 == n_buckets and launched0 == launched1 == steps * n_buckets
+            assert (n_buckets == 1) if bucket_bytes > 2048 else (n_buckets > 2)
+            for k in acc:
+                assert torch.equal(p0[k], p1[k]) and torch.equal(g0[k], g1[k]), (ci, k)   # replicas stay bit-identical
+                assert torch.equal(g0[k], acc_g[k]), (ci, k, 'first-step gradient')
+                assert torch.equal(p0[k], acc[k]), (ci, k, f'parameters after {steps} steps')
+            assert [[a, b] for a, b in zip(l0, l1)] == acc_losses
+            moved = sum(int(not torch.equal(start[k], acc[k])) for k in ranges)
+            assert moved >= len(ranges) // 2, 'the range parameters must actually train'
+            # semantic check: == the gradient of the mean loss over the concatenated batch
+            model, batches, targets = _qat_problem()
+            _, full_losses, _, _, full_g = _qat_run(model, batches, targets, lambda x: x, opt_name, bucket_bytes, 1, first)
+            assert abs((l0[0] + l1[0]) / 2 - full_losses[0]) <= 1e-5 * abs(full_losses[0]) + 1e-7
+            for k in acc:
+                scale = float(full_g[k].abs().max()) + 1e-12
+                tol = 1e-2 if k in ranges else 5e-4
+                assert float((g0[k] - full_g[k]).abs().max()) <= tol * scale + 1e-9, (ci, k)
+    finally:
+        _hip.set_backend(prev)
+
+
+def test_gradient_buckets_refuse_detached_gradients():
+    from quantization.data_parallel import GradientBuckets
+    lin = torch.nn.Linear(4, 3)
+    gb = GradientBuckets(lin.parameters(), bucket_bytes=16)
+    assert gb.n_buckets == 2 and sorted(gb.bucket_sizes()) == [12, 48]
+    lin(torch.ones(2, 4)).sum().backward()
+    assert torch.equal(lin.bias.grad, torch.full((3,), 2.0)) and gb.launched == 0
+    gb.finish()
+    gb.zero_()
+    assert float(lin.weight.grad.abs().sum()) == 0.0
+    torch.optim.SGD(lin.parameters(), lr=0.1).zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match='detached from its bucket'):
+        gb.zero_()

@@ -107,6 +107,17 @@ def test_bench_distributed_control_flow_over_rccl():
     out = json.loads(line)
     assert out['n_gpus'] == 1 and out['value'] > 0 and out['roofline']['achieved'] > 0
     assert out['calibration']['p2p_mailbox']['value'] > 0          # --mailbox leg (1-rank group: post + no peers)
+    # round 4: the latency-bound path and the data-parallel steps, on the raw 1-rank communicator (collectives forced on)
+    assert out['rccl_world_size'] == 1 and 'raw RCCL' in out['calibration']['transport']
+    cm = out['calibration_model']
+    assert 'raw RCCL' in cm['transport'], cm
+    for leg in ('weak', 'strong'):
+        assert cm[leg]['collectives_per_forward'] == 161 and cm[leg]['eager_ms'] > 0 and cm[leg]['hipgraph_ms'] > 0, cm[leg]
+    assert cm['strong']['per_rank_batch'] == [128, 128] and cm['fixed_range_forward']['hipgraph_ms'] > 0
+    assert set(cm['exchange_latency_us']) == {'8B', '6KB', '103KB', '9.4MB'} and all(v > 0 for v in cm['exchange_latency_us'].values())
+    assert out['adaround_dp']['gradient_allreduce_bytes'] == 3072 * 768 * 4 and out['adaround_dp']['ms_per_iter'] > 0
+    q = out['qat_dp']
+    assert q['allreduces_per_step'] == q['buckets'] >= 1 and q['eager_ms'] > 0 and q['hipgraph_ms'] > 0, q
 
 
 def test_bench_single_process_with_sweep():
@@ -121,6 +132,10 @@ def test_bench_single_process_with_sweep():
     assert out['steps'] == 3 and out['warmup'] == 1 and out['config']['workload']
     assert set(out['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
     assert len(out['sweep']) >= 3
+    assert out['config_shape']['shape'] == [8, 128, 768] and out['config_shape']['kernel_us'] > 0
+    cm = out['calibration_model']
+    assert cm['weak']['collectives_per_forward'] == 0 and cm['weak']['hipgraph_ms'] > 0 and cm['exchange_latency_us'] is None
+    assert out['adaround_dp']['ms_per_iter'] > 0 and out['qat_dp']['hipgraph_ms'] > 0 and out['qat_dp']['allreduces_per_step'] == 0
 
 
 def test_bench_gpus_2_spawns_two_ranks_with_real_kernels():
@@ -138,3 +153,8 @@ def test_bench_gpus_2_spawns_two_ranks_with_real_kernels():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['rccl_world_size'] == 2 and out['value'] > 0
     assert out['calibration']['value'] > 0 and 'all-reduce' in out['calibration']['what']
+    cm = out['calibration_model']                                  # 2 ranks, exchange through torch.distributed (gloo)
+    assert cm['world_size'] == 2 and cm['transport'] == 'torch.distributed'
+    assert cm['weak']['collectives_per_forward'] == 161 and cm['strong']['per_rank_batch'] == [64, 128]
+    assert cm['weak']['hipgraph_ms'] is None                       # c10d collectives are never captured
+    assert out['adaround_dp']['per_rank_samples_per_iter'] == 4 and out['qat_dp']['allreduces_per_step'] >= 1

@@ -5,7 +5,9 @@
 //     c10d host bookkeeping x 161 quantizer calls per BERT-base batch;
 //   * no watchdog thread polling events, so a calibrating forward INCLUDING its collectives captures as a hipGraph
 //     (ncclAllReduce on the capturing stream is a plain sequence of kernel launches).
-// librccl is bound at run time (dlopen + dlsym): libtq_hip.so keeps loading on a box without RCCL, and the process
+// librccl is bound at run time (dlopen + dlsym) and its handful of public types are restated below (checked against
+// <rccl/rccl.h> at compile time when that header is installed): libtq_hip.so builds and loads on a box without RCCL or
+// without its development headers, and the process
 // uses the SAME librccl that torch already mapped when there is one (tq_comm_load is handed torch/lib/librccl.so by
 // the Python side) -- never two RCCL runtimes in one process.  The communicator is created from a 128-byte
 // ncclUniqueId that rank 0 generates (tq_comm_get_unique_id) and the caller ships to the other ranks by any means
@@ -13,29 +15,54 @@
 #include <dlfcn.h>
 #include <string.h>
 
-#include <rccl/rccl.h>
-
 #include "tq_host.h"
+
+// The slice of the NCCL/RCCL public ABI this file calls (rccl.h: opaque communicator, 128-byte unique id, result /
+// type / reduction codes).  These values are frozen by NCCL's ABI; the static_asserts below compare them with the
+// installed header whenever there is one.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define TQ_HAVE_RCCL_H 1
+#endif
+
+namespace tq {
+namespace nccl_abi {
+struct Comm;
+using comm_t = Comm*;
+struct UniqueId { char internal[128]; };
+using result_t = int;        // ncclSuccess == 0
+constexpr int kSuccess = 0;
+constexpr int kUint8 = 1, kInt32 = 2, kFloat32 = 7, kFloat64 = 8;
+constexpr int kSum = 0, kMax = 2, kMin = 3;
+#ifdef TQ_HAVE_RCCL_H
+static_assert(sizeof(UniqueId) == sizeof(ncclUniqueId), "ncclUniqueId");
+static_assert(kSuccess == ncclSuccess && kUint8 == ncclUint8 && kInt32 == ncclInt32 && kFloat32 == ncclFloat32 &&
+              kFloat64 == ncclFloat64 && kSum == ncclSum && kMax == ncclMax && kMin == ncclMin, "nccl enum codes");
+static_assert(sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int) && sizeof(ncclRedOp_t) == sizeof(int),
+              "nccl enums are int-sized");
+#endif
+}  // namespace nccl_abi
+}  // namespace tq
 
 namespace tq {
 
 struct RcclApi {
   void* handle = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
-  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
-  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
-  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  ncclResult_t (*GetVersion)(int*) = nullptr;
+  nccl_abi::result_t (*GetUniqueId)(nccl_abi::UniqueId*) = nullptr;
+  nccl_abi::result_t (*CommInitRank)(nccl_abi::comm_t*, int, nccl_abi::UniqueId, int) = nullptr;
+  nccl_abi::result_t (*CommDestroy)(nccl_abi::comm_t) = nullptr;
+  nccl_abi::result_t (*CommAbort)(nccl_abi::comm_t) = nullptr;
+  nccl_abi::result_t (*CommCount)(const nccl_abi::comm_t, int*) = nullptr;
+  nccl_abi::result_t (*CommUserRank)(const nccl_abi::comm_t, int*) = nullptr;
+  nccl_abi::result_t (*AllReduce)(const void*, void*, size_t, int, int, nccl_abi::comm_t, hipStream_t) = nullptr;
+  nccl_abi::result_t (*Broadcast)(const void*, void*, size_t, int, int, nccl_abi::comm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(nccl_abi::result_t) = nullptr;
+  nccl_abi::result_t (*GetVersion)(int*) = nullptr;
 };
 
 static RcclApi g_rccl;
 
-static const char* rccl_err(ncclResult_t r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"; }
+static const char* rccl_err(nccl_abi::result_t r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"; }
 
 template <class F>
 static bool bind(void* h, const char* name, F& fn) {
@@ -83,12 +110,12 @@ static int load_rccl(const char* path) {
   return TQ_OK;
 }
 
-static int nccl_type(int dtype, ncclDataType_t* t) {
+static int nccl_type(int dtype, int* t) {
   switch (dtype) {
-    case TQ_COMM_F32: *t = ncclFloat32; return TQ_OK;
-    case TQ_COMM_F64: *t = ncclFloat64; return TQ_OK;
-    case TQ_COMM_I32: *t = ncclInt32; return TQ_OK;
-    case TQ_COMM_U8: *t = ncclUint8; return TQ_OK;
+    case TQ_COMM_F32: *t = nccl_abi::kFloat32; return TQ_OK;
+    case TQ_COMM_F64: *t = nccl_abi::kFloat64; return TQ_OK;
+    case TQ_COMM_I32: *t = nccl_abi::kInt32; return TQ_OK;
+    case TQ_COMM_U8: *t = nccl_abi::kUint8; return TQ_OK;
     default: return set_error(TQ_EINVAL, "tq_comm: unknown element type %d", dtype);
   }
 }
@@ -97,22 +124,22 @@ static int nccl_type(int dtype, ncclDataType_t* t) {
 
 using namespace tq;
 
-extern "C" size_t tq_comm_unique_id_bytes(void) { return sizeof(ncclUniqueId); }
+extern "C" size_t tq_comm_unique_id_bytes(void) { return sizeof(nccl_abi::UniqueId); }
 
 extern "C" int tq_comm_load(const char* librccl_path) { return load_rccl(librccl_path); }
 
 extern "C" int tq_comm_version(void) {
   int v = 0;
-  if (g_rccl.handle == nullptr || g_rccl.GetVersion == nullptr || g_rccl.GetVersion(&v) != ncclSuccess) return 0;
+  if (g_rccl.handle == nullptr || g_rccl.GetVersion == nullptr || g_rccl.GetVersion(&v) != nccl_abi::kSuccess) return 0;
   return v;
 }
 
 extern "C" int tq_comm_get_unique_id(void* id_out) {
   TQ_REQUIRE(id_out, "tq_comm_get_unique_id: NULL pointer");
   if (int e = load_rccl(nullptr)) return e;
-  ncclUniqueId id;
-  ncclResult_t r = g_rccl.GetUniqueId(&id);
-  if (r != ncclSuccess) return set_error(TQ_ELAUNCH, "ncclGetUniqueId: %s", rccl_err(r));
+  nccl_abi::UniqueId id;
+  nccl_abi::result_t r = g_rccl.GetUniqueId(&id);
+  if (r != nccl_abi::kSuccess) return set_error(TQ_ELAUNCH, "ncclGetUniqueId: %s", rccl_err(r));
   memcpy(id_out, &id, sizeof(id));
   return TQ_OK;
 }
@@ -121,11 +148,11 @@ extern "C" int tq_comm_init(const void* unique_id, int rank, int world, void** c
   TQ_REQUIRE(unique_id && comm_out, "tq_comm_init: NULL pointer");
   TQ_REQUIRE(world >= 1 && rank >= 0 && rank < world, "tq_comm_init: bad rank %d / world %d", rank, world);
   if (int e = load_rccl(nullptr)) return e;
-  ncclUniqueId id;
+  nccl_abi::UniqueId id;
   memcpy(&id, unique_id, sizeof(id));
-  ncclComm_t comm = nullptr;
-  ncclResult_t r = g_rccl.CommInitRank(&comm, world, id, rank);     // uses the calling thread's current device
-  if (r != ncclSuccess) return set_error(TQ_ELAUNCH, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_err(r));
+  nccl_abi::comm_t comm = nullptr;
+  nccl_abi::result_t r = g_rccl.CommInitRank(&comm, world, id, rank);     // uses the calling thread's current device
+  if (r != nccl_abi::kSuccess) return set_error(TQ_ELAUNCH, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_err(r));
   *comm_out = comm;
   return TQ_OK;
 }
@@ -133,17 +160,28 @@ extern "C" int tq_comm_init(const void* unique_id, int rank, int world, void** c
 extern "C" int tq_comm_destroy(void* comm) {
   if (comm == nullptr) return TQ_OK;
   TQ_REQUIRE(g_rccl.handle, "tq_comm_destroy: librccl is not loaded");
-  ncclResult_t r = g_rccl.CommDestroy(static_cast<ncclComm_t>(comm));
-  if (r != ncclSuccess) return set_error(TQ_ELAUNCH, "ncclCommDestroy: %s", rccl_err(r));
+  nccl_abi::result_t r = g_rccl.CommDestroy(static_cast<nccl_abi::comm_t>(comm));
+  if (r != nccl_abi::kSuccess) return set_error(TQ_ELAUNCH, "ncclCommDestroy: %s", rccl_err(r));
+  return TQ_OK;
+}
+
+extern "C" int tq_comm_abort(void* comm) {
+  if (comm == nullptr) return TQ_OK;
+  TQ_REQUIRE(g_rccl.handle, "tq_comm_abort: librccl is not loaded");
+  // ncclCommAbort does not wait for the peers (ncclCommDestroy may, when a collective of this communicator is still
+  // outstanding): the call for a communicator whose set-up was rejected by the agreement round or whose peer is gone
+  nccl_abi::result_t r = g_rccl.CommAbort ? g_rccl.CommAbort(static_cast<nccl_abi::comm_t>(comm))
+                                          : g_rccl.CommDestroy(static_cast<nccl_abi::comm_t>(comm));
+  if (r != nccl_abi::kSuccess) return set_error(TQ_ELAUNCH, "ncclCommAbort: %s", rccl_err(r));
   return TQ_OK;
 }
 
 extern "C" int tq_comm_rank_world(void* comm, int* rank, int* world) {
   TQ_REQUIRE(comm && rank && world, "tq_comm_rank_world: NULL pointer");
   TQ_REQUIRE(g_rccl.handle, "tq_comm_rank_world: librccl is not loaded");
-  ncclResult_t r = g_rccl.CommUserRank(static_cast<ncclComm_t>(comm), rank);
-  if (r == ncclSuccess) r = g_rccl.CommCount(static_cast<ncclComm_t>(comm), world);
-  if (r != ncclSuccess) return set_error(TQ_ELAUNCH, "ncclCommUserRank/Count: %s", rccl_err(r));
+  nccl_abi::result_t r = g_rccl.CommUserRank(static_cast<nccl_abi::comm_t>(comm), rank);
+  if (r == nccl_abi::kSuccess) r = g_rccl.CommCount(static_cast<nccl_abi::comm_t>(comm), world);
+  if (r != nccl_abi::kSuccess) return set_error(TQ_ELAUNCH, "ncclCommUserRank/Count: %s", rccl_err(r));
   return TQ_OK;
 }
 
@@ -152,11 +190,11 @@ extern "C" int tq_comm_allreduce(void* comm, void* buf, uint64_t count, int dtyp
   TQ_REQUIRE(g_rccl.handle, "tq_comm_allreduce: librccl is not loaded");
   TQ_REQUIRE(op == TQ_COMM_MAX || op == TQ_COMM_SUM || op == TQ_COMM_MIN, "tq_comm_allreduce: unknown op %d", op);
   if (count == 0) return TQ_OK;
-  ncclDataType_t t;
+  int t;
   if (int e = nccl_type(dtype, &t)) return e;
-  const ncclRedOp_t o = op == TQ_COMM_MAX ? ncclMax : (op == TQ_COMM_MIN ? ncclMin : ncclSum);
-  ncclResult_t r = g_rccl.AllReduce(buf, buf, count, t, o, static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream));
-  if (r != ncclSuccess) return set_error(TQ_ELAUNCH, "ncclAllReduce(%llu x type %d): %s", (unsigned long long)count, dtype, rccl_err(r));
+  const int o = op == TQ_COMM_MAX ? nccl_abi::kMax : (op == TQ_COMM_MIN ? nccl_abi::kMin : nccl_abi::kSum);
+  nccl_abi::result_t r = g_rccl.AllReduce(buf, buf, count, t, o, static_cast<nccl_abi::comm_t>(comm), static_cast<hipStream_t>(stream));
+  if (r != nccl_abi::kSuccess) return set_error(TQ_ELAUNCH, "ncclAllReduce(%llu x type %d): %s", (unsigned long long)count, dtype, rccl_err(r));
   return TQ_OK;
 }
 
@@ -164,10 +202,10 @@ extern "C" int tq_comm_broadcast(void* comm, void* buf, uint64_t count, int dtyp
   TQ_REQUIRE(comm && (buf || count == 0), "tq_comm_broadcast: NULL pointer");
   TQ_REQUIRE(g_rccl.handle, "tq_comm_broadcast: librccl is not loaded");
   if (count == 0) return TQ_OK;
-  ncclDataType_t t;
+  int t;
   if (int e = nccl_type(dtype, &t)) return e;
-  ncclResult_t r = g_rccl.Broadcast(buf, buf, count, t, root, static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream));
-  if (r != ncclSuccess) return set_error(TQ_ELAUNCH, "ncclBroadcast: %s", rccl_err(r));
+  nccl_abi::result_t r = g_rccl.Broadcast(buf, buf, count, t, root, static_cast<nccl_abi::comm_t>(comm), static_cast<hipStream_t>(stream));
+  if (r != nccl_abi::kSuccess) return set_error(TQ_ELAUNCH, "ncclBroadcast: %s", rccl_err(r));
   return TQ_OK;
 }
 

@@ -104,6 +104,7 @@ SIGNATURES = {
     'tq_comm_get_unique_id': (_int, [_vp]),
     'tq_comm_init': (_int, [_vp, _int, _int, C.POINTER(_vp)]),
     'tq_comm_destroy': (_int, [_vp]),
+    'tq_comm_abort': (_int, [_vp]),
     'tq_comm_rank_world': (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     'tq_comm_allreduce': (_int, [_vp, _vp, _u64, _int, _int, _vp]),
     'tq_comm_broadcast': (_int, [_vp, _vp, _u64, _int, _int, _vp]),

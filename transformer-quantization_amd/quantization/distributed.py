@@ -56,8 +56,9 @@ def enable(group=None, force=False, mailbox=None, raw=None):
 
     raw: True / False / None (= environment TQ_DIST_RAW_RCCL, default: on when the group's backend is `nccl`): device
     tensors are exchanged on a raw RCCL communicator owned by libtq_hip.so (quantization/rccl.py) -- no c10d in the data
-    path.  The communicator is self-tested on creation; if the test fails, torch.distributed stays in charge on every
-    rank (the verdict is reduced over all ranks).
+    path.  Bring-up is agreed by all ranks through the rendezvous store before and after ncclCommInitRank (a failure on
+    one rank makes EVERY rank fall back), and the communicator is self-tested; if the test fails, torch.distributed
+    stays in charge on every rank (the verdict is reduced over all ranks).
     mailbox: True / False / None (= environment TQ_DIST_MAILBOX, default off): exchange the <= 8 KB min/max buffers of
     the fused calibration step through the P2P mailbox kernel (quantization/mailbox.py) instead of an all-reduce.
     The path is self-tested against the all-reduce here; if the set-up or the test fails on any rank, it stays off."""
@@ -70,11 +71,13 @@ def enable(group=None, force=False, mailbox=None, raw=None):
     _close_transports()
     active = force or dist.get_world_size(group) > 1
     if active and _want_raw(group, raw):
-        from quantization.rccl import RawRcclComm
+        from quantization import rccl
         try:
-            comm = RawRcclComm()                # collective: every rank takes this branch (same env, same backend)
-        except Exception as e:      # noqa: BLE001 -- librccl not loadable / communicator refused: the same on every rank
-            if raw:                 # explicitly requested: do not hide it
+            # two-phase commit over the rendezvous store: either every rank holds a communicator afterwards or every
+            # rank gets RawSetupFailed with the same verdict -- a local failure never splits the transports
+            comm = rccl.RawRcclComm()
+        except rccl.RawSetupFailed as e:
+            if raw:                 # explicitly requested: do not hide it (raised on every rank alike)
                 raise
             logger.warning('raw RCCL exchange unavailable (%s): statistics go through torch.distributed', e)
             comm = None

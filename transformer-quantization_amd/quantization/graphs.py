@@ -11,13 +11,34 @@ import torch
 from quantization import options
 
 
+class CaptureRefused(RuntimeError):
+    """Raised instead of recording a graph that could not be replayed safely."""
+
+
+def _refuse_c10d_exchange(what):
+    """A capture whose collectives would go through torch.distributed's `nccl` backend is REFUSED.
+
+    c10d wraps every collective in work objects that its watchdog thread polls with event queries; such a query while a
+    capture is open invalidates the capture or aborts the process (round 2's red test), and the work objects recorded
+    during capture are not re-created on replay.  The raw communicator (`quantization/rccl.py`: `ncclAllReduce` called
+    from libtq_hip.so on the capturing stream, no c10d object involved) is the supported transport for captured sharded
+    calibration / data-parallel steps: `quantization.distributed.enable(raw=True)`."""
+    from quantization import distributed as tq_dist
+    if tq_dist.is_enabled() and tq_dist.raw_comm() is None:
+        raise CaptureRefused(
+            f'{what}: the statistics / gradient exchange is active and goes through torch.distributed; collectives '
+            'issued by c10d cannot be captured into a hipGraph.  Enable the raw RCCL transport first '
+            '(quantization.distributed.enable(raw=True), backend `nccl`), or capture with the exchange off '
+            '(`with quantization.distributed.suspended(): ...`).')
+
+
 def _quiesce():
     """Nothing of this process may be in flight when a capture opens.  Wait for the device; when a c10d `nccl` process
-    group exists, also give its watchdog thread one polling period to retire the (now complete) work objects of eager
-    collectives: an event query from that thread while a GLOBAL-mode capture is open aborts the process, which is why
-    the captures below also use `capture_error_mode='thread_local'` (only the capturing thread's calls are policed).
-    The raw-RCCL exchange (quantization/rccl.py) involves no watchdog at all and is the transport to use for captured
-    sharded calibration."""
+    group exists (it may: barriers and the like outside the captured region), also give its watchdog thread one polling
+    period to retire the (now complete) work objects of eager collectives: an event query from that thread while a
+    GLOBAL-mode capture is open aborts the process, which is why the captures below also use
+    `capture_error_mode='thread_local'` (only the capturing thread's calls are policed).  Collectives INSIDE the
+    captured region must come from the raw-RCCL exchange (quantization/rccl.py), see `_refuse_c10d_exchange`."""
     torch.cuda.synchronize()
     try:
         import torch.distributed as dist
@@ -43,6 +64,7 @@ class GraphedForward:
     def __init__(self, module, *example_inputs, warmup=2, restore_state=True, no_grad=True):
         if not all(torch.is_tensor(t) and t.is_cuda for t in example_inputs):
             raise ValueError('GraphedForward needs ROCm tensors as example inputs')
+        _refuse_c10d_exchange('GraphedForward')
         self.module = module
         self.static_inputs = tuple(t.clone() for t in example_inputs)
         self._no_grad = no_grad
@@ -102,14 +124,19 @@ class GraphedTrainStep:
     * the warm-up iterations (allocator pools, workspaces, optimizer state) are real optimisation steps on the example
       batch; with `restore_state=True` (default) parameters, buffers and optimizer state are put back to their values
       from before the warm-up after capture, so training starts from the model that was passed in;
-    * estimator state must not change during the step: ranges fixed (`fix_ranges`) or learnable, not estimating.
+    * estimator state must not change during the step: ranges fixed (`fix_ranges`) or learnable, not estimating;
+    * `grad_sync`: a `quantization.data_parallel.GradientBuckets` over the module's parameters makes this the
+      DATA-PARALLEL step (BASELINE configs[4]): the bucketed gradient all-reduces -- raw RCCL, on a second stream that
+      forks from and joins the capturing stream -- are part of the recorded graph, overlapped with the rest of backward.
     """
 
-    def __init__(self, module, loss_fn, optimizer, example_inputs, example_targets=(), warmup=3, restore_state=True):
+    def __init__(self, module, loss_fn, optimizer, example_inputs, example_targets=(), warmup=3, restore_state=True,
+                 grad_sync=None):
         tensors = tuple(example_inputs) + tuple(example_targets)
         if not tensors or not all(torch.is_tensor(t) and t.is_cuda for t in tensors):
             raise ValueError('GraphedTrainStep needs ROCm tensors as example inputs / targets')
-        self.module, self.loss_fn, self.optimizer = module, loss_fn, optimizer
+        _refuse_c10d_exchange('GraphedTrainStep')
+        self.module, self.loss_fn, self.optimizer, self.grad_sync = module, loss_fn, optimizer, grad_sync
         self.static_inputs = tuple(t.clone() for t in example_inputs)
         self.static_targets = tuple(t.clone() for t in example_targets)
         snap = {k: v.clone() for k, v in module.state_dict().items()} if restore_state else None
@@ -146,9 +173,14 @@ class GraphedTrainStep:
         options.invalidate_derived_caches()
 
     def _step(self):
-        self.optimizer.zero_grad(set_to_none=True)
+        if self.grad_sync is not None:
+            self.grad_sync.zero_()               # gradients stay views of the flat buckets
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss_fn(self.module(*self.static_inputs), *self.static_targets)
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
         self.optimizer.step()
         return loss.detach()
 
