@@ -309,6 +309,26 @@ with torch.no_grad():
     QMobileSelfAttention.fuse = False
     options.INT8_LINEAR = False
     QResidualNoNorm.fuse = False
+    # how far the integer evaluation moves the W4A4 network from the fp32 simulation (the reference's contract), per
+    # encoder layer: output-index flip rate on the SAME input and free-running (harness/divergence.py)
+    from harness.divergence import encoder_flip_rates
+
+    class _AllInteger:
+        def __enter__(self):
+            options.INT8_LINEAR = True
+            QResidualNoNorm.fuse = QBottleneckLayer.fuse = QMobileSelfAttention.fuse = QFFN.fuse = QMobileLayer.fuse_ffn = True
+
+        def __exit__(self, *exc):
+            options.INT8_LINEAR = False
+            QResidualNoNorm.fuse = QBottleneckLayer.fuse = QMobileSelfAttention.fuse = QFFN.fuse = QMobileLayer.fuse_ffn = False
+            return False
+    rows, first = encoder_flip_rates(mb, ids_mb, _AllInteger())
+    c['int8_divergence_vs_fp32_simulation'] = {
+        'first_diverging_layer_free_running': first,
+        'same_input_flip_rate_per_layer': [round(r['same_input']['flip_rate'], 6) for r in rows],
+        'same_input_max_index_distance': max(r['same_input']['max_steps'] for r in rows),
+        'free_running_flip_rate_per_layer': [round(r['free_running']['flip_rate'], 6) for r in rows],
+        'note': 'fraction of a layer\'s [8,128,512] 4-bit output indices that differ from the layered fp32-simulation forward'}
 # QAT step (training mode, fixed ranges, forward + backward): layered fp32 simulation vs integer MFMA forward
 mb.train()
 lab = torch.randint(0, 2, (8,), device=dev)

@@ -7,7 +7,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --headline-only"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $BENCH > "$OUT/bench_fetch.log" 2>&1

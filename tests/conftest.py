@@ -65,3 +65,14 @@ def golden_toy():
 @pytest.fixture(scope='session')
 def golden_adaround():
     return load_golden('adaround')
+
+
+def check_weights_reproduced(hf, z):
+    """The harness model carries exactly the parameters the fixture was generated on: both sides fill them from numpy's
+    legacy Mersenne-Twister stream (harness/weights.py), which does not depend on the torch / transformers build -- so
+    this is an ASSERTION (round 3: a different build could only skip here, silently dropping every whole-model parity
+    test).  Check sum: float64 sum of |w| over all parameters in name order (numpy pairwise sums: thread-count
+    independent), compared to 1e-12 relative."""
+    from harness.weights import weight_check_sum
+    got, want = weight_check_sum(hf), float(z['weight_check_sum'])
+    assert abs(got - want) <= 1e-12 * abs(want), ('harness weights differ from the fixture', got, want, str(z['versions']))

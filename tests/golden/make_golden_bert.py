@@ -15,8 +15,8 @@ W8A8 recipe (README.md:149-157: MSE / golden-section weight ranges, current min-
 calibration sample), i.e. the recipe BASELINE configs[0] is quoted on.
 
 Stores: logits, the 161 activation ranges (call order) and the 102 weight-quantizer deltas.
-Weights are NOT stored (440 MB): the test rebuilds them from the same seed with the same
-transformers / torch versions (same container image on the GPU box).
+Weights are NOT stored (440 MB): both sides regenerate them from numpy's legacy Mersenne-Twister stream
+(harness/weights.py: independent of the torch / transformers build).
 
     python tests/golden/make_golden_bert.py
 """
@@ -53,6 +53,16 @@ from models.quantized_bert import (  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 SEED = 1000
 
+# build-independent parameters: the SAME function the harness models use (numpy + torch only, loaded by path so that the
+# repo's `quantization` package is never imported next to the reference's)
+import importlib.util as _ilu  # noqa: E402
+_spec = _ilu.spec_from_file_location('tq_harness_weights', os.path.join(
+    os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'transformer-quantization_amd', 'harness',
+    'weights.py'))
+_hw = _ilu.module_from_spec(_spec)
+_spec.loader.exec_module(_hw)
+fill_from_numpy_stream, weight_check_sum = _hw.fill_from_numpy_stream, _hw.weight_check_sum
+
 
 def build_hf(num_layers=None):
     torch.manual_seed(SEED)
@@ -61,6 +71,7 @@ def build_hf(num_layers=None):
         cfg.num_hidden_layers = num_layers
     model = BertForSequenceClassification(cfg)
     model.eval()
+    fill_from_numpy_stream(model, SEED)
     # transformers 4.1 semantics: ACT2FN['gelu'] was torch.nn.functional.gelu, which the reference
     # turns into nn.GELU() and folds into the intermediate QuantLinear (quantized_bert.py:283-291);
     # today's GELUActivation module would silently escape that folding.
@@ -158,7 +169,8 @@ def main(recipe='default'):
         act_max=np.array([a[2] for a in act], ftype),
         w_names=np.array([w[0] for w in wts]), w_delta=np.array([w[1] for w in wts], ftype),
         versions=np.array(f'torch {torch.__version__} transformers {transformers.__version__}'),
-        first_weight_sum=np.array(float(hf.bert.encoder.layer[0].attention.self.query.weight.double().sum())))
+        first_weight_sum=np.array(float(hf.bert.encoder.layer[0].attention.self.query.weight.double().sum())),
+        weight_check_sum=np.array(weight_check_sum(hf)))
 
 
 def gen_nonorm():

@@ -54,6 +54,16 @@ from models.quantized_mobilebert import (  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 SEED = 1000
 
+# build-independent parameters: the SAME function the harness models use (numpy + torch only, loaded by path so that the
+# repo's `quantization` package is never imported next to the reference's)
+import importlib.util as _ilu  # noqa: E402
+_spec = _ilu.spec_from_file_location('tq_harness_weights', os.path.join(
+    os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'transformer-quantization_amd', 'harness',
+    'weights.py'))
+_hw = _ilu.module_from_spec(_spec)
+_spec.loader.exec_module(_hw)
+fill_from_numpy_stream, weight_check_sum = _hw.fill_from_numpy_stream, _hw.weight_check_sum
+
 
 class RefLayer(torch.nn.Module):
     """The reference's leaf blocks of one MobileBertLayer + the 4.1 container glue."""
@@ -81,24 +91,10 @@ class RefLayer(torch.nn.Module):
         return self.output(self.intermediate(a), a, h)
 
 
-def randomize_nonorm(hf, seed):
-    """HF initialises NoNorm to weight = 1, bias = 0.  The reference's QuantNoNorm quantizes weight AND bias with ONE
-    quantizer whose range ends up being the bias range (quirk q9, models/quantized_mobilebert.py:58-72): with an
-    all-zero bias every NoNorm weight would quantize to ~0 after fix_ranges and the network would output zeros.  A
-    trained checkpoint has non-trivial affine parameters; emulate that (same procedure in harness/mobilebert.py)."""
-    from transformers.models.mobilebert.modeling_mobilebert import NoNorm
-    g = torch.Generator().manual_seed(seed)
-    for m in hf.modules():
-        if isinstance(m, NoNorm):
-            m.weight.data = 1.0 + 0.1 * torch.randn(m.weight.shape, generator=g)
-            m.bias.data = 0.5 * torch.randn(m.bias.shape, generator=g)
-
-
 def main():
     torch.set_num_threads(8)
     torch.manual_seed(SEED)
-    hf = MobileBertForSequenceClassification(MobileBertConfig(num_labels=2)).eval()
-    randomize_nonorm(hf, SEED + 1)
+    hf = fill_from_numpy_stream(MobileBertForSequenceClassification(MobileBertConfig(num_labels=2)).eval(), SEED)
     qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=4, n_bits_act=4,
               weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax,
               quant_dict={'attn_probs_n_bits_act': 8})
@@ -151,7 +147,8 @@ def main():
         act_max=np.array([a[2] for a in act], np.float32), act_bits=np.array([a[3] for a in act], np.int32),
         w_names=np.array([w[0] for w in wts]), w_delta=np.array([w[1] for w in wts], np.float32),
         versions=np.array(f'torch {torch.__version__} transformers {transformers.__version__}'),
-        first_weight_sum=np.array(float(mb.encoder.layer[0].attention.self.query.weight.detach().double().sum())))
+        first_weight_sum=np.array(float(mb.encoder.layer[0].attention.self.query.weight.detach().double().sum())),
+        weight_check_sum=np.array(weight_check_sum(hf)))
 
 
 if __name__ == '__main__':

@@ -106,3 +106,54 @@ def test_product_package_never_imports_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M) or 'tq_oracle' in txt:
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_fastcall_stub_calls_the_same_library_through_raw_addresses():
+    """csrc_py/tq_fastcall.c (plain C over Python.h: no torch headers, no pybind) is built by build.py next to
+    libtq_hip.so; it reaches the SAME entry points through their raw addresses.  No compute call here (no GPU): the
+    version getter and an argument-validation error path are enough to prove the route."""
+    from quantization import _hip
+    fc = _hip.fastcall()
+    assert fc is not None, 'lib/_tq_fastcall*.so missing: python transformer-quantization_amd/build.py'
+    lib = _hip.load_library()
+    assert fc.call_ptrs(_hip.entry_address(lib.tq_abi_version)) == lib.tq_abi_version() == 1
+    # tq_fake_quant_fwd(x = NULL, ...) is rejected by the library's own argument checks on both routes
+    addr = _hip.entry_address(lib.tq_fake_quant_fwd)
+    rc_fast = fc.fake_quant_fwd(addr, 0, 0, 0, 0, 16, 0, 0, 0)
+    msg_fast = lib.tq_last_error()
+    rc_ctypes = lib.tq_fake_quant_fwd(None, None, None, 0, 16, 0, None, None)
+    assert rc_fast == rc_ctypes != 0 and msg_fast == lib.tq_last_error()
+    import pytest
+    with pytest.raises(ValueError):
+        fc.fake_quant_fwd(0, 0, 0, 0, 0, 16, 0, 0, 0)
+    with pytest.raises(TypeError):
+        fc.fake_quant_fwd(addr, 0)
+
+
+@pytest.mark.gpu
+def test_fixed_range_fast_path_is_identical_through_fastcall_and_ctypes():
+    import torch
+    from quantization import _hip
+    from quantization.base_quantized_classes import QuantizedActivation
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    x = torch.randn(8, 128, 768, device='cuda')
+    outs = {}
+    saved = (_hip._fastcall_mod, _hip._fastcall_tried)
+    try:
+        for route in ('fastcall', 'ctypes'):
+            if route == 'ctypes':
+                _hip._fastcall_mod, _hip._fastcall_tried = None, True
+            qa = QuantizedActivation(act_method=QMethods.asymmetric_uniform, n_bits_act=8,
+                                     act_range_method=RangeEstimators.running_minmax).cuda()
+            qa.quantized_acts()
+            qa.eval()
+            with torch.no_grad():
+                qa(x)
+                qa.activation_quantizer.fix_ranges()
+                outs[route] = qa(x)
+                plan = qa.activation_quantizer._fast_plan
+            assert plan is not None and (type(plan[2]) is tuple) == (route == 'fastcall')
+    finally:
+        _hip._fastcall_mod, _hip._fastcall_tried = saved
+    assert torch.equal(outs['fastcall'], outs['ctypes'])

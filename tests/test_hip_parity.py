@@ -549,6 +549,46 @@ def test_adaround_fused_step_vs_torch_adam(q, mode, method):
         assert torch.allclose(a_dev.cpu(), a_ref.detach(), rtol=1e-4, atol=2e-5), (mode, method, step)
 
 
+@pytest.mark.parametrize('beta', [2.0, 1.0, 0.5])
+def test_adaround_regulariser_gradient_at_the_kink(beta):
+    """the fused step's regulariser gradient where h(alpha) == 0.5 exactly (u = |2h - 1| = 0; alpha = 0 for
+    both sigmoid modes).  d/dalpha [1 - u^beta] there is 0 in torch for beta >= 1 (abs'(0) = sign(0) = 0) -- the kernel
+    agrees; for beta < 1 torch's chain rule gives 0 * inf = NaN (outside the reference's annealing range 20 -> 2,
+    adaround/config.py) and the kernel is DEFINED to return 0: a finite step instead of a NaN that would poison alpha."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(8, 64, generator=g) * 0.1
+    delta, signed = O.sym_params_from_range(w.min(), w.max(), 4)
+    qargs = (delta.to(DEV), None, signed.to(DEV), 4, True, False, 1e-8, 1, 1)
+    for mode, mcode in (('learned_sigmoid', 0), ('learned_hard_sigmoid', 1)):
+        alpha0 = torch.randn(8, 64, generator=g)
+        alpha0[:, ::4] = 0.0                                     # h == 0.5 exactly on a quarter of the entries
+        gw = torch.randn(8, 64, generator=g)
+        a_ref = alpha0.clone().requires_grad_(True)
+        _, wq_ref = O.ada_fake_quant(w, a_ref, delta, None, 4, True, bool(signed), mode, True, temperature=7.0)
+        obj = (wq_ref * gw).sum() + O.ada_round_reg(a_ref, mode, beta, 0.01, 7.0)
+        obj.backward()
+        g_ref = a_ref.grad
+        a_dev = alpha0.clone().to(DEV)
+        m_dev, v_dev = torch.zeros_like(a_dev), torch.zeros_like(a_dev)
+        g_dev = be.adaround_bwd_adam(w.to(DEV), gw.to(DEV), a_dev, m_dev, v_dev, qargs, mcode, 7.0, 0.01, beta, 1e-2, 0.9,
+                                     0.999, 1e-8, 1, want_grad=True).cpu()
+        kink = torch.zeros(8, 64, dtype=torch.bool)
+        kink[:, ::4] = True
+        assert torch.isfinite(g_dev).all() and torch.isfinite(a_dev).all(), (mode, beta)
+        assert torch.allclose(g_dev[~kink], g_ref[~kink], rtol=2e-4, atol=1e-6), (mode, beta)
+        # at the kink only the reconstruction term contributes
+        a2 = alpha0.clone().requires_grad_(True)
+        _, wq2 = O.ada_fake_quant(w, a2, delta, None, 4, True, bool(signed), mode, True, temperature=7.0)
+        (wq2 * gw).sum().backward()
+        assert torch.allclose(g_dev[kink], a2.grad[kink], rtol=2e-4, atol=1e-6), (mode, beta)
+        if beta >= 1.0:
+            assert torch.allclose(g_dev[kink], g_ref[kink], rtol=2e-4, atol=1e-6), (mode, beta)
+        else:
+            assert torch.isnan(g_ref[kink]).all()                # what the kernel deliberately does not reproduce
+
+
 def test_adaround_layer_gradient_well_conditioned(q):
     """Class path (QuantLinear + AdaRoundQuantizer + autograd through _AdaRoundFn) against the CPU
     oracle on a problem whose loss is O(1) (so that GEMM round-off does not dominate)."""

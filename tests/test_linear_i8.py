@@ -129,7 +129,23 @@ def test_bert_forward_with_integer_linears():
     assert n_plain == 12 * 6                      # q, k, v, attention-out, intermediate, output per layer
     span = float(layered.max() - layered.min())
     for y in (y_int, y_int_fused):
-        assert float((y - layered).abs().max()) <= 0.10 * span
+        assert float((y - layered).abs().max()) <= 0.08 * span           # measured 5-7 % (round 3), bar tightened from 10 %
+    # per encoder layer, on the SAME input: the fraction of 8-bit output indices the integer evaluation moves
+    from harness.divergence import encoder_flip_rates
+
+    class _Int8:
+        def __enter__(self):
+            options.INT8_LINEAR = True
+
+        def __exit__(self, *exc):
+            options.INT8_LINEAR = False
+            return False
+    rows, first = encoder_flip_rates(model, ids, _Int8())
+    same = [r['same_input']['flip_rate'] for r in rows]
+    print('BERT-base W8A8 integer Linears, same-input flip rate per layer: max %.2e, max index distance %d; first diverging '
+          'layer (free-running): %s' % (max(same), max(r['same_input']['max_steps'] for r in rows), first))
+    # (measured: max 6e-4 of a layer's 786 432 outputs, index distance <= 2)
+    assert max(same) <= 3e-3 and max(r['same_input']['max_steps'] for r in rows) <= 2, same
 
 
 def test_integer_linear_in_training_mode_qat_forward():

@@ -42,12 +42,8 @@ def _calibrate_and_run(model, ids):
 
 
 def _check_weights_reproduced(hf, z):
-    got = float(hf.mobilebert.encoder.layer[0].attention.self.query.weight.detach().double().sum())
-    # (the float64 sum itself depends on the host's thread count in its last bit -- parallel reduction order -- while a
-    # different random init moves it in the second digit: compare with a tolerance, not bit for bit)
-    want = float(z['first_weight_sum'])
-    if abs(got - want) > 1e-9 * max(1.0, abs(want)):
-        pytest.skip('random-init weights differ from the fixture (other torch/transformers build): ' + str(z['versions']))
+    from tests.conftest import check_weights_reproduced
+    check_weights_reproduced(hf, z)
 
 
 def _census(model):
@@ -340,3 +336,55 @@ def test_mobilebert_w4a4_integer_encoder_equals_integer_oracle():
         QMobileLayer.fuse_ffn = False
     assert torch.isfinite(h_gpu).all()
     assert torch.equal(h_gpu.cpu(), h_cpu)
+
+
+class _IntegerMode:
+    """Every Linear, NoNorm tail, feed-forward block and attention core of the MobileBERT harness as an integer launch."""
+
+    def __enter__(self):
+        from harness.mobilebert import QBottleneckLayer, QFFN, QMobileLayer, QMobileSelfAttention, QResidualNoNorm
+        from quantization import options
+        self.classes = (QBottleneckLayer, QFFN, QMobileSelfAttention, QResidualNoNorm)
+        options.INT8_LINEAR = True
+        for c in self.classes:
+            c.fuse = True
+        QMobileLayer.fuse_ffn = True
+
+    def __exit__(self, *exc):
+        from harness.mobilebert import QMobileLayer
+        from quantization import options
+        options.INT8_LINEAR = False
+        for c in self.classes:
+            c.fuse = False
+        QMobileLayer.fuse_ffn = False
+        return False
+
+
+@pytest.mark.gpu
+def test_mobilebert_w4a4_integer_path_divergence_is_published_per_layer():
+    """VERDICT r3 weak #2 / next #7.  The opt-in integer path is exact against ITS specification (previous test), but the
+    reference's contract is the fp32 simulation (hijacker.py:66-70), and at W4A4 the two separate: per encoder layer, the
+    fraction of output indices that differ when the layer is fed the SAME input in both modes (what one layer adds) and
+    on the free-running integer forward (what accumulates), with the first diverging layer named.  The bars are the
+    measured values with head-room (profiles/r04/config_bench.json carries the same table): the integer path is NOT a
+    reference-parity path at model level for 4-bit grids and stays opt-in."""
+    from harness.divergence import encoder_flip_rates
+    z = _fixture()
+    model, hf = _build('cuda')
+    _check_weights_reproduced(hf, z)
+    ids = torch.from_numpy(z['input_ids'])
+    _calibrate_and_run(model, ids)
+    rows, first = encoder_flip_rates(model, ids.cuda(), _IntegerMode())
+    same = np.array([r['same_input']['flip_rate'] for r in rows])
+    free = np.array([r['free_running']['flip_rate'] for r in rows])
+    print('first diverging layer:', first)
+    print('same-input flip rate per layer: median %.2e max %.2e' % (np.median(same), same.max()))
+    print('free-running flip rate per layer:', np.array2string(free, precision=3))
+    print('max index distance (same input):', max(r['same_input']['max_steps'] for r in rows))
+    assert len(rows) == 24 and first is not None and first <= 2        # it does diverge, from the first layers on
+    # one layer by itself: the GEMM round-off of the simulation flips a small fraction of a layer's 4-bit outputs
+    # (measured: median 2.8e-4, max 6.2e-3 of a layer's 524 288 outputs, index distance <= 2)
+    assert np.median(same) <= 2e-3 and same.max() <= 0.02, same
+    # accumulated over 24 layers the two forwards are different trajectories of a chaotic 4-bit network
+    # (measured: 0.6 % after layer 1, 13 % after layer 5, 27-31 % from layer 11 on)
+    assert free[0] <= 0.02 and free[-1] <= 0.45, free

@@ -195,7 +195,9 @@ def test_graph_replays_invalidate_derived_caches_and_keep_optimizer_state():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.SGD(params, lr=5e-2, momentum=0.9)
+    # (lr: large enough that three replays move the 8-bit logits, small enough that the 2-layer network does not run into
+    # the clamp of its output quantizer -- at 5e-2 it did with the round-4 weights and every logit became the same value)
+    opt = torch.optim.SGD(params, lr=1e-2, momentum=0.9)
     loss_fn = torch.nn.functional.cross_entropy
     # an optimizer with history: two eager steps first
     for i in range(2):

@@ -31,12 +31,8 @@ def _build(device):
 
 
 def _check_weights_reproduced(hf, z):
-    got = float(hf.roberta.encoder.layer[0].attention.self.query.weight.detach().double().sum())
-    # (the float64 sum itself depends on the host's thread count in its last bit -- parallel reduction order -- while a
-    # different random init moves it in the second digit: compare with a tolerance, not bit for bit)
-    want = float(z['first_weight_sum'])
-    if abs(got - want) > 1e-9 * max(1.0, abs(want)):
-        pytest.skip('random-init weights differ from the fixture (other torch/transformers build): ' + str(z['versions']))
+    from tests.conftest import check_weights_reproduced
+    check_weights_reproduced(hf, z)
 
 
 def _calibrate_and_run(model, ids, amask):

@@ -65,5 +65,21 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_fastcall(force=False, verbose=True):
+    """The CPython stub over the C ABI (csrc_py/tq_fastcall.c: plain C, Python.h only) -> lib/_tq_fastcall<EXT_SUFFIX>.
+    Optional at run time: quantization/_hip.py falls back to ctypes when it is absent."""
+    import sysconfig
+    src = os.path.join(HERE, 'csrc_py', 'tq_fastcall.c')
+    out = os.path.join(LIBDIR, '_tq_fastcall' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
+    os.makedirs(LIBDIR, exist_ok=True)
+    if force or _stale(out, [src]):
+        cmd = [os.environ.get('CC', 'gcc'), '-O2', '-fPIC', '-shared', '-Wall', '-I' + sysconfig.get_paths()['include'], src, '-o', out]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv))
+    print(build_fastcall(force='--force' in sys.argv))

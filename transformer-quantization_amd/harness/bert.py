@@ -169,13 +169,15 @@ class QBertForSequenceClassification(QuantizedModel):
 
 
 def build_bert_base(seed=1000, num_labels=2, num_layers=None, **qp):
-    """Random-init HF BERT-base (seeded on the CPU generator) wrapped with quantizers."""
+    """HF BERT-base architecture with parameters from the build-independent numpy stream (harness/weights.py),
+    wrapped with quantizers."""
     from transformers import BertConfig, BertForSequenceClassification
+    from harness.weights import fill_from_numpy_stream
     torch.manual_seed(seed)
     cfg = BertConfig(num_labels=num_labels)
     if num_layers is not None:
         cfg.num_hidden_layers = num_layers
-    hf = BertForSequenceClassification(cfg).eval()
+    hf = fill_from_numpy_stream(BertForSequenceClassification(cfg).eval(), seed)
     return QBertForSequenceClassification(hf, **qp), hf
 
 

@@ -239,26 +239,14 @@ class QMobileBertForSequenceClassification(QuantizedModel):
         return self.classifier(pooled)
 
 
-def randomize_nonorm(hf, seed):
-    """HF initialises NoNorm to weight = 1, bias = 0.  QuantNoNorm quantizes weight AND bias with ONE quantizer whose
-    range ends up being the bias range (upstream quirk q9): with an all-zero bias every NoNorm weight quantizes to ~0
-    once the ranges are fixed and the network outputs zeros.  A trained checkpoint has non-trivial affine parameters;
-    emulate that with seeded values (the fixture generator applies the same procedure)."""
-    from transformers.models.mobilebert.modeling_mobilebert import NoNorm
-    g = torch.Generator().manual_seed(seed)
-    for m in hf.modules():
-        if isinstance(m, NoNorm):
-            m.weight.data = 1.0 + 0.1 * torch.randn(m.weight.shape, generator=g)
-            m.bias.data = 0.5 * torch.randn(m.bias.shape, generator=g)
-
-
 def build_mobilebert(seed=1000, num_labels=2, num_layers=None, **qp):
-    """Random-init HF MobileBERT (seeded on the CPU generator) wrapped with quantizers."""
+    """HF MobileBERT architecture with parameters from the build-independent numpy stream (harness/weights.py: NoNorm
+    gets non-trivial affine parameters, see there), wrapped with quantizers."""
     from transformers import MobileBertConfig, MobileBertForSequenceClassification
+    from harness.weights import fill_from_numpy_stream
     torch.manual_seed(seed)
     cfg = MobileBertConfig(num_labels=num_labels)
     if num_layers is not None:
         cfg.num_hidden_layers = num_layers
-    hf = MobileBertForSequenceClassification(cfg).eval()
-    randomize_nonorm(hf, seed + 1)
+    hf = fill_from_numpy_stream(MobileBertForSequenceClassification(cfg).eval(), seed)
     return QMobileBertForSequenceClassification(hf, **qp), hf

@@ -48,12 +48,14 @@ class QRobertaForSequenceClassification(QuantizedModel):
 
 
 def build_roberta(seed=1000, num_labels=2, num_layers=None, **qp):
-    """Random-init HF RoBERTa-base (seeded on the CPU generator) wrapped with quantizers."""
+    """HF RoBERTa-base architecture with parameters from the build-independent numpy stream (harness/weights.py),
+    wrapped with quantizers."""
     from transformers import RobertaConfig, RobertaForSequenceClassification
+    from harness.weights import fill_from_numpy_stream
     torch.manual_seed(seed)
     cfg = RobertaConfig(num_labels=num_labels, vocab_size=50265, max_position_embeddings=514, type_vocab_size=1,
                         pad_token_id=1)
     if num_layers is not None:
         cfg.num_hidden_layers = num_layers
-    hf = RobertaForSequenceClassification(cfg).eval()
+    hf = fill_from_numpy_stream(RobertaForSequenceClassification(cfg).eval(), seed)
     return QRobertaForSequenceClassification(hf, **qp), hf

@@ -157,6 +157,40 @@ def load_library(path=None):
     return lib
 
 
+_fastcall_mod, _fastcall_tried = None, False
+
+
+def fastcall():
+    """The CPython stub over the C ABI (csrc_py/tq_fastcall.c -> lib/_tq_fastcall*.so: plain C, no torch headers) or None.
+    It calls the SAME entry points of the SAME mapped libtq_hip.so through their raw addresses, without ctypes' argument
+    marshalling (~2 us per call).  Optional: when it is not built, or with TQ_FASTCALL=0, every call goes through ctypes."""
+    global _fastcall_mod, _fastcall_tried
+    if _fastcall_tried:
+        return _fastcall_mod
+    _fastcall_tried = True
+    if os.environ.get('TQ_FASTCALL', '1') == '0':
+        return None
+    import glob
+    import importlib.machinery
+    import importlib.util
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(LIB_PATH), '_tq_fastcall*.so'))):
+        try:
+            loader = importlib.machinery.ExtensionFileLoader('_tq_fastcall', path)
+            spec = importlib.util.spec_from_loader('_tq_fastcall', loader)
+            mod = importlib.util.module_from_spec(spec)
+            loader.exec_module(mod)
+            _fastcall_mod = mod
+            break
+        except Exception:       # noqa: BLE001 -- built for another interpreter: ctypes it is
+            continue
+    return _fastcall_mod
+
+
+def entry_address(fn):
+    """Raw address of a ctypes function of the loaded library (what `fastcall()` calls through)."""
+    return C.cast(fn, C.c_void_p).value
+
+
 def _check(rc, lib):
     if rc != 0:
         raise TQError(f'libtq_hip: {lib.tq_last_error().decode()} (code {rc})')
@@ -341,6 +375,9 @@ class HipBackend:
         foreign call (the generic route through QuantizerBase.forward -> fake_quant costs ~6 us of Python per call,
         x 161 / 1333 quantizer calls per BERT-base / MobileBERT forward)."""
         d = self._qdesc(delta, zero_float, signed, n_bits, symmetric, log_domain, eps, 1, 1)
+        fc = fastcall()
+        if fc is not None:      # raw addresses for the CPython stub; `d` (kept in the plan) owns the descriptor memory
+            return fc.fake_quant_fwd, (entry_address(self.lib.tq_fake_quant_fwd), C.addressof(d)), d
         return self.lib.tq_fake_quant_fwd, C.byref(d), d
 
     def affine_fake_quant(self, x, w, b, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, want_idx=False):

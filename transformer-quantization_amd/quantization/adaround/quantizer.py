@@ -108,11 +108,22 @@ class AdaRoundQuantizer(QuantizerBase):
     def to_integer_forward(self, x_float):
         if not self._relaxed():
             return super().to_integer_forward(x_float)
-        # integer-valued only for hard targets; recovered from the dequantised kernel output
         self._ensure_alpha(x_float)
-        y = self.forward(x_float)
         zp = 0.0 if self.symmetric else self.zero_point
-        return y / self.scale + zp
+        if not self.soft_targets:
+            # hard targets: floor(x / s) + [alpha >= 0] (+ zp), clamped -- an exact integer.  Recovered from the kernel's
+            # dequantised output s * (x_int - zp): the quotient is within one ulp of that integer (|x_int - zp| < 2^22),
+            # so rounding restores it exactly (reference adaround/quantizer.py:72-79 returns the integer itself;
+            # found by tests/test_adaround_model.py: y / s alone gave 2.9999998 for 134 of 1152 entries of a layer).
+            y = self.forward(x_float)
+            return torch.round(y / self.scale) + zp
+        # soft targets: x_floor + h(alpha), differentiable in alpha -- the reference's own expression
+        # (adaround/quantizer.py:54-79); not on any hot path (the optimisation loop uses the fused kernels)
+        x_floor = torch.floor(x_float / self.scale)
+        x_int = x_floor + self.get_rest()
+        if not self.symmetric:
+            x_int = x_int + zp
+        return torch.clamp(x_int, self.int_min, self.int_max)
 
     def forward(self, x_float):
         if not self._relaxed():

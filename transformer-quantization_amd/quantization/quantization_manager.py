@@ -259,19 +259,27 @@ class QuantizationManager(nn.Module):
                 or (torch.is_grad_enabled() and x.requires_grad) or x.device.index != torch.cuda.current_device()):
             return None
         sg = bufs.get('_signed')
+        # (the key also names the quantizer's kind and the backend object, and the range buffers must live on
+        # x's device -- the generic route raises for a foreign pointer, this one must not launch with it)
         key = (q._range_gen, delta.data_ptr(), None if zf is None else zf.data_ptr(), None if sg is None else sg.data_ptr(),
-               q.n_bits, q.eps, x.device.index)
+               q.n_bits, q.eps, x.device.index, type(q), q.symmetric, q.scale_domain, id(_hip._backend))
         plan = self._fast_plan
         if plan is None or plan[0] != key:
             be = _hip.backend()
             if (delta.numel() != 1 or q.axis is not None or q.per_channel or not hasattr(be, 'fixed_quant_plan')
-                    or (q.symmetric and sg is None) or (not q.symmetric and zf is None) or delta.requires_grad):
+                    or (q.symmetric and sg is None) or (not q.symmetric and zf is None) or delta.requires_grad
+                    or delta.device != x.device or (zf is not None and zf.device != x.device)
+                    or (sg is not None and sg.device != x.device)):
                 return None
             plan = (key,) + be.fixed_quant_plan(delta, zf, sg, q.n_bits, q.symmetric,
                                              q.scale_domain == 'log', q.eps) + (be.lib,)
             object.__setattr__(self, '_fast_plan', plan)
         y = torch.empty_like(x)
-        rc = plan[1](x.data_ptr(), y.data_ptr(), None, 0, x.numel(), _FAST_DTYPES[x.dtype], plan[2], _hip._stream())
+        ref = plan[2]
+        if type(ref) is tuple:          # CPython stub (csrc_py/tq_fastcall.c): (entry address, descriptor address)
+            rc = plan[1](ref[0], x.data_ptr(), y.data_ptr(), 0, 0, x.numel(), _FAST_DTYPES[x.dtype], ref[1], _hip._stream())
+        else:                           # ctypes: the same entry point, marshalled
+            rc = plan[1](x.data_ptr(), y.data_ptr(), None, 0, x.numel(), _FAST_DTYPES[x.dtype], ref, _hip._stream())
         if rc != 0:
             _hip._check(rc, plan[4])
         return y
