@@ -436,6 +436,18 @@ int tq_argmin_select(const double* loss, uint64_t rows, uint64_t n_cand, const f
                      const float* thr_max, float* cur_min, float* cur_max, int64_t* best,
                      tq_stream_t stream);
 
+/* Order statistics: out[row, j] = the element of rank ranks[j] (0-based, ascending; NaN sorts last) of each row of x
+ * viewed as [rows, n], 1 <= m <= TQ_OSTAT_MAX_RANKS ranks per call, selected EXACTLY by a radix select -- no sort.
+ * Replaces the reference's host-side np.percentile (quantization/range_estimators.py:121-140: `to_numpy(x)` +
+ * np.percentile(data, (p, 100 - p)) for CurrentMinMaxEstimator's percentile option): method 'linear' interpolates
+ * between the two order statistics at floor / ceil of (n - 1) p / 100; the caller does that interpolation with numpy's
+ * own arithmetic (quantization/range_estimators.py `_percentile_rows`).  `ranks` is a HOST array (passed on by value);
+ * `out` fp32 device [rows, m]; n < 2^32.  No host synchronisation. */
+enum { TQ_OSTAT_MAX_RANKS = 4 };
+size_t tq_order_stats_workspace_bytes(uint64_t rows, uint32_t m);
+int tq_order_stats(const void* x, uint64_t rows, uint64_t n, int dtype, const uint64_t* ranks /* host */, uint32_t m,
+                   float* out, void* workspace, size_t workspace_bytes, tq_stream_t stream);
+
 /* ---- K10/K11/K13: AdaRound --------------------------------------------------------------------
  * K10: AdaRoundQuantizer.to_integer_forward + dequantise (adaround/quantizer.py:46-90,
  *      quantizers.py:209): w_q = scale * (clamp(floor(w/s) + r (+zp), lo, hi) - zp),

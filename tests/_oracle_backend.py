@@ -233,6 +233,11 @@ class OracleBackend:
     def argsort(self, v):
         return torch.argsort(v)
 
+    def order_stats(self, rows2d, ranks):
+        """test double of tq_order_stats: a full sort on the host (the kernel selects without sorting)"""
+        srt, _ = torch.sort(rows2d.detach().float(), dim=-1)
+        return torch.stack([srt[:, int(r)] for r in ranks], dim=1)
+
     def set_range_asym(self, x_min, x_max, n_bits, eps, log_domain):
         return O.asym_params_from_range(self._range_tensor(x_min), self._range_tensor(x_max), n_bits,
                                         eps, 'log' if log_domain else 'linear')

@@ -153,7 +153,7 @@ def test_fixed_range_fast_path_is_identical_through_fastcall_and_ctypes():
                 qa.activation_quantizer.fix_ranges()
                 outs[route] = qa(x)
                 plan = qa.activation_quantizer._fast_plan
-            assert plan is not None and (type(plan[2]) is tuple) == (route == 'fastcall')
+            assert plan is not None and plan[9] is not None and (type(plan[10]) is tuple) == (route == 'fastcall')
     finally:
         _hip._fastcall_mod, _hip._fastcall_tried = saved
     assert torch.equal(outs['fastcall'], outs['ctypes'])

@@ -764,6 +764,63 @@ def test_percentile_ranges_on_gpu(q):
         assert torch.equal(y.cpu(), ref)
 
 
+def test_order_statistics_radix_select_equals_a_full_sort():
+    """tq_order_stats (csrc/tq_select.hip): the elements of given ranks of every row, selected by an MSB-first radix
+    select -- against torch.sort on the CPU, exactly (bit patterns), on: one long row (per-tensor activation statistics,
+    grid-wide histogram passes), many short rows (per-channel, one block per row), heavy ties, infinities, NaN (sorts
+    last), denormals, a single-element row, bf16 storage, ranks 0 and n - 1."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(31)
+
+    def check(x, ranks):
+        got = be.order_stats(x.to(DEV), ranks).cpu()
+        srt, _ = torch.sort(x.float(), dim=-1)
+        want = torch.stack([srt[:, r] for r in ranks], dim=1)
+        # (bit-exact except the sign of a zero inside a run of +-0 ties, which a comparison sort leaves unspecified)
+        same = (got.view(torch.int32) == want.view(torch.int32)) | ((got == 0) & (want == 0)) | (got.isnan() & want.isnan())
+        assert bool(same.all()), (x.shape, ranks, got[~same][:4], want[~same][:4])
+
+    x = torch.randn(1, 786432, generator=g)                          # [8, 128, 768] activations as one row
+    x[0, ::97] *= 40.0
+    n = x.shape[1]
+    check(x, [0, 1, n // 2, n - 1])
+    check(x, [78, 79, n - 79, n - 78])                               # the ranks of percentile 0.01 and 99.99
+    check(x.to(torch.bfloat16), [5, n - 6])
+    w = torch.randn(3072, 768, generator=g) * 0.05                   # per-channel weights: one block per row
+    check(w, [0, 7, 760, 767])
+    check(w[:40], [383, 384])                                        # few short rows
+    t = torch.randint(-3, 4, (4, 20000), generator=g).float()        # heavy ties (7 distinct values)
+    check(t, [0, 9999, 10000, 19999])
+    s = torch.randn(2, 70000, generator=g)
+    s[0, :5] = float('inf')
+    s[0, 5:9] = float('-inf')
+    s[1, :3] = float('nan')
+    s[1, 3:6] = 1e-42                                                # denormals
+    s[1, 6] = -0.0
+    check(s, [0, 3, 69996, 69999])
+    check(torch.tensor([[2.5]]), [0, 0])
+    with pytest.raises(_hip.TQError, match='rank'):
+        be.order_stats(w.to(DEV), [768])
+    with pytest.raises(_hip.TQError, match='ranks per call'):
+        be.order_stats(w.to(DEV), [0, 1, 2, 3, 4])
+
+
+def test_percentile_per_tensor_on_gpu_equals_numpy(q):
+    """CurrentMinMaxEstimator(percentile=p) on an activation tensor (reference range_estimators.py:131-140: to_numpy +
+    np.percentile(data, (p, 100)), quirk q6: the upper end is the maximum) -- now without a device sort and without the
+    host round trip of the tensor: bit-equal to numpy."""
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(8, 128, 768, generator=g)
+    x[..., 308] *= 20
+    for p in (0.01, 0.5, 1.0, 25.0):
+        est = q.RangeEstimators.current_minmax.cls(percentile=p)
+        lo, hi = est(x.to(DEV))
+        r = np.percentile(x.numpy(), (p, 100))
+        assert torch.equal(lo.cpu().reshape(-1), torch.Tensor(np.atleast_1d(r[0]))), p
+        assert torch.equal(hi.cpu().reshape(-1), torch.Tensor(np.atleast_1d(r[1]))), p
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
 @pytest.mark.parametrize('symmetric', [False, True], ids=['asym', 'sym'])
 @pytest.mark.parametrize('mode', [0, 1, 2], ids=['current', 'all', 'running'])

@@ -98,6 +98,8 @@ SIGNATURES = {
     'tq_calibrate_minmax_mailbox': (_int, [_vp, _u64, _int, _u64, _u64, _int, _vp, _vp, _vp, _vp, _d, _u64, _vp, _int, _int, _f,
                                            _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp,
                                            C.c_uint32, _vp]),
+    'tq_order_stats_workspace_bytes': (_sz, [_u64, C.c_uint32]),
+    'tq_order_stats': (_int, [_vp, _u64, _u64, _int, C.POINTER(_u64), C.c_uint32, _vp, _vp, _sz, _vp]),
     'tq_comm_unique_id_bytes': (_sz, []),
     'tq_comm_load': (_int, [C.c_char_p]),
     'tq_comm_version': (_int, []),
@@ -1016,6 +1018,22 @@ class HipBackend:
                                                  float(temperature or 0.0), _ptr(sched.contiguous()), float(lr), float(b1),
                                                  float(b2), float(adam_eps), _stream())
         _check(rc, self.lib)
+
+    def order_stats(self, rows2d, ranks):
+        """[rows, len(ranks)] fp32: the elements of the given 0-based ascending ranks of every row (NaN last), selected
+        on the device without sorting (tq_order_stats: radix select; the percentile estimators need two order
+        statistics per percentile, reference range_estimators.py:121-140)."""
+        _need_device(rows2d, 'order_stats')
+        x = rows2d.detach().contiguous()
+        rows, n = x.shape
+        m = len(ranks)
+        out = torch.empty(rows, m, dtype=torch.float32, device=x.device)
+        ws = self._workspace(x.device, self.lib.tq_order_stats_workspace_bytes(rows, m))
+        rk = (C.c_uint64 * m)(*[int(r) for r in ranks])
+        rc = self.lib.tq_order_stats(_ptr(x), rows, n, _dtype_code(x, 'order_stats'), rk, m, _ptr(out), _ptr(ws),
+                                     ws.numel() * ws.element_size(), _stream())
+        _check(rc, self.lib)
+        return out
 
     def adaround_reg(self, alpha, mode, temperature, beta, weight):
         _need_device(alpha, 'adaround_reg')

@@ -135,7 +135,12 @@ class QuantizedActivation(QuantizedModule):
             init_params=self.act_range_options)
 
     def quantize_activations(self, x):
-        return self.activation_quantizer(x) if self._quant_a else x
+        # (sub-module through the registry: nn.Module.__getattr__ is the slow path of attribute access, and a fixed-range
+        # call is launch-bound)
+        if not self._quant_a:
+            return x
+        m = self._modules['activation_quantizer']
+        return m.quantize(x) if type(m) is QuantizationManager else m(x)
 
     def forward(self, x):
         return self.quantize_activations(x)

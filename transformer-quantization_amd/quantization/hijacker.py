@@ -91,6 +91,7 @@ class QuantizationHijacker(QuantizedModule):
             activations = self.activation_function(activations)
         self._save('', activations)
         if self._quant_a:
-            activations = self.activation_quantizer(activations)
+            m = self._modules['activation_quantizer']
+            activations = m.quantize(activations) if type(m) is QuantizationManager else m(activations)
             self._save('_Q', activations)
         return activations

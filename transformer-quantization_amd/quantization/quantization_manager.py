@@ -42,6 +42,10 @@ _FUSED_QUANTIZERS = (AsymmetricUniformQuantizer, SymmetricUniformQuantizer)
 # Fixed-range forwards of per-tensor quantizers skip the generic Python route (QuantizationManager._fixed_fast)
 FAST_FIXED_FORWARD = True
 _FAST_DTYPES = _hip._DTYPES
+from torch.nn.modules import module as _nn_module  # noqa: E402
+_GLOBAL_FWD_HOOKS, _GLOBAL_FWD_PRE_HOOKS = _nn_module._global_forward_hooks, _nn_module._global_forward_pre_hooks
+_current_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
+_raw_stream = _hip._raw_stream or (lambda dev: torch.cuda.current_stream(dev).cuda_stream)
 
 
 class Qstates(Enum):
@@ -220,6 +224,22 @@ class QuantizationManager(nn.Module):
                 return None
         return tuple(bufs)
 
+    def quantize(self, x):
+        """`self(x)` for callers inside the package (QuantizedActivation): identical result, but a fixed-range call of a
+        hook-free manager goes straight to the launch plan (`_fixed_fast`) without a second nn.Module.__call__ --
+        ~0.6 us of the ~7 us a launch-bound quantizer call costs on the host.  Anything out of the ordinary (hooks on
+        this manager, global module hooks, the integer path, PEG range collection, an ineligible quantizer) takes
+        `self(x)`."""
+        if (self.state is Qstates.fix_ranges and FAST_FIXED_FORWARD and not options.INT8_LINEAR
+                and not (self._forward_hooks or self._forward_pre_hooks or _GLOBAL_FWD_HOOKS or _GLOBAL_FWD_PRE_HOOKS)):
+            mods = self._modules
+            est = mods.get('range_estimator')
+            if est is None or not est.per_group_range_estimation:
+                y = self._fixed_fast(x, mods['quantizer'])
+                if y is not None:
+                    return y
+        return self(x)
+
     def forward(self, x):
         # (sub-modules through the registry: nn.Module.__getattr__ is the slow path of attribute access, and a
         # fixed-range call is launch-bound)
@@ -248,41 +268,63 @@ class QuantizationManager(nn.Module):
 
     def _fixed_fast(self, x, q):
         """Fixed per-tensor range, plain ROCm tensor, no autograd: torch.empty_like + one foreign call.  Bit-identical to
-        q(x) -- it IS the same entry point with the same descriptor, minus ~6 us of Python (module dispatch, argument
-        marshalling, layout checks) per call.  Returns None whenever anything is out of the ordinary (hooks on the
-        quantizer, per-axis / per-channel ranges, trainable or missing ranges, another device than the current one,
-        non-contiguous input, a backend double): the caller then takes the generic route."""
+        q(x) -- it IS the same entry point with the same descriptor, minus the Python of the generic route (module
+        dispatch, argument marshalling, layout checks) per call.  Returns None whenever anything is out of the ordinary
+        (hooks on the quantizer, per-axis / per-channel ranges, trainable or missing ranges, range buffers on another
+        device than x, another device than the current one, non-contiguous input, a backend double): the caller then
+        takes the generic route.
+
+        The launch plan is revalidated per call by IDENTITY of the range buffers it was built for (the plan holds them, so
+        an address cannot be recycled under it) plus the quantizer's rebinding counter: `.to()` / `load_state_dict` /
+        a new calibration all produce either new tensor objects or a new `_range_gen`; in-place value updates need no
+        new plan (the kernel reads the values from the buffers)."""
         bufs = q._buffers
-        delta, zf = bufs.get('_delta'), bufs.get('_zero_float')
-        if (delta is None or not x.is_cuda or not x.is_contiguous() or x.dtype not in _FAST_DTYPES
-                or q._forward_hooks or q._forward_pre_hooks or type(q) not in _FUSED_QUANTIZERS
-                or (torch.is_grad_enabled() and x.requires_grad) or x.device.index != torch.cuda.current_device()):
-            return None
-        sg = bufs.get('_signed')
-        # (ADVICE r3: the key also names the quantizer's kind and the backend object, and the range buffers must live on
-        # x's device -- the generic route raises for a foreign pointer, this one must not launch with it)
-        key = (q._range_gen, delta.data_ptr(), None if zf is None else zf.data_ptr(), None if sg is None else sg.data_ptr(),
-               q.n_bits, q.eps, x.device.index, type(q), q.symmetric, q.scale_domain, id(_hip._backend))
         plan = self._fast_plan
-        if plan is None or plan[0] != key:
-            be = _hip.backend()
-            if (delta.numel() != 1 or q.axis is not None or q.per_channel or not hasattr(be, 'fixed_quant_plan')
-                    or (q.symmetric and sg is None) or (not q.symmetric and zf is None) or delta.requires_grad
-                    or delta.device != x.device or (zf is not None and zf.device != x.device)
-                    or (sg is not None and sg.device != x.device)):
-                return None
-            plan = (key,) + be.fixed_quant_plan(delta, zf, sg, q.n_bits, q.symmetric,
-                                             q.scale_domain == 'log', q.eps) + (be.lib,)
-            object.__setattr__(self, '_fast_plan', plan)
+        try:
+            stale = (plan is None or plan[0] != q._range_gen or bufs.get('_delta') is not plan[1]
+                     or bufs.get('_zero_float') is not plan[2] or bufs.get('_signed') is not plan[3] or q.eps != plan[4]
+                     or q.scale_domain != plan[5] or _hip._backend is not plan[6] or type(q) is not plan[7])
+        except AttributeError:          # a quantizer class of the user's without eps / scale_domain: never eligible
+            stale = True
+        if stale:
+            plan = self._make_fast_plan(q)
+        call = plan[9]
+        if call is None:
+            return None
+        dev = plan[8]
+        # (get_device() is -1 for a host tensor: one call covers `is_cuda` and the device index)
+        if (x.get_device() != dev or x.dtype not in _FAST_DTYPES or q._forward_hooks or q._forward_pre_hooks
+                or (x.requires_grad and torch.is_grad_enabled()) or _current_device() != dev or not x.is_contiguous()):
+            return None
         y = torch.empty_like(x)
-        ref = plan[2]
+        ref = plan[10]
         if type(ref) is tuple:          # CPython stub (csrc_py/tq_fastcall.c): (entry address, descriptor address)
-            rc = plan[1](ref[0], x.data_ptr(), y.data_ptr(), 0, 0, x.numel(), _FAST_DTYPES[x.dtype], ref[1], _hip._stream())
+            rc = call(ref[0], x.data_ptr(), y.data_ptr(), 0, 0, x.numel(), _FAST_DTYPES[x.dtype], ref[1], _raw_stream(dev))
         else:                           # ctypes: the same entry point, marshalled
-            rc = plan[1](x.data_ptr(), y.data_ptr(), None, 0, x.numel(), _FAST_DTYPES[x.dtype], ref, _hip._stream())
+            rc = call(x.data_ptr(), y.data_ptr(), None, 0, x.numel(), _FAST_DTYPES[x.dtype], ref, _raw_stream(dev))
         if rc != 0:
-            _hip._check(rc, plan[4])
+            _hip._check(rc, plan[12])
         return y
+
+    def _make_fast_plan(self, q):
+        """(generation, delta, zero_float, signed, eps, scale_domain, backend, quantizer type, device index, call,
+        descriptor reference, descriptor owner, library) -- `call` is None when this quantizer is not eligible (the
+        verdict is cached under the same validity conditions as a plan)."""
+        bufs = q._buffers
+        delta, zf, sg = bufs.get('_delta'), bufs.get('_zero_float'), bufs.get('_signed')
+        be = _hip.backend()
+        head = (q._range_gen, delta, zf, sg, getattr(q, 'eps', None), getattr(q, 'scale_domain', None), be, type(q))
+        ok = (delta is not None and delta.is_cuda and type(q) in _FUSED_QUANTIZERS and delta.numel() == 1
+              and q.axis is None and not q.per_channel and be is not None and hasattr(be, 'fixed_quant_plan')
+              and not (q.symmetric and sg is None) and not (not q.symmetric and zf is None) and not delta.requires_grad
+              and (zf is None or zf.device == delta.device) and (sg is None or sg.device == delta.device))
+        if ok:
+            call, ref, owner = be.fixed_quant_plan(delta, zf, sg, q.n_bits, q.symmetric, q.scale_domain == 'log', q.eps)
+            plan = head + (delta.device.index, call, ref, owner, be.lib)
+        else:
+            plan = head + (-2, None, None, None, None)
+        object.__setattr__(self, '_fast_plan', plan)
+        return plan
 
     def _fixed_forward(self, x, q):
         if not options.INT8_LINEAR:

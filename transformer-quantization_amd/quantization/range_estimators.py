@@ -147,21 +147,25 @@ class CurrentMinMaxEstimator(RangeEstimatorBase):
 
 
 def _percentile_rows(rows, q):
-    """np.percentile(rows, q, axis=-1) (method 'linear') with the sort on the device.
+    """np.percentile(rows, q, axis=-1) (method 'linear') without sorting and without leaving the device.
 
-    The reference moves the whole tensor to the host and calls numpy (:121-140).  Here only the two
-    order statistics around each virtual index are combined, with numpy's own arithmetic: the
-    difference b - a in the data dtype (fp32), the interpolation in float64, the result narrowed to
-    fp32 by ``torch.Tensor(...)`` -- bit-identical to numpy on the same values."""
-    srt, _ = torch.sort(rows.detach().float(), dim=-1)
-    n = srt.shape[-1]
-    out = []
+    The reference moves the whole tensor to the host and calls numpy (:121-140).  numpy's result depends on exactly two
+    order statistics per percentile -- the elements at floor and ceil of the virtual index (n - 1) p / 100 -- which
+    `tq_order_stats` selects exactly (radix select, csrc/tq_select.hip); they are then combined with numpy's own
+    arithmetic: the difference b - a in the data dtype (fp32), the interpolation in float64, the result narrowed to
+    fp32 by ``torch.Tensor(...)`` -- bit-identical to numpy on the same values.  (A -0.0 / +0.0 tie may come out with
+    the other sign than numpy's sort would leave at that position; the values compare equal.)"""
+    rows = rows.detach()
+    n = rows.shape[-1]
+    plan = []
     for p in q:
         vidx = (n - 1) * (p / 100.0)
         lo_i = int(math.floor(vidx))
-        hi_i = min(lo_i + 1, n - 1)
-        t = vidx - lo_i
-        a, b = srt[:, lo_i], srt[:, hi_i]
+        plan.append((lo_i, min(lo_i + 1, n - 1), vidx - lo_i))
+    stats = _hip.backend().order_stats(rows.reshape(-1, n), [i for lo_i, hi_i, _ in plan for i in (lo_i, hi_i)])
+    out = []
+    for k, (_, _, t) in enumerate(plan):
+        a, b = stats[:, 2 * k], stats[:, 2 * k + 1]
         diff = (b - a).double()
         val = a.double() + diff * t if t < 0.5 else b.double() - diff * (1 - t)
         out.append(val.float())
