@@ -197,6 +197,31 @@ __device__ __forceinline__ float q_dequant(float xi, const QP& p) {
   return p.scale * (xi - p.zp);
 }
 
+// ------------------------------------------------------------------ exp(x), x <= 0, cheap and accurate
+// For the fused softmax (csrc/tq_fused_ln.hip), whose contract is a TOLERANCE (tests/test_fused_softmax.py: 1e-5 relative,
+// >= 99.9 % identical indices behind the probability quantizer) -- not the bit-exact `exp_neg_ieee` of the integer
+// attention core below.  libm's expf costs ~13 issue slots (range reduction, ldexp, two range checks with selects); here
+// the hardware 2^y does the range reduction and the rounding error of y = x log2(e) is repaired to first order:
+//   yh = RN(x c_hi), yl = (x c_hi - yh) [exact, one fma] + x c_lo;   e^x = 2^yh (1 + yl ln 2 + O(yl^2)),  |yl| < 2^-17
+// 8 slots, < 2 ulp for results >= 2^-126; smaller results (and x = -inf, where yl is inf - inf) return 0.  NaN -> NaN.
+__device__ __forceinline__ float exp_nonpos_fast(float x) {
+  const float yh = x * 1.44269502162933349609375f;
+  float yl = __builtin_fmaf(x, 1.44269502162933349609375f, -yh);
+  yl = __builtin_fmaf(x, 1.92596299112661746e-8f, yl);
+  const float e = __builtin_amdgcn_exp2f(yh);
+  const float r = __builtin_fmaf(e * 0.693147182464599609375f, yl, e);
+  return e == 0.0f ? 0.0f : r;
+}
+
+// max(a, b) as ONE v_max_f32: fmaxf() under IEEE semantics is preceded by a canonicalising `v_max_f32 v, v, v` per operand
+// (quiets signalling NaNs), which doubles the instruction count of a max reduction; quiet-NaN behaviour is the same
+// (the non-NaN operand wins).
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // ------------------------------------------------------------------ exp(x), x <= 0, from IEEE operations only
 // The softmax of the integer attention core is specified by THIS function (and its plain-C twin tq_exp_neg in
 // oracle/tq_int_oracle.c) rather than by libm's expf, whose v_exp_f32 core no CPU reproduces: Cephes-style range

@@ -64,12 +64,12 @@ __device__ __forceinline__ float group_sum(float v) {
 
 template <int LPR>
 __device__ __forceinline__ float group_max(float v) {      // fmaxf butterfly on the same paths as group_sum
-  v = fmaxf(v, dpp_f32<0xB1>(v));
-  v = fmaxf(v, dpp_f32<0x4E>(v));
-  if (LPR >= 8) v = fmaxf(v, dpp_f32<0x141>(v));
-  if (LPR >= 16) v = fmaxf(v, dpp_f32<0x140>(v));
-  if (LPR >= 32) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F)));
-  if (LPR >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+  v = max_raw(v, dpp_f32<0xB1>(v));
+  v = max_raw(v, dpp_f32<0x4E>(v));
+  if (LPR >= 8) v = max_raw(v, dpp_f32<0x141>(v));
+  if (LPR >= 16) v = max_raw(v, dpp_f32<0x140>(v));
+  if (LPR >= 32) v = max_raw(v, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F)));
+  if (LPR >= 64) v = max_raw(v, __shfl_xor(v, 32, 64));
   return v;
 }
 
@@ -90,13 +90,16 @@ __device__ __forceinline__ f32x2 apply_f2(f32x2 v, const FusedF& q) { return q.o
 // on bf16 rows (3.1-3.3 TB/s).  NaN: an unordered input pair poisons its element before the statistics (so a LayerNorm
 // row turns NaN as a whole, like the reference) and a NaN pre-quantizer value is passed through at the end.  FAST = false
 // is the division path (scales outside [2^-100, 2^100], grids of 2^22+ steps); IDX also emits int8(index - 128).
-template <int DT, int LPR, int NV, bool IDX, bool FAST, bool ALLON>
+template <int DT, int LPR, int NV, bool IDX, bool FAST, bool ALLON, bool AFF>
 __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
                                             u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                             float ln_eps, const tq_quantizer& q1, const tq_quantizer& q2,
-                                            const tq_quantizer& q3, int on1_, int on2_, int on3_, int affine_only, int nt,
-                                            uint32_t iters) {
+                                            const tq_quantizer& q3, int on1_, int on2_, int on3_, int nt, uint32_t iters) {
+  // AFF (NoNorm: affine map only, no statistics) is a compile-time property: as a run-time flag every NaN rule of BOTH
+  // variants was evaluated per element and selected (4-5 v_cndmask / v_cmp per element of ~29 VALU instructions on the
+  // bf16 LayerNorm rows, found in the ISA in round 4)
+  constexpr bool affine_only = AFF;
   // ALLON: the three quantizers are present (the configuration the tails exist for) -> compile-time flags, no uniform
   // branch around every quantizer application (those branches split the row into ~40 basic blocks and serialised it)
   const int on1 = ALLON ? 1 : on1_, on2 = ALLON ? 1 : on2_, on3 = ALLON ? 1 : on3_;
@@ -271,23 +274,23 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
   }
 }
 
-template <int DT, int LPR, int NV, bool IDX>
+template <int DT, int LPR, int NV, bool IDX, bool AFF>
 __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
                                                          u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          float ln_eps, tq_quantizer q1, tq_quantizer q2, tq_quantizer q3,
-                                                         int on1, int on2, int on3, int affine_only, int nt, uint32_t iters) {
+                                                         int on1, int on2, int on3, int nt, uint32_t iters) {
   // wave-uniform: every enabled quantizer admits the branch-free exact path (tq_device.h, QF)
   bool fast = true;
   if (on1) fast = fast && make_qf(make_qp(q1, 0)).ok;
   if (on2) fast = fast && make_qf(make_qp(q2, 0)).ok;
   if (on3) fast = fast && make_qf(make_qp(q3, 0)).ok;
   if (fast && on1 && on2 && on3)
-    res_ln_body<DT, LPR, NV, IDX, true, true>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, 1, 1, 1, affine_only, nt, iters);
+    res_ln_body<DT, LPR, NV, IDX, true, true, AFF>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, 1, 1, 1, nt, iters);
   else if (fast)
-    res_ln_body<DT, LPR, NV, IDX, true, false>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, affine_only, nt, iters);
+    res_ln_body<DT, LPR, NV, IDX, true, false, AFF>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, nt, iters);
   else
-    res_ln_body<DT, LPR, NV, IDX, false, false>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, affine_only, nt, iters);
+    res_ln_body<DT, LPR, NV, IDX, false, false, AFF>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, nt, iters);
 }
 
 template <int DT>
@@ -302,22 +305,24 @@ static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, u
   auto yv = static_cast<u32x4*>(y);
   const uint64_t vpr = d / V;
   const int nt = rows * d * elem_size(DT) >= (64ull << 20);
+#define TQ_LN_GO(LPR, NV, IDXV, AFFV)                                                                           \
+  hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV, IDXV, AFFV>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, \
+                     eps, c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, nt, iters)
 #define TQ_LN(LPR, NV)                                                                                          \
   if (vpr == (uint64_t)(LPR) * (NV)) {                                                                          \
     const unsigned rpb = kBlock / (LPR);                                                                        \
     const uint32_t iters = (uint32_t)std::max<int>(1, std::min<uint64_t>(tuning("TQ_TAIL_ITERS", DT == TQ_F32 ? 2 : 8), ceil_div(rows, (uint64_t)rpb * 2048))); \
     const unsigned grid = (unsigned)std::max<uint64_t>(ceil_div(rows, (uint64_t)rpb * iters), 1);               \
-    if (y_idx != nullptr)                                                                                       \
-      hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV, true>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, \
-                         eps, c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, affine_only, nt, iters); \
-    else                                                                                                        \
-      hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV, false>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, \
-                         eps, c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, affine_only, nt, iters); \
+    if (y_idx != nullptr && affine_only)      TQ_LN_GO(LPR, NV, true, true);                                    \
+    else if (y_idx != nullptr)                TQ_LN_GO(LPR, NV, true, false);                                   \
+    else if (affine_only)                     TQ_LN_GO(LPR, NV, false, true);                                   \
+    else                                      TQ_LN_GO(LPR, NV, false, false);                                  \
     return check_launch("res_ln_quant_k");                                                                      \
   }
   // d (bf16 | fp32): 768 -> 96 | 192 vectors, 3072 -> 384 | 768, 512 -> 64 | 128, 128 -> 16 | 32, 1024 -> 128 | 256
   TQ_LN(32, 3) TQ_LN(64, 3) TQ_LN(64, 6) TQ_LN(64, 12) TQ_LN(64, 1) TQ_LN(64, 2) TQ_LN(64, 4) TQ_LN(16, 1) TQ_LN(32, 1) TQ_LN(64, 8)
 #undef TQ_LN
+#undef TQ_LN_GO
   return set_error(TQ_EUNSUPPORTED, "tq_residual_layernorm_quant_fwd: row length %llu has no instantiation",
                    (unsigned long long)d);
 }
@@ -400,7 +405,7 @@ __device__ __forceinline__ void softmax_fast_body(const f32x4* __restrict__ s, f
       }
       mx[r] = -__builtin_huge_valf();
 #pragma unroll
-      for (int i = 0; i < P; ++i) mx[r] = fmaxf(mx[r], fmaxf(t[r][i].x, t[r][i].y));
+      for (int i = 0; i < P; ++i) mx[r] = max_raw(mx[r], max_raw(t[r][i].x, t[r][i].y));
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) mx[r] = group_max<LPR>(mx[r]);
@@ -409,8 +414,8 @@ __device__ __forceinline__ void softmax_fast_body(const f32x4* __restrict__ s, f
       sum[r] = 0.f;
 #pragma unroll
       for (int i = 0; i < P; ++i) {
-        t[r][i].x = expf(t[r][i].x - mx[r]);
-        t[r][i].y = expf(t[r][i].y - mx[r]);
+        t[r][i].x = exp_nonpos_fast(t[r][i].x - mx[r]);      // tolerance contract (see tq_device.h), ~8 slots instead of ~13
+        t[r][i].y = exp_nonpos_fast(t[r][i].y - mx[r]);
         sum[r] += t[r][i].x;             // the scalar kernel's (and the oracle's) left-to-right order
         sum[r] += t[r][i].y;
       }

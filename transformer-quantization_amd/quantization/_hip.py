@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libtq_hip.so')
+LIB_PATH = os.environ.get('TQ_LIB_PATH') or os.path.join(os.path.dirname(_HERE), 'lib', 'libtq_hip.so')   # TQ_LIB_PATH: A/B of two builds on one box
 
 TQ_F32, TQ_BF16, TQ_F16 = 0, 1, 2
 IDX_NONE, IDX_F32, IDX_I8, IDX_U8, IDX_I16, IDX_I32, IDX_I8_M128 = range(7)
