@@ -649,7 +649,7 @@ def main():
     del xs
 
     # ---- everything below runs under the watchdog -----------------------------------------------------------------------
-    wd = _Watchdog(out, rank, float(os.environ.get('TQ_BENCH_WATCHDOG_S', '480')))
+    wd = _Watchdog(out, rank, float(os.environ.get('TQ_BENCH_WATCHDOG_S', '300')))
 
     # statistics exchange: the raw RCCL communicator inside libtq_hip.so when the backend is `nccl` (quantization/rccl.py:
     # two-phase bring-up agreed through the rendezvous store, self-tested); torch.distributed is the fallback

@@ -152,13 +152,6 @@ static int* dY;
 // epilogue of EPI dependent fma per output element (the product's GELU + quantizer epilogue is ~36 issue slots per
 // element), as (a) one block per tile, (b) persistent blocks of TPB tiles, optionally with the SECOND block to arrive on
 // a CU delayed by `delay_clk` shader clocks once, so that its epilogues meet the first block's main loops.
-__device__ __forceinline__ uint32_t cu_slot() {
-  uint32_t hw, xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const uint32_t cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;   // gfx9 HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
-  return ((xcc & 15) * 8 + se) * 32 + sh * 16 + cu;
-}
 
 template <int EPI, int KS, int ST, int OCC, bool LATE_ISSUE>
 __global__ __launch_bounds__(256, OCC) void gemm_epi(const int8_t* __restrict__ X, const int8_t* __restrict__ W, float* __restrict__ Y,
@@ -311,6 +304,133 @@ static void run_epi(const char* name, Prob p, int pad_kb = 0) {
   fflush(stdout);
 }
 
+// ---- persistent blocks with the SECOND block to arrive on a CU delayed once by `delay_clk` shader clocks, so that its
+// epilogues meet the first block's main loops (product tiling, synthetic epilogue of EPI fma per output)
+__device__ __forceinline__ uint32_t cu_slot() {
+  uint32_t hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const uint32_t cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;   // HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
+  return ((xcc & 15) * 8 + se) * 32 + sh * 16 + cu;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_persist(const int8_t* __restrict__ X, const int8_t* __restrict__ W, float* __restrict__ Y,
+                                                        uint32_t M, uint32_t N, uint32_t K, uint32_t tiles_per_block,
+                                                        uint32_t delay_clk, uint32_t* __restrict__ cu_count) {
+  constexpr int WT = 64, BT = 128, NI = 4, MI = 4, LPW = 4, OPB = BT * 128, STB = 2 * OPB;
+  extern __shared__ __attribute__((aligned(1024))) int8_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tiles_m = M / BT, n_tiles = tiles_m * (N / BT);
+  const int wn = (wave >> 1) * WT, wm = (wave & 1) * WT;
+  const int r16 = lane & 15, kg = lane >> 4, swz = (r16 >> 1) & 7;
+  const int off[2] = {r16 * 128 + ((kg ^ swz) << 4), r16 * 128 + (((4 + kg) ^ swz) << 4)};
+  const uint32_t nk = K / 128;
+  if (delay_clk) {
+    __shared__ uint32_t arrival;
+    if (tid == 0) arrival = atomicAdd(cu_count + cu_slot(), 1u);
+    __syncthreads();
+    if (arrival & 1) {
+      const uint64_t t0 = __builtin_readcyclecounter();
+      while (__builtin_readcyclecounter() - t0 < delay_clk) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  const uint32_t first = blockIdx.x * tiles_per_block, last = min(first + tiles_per_block, n_tiles);
+  for (uint32_t tile = first; tile < last; ++tile) {
+    const uint32_t n0 = (tile / tiles_m) * BT, m0 = (tile % tiles_m) * BT;
+    const int8_t *wsrc[LPW], *xsrc[LPW];
+#pragma unroll
+    for (int q = 0; q < LPW; ++q) {
+      const int row = wave * (WT / 2) + q * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      wsrc[q] = W + (size_t)(n0 + row) * K + chunk * 16;
+      xsrc[q] = X + (size_t)(m0 + row) * K + chunk * 16;
+    }
+    auto issue = [&](int stage, uint32_t k) {
+      int8_t* bw = lds + stage * STB + wave * (WT / 2) * 128;
+#pragma unroll
+      for (int q = 0; q < LPW; ++q) {
+        GLDS16(wsrc[q] + k, bw + q * 1024);
+        GLDS16(xsrc[q] + k, bw + OPB + q * 1024);
+      }
+    };
+    v4i acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+    issue(0, 0);
+    for (uint32_t kb = 0; kb < nk; ++kb) {
+      wait_vm<0>();
+      __syncthreads();
+      if (kb + 1 < nk) issue((kb + 1) & 1, (kb + 1) * 128);
+      const int8_t* bw = lds + (kb & 1) * STB + wn * 128;
+      const int8_t* bx = lds + (kb & 1) * STB + OPB + wm * 128;
+      v4i fw[2][NI], fx[2][MI];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fw[s2][i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s2]);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) fx[s2][j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s2]);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[s][i], fx[s][j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float v[MI][4];
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j][r] = (float)acc[i][j][r];
+#pragma unroll 2
+      for (int e = 0; e < EPI; ++e)
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[j][r] = __builtin_fmaf(v[j][r], 0.999f, 0.125f);
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += v[j][r];
+    }
+    if (sum == 123456.789f) Y[tile] = sum;
+  }
+}
+
+template <int EPI>
+static void run_persist(const char* name, Prob p, uint32_t tpb, uint32_t delay_clk, uint32_t* d_count, float* dYf) {
+  const uint32_t n_tiles = (p.M / 128) * (p.N / 128), grid = (n_tiles + tpb - 1) / tpb;
+  auto k = gemm_persist<EPI>;
+  const size_t lds = 2 * 2 * 128 * 128;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  float total = 0.0f;
+  const int reps = 20;
+  for (int w = 0; w < reps + 3; ++w) {
+    CK(hipMemsetAsync(d_count, 0, 4096 * 4));
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, dX, dW, dYf, p.M, p.N, p.K, tpb, delay_clk, d_count);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    if (w >= 3) total += ms;
+  }
+  printf("%-50s EPI %3d tiles/block %u delay %6u clk grid %-5u: %6.2f us (single launches, one event pair each)\n", name, EPI, tpb,
+         delay_clk, grid, total * 1000.0f / reps);
+  fflush(stdout);
+}
+
 // ---- do MFMA and VALU work of DIFFERENT waves on one SIMD overlap?  Block = 512 threads (2 waves per SIMD on one CU when
 // one block per CU): role bit per wave: 1 = MFMA chain (16 independent accumulators), 2 = VALU fma chains.  `who` selects which
 // waves work: 1 = the first four waves run MFMAs, the rest idle; 2 = the last four run VALU; 3 = both at once.
@@ -451,6 +571,12 @@ int main(int argc, char** argv) {
     run_epi<64, 2, 4, false>("64-byte slabs, 2 st, launch_bounds 4", p);
     run_epi<64, 3, 3, true>("64-byte slabs, 3 st, lb 3, late issue", p);
     run_epi<128, 2, 2, false>("product tiling, 1 block/CU (pad)", p, 32);
+    uint32_t* d_count;
+    CK(hipMalloc(&d_count, 4096 * 4));
+    run_persist<34>("persistent, 3 tiles per block (2 blocks/CU)", p, 3, 0, d_count, dYf);
+    for (uint32_t d : {2000u, 4000u, 8000u, 12000u, 100000u})
+      run_persist<34>("persistent 3, 2nd block of every CU delayed once", p, 3, d, d_count, dYf);
+    run_persist<34>("persistent, 6 tiles per block (1 block/CU)", p, 6, 0, d_count, dYf);
   }
   if (argc > 2) return 0;
   for (int pi = 0; pi < nprob; ++pi) {
