@@ -146,7 +146,7 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
     const uint64_t nrow = row + RPB;
     if (it + 1 < iters && nrow < rows) load_row(nrow, na, nr);
     f32x2 u[NV][H];
-    f32x2 s2 = {0.f, 0.f};
+    f32x2 s2 = {0.f, 0.f}, s2b = {0.f, 0.f};      // two chains for the row sum (LayerNorm only)
     bool lane_nan = false;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -186,9 +186,15 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
           u[v][j] = f32x2{apply_q(apply_q(fa[2 * j], g1) + fr[2 * j], g2),
                           apply_q(apply_q(fa[2 * j + 1], g1) + fr[2 * j + 1], g2)};
       }
+      if (!affine_only) {
 #pragma unroll
-      for (int j = 0; j < H; ++j) s2 = s2 + u[v][j];
+        for (int j = 0; j < H; ++j) {
+          if (j & 1) s2b = s2b + u[v][j];
+          else s2 = s2 + u[v][j];
+        }
+      }
     }
+    s2 = s2 + s2b;
     // MobileBERT's NoNorm (models/quantized_mobilebert.py:58-72) is the affine part alone: u * w + b.  With
     // mean = 0 and rstd = 1 the expression below evaluates exactly that ((u - 0) * 1 is exact).
     float mean = 0.0f, rstd = 1.0f;
@@ -196,11 +202,19 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
     if (!affine_only) {
       mean = group_sum<LPR>(s2.x + s2.y) * inv_d;
       const f32x2 m2 = {mean, mean};
-      f32x2 ss2 = {0.f, 0.f};
+      // centred sum of squares: two independent packed accumulators fed by fma (a single `ss2 = ss2 + c * c` chain was
+      // 2 packed ops per pair plus a wait state after each: 46 s_nop per 24-element lane row in the round-3 ISA).  The
+      // LayerNorm statistics carry a tolerance contract (tests/test_fused_ln.py); NoNorm has no statistics.
+      f32x2 ssa = {0.f, 0.f}, ssb = {0.f, 0.f};
 #pragma unroll
       for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int j = 0; j < H; ++j) { const f32x2 c = u[v][j] - m2; ss2 = ss2 + c * c; }
+        for (int j = 0; j < H; ++j) {
+          const f32x2 c = u[v][j] - m2;
+          if ((v * H + j) & 1) ssb = __builtin_elementwise_fma(c, c, ssb);
+          else ssa = __builtin_elementwise_fma(c, c, ssa);
+        }
+      const f32x2 ss2 = ssa + ssb;
       rstd = 1.0f / sqrtf(group_sum<LPR>(ss2.x + ss2.y) * inv_d + ln_eps);
       if (FAST) {
         // rows with a NaN input: the statistics are NaN upstream, hence every output of the row
