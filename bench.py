@@ -247,9 +247,18 @@ class _Watchdog:
         if self._done.wait(seconds):
             return
         if self.rank == 0:
-            self.out.setdefault('incomplete', []).append(f'optional block stalled in stage {self.stage!r} '
-                                                         f'(watchdog, {seconds:.0f} s); headline fields are complete')
-            print(json.dumps(self.out), flush=True)
+            note = (f'optional block stalled in stage {self.stage!r} (watchdog, {seconds:.0f} s); headline fields are '
+                    'complete')
+            line = None
+            for _ in range(5):                   # the main thread may be adding a key right now
+                try:
+                    snap = dict(self.out)
+                    snap['incomplete'] = list(snap.get('incomplete', [])) + [note]
+                    line = json.dumps(snap)
+                    break
+                except RuntimeError:
+                    time.sleep(0.01)
+            print(line if line is not None else json.dumps({'incomplete': [note]}), flush=True)
         else:
             time.sleep(2.0)                  # let rank 0 print first
         os._exit(0)
@@ -651,63 +660,70 @@ def main():
     # ---- everything below runs under the watchdog -----------------------------------------------------------------------
     wd = _Watchdog(out, rank, float(os.environ.get('TQ_BENCH_WATCHDOG_S', '300')))
 
-    # statistics exchange: the raw RCCL communicator inside libtq_hip.so when the backend is `nccl` (quantization/rccl.py:
-    # two-phase bring-up agreed through the rendezvous store, self-tested); torch.distributed is the fallback
-    transport = 'none'
-    if use_dist:
-        wd.stage = 'exchange bring-up'
-        try:
-            tq_dist.enable(force=(world == 1))
-        except Exception as e:       # noqa: BLE001
-            print(f'[bench] raw RCCL exchange unavailable ({e!r}): statistics go through torch.distributed', file=sys.stderr)
-            tq_dist.enable(force=(world == 1), raw=False)
-        raw = tq_dist.raw_comm()
-        transport = 'raw RCCL (tq_calibrate_minmax_rccl)' if raw is not None else f'torch.distributed ({backend})'
-        # the size of the communicator the data path actually uses (ncclCommCount), not the launcher's environment
-        out['rccl_world_size'] = raw.rank_world()[1] if raw is not None else dist.get_world_size()
-        assert out['rccl_world_size'] == world, f'communicator spans {out["rccl_world_size"]} ranks, WORLD_SIZE is {world}'
-    else:
-        out['rccl_world_size'] = 1
+    # Everything from here on is optional: an exception is recorded in the line instead of costing the headline.
+    try:
+        # statistics exchange: the raw RCCL communicator inside libtq_hip.so when the backend is `nccl` (quantization/rccl.py:
+        # two-phase bring-up agreed through the rendezvous store, self-tested); torch.distributed is the fallback
+        transport = 'none'
+        if use_dist:
+            wd.stage = 'exchange bring-up'
+            try:
+                tq_dist.enable(force=(world == 1))
+            except Exception as e:       # noqa: BLE001
+                print(f'[bench] raw RCCL exchange unavailable ({e!r}): statistics go through torch.distributed', file=sys.stderr)
+                tq_dist.enable(force=(world == 1), raw=False)
+            raw = tq_dist.raw_comm()
+            transport = 'raw RCCL (tq_calibrate_minmax_rccl)' if raw is not None else f'torch.distributed ({backend})'
+            # the size of the communicator the data path actually uses (ncclCommCount), not the launcher's environment
+            out['rccl_world_size'] = raw.rank_world()[1] if raw is not None else dist.get_world_size()
+            assert out['rccl_world_size'] == world, f'communicator spans {out["rccl_world_size"]} ranks, WORLD_SIZE is {world}'
+        else:
+            out['rccl_world_size'] = 1
 
-    # ---- calibration of ONE quantizer on the large tensor: estimate + quantize, one fused MAX all-reduce per step ------
-    wd.stage = 'calibration (one quantizer)'
-    qc = new_quantizer()
-    for xb in (x, make_hidden(B, S, device, seed=2000 + rank)):
-        qc(xb)
-    cal_steps = max(4, min(args.steps, 20))
-    cal_wall, _ = timed_region(lambda: qc(x), cal_steps, use_dist)
-    # --mailbox / TQ_BENCH_MAILBOX=1: the same step with the statistics exchanged through the P2P mailbox kernel instead
-    # of ncclAllReduce (reported next to the RCCL figure, never instead of it; skipped if the set-up or the self-test
-    # against RCCL fails).  Opt-in: validated with two processes on one device and with a 1-rank RCCL group only.
-    mail_wall = None
-    if use_dist and backend == 'nccl' and (args.mailbox or os.environ.get('TQ_BENCH_MAILBOX', '0') == '1'):
-        wd.stage = 'calibration (mailbox)'
-        try:
-            tq_dist.enable(force=(world == 1), mailbox=True, raw=tq_dist.raw_comm() is not None)
-            if tq_dist.mailbox_active():
-                qc(x)
-                mail_wall, _ = timed_region(lambda: qc(x), cal_steps, use_dist)
-        except Exception as e:       # noqa: BLE001
-            print(f'[bench] mailbox leg skipped: {e!r}', file=sys.stderr)
-        finally:
-            tq_dist.enable(force=(world == 1), mailbox=False, raw=tq_dist.raw_comm() is not None)
-    cal_wall, mw = _max_over_ranks([cal_wall, mail_wall if mail_wall is not None else -1.0], device, use_dist)
-    mail_wall = mw if mail_wall is not None else None
-    out['calibration'] = {
-        'what': 'estimate (tq_minmax -> range_update -> set_range) + quantize per step; '
-                + ('one fused MAX all-reduce of [-min;max] per step over RCCL' if world > 1
-                   else ('1-rank communicator, collectives forced on' if use_dist else 'single GPU, no collective')),
-        'transport': transport,
-        'value': round(n_elems * world * cal_steps / cal_wall / 1e6, 1),
-        'unit': 'M elems/s',
-        'ms_per_step': round(cal_wall / cal_steps * 1e3, 4),
-    }
-    if mail_wall is not None:
-        out['calibration']['p2p_mailbox'] = {
-            'what': 'same step, [-min;max] exchanged by the P2P mailbox kernel (tq_mailbox_allreduce_max) instead of RCCL',
-            'value': round(n_elems * world * cal_steps / mail_wall / 1e6, 1), 'unit': 'M elems/s',
-            'ms_per_step': round(mail_wall / cal_steps * 1e3, 4)}
-    del x, qc, qa
+        # ---- calibration of ONE quantizer on the large tensor: estimate + quantize, one fused MAX all-reduce per step ------
+        wd.stage = 'calibration (one quantizer)'
+        qc = new_quantizer()
+        for xb in (x, make_hidden(B, S, device, seed=2000 + rank)):
+            qc(xb)
+        cal_steps = max(4, min(args.steps, 20))
+        cal_wall, _ = timed_region(lambda: qc(x), cal_steps, use_dist)
+        # --mailbox / TQ_BENCH_MAILBOX=1: the same step with the statistics exchanged through the P2P mailbox kernel instead
+        # of ncclAllReduce (reported next to the RCCL figure, never instead of it; skipped if the set-up or the self-test
+        # against RCCL fails).  Opt-in: validated with two processes on one device and with a 1-rank RCCL group only.
+        mail_wall = None
+        if use_dist and backend == 'nccl' and (args.mailbox or os.environ.get('TQ_BENCH_MAILBOX', '0') == '1'):
+            wd.stage = 'calibration (mailbox)'
+            try:
+                tq_dist.enable(force=(world == 1), mailbox=True, raw=tq_dist.raw_comm() is not None)
+                if tq_dist.mailbox_active():
+                    qc(x)
+                    mail_wall, _ = timed_region(lambda: qc(x), cal_steps, use_dist)
+            except Exception as e:       # noqa: BLE001
+                print(f'[bench] mailbox leg skipped: {e!r}', file=sys.stderr)
+            finally:
+                tq_dist.enable(force=(world == 1), mailbox=False, raw=tq_dist.raw_comm() is not None)
+        cal_wall, mw = _max_over_ranks([cal_wall, mail_wall if mail_wall is not None else -1.0], device, use_dist)
+        mail_wall = mw if mail_wall is not None else None
+        out['calibration'] = {
+            'what': 'estimate (tq_minmax -> range_update -> set_range) + quantize per step; '
+                    + ('one fused MAX all-reduce of [-min;max] per step over RCCL' if world > 1
+                       else ('1-rank communicator, collectives forced on' if use_dist else 'single GPU, no collective')),
+            'transport': transport,
+            'value': round(n_elems * world * cal_steps / cal_wall / 1e6, 1),
+            'unit': 'M elems/s',
+            'ms_per_step': round(cal_wall / cal_steps * 1e3, 4),
+        }
+        if mail_wall is not None:
+            out['calibration']['p2p_mailbox'] = {
+                'what': 'same step, [-min;max] exchanged by the P2P mailbox kernel (tq_mailbox_allreduce_max) instead of RCCL',
+                'value': round(n_elems * world * cal_steps / mail_wall / 1e6, 1), 'unit': 'M elems/s',
+                'ms_per_step': round(mail_wall / cal_steps * 1e3, 4)}
+        del x, qc, qa
+    except Exception as e:       # noqa: BLE001
+        out.setdefault('incomplete', []).append(f'stage {wd.stage!r} failed: {e!r}'[:600])
+        print(f'[bench] rank {rank}: stage {wd.stage!r} failed: {e!r}', file=sys.stderr)
+        if out.get('rccl_world_size') is None:
+            out['rccl_world_size'] = dist.get_world_size() if use_dist else 1
 
     # ---- whole-model sharded calibration, data-parallel AdaRound / QAT steps, CPU baseline ------------------------------
     if not args.headline_only:

@@ -30,6 +30,9 @@ DEFAULT_BUCKET_BYTES = 25 << 20
 class GradientBuckets:
     """``gb = GradientBuckets(model.parameters()); gb.zero_(); loss.backward(); gb.finish(); optimizer.step()``
 
+    ONE backward per step: a bucket is reduced when each of its gradients has been accumulated once since `zero_()`;
+    micro-batch accumulation over several backward calls would have to suspend the exchange
+    (`quantization.distributed.suspended()`) for all but the last of them.
     `average=True` divides the sum by the world size (mean-reduced loss, equal shards).  With no active exchange
     (`quantization.distributed` disabled or one rank without `force`) the object only provides the flat gradient storage
     and `finish()` is a no-op, so the same training loop runs on one GPU."""
