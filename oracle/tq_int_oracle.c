@@ -90,21 +90,22 @@ float tq_exp_neg(float x) {
   return ldexpf(y, (int)k);
 }
 
-/* GELU(v) = 0.5 v (1 + erf(v / sqrt 2)) with the two minimax fits of csrc/tq_linear_i8.hip (gelu_erf_n) */
+/* GELU(v) = 0.5 v (1 + erf(v / sqrt 2)) with the single fit of csrc/tq_linear_i8.hip (gelu_erf_n, round 4):
+ * erfc(t) = 2^(-t Q(t)), t = |v| / sqrt 2, Q of degree 7 -- the same single IEEE operations in the same order; exp2f here,
+ * v_exp_f32 on the device (<= 1 ulp apart: the one documented exception of the integer path's bit-exactness) */
 static float gelu_fit(float v) {
   const float a = v * 0.70710678118654752440f;
-  const float t = fabsf(a), s = t * t;
-  float p = fmaf(t, 1.699881067906972e-05f, -0.00037867785431444645f);
-  float q = fmaf(s, -0.000561801774892956f, 0.004913816228508949f);
-  p = fmaf(t, p, 0.003857815871015191f);   q = fmaf(s, q, -0.026707515120506287f);
-  p = fmaf(t, p, -0.024181697517633438f);  q = fmaf(s, q, 0.11280010640621185f);
-  p = fmaf(t, p, 0.10666826367378235f);    q = fmaf(s, q, -0.37612295150756836f);
-  p = fmaf(t, p, 0.6349332928657532f);     q = fmaf(s, q, 0.12837910652160645f);
-  p = fmaf(t, p, 0.12868940830230713f);    q = fmaf(t, q, t);
-  p = fmaf(t, p, t);
-  p = p * -1.4426950408889634f;
-  const float e = 1.0f - exp2f(p);
-  const float r = copysignf(t < 1.0f ? q : e, a);
+  const float t = fabsf(a);
+  float q = fmaf(t, -4.5358574425335974e-05f, 0.00044550743768922985f);
+  q = fmaf(t, q, -0.0014894409105181694f);
+  q = fmaf(t, q, -0.0007746309274807572f);
+  q = fmaf(t, q, 0.02825368195772171f);
+  q = fmaf(t, q, -0.14848162233829498f);
+  q = fmaf(t, q, -0.9184163808822632f);
+  q = fmaf(t, q, -1.6279085874557495f);
+  q = q * t;
+  const float e = 1.0f - exp2f(q);
+  const float r = copysignf(e, a);
   return (v * 0.5f) * (1.0f + r);
 }
 
