@@ -99,3 +99,21 @@ def test_clamping_the_operand_equals_clamping_the_index():
                     x = ulp_step(x0, du)
                     ref = min(max(Q(x, s), klo), khi)
                     assert Q(min(max(x, ylo), yhi), s) == ref, (float(x), float(s), klo, khi)
+
+
+def test_dequantisation_as_one_fma_normalises_the_zero():
+    """Round 4: y = fma(s, h, +0) replaces y = s * (h + 0) (tq_device.h `qf_dequant2`).  For h != 0 adding an exact zero to
+    the exact product changes nothing, so RN(s h + 0) == RN(s h) == the fp32 product; for h = -0 the exact product is
+    -0 and (-0) + (+0) = +0 under round-to-nearest -- the +0 the reference's `scale * (x_int - zero_point)` yields.
+    float64 holds the product of two fp32 numbers exactly, so `np.float32(float64 product + 0.0)` IS the fused result."""
+    import numpy as np
+    rs = np.random.RandomState(3)
+    s = np.concatenate([rs.uniform(1e-6, 4.0, 20000), 2.0 ** rs.uniform(-90, 90, 20000)]).astype(np.float32)
+    h = np.concatenate([rs.randint(-(1 << 21), 1 << 21, 20000), rs.randint(-255, 256, 20000)]).astype(np.float32)
+    fused = (s.astype(np.float64) * h.astype(np.float64) + np.float64(0.0)).astype(np.float32)
+    two_step = s * (h + np.float32(0.0))
+    assert np.array_equal(fused.view(np.uint32), two_step.view(np.uint32))
+    neg_zero = np.float32(-0.0)
+    z = (s.astype(np.float64) * np.float64(neg_zero) + np.float64(0.0)).astype(np.float32)
+    assert not np.signbit(z).any() and np.array_equal(z, np.zeros_like(z))
+    assert np.signbit(s * neg_zero).all()                 # what the bare product would have returned

@@ -246,7 +246,7 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
               oi.e[2 * j] = (int8_t)((int)(h[j].x + f3.f.zp) - 128);
               oi.e[2 * j + 1] = (int8_t)((int)(h[j].y + f3.f.zp) - 128);
             }
-            const f32x2 yq = f3.f.scale * (h[j] + f32x2{0.0f, 0.0f});     // + 0: -0 -> +0 like (x_int - zp)
+            const f32x2 yq = qf_dequant2(h[j], f3.f);                     // -0 -> +0 like (x_int - zp), one fma
             if (affine_only) {            // NoNorm: element-local NaN passes through
               t[j].x = (t[j].x != t[j].x) ? t[j].x : yq.x;
               t[j].y = (t[j].y != t[j].y) ? t[j].y : yq.y;

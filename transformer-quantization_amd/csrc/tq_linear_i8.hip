@@ -204,7 +204,7 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
       if (HASQ) {
         qf_round2_n<NP>(v, qf, hq);
 #pragma unroll
-        for (int e = 0; e < NP; ++e) v[e] = qf.scale * (hq[e] + f32x2{0.0f, 0.0f});
+        for (int e = 0; e < NP; ++e) v[e] = qf_dequant2(hq[e], qf);
       }
       if (TAIL == 2) {                                      // + residual, then the sum quantizer
 #pragma unroll
@@ -217,7 +217,7 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
         if (p.on_t1) {
           qf_round2_n<NP>(v, qf1, hq);
 #pragma unroll
-          for (int e = 0; e < NP; ++e) v[e] = qf1.scale * (hq[e] + f32x2{0.0f, 0.0f});
+          for (int e = 0; e < NP; ++e) v[e] = qf_dequant2(hq[e], qf1);
         }
       }
       if (TAIL >= 1) {                                      // NoNorm affine (mul, then add), then its output quantizer
@@ -240,7 +240,7 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
         if (p.on_t2) {
           qf_round2_n<NP>(v, qf2, hq);
 #pragma unroll
-          for (int e = 0; e < NP; ++e) v[e] = qf2.scale * (hq[e] + f32x2{0.0f, 0.0f});
+          for (int e = 0; e < NP; ++e) v[e] = qf_dequant2(hq[e], qf2);
         }
       }
 #pragma unroll
