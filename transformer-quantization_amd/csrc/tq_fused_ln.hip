@@ -254,11 +254,8 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
               t[j] = yq;                  // LayerNorm: NaN rows are patched below
             }
           }
-          if (!affine_only && __ballot(row_nan)) {
-#pragma unroll
-            for (int j = 0; j < H; ++j)
-              if (row_nan) t[j] = f32x2{__builtin_nanf(""), __builtin_nanf("")};
-          }
+          // (LayerNorm rows with a NaN input are overwritten AFTER the stores below, in a branch that is practically never
+          // taken: patching t[] here became one select per element of every row)
         } else {
 #pragma unroll
           for (int j = 0; j < H; ++j) {
@@ -282,6 +279,16 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
     } else {
 #pragma unroll
       for (int v = 0; v < NV; ++v) y[base + v * LPR + lane] = packed[v];
+    }
+    if (FAST && !affine_only && f3.on && __ballot(row_nan)) {          // rare: a LayerNorm row with a NaN input is NaN as a whole
+      if (row_nan) {
+        float nanv[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) nanv[e] = __builtin_nanf("");
+        const u32x4 pn = Store<DT>::pack(nanv);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) y[base + v * LPR + lane] = pn;
+      }
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) { va[v] = na[v]; vr[v] = nr[v]; }
