@@ -249,10 +249,10 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
     }
     float mx = -__builtin_huge_valf();
 #pragma unroll
-    for (int i = 0; i < P; ++i) mx = fmaxf(mx, fmaxf(x[i].x, x[i].y));
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (SPLIT) mx = fmaxf(mx, pair_exchange(s_red[0], mx, wave, kh, r16, g));   // (the barrier inside also publishes V^T)
+    for (int i = 0; i < P; ++i) mx = max_raw(mx, max_raw(x[i].x, x[i].y));
+    mx = max_raw(mx, __shfl_xor(mx, 16));
+    mx = max_raw(mx, __shfl_xor(mx, 32));
+    if (SPLIT) mx = max_raw(mx, pair_exchange(s_red[0], mx, wave, kh, r16, g));   // (the barrier inside also publishes V^T)
     // The denominator's summation order is part of the contract (oracle/tq_int_oracle.c restates it): per key half,
     // a lane group adds its exponentials sequentially (tile-major), groups combine as (s0 + s1) + (s2 + s3), the two
     // halves are added last -- the same tree whether one wave owns the whole row or two waves own a half each.
@@ -310,13 +310,13 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
         v = denom_pow2 ? v * inv_denom : v / p.denom;      // x / 2^k == x * 2^-k exactly (sqrt(64) = 8)
         if (p.mask) v = v + mk[r];
         sc[t][r] = v;
-        mx = fmaxf(mx, v);
+        mx = max_raw(mx, v);
       }
     }
     // ---- softmax over the T keys of this lane's query: in-lane, then across the 4 lane groups ------------
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (SPLIT) mx = fmaxf(mx, pair_exchange(s_red[0], mx, wave, kh, r16, g));   // (the barrier inside also publishes V^T)
+    mx = max_raw(mx, __shfl_xor(mx, 16));
+    mx = max_raw(mx, __shfl_xor(mx, 32));
+    if (SPLIT) mx = max_raw(mx, pair_exchange(s_red[0], mx, wave, kh, r16, g));   // (the barrier inside also publishes V^T)
     float sum = 0.f, sum_hi = 0.f;                     // same summation tree as the branch-free form above
 #pragma unroll
     for (int t = 0; t < NT; ++t)

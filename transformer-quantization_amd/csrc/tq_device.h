@@ -247,8 +247,9 @@ __device__ __forceinline__ float exp_neg_ieee(float x) {
   y = __builtin_fmaf(y, z, r);
   y = y + 1.0f;
   y = ldexpf(y, (int)k);
-  y = x < -86.0f ? 0.0f : y;
-  return x != x ? x : y;
+  // NaN needs no select of its own: k, r and y are NaN with x (rndne / fma propagate it), v_cvt_i32_f32(NaN) = 0, so
+  // ldexp(NaN, 0) = NaN, and `x < -86` is false for NaN -- the oracle's explicit `x != x ? x : y` returns the same bits' class
+  return x < -86.0f ? 0.0f : y;
 }
 
 // ------------------------------------------------------------------ storage <-> fp32
