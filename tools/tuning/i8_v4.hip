@@ -431,6 +431,151 @@ static void run_persist(const char* name, Prob p, uint32_t tpb, uint32_t delay_c
   fflush(stdout);
 }
 
+// ---- W-resident persistent variant: a block (8 waves: 4 x 2 of 32 x 64) owns ONE 128-feature panel of W for its whole run of
+// M tiles -- the panel's K slabs stay in LDS (K * 128 B = 96 KB at K = 768) -- and streams X through a 3-slab ring that runs
+// ahead across tile boundaries.  Operand traffic per tile: X only (98 KB instead of 196 KB).
+template <int EPI, int KMAX>
+__global__ __launch_bounds__(512, 1) void gemm_wres(const int8_t* __restrict__ X, const int8_t* __restrict__ W, int* __restrict__ Y,
+                                                     uint32_t M, uint32_t N, uint32_t K, uint32_t tiles_per_block, int store) {
+  constexpr int WM = 32, WN = 64, NI = WN / 16, MI = WM / 16, ST = 3, XSL = 128 * 128;     // X slab bytes
+  extern __shared__ __attribute__((aligned(1024))) int8_t lds[];                             // [W: K/128 slabs x 128 rows x 128 B][X ring]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t nk = K / 128, tiles_m = M / 128, n_tiles = tiles_m * (N / 128);
+  int8_t* wl = lds;
+  int8_t* xl = lds + (size_t)nk * XSL;
+  const int wn = (wave >> 2) * WN, wm = (wave & 3) * WM;
+  const int r16 = lane & 15, kg = lane >> 4, swz = (r16 >> 1) & 7;
+  const int off[2] = {r16 * 128 + ((kg ^ swz) << 4), r16 * 128 + (((4 + kg) ^ swz) << 4)};
+  const uint32_t first = blockIdx.x * tiles_per_block, last = min(first + tiles_per_block, n_tiles);
+  if (first >= last) return;
+  // this wave's 2 pieces (16 rows) of every 128-row slab
+  const int rowA = wave * 16 + (lane >> 3), rowB = rowA + 8;
+  const int chA = (lane & 7) ^ ((rowA >> 1) & 7), chB = (lane & 7) ^ ((rowB >> 1) & 7);
+  uint32_t panel = 0xffffffffu;
+  const uint32_t total_slabs = (last - first) * nk;
+  auto x_issue = [&](uint32_t s) {             // flat slab index of this block's run
+    const uint32_t tile = first + s / nk, kb = s % nk;
+    const uint32_t m0 = (tile % tiles_m) * 128;
+    int8_t* b = xl + (s % ST) * XSL + wave * 2048;
+    GLDS16(X + (size_t)(m0 + rowA) * K + kb * 128 + chA * 16, b);
+    GLDS16(X + (size_t)(m0 + rowB) * K + kb * 128 + chB * 16, b + 1024);
+  };
+  x_issue(0);
+  if (total_slabs > 1) x_issue(1);
+  uint32_t s = 0;
+  for (uint32_t tile = first; tile < last; ++tile) {
+    const uint32_t n0 = (tile / tiles_m) * 128, m0 = (tile % tiles_m) * 128;
+    if (tile / tiles_m != panel) {             // (re)load the W panel: nk slabs x 2 pieces per wave
+      panel = tile / tiles_m;
+      __syncthreads();                          // nobody reads the old panel any more
+      for (uint32_t kb = 0; kb < nk; ++kb) {
+        int8_t* b = wl + (size_t)kb * XSL + wave * 2048;
+        GLDS16(W + (size_t)(n0 + rowA) * K + kb * 128 + chA * 16, b);
+        GLDS16(W + (size_t)(n0 + rowB) * K + kb * 128 + chB * 16, b + 1024);
+      }
+    }
+    v4i acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+    for (uint32_t kb = 0; kb < nk; ++kb, ++s) {
+      // slab s (and, first time round, the W panel) must have landed; the younger X slab may still be in flight
+      if (s + 1 < total_slabs && !(tile == first && kb == 0) && kb != 0) wait_vm<2>(); else wait_vm<0>();
+      __syncthreads();
+      if (s + 2 < total_slabs) x_issue(s + 2);
+      const int8_t* bw = wl + (size_t)kb * XSL + wn * 128;
+      const int8_t* bx = xl + (s % ST) * XSL + wm * 128;
+      v4i fw[2][NI], fx[2][MI];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fw[s2][i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s2]);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) fx[s2][j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s2]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[s2][i], fx[s2][j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (store) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+          *reinterpret_cast<v4i*>(Y + (size_t)(m0 + wm + j * 16 + r16) * N + n0 + wn + i * 16 + kg * 4) = acc[i][j];
+    } else {
+      float sum = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        float v[MI][4];
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[j][r] = (float)acc[i][j][r];
+#pragma unroll 2
+        for (int e = 0; e < EPI; ++e)
+#pragma unroll
+          for (int j = 0; j < MI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j][r] = __builtin_fmaf(v[j][r], 0.999f, 0.125f);
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sum += v[j][r];
+      }
+      if (sum == 123456.789f) Y[tile] = (int)sum;
+    }
+  }
+}
+
+template <int EPI>
+static float wres_time(Prob p, uint32_t tpb, bool check, int* bad_out) {
+  const uint32_t n_tiles = (p.M / 128) * (p.N / 128), grid = (n_tiles + tpb - 1) / tpb;
+  auto k = gemm_wres<EPI, 768>;
+  const size_t lds = (size_t)(p.K / 128) * 128 * 128 + 3 * 128 * 128;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (check) {
+    CK(hipMemset(dY, 0xff, (size_t)p.M * p.N * 4));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, dX, dW, dY, p.M, p.N, p.K, tpb, 1);
+    CK(hipDeviceSynchronize());
+    std::vector<int> hY((size_t)p.M * p.N);
+    CK(hipMemcpy(hY.data(), dY, hY.size() * 4, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int t = 0; t < 3000; ++t) {
+      const uint32_t m = (uint32_t)((t * 2654435761u) % p.M), n = (uint32_t)((t * 40503u + 17) % p.N);
+      int ref = 0;
+      for (uint32_t kk = 0; kk < p.K; ++kk) ref += (int)hX[(size_t)m * p.K + kk] * (int)hW[(size_t)n * p.K + kk];
+      bad += ref != hY[(size_t)m * p.N + n];
+    }
+    *bad_out = bad;
+  }
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, dX, dW, dY, p.M, p.N, p.K, tpb, 0);
+  CK(hipEventRecord(a));
+  for (int w = 0; w < 30; ++w) hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, dX, dW, dY, p.M, p.N, p.K, tpb, 0);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms * 1000.0f / 30;
+}
+
+static void run_wres(Prob p) {
+  for (uint32_t tpb : {6u, 8u, 4u, 3u}) {
+    int bad = 0;
+    const float t0 = wres_time<0>(p, tpb, true, &bad), t17 = wres_time<17>(p, tpb, false, &bad), t34 = wres_time<34>(p, tpb, false, &bad);
+    printf("W-resident persistent, 8 waves, %u tiles per block (grid %u): %s  main loop %6.2f us | + 17 fma/elem %6.2f | + 34 fma/elem %6.2f\n",
+           tpb, ((p.M / 128) * (p.N / 128) + tpb - 1) / tpb, bad ? "WRONG" : "ok", t0, t17, t34);
+    fflush(stdout);
+  }
+}
+
 // ---- do MFMA and VALU work of DIFFERENT waves on one SIMD overlap?  Block = 512 threads (2 waves per SIMD on one CU when
 // one block per CU): role bit per wave: 1 = MFMA chain (16 independent accumulators), 2 = VALU fma chains.  `who` selects which
 // waves work: 1 = the first four waves run MFMAs, the rest idle; 2 = the last four run VALU; 3 = both at once.
@@ -562,6 +707,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dYf, 1 << 20));
     const Prob p = all[0];
     run_overlap_probe(dYf);
+    run_wres(p);
     run_epi<128, 2, 2, false>("product tiling (2 blocks/CU)", p);
     run_epi<128, 2, 2, true>("product tiling, DMA issued after k-step 0", p);
     run_epi<64, 2, 2, false>("64-byte slabs, 2 st (32 KB: up to 4 blocks/CU?)", p);
@@ -583,6 +729,9 @@ int main(int argc, char** argv) {
     const Prob p = all[pi];
     // (X / W of a smaller problem are the leading bytes of the big buffers, read with the problem's own K pitch)
     run<64, 64, 2, 2, 2, 0, 0, true>("DMA 64x64 2x2 2st (2 blk/CU) = product", p);
+    run<32, 64, 4, 2, 2, 0, 0, true>("DMA 32x64 4x2 8 waves, 128x128 blk (2 blk/CU)", p);
+    run<64, 32, 2, 4, 2, 0, 0, true>("DMA 64x32 2x4 8 waves, 128x128 blk (2 blk/CU)", p);
+    run<32, 32, 4, 4, 2, 0, 0, false>("DMA 32x32 4x4 16 waves, 128x128 blk (2 blk/CU)", p);
     run<64, 64, 2, 2, 2, 0, 32, true>("DMA 64x64 2x2 2st, 1 blk/CU", p);
     run<64, 64, 2, 2, 2, 1, 0, true>("REG 64x64 2x2 (2 blk/CU)", p);
     run<64, 64, 2, 2, 2, 1, 32, true>("REG 64x64 2x2, 1 blk/CU", p);
