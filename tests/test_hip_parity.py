@@ -799,6 +799,8 @@ def test_order_statistics_radix_select_equals_a_full_sort():
     s[1, 3:6] = 1e-42                                                # denormals
     s[1, 6] = -0.0
     check(s, [0, 3, 69996, 69999])
+    check(torch.randn(100, 10000, generator=g), [0, 4999, 5000, 9999])         # many rows AND long rows: one block per row
+    check(torch.randn(64, 5000, generator=g).to(torch.float16), [17, 4000])     # the last row count of the grid-wide mode, fp16
     check(torch.tensor([[2.5]]), [0, 0])
     with pytest.raises(_hip.TQError, match='rank'):
         be.order_stats(w.to(DEV), [768])
