@@ -482,6 +482,9 @@ def qat_dp_block(device, rank, world, use_dist, wd):
     model.learn_ranges()
     model.set_quant_state(True, True)
     model.train()
+    if use_dist and tq_dist.is_enabled():
+        from quantization.data_parallel import broadcast_parameters
+        broadcast_parameters(model)          # every rank calibrated on its own batch: replicas start from rank 0's ranges
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD(params, lr=1e-4)
     gb = GradientBuckets(params)
