@@ -7,10 +7,11 @@ raw communicator is active: one ctypes call into libtq_hip.so (`tq_comm_allreduc
 thread, no extra stream hop: ~3 us of host time per collective instead of ~37 us, and the launches capture into a
 hipGraph like any other kernel.
 
-Set-up needs ONE out-of-band exchange: the 128-byte ncclUniqueId made by rank 0.  It travels through a key-value
-store -- the default process group's rendezvous store when torch.distributed is initialised (any backend: `gloo` is
-enough, no c10d collective is issued), else a `TCPStore` on MASTER_ADDR / MASTER_PORT.  librccl itself is the one torch
-already mapped (`torch/lib/librccl.so`), so the process never holds two RCCL runtimes.
+Set-up goes through a key-value store -- the default process group's rendezvous store when torch.distributed is
+initialised (any backend: `gloo` is enough, no c10d collective is issued), else a `TCPStore` on MASTER_ADDR /
+MASTER_PORT: the 128-byte ncclUniqueId made by rank 0 travels through it, and so do the two agreement rounds that make
+bring-up a two-phase commit (`RawRcclComm.__init__`: a failure on one rank is a failure on all).  librccl itself is the
+one torch already mapped (`torch/lib/librccl.so`), so the process never holds two RCCL runtimes.
 """
 import ctypes as C
 import os
