@@ -138,6 +138,28 @@ int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_
                      const float* w_delta, uint64_t w_n_params, float w_eps, int activation,
                      const tq_quantizer* q_out, tq_stream_t stream);
 
+/* Activation + output quantizer of tq_linear_i8_fwd as a STAIRCASE TABLE (csrc/tq_stair.hip).  For a per-tensor <= 8-bit
+ * q_out,  h(v) = clamp(rne(RN32(act(v)) / scale) + zp, lo, hi) - zp  is a step function of the fp32 pre-activation v with
+ * <= 255 steps; RN32(act(v)) is the CORRECTLY ROUNDED fp32 activation (float64 evaluation of nn.GELU()'s erf form, then
+ * narrowed), followed by the reference quantizer's own arithmetic (quantizers.py:184-185).  tq_act_stair_build tabulates
+ * h on the device over n_bins uniform bins of v (one launch, no host read of the range buffers; rebuild whenever the
+ * quantizer's buffers change) into table[tq_act_stair_bytes(n_bins)]: a 16-byte header {1 / bin width, offset, n_bins - 1,
+ * ok} and 8 bytes per bin.  ok = 0 when some bin would hold two steps (grid finer than ~n_bins / 75 steps per unit of v):
+ * consumers then keep the arithmetic epilogue.  tq_linear_i8_stair_fwd == tq_linear_i8_fwd, except that with a table
+ * whose header says ok the epilogue evaluates activation + quantizer by one table read per output (~14 instead of ~30
+ * VALU issue slots with GELU); `activation` and `q_out` must be the ones the table was built for.  The table is used by
+ * the LDS-tiled kernels (M, N % 64 == 0, K % 128 == 0) when it fits beside the operand stages (n_bins <= 800 for 64 x 64
+ * tiles, <= 1664 for 128 x 128); otherwise, and with act_stair == NULL, the call IS tq_linear_i8_fwd.
+ * activation: TQ_ACT_NONE / TQ_ACT_RELU / TQ_ACT_GELU.                                                              */
+size_t tq_act_stair_bytes(uint32_t n_bins);
+int tq_act_stair_build(int activation, const tq_quantizer* q_out, uint32_t n_bins, void* table, size_t table_bytes,
+                       tq_stream_t stream);
+int tq_linear_i8_stair_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum,
+                           const float* bias, void* y, int8_t* y_idx, int y_dtype, uint64_t M, uint64_t N, uint64_t K,
+                           const float* x_delta, const float* x_zero_float, int x_n_bits, float x_eps,
+                           const float* w_delta, uint64_t w_n_params, float w_eps, int activation,
+                           const tq_quantizer* q_out, const void* act_stair, uint32_t stair_bins, tq_stream_t stream);
+
 /* Linear -> (+ residual) -> NoNorm -> quantizers as one launch (MobileBERT bottlenecks / residual tails; reference
  * models/quantized_mobilebert.py:58-72 with :287-304, :330-352 behind hijacker.py:66-116):
  *   residual == NULL:  y = Q_out( Q_dense(lin) * nn_weight + nn_bias )

@@ -109,11 +109,20 @@ static float gelu_fit(float v) {
   return (v * 0.5f) * (1.0f + r);
 }
 
+/* act 4: the specification of the staircase epilogue (csrc/tq_stair.hip, tq_linear_i8_stair_fwd with a table whose
+ * header says ok): the CORRECTLY ROUNDED fp32 value of nn.GELU()'s erf form -- float64 evaluation, narrowed once -- in
+ * front of the reference's own fp32 quantizer arithmetic.  No table here: every element is evaluated directly. */
+static float gelu_rn32(float v) {
+  const double x = (double)v;
+  return (float)(0.5 * x * (1.0 + erf(x * 0.70710678118654752440)));
+}
+
 static float act_fn(float v, int act) {
   switch (act) {
     case 1: return v > 0.0f ? v : 0.0f;
     case 2: return gelu_fit(v);
     case 3: return tanhf(v);
+    case 4: return gelu_rn32(v);
     default: return v;
   }
 }

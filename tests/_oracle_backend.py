@@ -98,9 +98,16 @@ class OracleBackend:
     def rowsum_i8(self, w_idx):
         return w_idx.to(torch.int32).sum(1, dtype=torch.int32)
 
+    def act_stair(self, activation, q_out, n_bins=None):
+        """The staircase of the HIP backend is a table of the exact specification; here the specification itself is
+        evaluated (oracle activation code 4: correctly rounded GELU), so the 'table' is only a marker."""
+        return ('oracle-stair', 0)
+
     def linear_i8(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta, w_eps, activation, q_out, out_dtype, want_idx=False,
-                  want_y=True):
+                  want_y=True, stair=None):
         from oracle import int_oracle
+        if stair is not None and activation == 2:
+            activation = 4
         y, yi = int_oracle.linear_i8(x_idx, w_idx, bias, tuple(float(v) for v in x_q), w_delta, w_eps, activation,
                                      self._q7(q_out))
         y = y.to(out_dtype) if want_y else None

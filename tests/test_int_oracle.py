@@ -135,6 +135,101 @@ def test_linear_i8_gelu_vs_integer_oracle():
     assert int(d.max()) <= 1 and float((d != 0).float().mean()) <= 1e-5, (int(d.max()), float((d != 0).float().mean()))
 
 
+def _f(q):
+    return None if q is None else tuple(float(v) if torch.is_tensor(v) else v for v in q)
+
+
+# ---- GELU + quantizer as a staircase table (csrc/tq_stair.hip): the specification is the CORRECTLY ROUNDED fp32 GELU in
+# front of the reference quantizer (oracle act code 4), and the table reproduces it for every fp32 pre-activation
+def _stair_header(stair):
+    return stair[0][:16].view(torch.float32).cpu().tolist()          # 1 / bin width, offset, n_bins - 1, ok
+
+
+def _gelu_q(scale, zero, bits=8):
+    return (torch.tensor(float(scale)), torch.tensor(float(zero)), None, bits, False, False, 1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(1024, 3072, 768), (4096, 4096, 128)], ids=['64x64-tiles', '128x128-tiles'])
+def test_linear_i8_gelu_staircase_equals_the_exact_gelu_oracle_bit_for_bit(shape):
+    from quantization import _hip
+    be = _hip.backend()
+    M, N, K = shape
+    x_idx, w_idx, x_q, w_delta, bias, q_sym = _rand_layer(M, N, K, seed=91 + K)
+    q_out = _gelu_q(float(q_sym[0]) * 0.55, 9.0)                     # GELU outputs: [-0.17, ~spread]
+    stair = be.act_stair(2, _dev(q_out))
+    assert _stair_header(stair)[3] == 1.0, _stair_header(stair)
+    ref_y, ref_i = IO.linear_i8(x_idx, w_idx, bias, x_q, w_delta, 1e-8, 4, _f(q_out))
+    wi = w_idx.to(DEV)
+    args = (x_idx.to(DEV), wi, be.rowsum_i8(wi), bias.to(DEV), _xq_dev(x_q), w_delta.to(DEV), 1e-8, 2, _dev(q_out), torch.float32)
+    y, yi = be.linear_i8(*args, want_idx=True, stair=stair)
+    assert torch.equal(yi.cpu(), ref_i) and torch.equal(y.cpu(), ref_y)
+    assert ref_i.unique().numel() > 100                              # the case exercises most of the grid
+    _, yi2 = be.linear_i8(*args, want_idx=True, want_y=False, stair=stair)
+    assert torch.equal(yi2.cpu(), ref_i)
+    # and the arithmetic epilogue (single erf fit, 8.5e-8 absolute) stays within its documented distance of the exact one
+    _, ya = be.linear_i8(*args, want_idx=True)
+    d = (ya.cpu().int() - ref_i.int()).abs()
+    assert int(d.max()) <= 1 and float((d != 0).float().mean()) <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('q_out', [_gelu_q(0.036, 5.0), _gelu_q(0.0131, 13.0), _gelu_q(0.25, 1.0, 4), _gelu_q(0.02, 200.0),
+                                   (torch.tensor(0.05), None, torch.tensor(True), 8, True, False, 1e-8)],
+                         ids=['s0.036', 's0.0131', '4bit', 'mostly-clamped', 'symmetric-signed'])
+def test_gelu_staircase_is_exact_at_every_step_of_the_table(q_out):
+    """Zero weights make the pre-activation of column n the bias b[n] exactly, so ANY fp32 value can be pushed through the
+    table: every threshold the builder found, its two fp32 neighbours, the bin edges, the neighbourhood of GELU's
+    minimum, zeros, denormals, huge values and a dense random sample -- all equal to the direct evaluation."""
+    from quantization import _hip
+    be = _hip.backend()
+    stair = be.act_stair(2, _dev(q_out))
+    inv_w, c0, nbm1, ok = _stair_header(stair)
+    assert ok == 1.0
+    tab = stair[0][16:].view(torch.int32).cpu().numpy().reshape(-1, 2)
+    T = tab[:, 0].copy().view(np.float32)
+    T = T[np.isfinite(T) & (np.abs(T) < 1e30)]
+    edges = ((np.arange(int(nbm1) + 2) - np.float64(c0)) / np.float64(inv_w)).astype(np.float32)
+    rng = np.random.RandomState(5)
+    pts = [T, np.nextafter(T, np.float32(-np.inf)), np.nextafter(T, np.float32(np.inf)), edges,
+           np.nextafter(edges, np.float32(-np.inf)), np.nextafter(edges, np.float32(np.inf)),
+           np.float32(-0.7517916) + np.arange(-64, 65, dtype=np.float32) * np.float32(2.0 ** -23),
+           np.array([0.0, -0.0, 1e-40, -1e-40, 1e30, -1e30, 3.4e38, -3.4e38, 1e-20, -1e-20], np.float32),
+           (rng.randn(20000) * 3).astype(np.float32), (rng.rand(8000) * 14 - 8).astype(np.float32)]
+    v = np.concatenate([np.asarray(a, np.float32).ravel() for a in pts])
+    N = -(-v.size // 64) * 64
+    bias = torch.from_numpy(np.concatenate([v, np.zeros(N - v.size, np.float32)]))
+    M, K = 64, 128
+    x_idx = torch.zeros(M, K, dtype=torch.int8)
+    w_idx = torch.zeros(N, K, dtype=torch.int8)
+    x_q, w_delta = (0.02, 117.0, 8, 1e-8), torch.tensor([0.001])
+    ref_y, _ = IO.linear_i8(x_idx, w_idx, bias, x_q, w_delta, 1e-8, 4, _f(q_out))
+    wi = w_idx.to(DEV)
+    y = be.linear_i8(x_idx.to(DEV), wi, be.rowsum_i8(wi), bias.to(DEV), _xq_dev(x_q), w_delta.to(DEV), 1e-8, 2, _dev(q_out),
+                     torch.float32, stair=stair)
+    bad = (y.cpu() != ref_y).nonzero()
+    assert bad.numel() == 0, [(float(bias[j]), float(y[i, j]), float(ref_y[i, j])) for i, j in bad[:5].tolist()]
+
+
+@pytest.mark.gpu
+def test_gelu_staircase_declines_a_grid_it_cannot_hold():
+    """A grid much finer than the bins: the builder says so in the header and the consumer keeps its arithmetic epilogue
+    (identical output to the call without a table)."""
+    from quantization import _hip
+    be = _hip.backend()
+    q_out = _gelu_q(0.0009, 190.0)
+    stair = be.act_stair(2, _dev(q_out))
+    assert _stair_header(stair)[3] == 0.0
+    M, N, K = 256, 512, 256
+    x_idx, w_idx, x_q, w_delta, bias, _ = _rand_layer(M, N, K, seed=12)
+    w_delta = w_delta * 0.05
+    wi = w_idx.to(DEV)
+    args = (x_idx.to(DEV), wi, be.rowsum_i8(wi), bias.to(DEV), _xq_dev(x_q), w_delta.to(DEV), 1e-8, 2, _dev(q_out), torch.float32)
+    y0, i0 = be.linear_i8(*args, want_idx=True)
+    y1, i1 = be.linear_i8(*args, want_idx=True, stair=stair)
+    assert torch.equal(y0, y1) and torch.equal(i0, i1) and i0.unique().numel() > 50
+
+
 def _tail_args(N, seed):
     g = torch.Generator().manual_seed(seed)
     nn_w = torch.rand(N, generator=g) + 0.5
@@ -142,10 +237,6 @@ def _tail_args(N, seed):
     q_sum = (torch.tensor(0.07), torch.tensor(121.0), None, 8, False, False, 1e-8)
     q_fin = (torch.tensor(0.6), torch.tensor(7.0), None, 4, False, False, 1e-8)
     return nn_w, nn_b, q_sum, q_fin
-
-
-def _f(q):
-    return None if q is None else tuple(float(v) if torch.is_tensor(v) else v for v in q)
 
 
 @pytest.mark.gpu

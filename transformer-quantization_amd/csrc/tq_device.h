@@ -258,6 +258,26 @@ __device__ __forceinline__ float exp_neg_ieee(float x) {
 __device__ __forceinline__ float bits_to_f32(uint32_t w) { return __builtin_bit_cast(float, w); }
 __device__ __forceinline__ uint32_t f32_to_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
+// ------------------------------------------------------------------ activation + quantizer as a staircase
+// h(v) = Q(act(v)) - zero_point of a <= 8-bit quantizer is a step function of the fp32 pre-activation v with at most 255
+// steps.  csrc/tq_stair.hip tabulates it over uniform bins of v that hold at most ONE step each; a consumer (the integer
+// Linear's epilogue) then needs one fma + clamp + convert for the bin, one 8-byte table read, one compare and a select
+// instead of evaluating the activation and the quantizer's quotient: ~14 instead of ~30 issue slots per output with
+// GELU.  Table: [StairHdr | nb entries {T, packed}], packed = bf16(h right of T) << 16 | bf16(h left of T) (|h| <= 256
+// is exact in bf16), h(v) = v >= T ? right : left inside the bin.  `stair_bin` is THE bin map: the builder derives
+// every bin's fp32 interval from this very function, so builder and consumers agree on every input bit pattern.
+struct StairHdr {
+  float inv_w, c0, nbm1;   // bin = trunc(clamp(fma(v, inv_w, c0), 0, nbm1))
+  float ok;                // 1 = the table is exact for every finite fp32 v; 0 = use the arithmetic path
+};
+__device__ __forceinline__ uint32_t stair_bin(float v, float inv_w, float c0, float nbm1) {
+  return (uint32_t)__builtin_amdgcn_fmed3f(__builtin_fmaf(v, inv_w, c0), 0.0f, nbm1);   // NaN -> bin 0
+}
+__device__ __forceinline__ float stair_pick(float v, float T, uint32_t packed) {
+  const uint32_t w = v >= T ? packed : (packed << 16);
+  return bits_to_f32(w & 0xffff0000u);
+}
+
 template <int DT> struct Store;   // DT = TQ_F32 / TQ_BF16 / TQ_F16
 
 template <> struct Store<TQ_F32> {

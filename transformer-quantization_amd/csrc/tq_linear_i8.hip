@@ -69,6 +69,15 @@ struct LinArgs {
   const float* nn_b;      // [N] fake-quantized NoNorm bias
   tq_quantizer q_t1, q_t2;
   int on_t1, on_t2;
+  // optional staircase table of act + q_out (tq_act_stair_build; LDS kernels only): replaces the activation and the
+  // quantizer's quotient in the epilogue when its header says it is exact
+  const float* stair;
+  uint32_t stair_bins;
+};
+
+struct StairRef {                // the table as the epilogue sees it: entries in LDS, geometry in scalars
+  const u32x2* tab;
+  float inv_w, c0, nbm1;
 };
 
 // ---- epilogue: zero-point correction, scales, bias, activation, output quantizer ----------------------
@@ -133,6 +142,39 @@ __device__ __forceinline__ void store_y4(void* y, size_t at, f32x2 lo, f32x2 hi)
     pk[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
     pk[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2));
     *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(y) + at) = pk;
+  }
+}
+
+// Staged output of one pass (PR token rows x WTN output features of a wave, parked in its private LDS area): row-contiguous
+// stores, every instruction covering whole 128-byte lines; non-temporal for y (not read again by this kernel).
+// Wave-private staging: program order (+ the compiler's lgkmcnt) is all the synchronisation needed.
+template <int WTN, int PR, int YDT>
+__device__ __forceinline__ void stage_flush(const LinArgs& p, const int8_t* ystage, const int8_t* istage, uint32_t n0, uint32_t mrow0,
+                                            int lane, bool want_idx) {
+  constexpr int ES = YDT == TQ_F32 ? 4 : 2;
+  constexpr int YP = WTN * ES + 16, IP = WTN + 16;
+  if (p.y != nullptr) {
+    constexpr int LPR = WTN * ES / 16, RPI = 64 / LPR;   // lanes per row, rows per store instruction
+#pragma unroll
+    for (int t = 0; t < (PR + RPI - 1) / RPI; ++t) {
+      const int row = t * RPI + lane / LPR;
+      if (RPI <= PR || row < PR) {
+        const u32x4 d = *reinterpret_cast<const u32x4*>(ystage + row * YP + (lane % LPR) * 16);
+        __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(static_cast<int8_t*>(p.y) +
+                                                                ((size_t)(mrow0 + row) * p.N + n0) * ES + (lane % LPR) * 16));
+      }
+    }
+  }
+  if (want_idx) {
+    constexpr int LPR = WTN / 16, RPI = 64 / LPR;
+#pragma unroll
+    for (int t = 0; t < (PR + RPI - 1) / RPI; ++t) {
+      const int row = t * RPI + lane / LPR;
+      if (RPI <= PR || row < PR) {
+        const u32x4 d = *reinterpret_cast<const u32x4*>(istage + row * IP + (lane % LPR) * 16);
+        *reinterpret_cast<u32x4*>(p.y_idx + (size_t)(mrow0 + row) * p.N + n0 + (lane % LPR) * 16) = d;
+      }
+    }
   }
 }
 
@@ -265,33 +307,76 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
         }
       }
     }
-    if (STAGED) {
-      // wave-private staging: program order (+ the compiler's lgkmcnt) is all the synchronisation needed
-      const uint32_t mrow0 = m0 + h * PR;
-      if (p.y != nullptr) {
-        constexpr int LPR = WTN * ES / 16, RPI = 64 / LPR;   // lanes per row, rows per store instruction
+    if (STAGED) stage_flush<WTN, PR, YDT>(p, ystage, istage, n0, m0 + h * PR, lane, want_idx);
+  }
+}
+
+// Staircase form (LDS kernels, no tail): h = Q(act(v)) - zp straight from the table of csrc/tq_stair.hip -- per output
+// one fma + clamp + convert for the bin, one 8-byte LDS read, compare, select -- in two phases per pass so that the table
+// reads of ALL the pass's outputs (32 per lane for a 64 x 64 wave tile) are in flight together: with one or two waves per
+// SIMD nothing else hides an LDS round trip, and issued group by group the reads cost more than the arithmetic they replace.
+template <int NI, int MI, int YDT>
+__device__ __forceinline__ void linear_epilogue_stair(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
+                                                      int kg, const QF& qf, int8_t* stage, const float* cst, int cs,
+                                                      const StairRef& sr) {
+  constexpr int JP = MI >= 2 ? 2 : 1, PR = JP * 16, NP = 2 * JP, WTN = NI * 16;
+  constexpr int ES = YDT == TQ_F32 ? 4 : 2;
+  constexpr int YP = WTN * ES + 16, IP = WTN + 16;
+  const f32x2 zpb = {qf.zp, qf.zp};
+  const int lane = kg * 16 + r16;
+  int8_t* ystage = stage;
+  int8_t* istage = stage + PR * YP;
+  const bool want_idx = p.y_idx != nullptr;
 #pragma unroll
-        for (int t = 0; t < (PR + RPI - 1) / RPI; ++t) {
-          const int row = t * RPI + lane / LPR;
-          if (RPI <= PR || row < PR) {
-            const u32x4 d = *reinterpret_cast<const u32x4*>(ystage + row * YP + (lane % LPR) * 16);
-            __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(static_cast<int8_t*>(p.y) +
-                                                                    ((size_t)(mrow0 + row) * p.N + n0) * ES + (lane % LPR) * 16));
-          }
-        }
+  for (int h = 0; h < MI / JP; ++h) {
+    f32x2 v[NI][NP];
+    u32x2 e0[NI][NP], e1[NI][NP];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = i * 16 + kg * 4;
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(cst + col);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(cst + cs + col);
+      const v4i r4 = *reinterpret_cast<const v4i*>(cst + 2 * cs + col);
+      const f32x2 sw0 = {s4.x, s4.y}, sw1 = {s4.z, s4.w}, bs0 = {b4.x, b4.y}, bs1 = {b4.z, b4.w};
+#pragma unroll
+      for (int jj = 0; jj < JP; ++jj) {
+        const int j = h * JP + jj;
+        const f32x2 lo = {(float)(acc[i][j][0] + r4.x), (float)(acc[i][j][1] + r4.y)};
+        const f32x2 hi = {(float)(acc[i][j][2] + r4.z), (float)(acc[i][j][3] + r4.w)};
+        v[i][2 * jj] = lo * sw0 + bs0;                     // separate mul and add as in the reference (no contraction)
+        v[i][2 * jj + 1] = hi * sw1 + bs1;
       }
-      if (want_idx) {
-        constexpr int LPR = WTN / 16, RPI = 64 / LPR;
 #pragma unroll
-        for (int t = 0; t < (PR + RPI - 1) / RPI; ++t) {
-          const int row = t * RPI + lane / LPR;
-          if (RPI <= PR || row < PR) {
-            const u32x4 d = *reinterpret_cast<const u32x4*>(istage + row * IP + (lane % LPR) * 16);
-            *reinterpret_cast<u32x4*>(p.y_idx + (size_t)(mrow0 + row) * p.N + n0 + (lane % LPR) * 16) = d;
-          }
-        }
+      for (int e = 0; e < NP; ++e) {
+        e0[i][e] = sr.tab[stair_bin(v[i][e].x, sr.inv_w, sr.c0, sr.nbm1)];
+        e1[i][e] = sr.tab[stair_bin(v[i][e].y, sr.inv_w, sr.c0, sr.nbm1)];
       }
     }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      f32x2 hq[NP], y[NP];
+#pragma unroll
+      for (int e = 0; e < NP; ++e) {
+        const uint32_t t0 = e0[i][e].x, p0 = e0[i][e].y, t1 = e1[i][e].x, p1 = e1[i][e].y;
+        hq[e] = f32x2{stair_pick(v[i][e].x, bits_to_f32(t0), p0), stair_pick(v[i][e].y, bits_to_f32(t1), p1)};
+        y[e] = qf_dequant2(hq[e], qf);
+      }
+#pragma unroll
+      for (int jj = 0; jj < JP; ++jj) {
+        const int row = jj * 16 + r16, col = i * 16 + kg * 4;
+        if (want_idx) {                                   // int8(index - 128): u8 index with the top bit flipped
+          const f32x2 a = hq[2 * jj] + zpb, b = hq[2 * jj + 1] + zpb;
+          uint32_t w = 0;
+          w = __builtin_amdgcn_cvt_pk_u8_f32(a.x, 0, w);
+          w = __builtin_amdgcn_cvt_pk_u8_f32(a.y, 1, w);
+          w = __builtin_amdgcn_cvt_pk_u8_f32(b.x, 2, w);
+          w = __builtin_amdgcn_cvt_pk_u8_f32(b.y, 3, w) ^ 0x80808080u;
+          *reinterpret_cast<uint32_t*>(istage + row * IP + col) = w;
+        }
+        if (p.y != nullptr) store_y4<YDT>(ystage + row * YP, col, y[2 * jj], y[2 * jj + 1]);
+      }
+    }
+    stage_flush<WTN, PR, YDT>(p, ystage, istage, n0, m0 + h * PR, lane, want_idx);
   }
 }
 
@@ -356,6 +441,8 @@ struct EpiCtx {
   float sx;
   int shift;
   bool fast;
+  bool stair;                    // the staircase table is present and exact (its header's verdict, read on the device)
+  float st_inv_w, st_c0, st_nbm1;
 };
 
 template <bool WITH_TAIL>
@@ -372,6 +459,12 @@ __device__ __forceinline__ EpiCtx epilogue_prepare(const LinArgs& p, uint32_t n0
   }
   c.qf = make_qf(c.qo);
   c.fast = p.act != ACT_TANH && (!p.has_q || c.qf.ok) && p.fast_epi != 0;
+  c.stair = false;
+  c.st_inv_w = c.st_c0 = c.st_nbm1 = 0.0f;
+  if (!WITH_TAIL && p.stair != nullptr && p.has_q && c.fast) {
+    c.st_inv_w = p.stair[0]; c.st_c0 = p.stair[1]; c.st_nbm1 = p.stair[2];
+    c.stair = p.stair[3] == 1.0f && c.st_nbm1 == (float)(p.stair_bins - 1);
+  }
   c.qf1 = c.qf2 = c.qf;
   if (WITH_TAIL) {
     c.qf1 = make_qf(p.on_t1 ? make_qp(p.q_t1, 0) : QP{1.f, 0.f, 0.f, 1.f});
@@ -384,7 +477,8 @@ __device__ __forceinline__ EpiCtx epilogue_prepare(const LinArgs& p, uint32_t n0
 template <int NI, int MI, int YDT, bool STAGED, bool WITH_TAIL>
 __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
                                                 int kg, const EpiCtx& c, int8_t* stage = nullptr, const float* cst = nullptr,
-                                                int cs = 2 * NI * 16, const f32x4 (*res_pre)[MI] = nullptr) {
+                                                int cs = 2 * NI * 16, const f32x4 (*res_pre)[MI] = nullptr,
+                                                const u32x2* stair_lds = nullptr) {
   if (!c.fast) return linear_epilogue_generic<NI, MI, YDT>(p, acc, n0, m0, r16, kg, c.qo, c.shift, c.sx);
   if (WITH_TAIL) {                 // separate kernel instantiation: the plain Linear keeps its register budget
 #define TQ_EPI_T(Q, T) linear_epilogue_fast<NI, MI, YDT, ACT_NONE, Q, STAGED, T>(p, acc, n0, m0, r16, kg, c.qf, c.shift, c.sx, stage, cst, c.qf1, c.qf2, cs, res_pre)
@@ -395,6 +489,10 @@ __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI]
   }
   // wave-uniform dispatch: one straight-line body per (activation, quantizer) combination
 #define TQ_EPI(A, Q) linear_epilogue_fast<NI, MI, YDT, A, Q, STAGED>(p, acc, n0, m0, r16, kg, c.qf, c.shift, c.sx, stage, cst, QF{}, QF{}, cs)
+  if (STAGED && c.stair && stair_lds != nullptr) {
+    linear_epilogue_stair<NI, MI, YDT>(p, acc, n0, m0, r16, kg, c.qf, stage, cst, cs, StairRef{stair_lds, c.st_inv_w, c.st_c0, c.st_nbm1});
+    return;
+  }
   if (p.has_q) {
     if (p.act == ACT_GELU)      TQ_EPI(ACT_GELU, true);
     else if (p.act == ACT_RELU) TQ_EPI(ACT_RELU, true);
@@ -495,6 +593,7 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
   const int swz = (r16 >> 1) & 7;
   const int off[2] = {r16 * 128 + ((kg ^ swz) << 4), r16 * 128 + (((4 + kg) ^ swz) << 4)};
   float* cst = reinterpret_cast<float*>(lds_i8 + 2 * STB);
+  u32x2* stab = reinterpret_cast<u32x2*>(lds_i8 + 2 * STB + 5 * BT * 4);   // staircase entries (allocated only with p.stair)
   const uint32_t nk = p.K / 128;
 
   // One block per output tile.  (Round 3 tried persistent blocks working through runs of tiles -- parameters loaded
@@ -544,6 +643,10 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
       reinterpret_cast<int*>(cst)[2 * BT + tid] = ld_rs * ectx.shift;
       if (WITH_TAIL) { cst[3 * BT + tid] = ld_nw; cst[4 * BT + tid] = ld_nb; }
     }
+    if (!WITH_TAIL && ectx.stair) {                 // table -> LDS (L2-hot: every block reads the same <= 14 KB), published like cst
+      const u32x2* gtab = reinterpret_cast<const u32x2*>(p.stair + 4);
+      for (uint32_t i = tid; i < p.stair_bins; i += kBlock) stab[i] = gtab[i];
+    }
     for (uint32_t kb = 0; kb < nk; ++kb) {
       lds_dma_wait_all();
       __syncthreads();                              // slab kb landed (vmcnt(0) + barrier); slab kb - 1 is no longer read
@@ -592,7 +695,8 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
 #endif
     constexpr int kStageBytes = 32 * (WT * 4 + 16) + 32 * (WT + 16);
     static_assert(4 * kStageBytes <= 2 * STB, "output staging must fit the operand stages");
-    linear_epilogue<NI, MI, YDT, true, WITH_TAIL>(p, acc, n0 + wn, m0 + wm, r16, kg, ectx, lds_i8 + wave * kStageBytes, cst + wn);
+    linear_epilogue<NI, MI, YDT, true, WITH_TAIL>(p, acc, n0 + wn, m0 + wm, r16, kg, ectx, lds_i8 + wave * kStageBytes, cst + wn,
+                                                  2 * NI * 16, nullptr, stab);
   }
 }
 
@@ -843,10 +947,15 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     // 128 x 128 block tiles once they still give >= 4 blocks per CU, else 64 x 64
     const bool big = a.M % 128 == 0 && a.N % 128 == 0 && (uint64_t)(a.M / 128) * (a.N / 128) >= (uint64_t)tuning("TQ_I8_BIG_MIN", 1024);
     const uint64_t grid = big ? (uint64_t)(a.M / 128) * (a.N / 128) : (uint64_t)(a.M / 64) * (a.N / 64);   // one block per tile
-    if (big) hipLaunchKernelGGL((linear_i8_lds_k<64, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock),
-                                2 * 2 * 128 * 128 + 5 * 128 * 4 + (size_t)tuning("TQ_I8_LDS_PAD", 0), st, a);
-    else     hipLaunchKernelGGL((linear_i8_lds_k<32, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock),
-                                2 * 2 * 64 * 128 + 5 * 64 * 4, st, a);
+    // the staircase entries sit behind the per-column constants; dropped when they would cost a resident block
+    // (160 KB per CU: 2 blocks of 128 x 128 tiles, 4 of 64 x 64)
+    const size_t base = big ? 2 * 2 * 128 * 128 + 5 * 128 * 4 : 2 * 2 * 64 * 128 + 5 * 64 * 4;
+    const size_t room = (big ? 80 * 1024 : 40 * 1024) - 512 - base;
+    LinArgs b = a;
+    if (b.stair != nullptr && ((size_t)b.stair_bins * 8 > room || !tuning("TQ_I8_STAIR", 1))) b.stair = nullptr;
+    const size_t lds = base + (b.stair != nullptr ? (size_t)b.stair_bins * 8 : 0) + (big ? (size_t)tuning("TQ_I8_LDS_PAD", 0) : 0);
+    if (big) hipLaunchKernelGGL((linear_i8_lds_k<64, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock), lds, st, b);
+    else     hipLaunchKernelGGL((linear_i8_lds_k<32, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock), lds, st, b);
     return check_launch("linear_i8_lds_k");
   }
   // odd shapes (M, N % 32 == 0, K % 64 == 0): LDS-free kernel, 32 x 32 wave tiles
@@ -915,7 +1024,19 @@ extern "C" int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const 
                                 const float* x_zero_float, int x_n_bits, float x_eps, const float* w_delta,
                                 uint64_t w_n_params, float w_eps, int activation, const tq_quantizer* q_out,
                                 tq_stream_t stream) {
+  return tq_linear_i8_stair_fwd(x_idx, w_idx, w_rowsum, bias, y, y_idx, y_dtype, M, N, K, x_delta, x_zero_float, x_n_bits, x_eps,
+                                w_delta, w_n_params, w_eps, activation, q_out, nullptr, 0, stream);
+}
+
+extern "C" int tq_linear_i8_stair_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum, const float* bias,
+                                      void* y, int8_t* y_idx, int y_dtype, uint64_t M, uint64_t N, uint64_t K,
+                                      const float* x_delta, const float* x_zero_float, int x_n_bits, float x_eps,
+                                      const float* w_delta, uint64_t w_n_params, float w_eps, int activation,
+                                      const tq_quantizer* q_out, const void* act_stair, uint32_t stair_bins,
+                                      tq_stream_t stream) {
   if (M == 0 || N == 0) return TQ_OK;
+  TQ_REQUIRE(act_stair == nullptr || (q_out != nullptr && stair_bins >= 64 && stair_bins <= 2048 && aligned16(act_stair)),
+             "tq_linear_i8_stair_fwd: the staircase needs an output quantizer, 64..2048 bins and 16-byte alignment");
   TQ_REQUIRE(x_idx && w_idx && w_rowsum && (y || y_idx) && x_delta && x_zero_float && w_delta, "tq_linear_i8_fwd: NULL pointer");
   TQ_REQUIRE(y_dtype == TQ_F32 || y_dtype == TQ_BF16, "tq_linear_i8_fwd: y dtype must be fp32 or bf16");
   TQ_REQUIRE(M % 32 == 0 && N % 32 == 0 && K % 64 == 0 && K >= 64 && K <= 16384 && M < (1u << 31) && N < (1u << 31),
@@ -939,6 +1060,8 @@ extern "C" int tq_linear_i8_fwd(const int8_t* x_idx, const int8_t* w_idx, const 
     TQ_REQUIRE(q_out->n_params == 1, "tq_linear_i8_fwd: per-tensor output quantizer only");
     a.q_out = *q_out;
   }
+  a.stair = static_cast<const float*>(act_stair);
+  a.stair_bins = stair_bins;
   hipStream_t st = static_cast<hipStream_t>(stream);
   return y_dtype == TQ_F32 ? launch_linear<TQ_F32>(a, st) : launch_linear<TQ_BF16>(a, st);
 }

@@ -74,6 +74,10 @@ SIGNATURES = {
                                        _vp, _u64, _f, _QP, _QP, _QP, _vp]),
     'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
                                 _int, _QP, _vp]),
+    'tq_linear_i8_stair_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
+                                      _int, _QP, _vp, C.c_uint32, _vp]),
+    'tq_act_stair_bytes': (_sz, [C.c_uint32]),
+    'tq_act_stair_build': (_int, [_int, _QP, C.c_uint32, _vp, _sz, _vp]),
     'tq_fake_quant_bwd_workspace_bytes': (_sz, [_u64]),
     'tq_fake_quant_bwd_params_workspace_bytes': (_sz, [_u64, _u64, _u64]),
     'tq_fake_quant_bwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _int, _QP, _vp, _sz, _vp]),
@@ -503,11 +507,26 @@ class HipBackend:
         _check(rc, self.lib)
         return out
 
+    STAIR_BINS = 768        # fits beside the operand stages of both LDS-tiled kernels (include/tq_hip.h)
+
+    def act_stair(self, activation, q_out, n_bins=None):
+        """Staircase table of `activation` followed by the per-tensor <= 8-bit quantizer `q_out` (its 7-tuple) for
+        `linear_i8(..., stair=...)`: one launch, no host read; the table's own header says whether it is exact (a grid
+        too fine for the bin count makes the consumer keep its arithmetic epilogue).  Valid for the VALUES the range
+        buffers hold now: rebuild when they change."""
+        n_bins = int(n_bins or self.STAIR_BINS)
+        dev = q_out[0].device
+        table = torch.empty(self.lib.tq_act_stair_bytes(n_bins), dtype=torch.uint8, device=dev)
+        qd = self._qdesc(*q_out, 1, 1)
+        rc = self.lib.tq_act_stair_build(int(activation), C.byref(qd), n_bins, table.data_ptr(), table.numel(), _stream())
+        _check(rc, self.lib)
+        return table, n_bins
+
     def linear_i8(self, x_idx, w_idx, w_rowsum, bias, x_q, w_delta, w_eps, activation, q_out, out_dtype,
-                  want_idx=False, want_y=True):
+                  want_idx=False, want_y=True, stair=None):
         """x_idx int8 [..., K]; x_q = (delta, zero_float, n_bits, eps) of the input quantizer;
         q_out None or the 7-tuple of a per-tensor quantizer.  -> y [..., N] (, y_idx); want_y=False (needs want_idx):
-        index-only output, y is None."""
+        index-only output, y is None.  stair: (table, n_bins) of `act_stair(activation, q_out)` or None."""
         K = x_idx.shape[-1]
         M = x_idx.numel() // K
         N = w_idx.shape[0]
@@ -515,10 +534,11 @@ class HipBackend:
         y = torch.empty(shape, dtype=out_dtype, device=x_idx.device) if want_y else None
         y_idx = torch.empty(shape, dtype=torch.int8, device=x_idx.device) if want_idx else None
         qd = None if q_out is None else self._qdesc(*q_out, 1, 1)
-        rc = self.lib.tq_linear_i8_fwd(
+        rc = self.lib.tq_linear_i8_stair_fwd(
             _ptr(x_idx), _ptr(w_idx), _ptr(w_rowsum), _ptr(bias), _ptr(y), _ptr(y_idx), _DTYPES[out_dtype], M, N, K,
             _ptr(x_q[0]), _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(w_delta), w_delta.numel(),
-            float(w_eps), int(activation), None if qd is None else C.byref(qd), _stream())
+            float(w_eps), int(activation), None if qd is None else C.byref(qd),
+            None if stair is None else stair[0].data_ptr(), 0 if stair is None else int(stair[1]), _stream())
         _check(rc, self.lib)
         return (y, y_idx) if want_idx else y
 

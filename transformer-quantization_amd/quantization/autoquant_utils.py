@@ -38,6 +38,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         super().__init__(*args, **kwargs)
         self._int8_cache = None
         self._int8_signed = None
+        self._int8_stair = None
 
     def run_forward(self, x, weight, bias, offsets=None):
         return F.linear(x.contiguous(), weight.contiguous(), bias=bias)
@@ -133,6 +134,22 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         return (x_idx, w_idx, rowsum, bias, (src._delta, src._zero_float, src.n_bits, src.eps), wq._delta.reshape(-1),
                 wq.eps)
 
+    def _int8_act_stair(self, act_code, q_out):
+        """(table, n_bins) of GELU + this layer's output quantizer for the integer epilogue, cached per range state of
+        that quantizer (built by one launch, no host read), or None (no GELU, no output quantizer, > 8 bits, switched
+        off).  Like the int8 weights, the table is rebuilt on every call while a hipGraph is being recorded under
+        autograd: the recorded launches must not depend on a cache hit."""
+        if (act_code != _hip.ACT_GELU or q_out is None or q_out[3] > 8 or not options.INT8_ACT_STAIR
+                or not hasattr(_hip.backend(), 'act_stair')):
+            return None
+        key = self.activation_quantizer.quantizer.range_state_key()
+        cached = self._int8_stair
+        recording = torch.is_grad_enabled() and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if (cached is None or cached[0] != key or recording
+                or getattr(cached[1][0], 'device', q_out[0].device) != q_out[0].device):
+            cached = self._int8_stair = (key, _hip.backend().act_stair(act_code, q_out))
+        return cached[1]
+
     def _int8_compute(self, x, plan, x_idx=None, index_only=False):
         """The fused integer Linear itself (no autograd): y [, its int8 indices] or None (unsigned weight grid).
         index_only: only the int8 indices of the output are produced and returned (the consumer is another integer
@@ -147,8 +164,9 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         if index_only:
             assert want_idx, 'index-only output needs an asymmetric <= 8-bit output quantizer'
             return _hip.backend().linear_i8(*ops[:5], ops[5], ops[6], act_code, q_out, torch.float32, want_idx=True,
-                                            want_y=False)[1]
-        out = _hip.backend().linear_i8(*ops[:5], ops[5], ops[6], act_code, q_out, torch.float32, want_idx=want_idx)
+                                            want_y=False, stair=self._int8_act_stair(act_code, q_out))[1]
+        out = _hip.backend().linear_i8(*ops[:5], ops[5], ops[6], act_code, q_out, torch.float32, want_idx=want_idx,
+                                       stair=self._int8_act_stair(act_code, q_out))
         y = out[0] if want_idx else out
         if q_out is not None:
             provenance.tag(y, amgr.quantizer, out[1] if want_idx else None)   # the next integer Linear consumes these

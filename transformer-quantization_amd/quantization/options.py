@@ -9,6 +9,12 @@
 # output that sits on a rounding boundary by one grid step.
 INT8_LINEAR = False
 
+# Integer Linears with a GELU: evaluate activation + output quantizer through a staircase table built on the device from
+# the quantizer's range (csrc/tq_stair.hip, one extra launch per range state) instead of the erf fit + exact quotient in
+# the epilogue.  The table is the correctly rounded GELU followed by the reference quantizer, exact by construction; the
+# arithmetic epilogue stays in place for grids the table cannot hold (decided on the device).
+INT8_ACT_STAIR = True
+
 # Estimator state (current_xmin / current_xmax) and quantizer parameters (_delta / _zero_float / _signed)
 # are rebound to FRESH tensors on every calibrating forward, like the reference does.  With this switch
 # the fused calibration step updates the existing buffers IN PLACE once they exist (same values, same
