@@ -152,6 +152,17 @@ def fam_i8():
                 lambda: be.linear_i8(x, w, rs, b, (xd, xz, 8, 1e-8), wd, 1e-8, _hip.ACT_GELU, qo, torch.float32,
                                      want_idx=True, want_y=False),
                 2.0 * M * N * K, 'mfma_i8', note=f'M={M} N={N} K={K}, int8 indices only')
+            # the same with GELU + quantizer evaluated through the staircase table (csrc/tq_stair.hip; the default of
+            # QuantLinear's integer path, options.INT8_ACT_STAIR)
+            st = be.act_stair(_hip.ACT_GELU, qo)
+            assert st[0][:16].view(torch.float32)[3].item() == 1.0
+            run('i8', f'integer Linear+GELU+quant STAIRCASE M={M} N={N} K={K}', 'linear_i8_lds_k',
+                lambda: be.linear_i8(x, w, rs, b, (xd, xz, 8, 1e-8), wd, 1e-8, _hip.ACT_GELU, qo, torch.float32, stair=st),
+                2.0 * M * N * K, 'mfma_i8', note=f'M={M} N={N} K={K}, staircase epilogue')
+            run('i8', f'integer Linear+GELU+quant STAIRCASE INDEX-ONLY M={M} N={N} K={K}', 'linear_i8_lds_k',
+                lambda: be.linear_i8(x, w, rs, b, (xd, xz, 8, 1e-8), wd, 1e-8, _hip.ACT_GELU, qo, torch.float32,
+                                     want_idx=True, want_y=False, stair=st),
+                2.0 * M * N * K, 'mfma_i8', note=f'M={M} N={N} K={K}, staircase epilogue, int8 indices only')
     # MobileBERT shapes (M = 1024 tokens): Linear 512 -> 128 with the residual NoNorm tail in its epilogue, and a whole
     # feed-forward block (128 -> 512 ReLU quant -> 128 + tail) as one launch
     M = 1024
