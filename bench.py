@@ -231,6 +231,31 @@ def dry_run(args, rank, world):
 
 # ---- optional blocks of the JSON line (after the headline measurement; a failure or a stall in any of them never
 # ---- costs the headline: see _Watchdog) ---------------------------------------------------------------------------------
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout, but native libraries write to file descriptor 1 as well: RCCL prints a
+    five-line version banner when a communicator is created (`RCCL version : ...`, seen in front of the line of every
+    run that creates one).  From here on fd 1 is an alias of stderr for everybody, and the line goes out through the
+    saved descriptor (`_emit`)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    data = (line + '\n').encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line + '\n')
+        sys.stdout.flush()
+        return
+    while data:
+        data = data[os.write(_REAL_STDOUT, data):]
+
+
 class _Watchdog:
     """The blocks below contain collectives that have never met more than one rank on this pool (raw RCCL bring-up, a
     captured ncclAllReduce, ...).  If they stall, every rank's timer fires: rank 0 prints the line it has -- headline
@@ -258,7 +283,7 @@ class _Watchdog:
                     break
                 except RuntimeError:
                     time.sleep(0.01)
-            print(line if line is not None else json.dumps({'incomplete': [note]}), flush=True)
+            _emit(line if line is not None else json.dumps({'incomplete': [note]}))
         else:
             time.sleep(2.0)                  # let rank 0 print first
         os._exit(0)
@@ -536,6 +561,7 @@ def main():
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (there is no CPU fallback in the product path)')
+    _claim_stdout()
     # TQ_BENCH_SAME_DEVICE=1 + TQ_BENCH_BACKEND=gloo: control-flow test of the N>1 path on a
     # 1-GPU box (every rank on cuda:0, host-staged collectives).  Never used for reported numbers.
     if os.environ.get('TQ_BENCH_SAME_DEVICE') == '1':
@@ -744,7 +770,7 @@ def main():
     wd.cancel()
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        _emit(json.dumps(out))
     if use_dist:
         try:
             tq_dist.disable()
