@@ -97,6 +97,13 @@ with torch.no_grad():
     QLayer.fuse_ffn = True
     graphed('fixed_range_forward_all_fused_index_only_ffn')
     c['index_only_ffn_equal_to_separate_launches'] = bool(torch.equal(model(ids), o_fast))
+    from quantization.autoquant_utils import int8_stair_status
+    st = int8_stair_status(model)
+    c['gelu_staircase_tables'] = {'linears_with_a_table': len(st),
+                                  'accepted_by_the_builder': sum(all(v.values()) for v in st.values()),
+                                  'note': 'GELU + output quantizer of the 12 intermediate Linears as exact staircase tables '
+                                          '(csrc/tq_stair.hip); a table the builder declines (grid too fine for its bins) '
+                                          'leaves the arithmetic epilogue in place'}
     QLayer.fuse_ffn = False
     QResidualBlock.fuse = QSelfAttention.fuse = False
     options.INT8_LINEAR = False

@@ -94,3 +94,41 @@ def test_tail_and_calibration_entry_points(env):
     assert cal(mode=7) == -1 and 'mode' in _err(lib)
     assert cal(cnt=None) == -1
     assert cal(wsb=4) == -1 and 'workspace' in _err(lib)
+
+
+def test_staircase_entry_points(env):
+    _hip, be, lib, q, (d, z) = env
+    st = torch.cuda.current_stream().cuda_stream
+    nb = 768
+    assert lib.tq_act_stair_bytes(nb) == 16 + 8 * nb
+    table = torch.empty(lib.tq_act_stair_bytes(nb), dtype=torch.uint8, device='cuda')
+    build = lambda **kw: lib.tq_act_stair_build(kw.get('act', 2), kw.get('q', C.byref(q)), kw.get('nb', nb),
+                                                kw.get('table', table.data_ptr()), kw.get('bytes', table.numel()), st)
+    assert build() == 0
+    assert build(act=3) == -1 and 'no staircase' in _err(lib)                       # tanh: arithmetic path only
+    assert build(nb=32) == -1 and 'bins' in _err(lib)
+    assert build(nb=4096) == -1 and 'bins' in _err(lib)
+    assert build(bytes=100) == -1 and 'too small' in _err(lib)
+    assert build(table=None) == -1 and 'NULL' in _err(lib)
+    assert build(table=table.data_ptr() + 4) == -1 and 'alignment' in _err(lib)
+    q16 = _hip.tq_quantizer(d.data_ptr(), z.data_ptr(), None, 16, 0, 0, 1e-8, 1, 1)
+    assert build(q=C.byref(q16)) == -1 and '8-bit' in _err(lib)
+    # consumer: a table without an output quantizer, or with an impossible bin count, is refused; a table too large for
+    # the kernel's LDS budget is simply not used (same result as without it)
+    M, N, K = 64, 128, 128
+    x = torch.zeros(M, K, dtype=torch.int8, device='cuda')
+    w = torch.zeros(N, K, dtype=torch.int8, device='cuda')
+    rs = torch.zeros(N, dtype=torch.int32, device='cuda')
+    wd = torch.full((N,), 0.01, device='cuda')
+    y = torch.empty(M, N, device='cuda')
+    call = lambda **kw: lib.tq_linear_i8_stair_fwd(x.data_ptr(), w.data_ptr(), rs.data_ptr(), None, y.data_ptr(), None, 0, M, N, K,
+                                                   d.data_ptr(), z.data_ptr(), 8, 1e-8, wd.data_ptr(), N, 1e-8, 2,
+                                                   kw.get('q', C.byref(q)), kw.get('table', table.data_ptr()), kw.get('nb', nb), st)
+    assert call() == 0
+    assert call(q=None) == -1 and 'staircase' in _err(lib)
+    assert call(nb=7) == -1 and 'staircase' in _err(lib)
+    assert call(table=None, nb=0) == 0
+    big = torch.empty(lib.tq_act_stair_bytes(2048), dtype=torch.uint8, device='cuda')
+    assert lib.tq_act_stair_build(2, C.byref(q), 2048, big.data_ptr(), big.numel(), st) == 0
+    y_ref = y.clone()
+    assert call(table=big.data_ptr(), nb=2048) == 0 and torch.equal(y, y_ref)

@@ -127,6 +127,12 @@ def test_bert_forward_with_integer_linears():
         QResidualBlock.fuse = False
         be.__dict__.pop('linear_i8', None)        # drop the instance attribute again (other tests patch the class)
     assert n_plain == 12 * 6                      # q, k, v, attention-out, intermediate, output per layer
+    # the 12 intermediate Linears (GELU) went through staircase tables, one per layer, built on the device; the verdict
+    # of each builder is in its table (a grid too fine for the bins keeps the arithmetic epilogue: also a valid outcome)
+    from quantization.autoquant_utils import int8_stair_status
+    tables = int8_stair_status(model)
+    assert len(tables) == 12 and all('intermediate' in n for n in tables), list(tables)
+    print('GELU staircase tables accepted by their builders: %d of 12' % sum(all(v.values()) for v in tables.values()))
     span = float(layered.max() - layered.min())
     for y in (y_int, y_int_fused):
         assert float((y - layered).abs().max()) <= 0.08 * span           # measured 5-7 % (round 3), bar tightened from 10 %

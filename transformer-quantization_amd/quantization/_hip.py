@@ -508,6 +508,14 @@ class HipBackend:
         return out
 
     STAIR_BINS = 768        # fits beside the operand stages of both LDS-tiled kernels (include/tq_hip.h)
+    STAIR_BINS_BIG = 1536   # fits the 128 x 128-tile kernel only (grids down to ~0.005 per step instead of ~0.01)
+
+    def stair_bins_for(self, M, N):
+        """Bin count for a Linear of M rows and N output features: the launcher's tile rule (csrc/tq_linear_i8.hip,
+        launch_linear_t) restated -- a table too large for the kernel that ends up running is ignored there, so a
+        mismatch only loses the optimisation."""
+        big = M % 128 == 0 and N % 128 == 0 and (M // 128) * (N // 128) >= 1024
+        return self.STAIR_BINS_BIG if big else self.STAIR_BINS
 
     def act_stair(self, activation, q_out, n_bins=None):
         """Staircase table of `activation` followed by the per-tensor <= 8-bit quantizer `q_out` (its 7-tuple) for

@@ -33,6 +33,18 @@ def _fixed_per_tensor_manager(mgr):
             and mgr.quantizer.is_initialized and mgr.quantizer._delta.numel() == 1)
 
 
+def int8_stair_status(model):
+    """{QuantLinear name: {n_bins: table accepted by its builder?}} for every integer Linear below `model` that has built a
+    GELU staircase table so far.  Reads the tables' headers (a host synchronisation): diagnostics, not the data path."""
+    report = {}
+    for name, m in model.named_modules():
+        tables = getattr(m, '_int8_stair', None)
+        if isinstance(m, QuantLinear) and tables:
+            report[name] = {n_bins: bool(entry[1][0][:16].view(torch.float32)[3].item() == 1.0)
+                            for n_bins, entry in tables.items() if torch.is_tensor(entry[1][0])}
+    return report
+
+
 class QuantLinear(QuantizationHijacker, nn.Linear):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -134,20 +146,24 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         return (x_idx, w_idx, rowsum, bias, (src._delta, src._zero_float, src.n_bits, src.eps), wq._delta.reshape(-1),
                 wq.eps)
 
-    def _int8_act_stair(self, act_code, q_out):
-        """(table, n_bins) of GELU + this layer's output quantizer for the integer epilogue, cached per range state of
-        that quantizer (built by one launch, no host read), or None (no GELU, no output quantizer, > 8 bits, switched
-        off).  Like the int8 weights, the table is rebuilt on every call while a hipGraph is being recorded under
-        autograd: the recorded launches must not depend on a cache hit."""
+    def _int8_act_stair(self, act_code, q_out, rows):
+        """(table, n_bins) of GELU + this layer's output quantizer for the integer epilogue of a call with `rows` input
+        rows, cached per range state of that quantizer and bin count (built by one launch, no host read), or None (no
+        GELU, no output quantizer, > 8 bits, switched off).  Like the int8 weights, the table is rebuilt on every call
+        while a hipGraph is being recorded under autograd: the recorded launches must not depend on a cache hit."""
+        be = _hip.backend()
         if (act_code != _hip.ACT_GELU or q_out is None or q_out[3] > 8 or not options.INT8_ACT_STAIR
-                or not hasattr(_hip.backend(), 'act_stair')):
+                or not hasattr(be, 'act_stair')):
             return None
+        n_bins = be.stair_bins_for(rows, self.out_features) if hasattr(be, 'stair_bins_for') else None
         key = self.activation_quantizer.quantizer.range_state_key()
-        cached = self._int8_stair
+        if self._int8_stair is None:
+            self._int8_stair = {}
+        cached = self._int8_stair.get(n_bins)           # one table per bin count (two call shapes may alternate)
         recording = torch.is_grad_enabled() and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         if (cached is None or cached[0] != key or recording
                 or getattr(cached[1][0], 'device', q_out[0].device) != q_out[0].device):
-            cached = self._int8_stair = (key, _hip.backend().act_stair(act_code, q_out))
+            cached = self._int8_stair[n_bins] = (key, be.act_stair(act_code, q_out, n_bins))
         return cached[1]
 
     def _int8_compute(self, x, plan, x_idx=None, index_only=False):
@@ -161,12 +177,12 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         amgr = self.activation_quantizer
         want_idx = q_out is not None and not amgr.quantizer.symmetric and amgr.quantizer.n_bits <= 8
         INT8_STATS['kernel_calls'] += 1
+        stair = self._int8_act_stair(act_code, q_out, ops[0].numel() // self.in_features)
         if index_only:
             assert want_idx, 'index-only output needs an asymmetric <= 8-bit output quantizer'
             return _hip.backend().linear_i8(*ops[:5], ops[5], ops[6], act_code, q_out, torch.float32, want_idx=True,
-                                            want_y=False, stair=self._int8_act_stair(act_code, q_out))[1]
-        out = _hip.backend().linear_i8(*ops[:5], ops[5], ops[6], act_code, q_out, torch.float32, want_idx=want_idx,
-                                       stair=self._int8_act_stair(act_code, q_out))
+                                            want_y=False, stair=stair)[1]
+        out = _hip.backend().linear_i8(*ops[:5], ops[5], ops[6], act_code, q_out, torch.float32, want_idx=want_idx, stair=stair)
         y = out[0] if want_idx else out
         if q_out is not None:
             provenance.tag(y, amgr.quantizer, out[1] if want_idx else None)   # the next integer Linear consumes these
