@@ -688,6 +688,122 @@ static void run(const char* name, Prob p) {
   fflush(stdout);
 }
 
+
+// ---- warp specialisation: NL extra LOADER waves per block issue all the LDS-DMA of a slab; the NWM x NWN compute waves only
+// read fragments and run MFMAs (a compute wave that issues its own 8 pieces per slab sits ~150 cycles in each: in-order issue).
+template <int WM, int WN, int NWM, int NWN, int NL, int ST>
+__global__ __launch_bounds__(64 * (NWM * NWN + NL)) void gemm_spec(const int8_t* __restrict__ X, const int8_t* __restrict__ W,
+                                                                   int* __restrict__ Y, uint32_t M, uint32_t N, uint32_t K, int store) {
+  constexpr int NW = NWM * NWN, BM = WM * NWM, BN = WN * NWN, NI = WN / 16, MI = WM / 16;
+  constexpr int ROWS = BN + BM, STB = ROWS * 128;
+  constexpr int LPL = ROWS / 8 / NL;                        // 1 KB pieces per loader wave and slab
+  static_assert(ROWS % (8 * NL) == 0, "rows must split evenly over the loader waves");
+  extern __shared__ __attribute__((aligned(1024))) int8_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tiles_m = M / BM;
+  const uint32_t n0 = (blockIdx.x / tiles_m) * BN, m0 = (blockIdx.x % tiles_m) * BM;
+  const uint32_t nk = K / 128;
+  if (wave >= NW) {                                          // ---- loader wave
+    const int lw = wave - NW;
+    const int8_t* src[LPL];
+#pragma unroll
+    for (int q = 0; q < LPL; ++q) {
+      const int row = (lw * LPL + q) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      src[q] = row < BN ? W + (size_t)(n0 + row) * K + chunk * 16 : X + (size_t)(m0 + row - BN) * K + chunk * 16;
+    }
+    auto issue = [&](uint32_t kb) {
+      int8_t* b = lds + (kb % ST) * STB + lw * LPL * 1024;
+#pragma unroll
+      for (int q = 0; q < LPL; ++q) GLDS16(src[q] + kb * 128, b + q * 1024);
+    };
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s)
+      if ((uint32_t)s < nk) issue(s);
+    for (uint32_t kb = 0; kb < nk; ++kb) {
+      if (kb + ST - 1 <= nk) wait_vm<(ST - 2) * LPL>(); else wait_vm<0>();
+      __syncthreads();                                       // slab kb published; slab kb - 1 no longer read
+      if (kb + ST - 1 < nk) issue(kb + ST - 1);
+    }
+    return;
+  }
+  const int wn = (wave / NWM) * WN, wm = (wave % NWM) * WM;
+  const int r16 = lane & 15, kg = lane >> 4, swz = (r16 >> 1) & 7;
+  const int off[2] = {r16 * 128 + ((kg ^ swz) << 4), r16 * 128 + (((4 + kg) ^ swz) << 4)};
+  v4i acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+  for (uint32_t kb = 0; kb < nk; ++kb) {
+    __syncthreads();
+    const int8_t* bw = lds + (kb % ST) * STB + wn * 128;
+    const int8_t* bx = lds + (kb % ST) * STB + BN * 128 + wm * 128;
+    v4i fw[2][NI], fx[2][MI];
+    auto load_frags = [&](int s2) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) fw[s2][i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s2]);
+#pragma unroll
+      for (int j = 0; j < MI; ++j) fx[s2][j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s2]);
+    };
+    load_frags(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s == 0) load_frags(1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[s][i], fx[s][j], acc[i][j], 0, 0, 0);
+    }
+  }
+  if (store) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+        *reinterpret_cast<v4i*>(Y + (size_t)(m0 + wm + j * 16 + r16) * N + n0 + wn + i * 16 + kg * 4) = acc[i][j];
+  } else {
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) t ^= acc[i][j][0] ^ acc[i][j][1] ^ acc[i][j][2] ^ acc[i][j][3];
+    if (t == 0x7ffffff1) Y[0] = t;
+  }
+}
+
+template <int WM, int WN, int NWM, int NWN, int NL, int ST>
+static void run_spec(const char* name, Prob p, int pad_kb = 0) {
+  constexpr int BM = WM * NWM, BN = WN * NWN;
+  const size_t lds = (size_t)ST * (BM + BN) * 128 + pad_kb * 1024;
+  auto k = gemm_spec<WM, WN, NWM, NWN, NL, ST>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((p.M / BM) * (p.N / BN)), block(64 * (NWM * NWN + NL));
+  CK(hipMemset(dY, 0xff, (size_t)p.M * p.N * 4));
+  hipLaunchKernelGGL(k, grid, block, lds, 0, dX, dW, dY, p.M, p.N, p.K, 1);
+  CK(hipDeviceSynchronize());
+  std::vector<int> hY((size_t)p.M * p.N);
+  CK(hipMemcpy(hY.data(), dY, hY.size() * 4, hipMemcpyDeviceToHost));
+  int bad = 0;
+  for (int t = 0; t < 3000; ++t) {
+    const uint32_t m = (uint32_t)((t * 2654435761u) % p.M), n = (uint32_t)((t * 40503u + 17) % p.N);
+    int ref = 0;
+    for (uint32_t kk = 0; kk < p.K; ++kk) ref += (int)hX[(size_t)m * p.K + kk] * (int)hW[(size_t)n * p.K + kk];
+    bad += ref != hY[(size_t)m * p.N + n];
+  }
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(k, grid, block, lds, 0, dX, dW, dY, p.M, p.N, p.K, 0);
+  CK(hipEventRecord(a));
+  for (int w = 0; w < 30; ++w) hipLaunchKernelGGL(k, grid, block, lds, 0, dX, dW, dY, p.M, p.N, p.K, 0);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  printf("%-62s M=%-5u N=%-5u K=%-5u lds %3zu KB %s  %6.2f us\n", name, p.M, p.N, p.K, lds >> 10, bad ? "WRONG" : "ok", ms * 1000.0f / 30);
+  fflush(stdout);
+}
+
 int main(int argc, char** argv) {
   const Prob all[] = {{8192, 3072, 768}, {1024, 3072, 768}, {1024, 768, 768}, {1024, 768, 3072}};
   const int nprob = argc > 1 ? atoi(argv[1]) : 4;
@@ -702,6 +818,23 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dX, maxX)); CK(hipMalloc(&dW, maxW)); CK(hipMalloc(&dY, maxY * 4));
   CK(hipMemcpy(dX, hX.data(), maxX, hipMemcpyHostToDevice));
   CK(hipMemcpy(dW, hW.data(), maxW, hipMemcpyHostToDevice));
+  if (getenv("I8_SPEC")) {
+    for (int pi = 0; pi < nprob; ++pi) {
+      const Prob p = all[pi];
+      run<64, 64, 2, 2, 2, 0, 0, false>("baseline: every wave loads (64x64 2x2, 2 st, 2 blk/CU)", p);
+      run_spec<64, 64, 2, 2, 1, 2>("4 compute + 1 loader wave, 2 st", p);
+      run_spec<64, 64, 2, 2, 2, 2>("4 compute + 2 loader waves, 2 st", p);
+      run_spec<64, 64, 2, 2, 4, 2>("4 compute + 4 loader waves, 2 st", p);
+      run_spec<64, 64, 2, 2, 2, 2>("4 compute + 2 loader waves, 2 st, 1 blk/CU", p, 32);
+      run_spec<32, 64, 4, 2, 2, 2>("8 compute (32x64) + 2 loader waves, 2 st", p);
+      run_spec<32, 64, 4, 2, 4, 2>("8 compute (32x64) + 4 loader waves, 2 st", p);
+      run_spec<64, 64, 2, 2, 2, 3>("4 compute + 2 loader waves, 3 st (1 blk/CU)", p);
+      run_spec<32, 32, 2, 2, 1, 2>("64x64 tile: 4 compute (32x32) + 1 loader, 2 st", p);
+      run_spec<32, 32, 2, 2, 2, 2>("64x64 tile: 4 compute (32x32) + 2 loaders, 2 st", p);
+      run<32, 32, 2, 2, 2, 0, 0, false>("64x64 tile baseline: every wave loads (32x32 2x2)", p);
+    }
+    return 0;
+  }
   {
     float* dYf;
     CK(hipMalloc(&dYf, 1 << 20));
