@@ -128,6 +128,18 @@ def test_fastcall_stub_calls_the_same_library_through_raw_addresses():
         fc.fake_quant_fwd(0, 0, 0, 0, 0, 16, 0, 0, 0)
     with pytest.raises(TypeError):
         fc.fake_quant_fwd(addr, 0)
+    # the calibrating call: 21 arguments, two of them floating point -- the NULL-pointer rejection comes back through both
+    # routes with the same message
+    caddr = _hip.entry_address(lib.tq_calibrate_tensor)
+    rc_fast = fc.calibrate_tensor(caddr, 0, 16, 0, 0, None, None, 0, 0, 0.1, 8, 0, 1e-8, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    msg_fast = lib.tq_last_error()
+    rc_ctypes = lib.tq_calibrate_tensor(None, 16, 0, 0, None, None, None, None, 0.1, 8, 0, 1e-8, 0, None, None, None, None, None, 0,
+                                        None, None)
+    assert rc_fast == rc_ctypes != 0 and msg_fast == lib.tq_last_error()
+    with pytest.raises(TypeError):
+        fc.calibrate_tensor(caddr, 0, 16)
+    with pytest.raises(TypeError):
+        fc.calibrate_tensor(caddr, 0, 16, 0, 0, None, None, 0, 0, 'momentum', 8, 0, 1e-8, 0, 0, 0, 0, 0, 0, 0, 0, 0)
 
 
 @pytest.mark.gpu
@@ -138,7 +150,7 @@ def test_fixed_range_fast_path_is_identical_through_fastcall_and_ctypes():
     from quantization.quantizers import QMethods
     from quantization.range_estimators import RangeEstimators
     x = torch.randn(8, 128, 768, device='cuda')
-    outs = {}
+    outs, cal = {}, {}
     saved = (_hip._fastcall_mod, _hip._fastcall_tried)
     try:
         for route in ('fastcall', 'ctypes'):
@@ -149,7 +161,11 @@ def test_fixed_range_fast_path_is_identical_through_fastcall_and_ctypes():
             qa.quantized_acts()
             qa.eval()
             with torch.no_grad():
-                qa(x)
+                for _ in range(3):                      # calibrating calls: tq_calibrate_tensor through the same route
+                    y_cal = qa(x * 1.5) if _ == 1 else qa(x)
+                est = qa.activation_quantizer.range_estimator
+                cal[route] = (y_cal, est.current_xmin.clone(), est.current_xmax.clone(),
+                              qa.activation_quantizer.quantizer._delta.clone())
                 qa.activation_quantizer.fix_ranges()
                 outs[route] = qa(x)
                 plan = qa.activation_quantizer._fast_plan
@@ -157,3 +173,4 @@ def test_fixed_range_fast_path_is_identical_through_fastcall_and_ctypes():
     finally:
         _hip._fastcall_mod, _hip._fastcall_tried = saved
     assert torch.equal(outs['fastcall'], outs['ctypes'])
+    assert all(torch.equal(a, b) for a, b in zip(cal['fastcall'], cal['ctypes']))

@@ -11,6 +11,8 @@
  *   fake_quant_fwd(fn, x, y, idx, idx_dtype, n, dtype, q, stream) -> int
  *       int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtype, uint64_t n, int dtype,
  *                             const tq_quantizer* q, tq_stream_t stream)            (include/tq_hip.h:81)
+ *   calibrate_tensor(fn, <21 arguments>) -> int
+ *       int tq_calibrate_tensor(...)   the calibrating call of a per-tensor quantizer                (include/tq_hip.h:275)
  *   call_ptrs(fn, a0, ..., a11) -> int
  *       any `int f(uintptr_t x 12)` shaped entry point whose arguments are all pointers / 64-bit sizes passed in
  *       integer registers (System V x86-64: the first six in registers, the rest on the stack, unused ones ignored)
@@ -49,6 +51,46 @@ static PyObject* fake_quant_fwd(PyObject* self, PyObject* const* args, Py_ssize_
   return PyLong_FromLong(rc);
 }
 
+/* int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mode, const float* prev_min, const float* prev_max,
+ *                         float* cur_min, float* cur_max, double momentum, int n_bits, int symmetric, float eps,
+ *                         int log_domain, float* delta, float* zero_float, uint8_t* signed_flag, void* y, void* workspace,
+ *                         size_t workspace_bytes, uint32_t* counter, tq_stream_t stream)           (include/tq_hip.h:275)
+ * the launch-bound CALIBRATING call of a per-tensor quantizer (161 per BERT-base calibration batch): arguments in the
+ * order of the C prototype, after the entry point's address. */
+typedef int (*calib_tensor_t)(const void*, uint64_t, int, int, const float*, const float*, float*, float*, double, int, int,
+                              float, int, float*, float*, uint8_t*, void*, void*, size_t, uint32_t*, void*);
+
+static PyObject* calibrate_tensor(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  (void)self;
+  if (nargs != 22) {
+    PyErr_SetString(PyExc_TypeError, "calibrate_tensor(fn, <the 21 arguments of tq_calibrate_tensor>)");
+    return NULL;
+  }
+  uint64_t v[22];
+  double momentum = 0.0, eps = 0.0;
+  for (int i = 0; i < 22; ++i) {
+    if (i == 9 || i == 12) {                      /* momentum (double), eps (float) */
+      const double d = PyFloat_AsDouble(args[i]);
+      if (d == -1.0 && PyErr_Occurred()) return NULL;
+      if (i == 9) momentum = d; else eps = d;
+      v[i] = 0;
+    } else if (as_u64(args[i], &v[i])) {
+      return NULL;
+    }
+  }
+  if (v[0] == 0) {
+    PyErr_SetString(PyExc_ValueError, "calibrate_tensor: NULL entry point");
+    return NULL;
+  }
+  calib_tensor_t fn = (calib_tensor_t)(uintptr_t)v[0];
+#define P(i) ((void*)(uintptr_t)v[i])
+  int rc = fn(P(1), v[2], (int)v[3], (int)v[4], (const float*)P(5), (const float*)P(6), (float*)P(7), (float*)P(8), momentum,
+              (int)v[10], (int)v[11], (float)eps, (int)v[13], (float*)P(14), (float*)P(15), (uint8_t*)P(16), P(17), P(18),
+              (size_t)v[19], (uint32_t*)P(20), P(21));
+#undef P
+  return PyLong_FromLong(rc);
+}
+
 typedef int (*ptr12_t)(uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t,
                        uintptr_t, uintptr_t, uintptr_t);
 
@@ -71,6 +113,7 @@ static PyObject* call_ptrs(PyObject* self, PyObject* const* args, Py_ssize_t nar
 
 static PyMethodDef methods[] = {
     {"fake_quant_fwd", (PyCFunction)(void (*)(void))fake_quant_fwd, METH_FASTCALL, "tq_fake_quant_fwd through a raw address"},
+    {"calibrate_tensor", (PyCFunction)(void (*)(void))calibrate_tensor, METH_FASTCALL, "tq_calibrate_tensor through a raw address"},
     {"call_ptrs", (PyCFunction)(void (*)(void))call_ptrs, METH_FASTCALL, "int f(uintptr_t...) through a raw address"},
     {NULL, NULL, 0, NULL}};
 
