@@ -2,6 +2,13 @@ import json
 import os
 import sys
 
+# Before torch (libgomp) loads: idle OpenMP workers SLEEP instead of spinning.  The whole-model CPU tests run 8 torch
+# threads; with the default active wait policy any other load on the box (measured: four busy cores next to the suite)
+# turns their fork-join barriers into spin contention -- the README-recipe test goes from 18 s to 164 s, MobileBERT from 3 s
+# to 139 s, the CPU suite from 3 to 9 minutes.  Passive waiting costs ~10 % on an idle box and keeps the suite at 3-4
+# minutes on a busy one.
+os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
+
 import numpy as np
 import pytest
 
