@@ -175,8 +175,10 @@ def test_linear_i8_gelu_staircase_equals_the_exact_gelu_oracle_bit_for_bit(shape
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('q_out', [_gelu_q(0.036, 5.0), _gelu_q(0.0131, 13.0), _gelu_q(0.25, 1.0, 4), _gelu_q(0.02, 200.0),
-                                   (torch.tensor(0.05), None, torch.tensor(True), 8, True, False, 1e-8)],
-                         ids=['s0.036', 's0.0131', '4bit', 'mostly-clamped', 'symmetric-signed'])
+                                   (torch.tensor(0.05), None, torch.tensor(True), 8, True, False, 1e-8),
+                                   (torch.tensor(0.03), None, torch.tensor(False), 8, True, False, 1e-8),
+                                   _gelu_q(1.3, 0.0, 2)],
+                         ids=['s0.036', 's0.0131', '4bit', 'mostly-clamped', 'symmetric-signed', 'symmetric-unsigned', '2bit'])
 def test_gelu_staircase_is_exact_at_every_step_of_the_table(q_out):
     """Zero weights make the pre-activation of column n the bias b[n] exactly, so ANY fp32 value can be pushed through the
     table: every threshold the builder found, its two fp32 neighbours, the bin edges, the neighbourhood of GELU's
@@ -217,6 +219,7 @@ def test_gelu_staircase_declines_a_grid_it_cannot_hold():
     (identical output to the call without a table)."""
     from quantization import _hip
     be = _hip.backend()
+    assert _stair_header(be.act_stair(2, _dev(_gelu_q(1e-9, 3.0))))[3] == 0.0      # delta below eps: scale = eps = 1e-8
     q_out = _gelu_q(0.0009, 190.0)
     stair = be.act_stair(2, _dev(q_out))
     assert _stair_header(stair)[3] == 0.0
