@@ -19,9 +19,11 @@
  *
  * Two places are specified BY THIS FILE rather than by the reference (whose torch.exp / torch.erf are not reproducible
  * bit for bit on any other implementation): the softmax exponential `tq_exp_neg` (Cephes-style range reduction +
- * degree-5 polynomial, IEEE operations only -- csrc/tq_device.h holds the identical device function) and GELU's erf
- * (the minimax fits of csrc/tq_linear_i8.hip; its exp2 is the hardware v_exp_f32 on the GPU and exp2f here: results
- * may differ in the last bit, tests compare GELU outputs at a tolerance and everything else exactly).
+ * degree-5 polynomial, IEEE operations only -- csrc/tq_device.h holds the identical device function) and GELU, in two
+ * forms: activation code 4 = the correctly rounded fp32 value of x/2 (1 + erf(x / sqrt 2)) (float64 evaluation, narrowed
+ * once), which the kernels reproduce EXACTLY through the staircase table of csrc/tq_stair.hip (compared at zero
+ * tolerance), and code 2 = the single minimax fit of the arithmetic epilogue of csrc/tq_linear_i8.hip (its exp2 is the
+ * hardware v_exp_f32 on the GPU and exp2f here: results may differ in the last bit, compared at a tolerance).
  */
 #include <math.h>
 #include <stddef.h>
