@@ -499,3 +499,21 @@ def test_drop_in_equals_the_reference_on_random_networks(tmp_path):
                 assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), (other, k)
                 n_ok += 1
         assert n_ok > (200 if 'double' not in other else 80)          # most cases are valid, with 10-40 observables each
+
+
+def test_a_recorded_graph_keeps_the_derived_cache_tensors_it_reads_alive():
+    """`derived_cache_tensors` finds every tensor the modules hold in a derived cache (the reference's cached quantized
+    parameters, int8 weights, staircase tables, ...): GraphedForward / GraphedTrainStep store these references, so a
+    cache rebuilt after capture cannot free memory a replay still reads by address."""
+    import torch
+    from torch import nn
+    from quantization.graphs import derived_cache_tensors
+    from quantization.autoquant_utils import QuantLinear
+    net = nn.Sequential(QuantLinear(8, 8), nn.Sequential(QuantLinear(8, 4)))
+    a, b, c, d = (torch.zeros(3) for _ in range(4))
+    net[0].cached_params = (a, None)
+    net[0]._int8_cache = (('key',), b, c)
+    net[1][0]._int8_stair = {768: (('key', 768), (d, 768))}
+    got = derived_cache_tensors(net)
+    assert {id(t) for t in got} == {id(a), id(b), id(c), id(d)}
+    assert derived_cache_tensors(nn.Linear(2, 2)) == []

@@ -149,8 +149,10 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
     def _int8_act_stair(self, act_code, q_out, rows):
         """(table, n_bins) of GELU + this layer's output quantizer for the integer epilogue of a call with `rows` input
         rows, cached per range state of that quantizer and bin count (built by one launch, no host read), or None (no
-        GELU, no output quantizer, > 8 bits, switched off).  Like the int8 weights, the table is rebuilt on every call
-        while a hipGraph is being recorded under autograd: the recorded launches must not depend on a cache hit."""
+        GELU, no output quantizer, > 8 bits, switched off).  Unlike the int8 weights it is NOT rebuilt while a training
+        step is being recorded: the integer path requires FIXED output ranges (`_int8_plan_from`), so the table a recorded
+        launch reads stays valid for every replay, and `GraphedForward` / `GraphedTrainStep` keep the tensors of all
+        derived caches they recorded alive (`quantization.graphs.derived_cache_tensors`)."""
         be = _hip.backend()
         if (act_code != _hip.ACT_GELU or q_out is None or q_out[3] > 8 or not options.INT8_ACT_STAIR
                 or not hasattr(be, 'act_stair')):
@@ -160,8 +162,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         if self._int8_stair is None:
             self._int8_stair = {}
         cached = self._int8_stair.get(n_bins)           # one table per bin count (two call shapes may alternate)
-        recording = torch.is_grad_enabled() and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
-        if (cached is None or cached[0] != key or recording
+        if (cached is None or cached[0] != key
                 or getattr(cached[1][0], 'device', q_out[0].device) != q_out[0].device):
             cached = self._int8_stair[n_bins] = (key, be.act_stair(act_code, q_out, n_bins))
         return cached[1]

@@ -50,6 +50,33 @@ def _quiesce():
         pass
 
 
+_CACHE_ATTRS = ('cached_params', '_int8_cache', '_int8_stair', '_qparam_cache', '_stacked_i8_cache')
+
+
+def _tensors_in(obj, out, depth=0):
+    if torch.is_tensor(obj):
+        out.append(obj)
+    elif isinstance(obj, dict) and depth < 4:
+        for v in obj.values():
+            _tensors_in(v, out, depth + 1)
+    elif isinstance(obj, (tuple, list)) and depth < 4:
+        for v in obj:
+            _tensors_in(v, out, depth + 1)
+
+
+def derived_cache_tensors(module):
+    """Every tensor the modules below `module` hold in a derived cache right now (the reference's cached quantized
+    parameters, int8 weight indices and row sums, stacked Q|K|V operands, NoNorm parameters, GELU staircase tables).  A
+    recorded graph reads them by ADDRESS: the graph object keeps these references so that a cache that is rebuilt later
+    (another range state, `options.invalidate_derived_caches()`, `.train()`) cannot hand the memory a replay still reads
+    back to the allocator."""
+    out = []
+    for m in module.modules():
+        for attr in _CACHE_ATTRS:
+            _tensors_in(m.__dict__.get(attr), out)
+    return out
+
+
 class GraphedForward:
     """``g = GraphedForward(model, example_ids); logits = g(ids)``.
 
@@ -79,6 +106,7 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.static_outputs = self._run()
+        self._cache_refs = derived_cache_tensors(module)       # read by address in every replay: see derived_cache_tensors
         if snap is not None:
             live = module.state_dict()
             if live.keys() != snap.keys():
@@ -156,6 +184,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.static_loss = self._step()
+        self._cache_refs = derived_cache_tensors(module)       # read by address in every replay: see derived_cache_tensors
         if snap is not None:
             live = module.state_dict()
             for k, v in live.items():
