@@ -119,3 +119,36 @@ def test_graphed_forward_helper_calibrating_and_fixed():
     assert torch.equal(out, ref_fixed) and torch.equal(out2, eager2)
     with pytest.raises(ValueError):
         gf(batches[0][:4])
+
+
+def test_replay_survives_derived_caches_rebuilt_after_capture():
+    """A recorded fixed-range forward with integer Linears reads its derived caches (cached quantized parameters, int8
+    weight indices, row sums, GELU staircase tables) by ADDRESS.  When they are rebuilt afterwards -- here:
+    `invalidate_derived_caches()` + an eager forward -- the old tensors would return to the allocator and be overwritten
+    by the next allocation; the graph object keeps them alive, so the replay is unchanged."""
+    from quantization import options
+    from quantization.graphs import GraphedForward, derived_cache_tensors
+    batches = _batches(3)
+    options.INT8_LINEAR = True
+    try:
+        with torch.no_grad():
+            m = _model(2)
+            for b in batches:
+                m(b)
+            m.fix_ranges()
+            g = GraphedForward(m, batches[0])
+            want = g(batches[1]).clone()
+            held = {t.data_ptr() for t in g._cache_refs}
+            assert len(held) >= 2 * 6 * 2                    # per layer: six Linears x (indices, row sums) at least
+            options.invalidate_derived_caches()
+            m(batches[2])                                    # every derived cache is rebuilt: new tensors
+            fresh = {t.data_ptr() for t in derived_cache_tensors(m)}
+            assert len(held - fresh) >= 2 * 6 * 2          # int8 indices / row sums / tables were replaced (the reference's own
+            #                                               cached_params are not keyed by the epoch and stay)
+            junk = [torch.full((1 << 20,), 7, dtype=torch.int8, device='cuda') for _ in range(64)]   # recycle freed blocks
+            torch.cuda.synchronize()
+            got = g(batches[1]).clone()
+            del junk
+    finally:
+        options.INT8_LINEAR = False
+    assert torch.equal(got, want)
