@@ -218,6 +218,38 @@ def test_gelu_staircase_is_exact_at_every_step_of_the_table(q_out):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('act', [0, 1], ids=['none', 'relu'])
+def test_staircase_of_identity_and_relu_equals_the_arithmetic_epilogue(act):
+    """tq_act_stair_build also tabulates the quantizer alone and ReLU + quantizer (the Python layer only uses it for
+    GELU, where it pays).  There the correctly rounded activation IS the fp32 activation, so the table must reproduce the
+    arithmetic epilogue -- and the oracle -- bit for bit, at every threshold and its neighbours."""
+    from quantization import _hip
+    be = _hip.backend()
+    q_out = _gelu_q(0.021, 97.0)
+    stair = be.act_stair(act, _dev(q_out))
+    inv_w, c0, nbm1, ok = _stair_header(stair)
+    assert ok == 1.0
+    tab = stair[0][16:].view(torch.int32).cpu().numpy().reshape(-1, 2)
+    T = tab[:, 0].copy().view(np.float32)
+    T = T[np.isfinite(T) & (np.abs(T) < 1e30)]
+    rng = np.random.RandomState(6)
+    v = np.concatenate([T, np.nextafter(T, np.float32(-np.inf)), np.nextafter(T, np.float32(np.inf)),
+                        (rng.randn(8000) * 2).astype(np.float32), np.array([0.0, -0.0, 1e30, -1e30, 1e-40], np.float32)])
+    N = -(-v.size // 64) * 64
+    bias = torch.from_numpy(np.concatenate([v, np.zeros(N - v.size, np.float32)]))
+    M, K = 64, 128
+    x_idx, w_idx = torch.zeros(M, K, dtype=torch.int8), torch.zeros(N, K, dtype=torch.int8)
+    x_q, w_delta = (0.02, 117.0, 8, 1e-8), torch.tensor([0.001])
+    ref_y, ref_i = IO.linear_i8(x_idx, w_idx, bias, x_q, w_delta, 1e-8, act, _f(q_out))
+    wi = w_idx.to(DEV)
+    args = (x_idx.to(DEV), wi, be.rowsum_i8(wi), bias.to(DEV), _xq_dev(x_q), w_delta.to(DEV), 1e-8, act, _dev(q_out), torch.float32)
+    y, yi = be.linear_i8(*args, want_idx=True, stair=stair)
+    y0, yi0 = be.linear_i8(*args, want_idx=True)
+    assert torch.equal(yi.cpu(), ref_i) and torch.equal(y.cpu(), ref_y)
+    assert torch.equal(yi, yi0) and torch.equal(y, y0) and ref_i.unique().numel() > 100
+
+
+@pytest.mark.gpu
 def test_gelu_staircase_declines_a_grid_it_cannot_hold():
     """A grid much finer than the bins: the builder says so in the header and the consumer keeps its arithmetic epilogue
     (identical output to the call without a table)."""
