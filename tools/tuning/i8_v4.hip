@@ -818,6 +818,19 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dX, maxX)); CK(hipMalloc(&dW, maxW)); CK(hipMalloc(&dY, maxY * 4));
   CK(hipMemcpy(dX, hX.data(), maxX, hipMemcpyHostToDevice));
   CK(hipMemcpy(dW, hW.data(), maxW, hipMemcpyHostToDevice));
+  if (getenv("I8_RING")) {      // deeper LDS rings for the small-tile kernel the M = 1024 shapes run
+    for (int pi = 1; pi < 4; ++pi) {
+      const Prob p = all[pi];
+      run<32, 32, 2, 2, 2, 0, 0, false>("DMA 32x32 2x2 2 stages (product at M = 1024)", p);
+      run<32, 32, 2, 2, 3, 0, 0, false>("DMA 32x32 2x2 3 stages", p);
+      run<32, 32, 2, 2, 4, 0, 0, false>("DMA 32x32 2x2 4 stages", p);
+      run<32, 32, 2, 2, 6, 0, 0, false>("DMA 32x32 2x2 6 stages", p);
+      run<16, 32, 2, 2, 4, 0, 0, false>("DMA 16x32 2x2 (32x64 tiles) 4 stages", p);
+      run<32, 16, 2, 2, 4, 0, 0, false>("DMA 32x16 2x2 (64x32 tiles) 4 stages", p);
+      run<16, 32, 2, 2, 2, 0, 0, false>("DMA 16x32 2x2 (32x64 tiles) 2 stages", p);
+    }
+    return 0;
+  }
   if (getenv("I8_SPEC")) {
     for (int pi = 0; pi < nprob; ++pi) {
       const Prob p = all[pi];
