@@ -3,7 +3,8 @@
 # int8 indices, fp32 y), four separate --pmc passes with --kernel-trace only -> gpurun_out/i8_linear_pmc.json
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/i8_linear_pmc.json
+MODE=${1:-fused}
+OUT=$R/gpurun_out/i8_linear_pmc_$MODE.json
 echo "{" > $OUT
 first=1
 for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
@@ -11,7 +12,7 @@ for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_MFMA SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_ADDR_CONFLICT"; do
   rm -rf /tmp/pmc
-  timeout 200 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc -o p --output-format csv -- python $R/tools/tuning/i8_one.py fused > /dev/null 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc -o p --output-format csv -- python $R/tools/tuning/i8_one.py $MODE > /dev/null 2>&1
   python3 - "$OUT" "$first" <<'PY'
 import csv, glob, collections, sys
 acc = collections.defaultdict(list)
@@ -27,7 +28,7 @@ PY
 done
 cat >> $OUT <<'EOF2'
 ,
- "_kernel": "tq::linear_i8_lds_k<64, fp32 y>, M=8192 N=3072 K=768, GELU + 8-bit output quantizer + int8 index output, average over 10 launches",
+ "_kernel": "tq::linear_i8_lds_k<64, fp32 y>, M=8192 N=3072 K=768, GELU + 8-bit output quantizer, average over 10 launches; mode (tools/tuning/i8_one.py): fused = arithmetic epilogue, y + int8 indices; fused_idx = indices only; stair / stair_idx = the same through the staircase table",
  "_units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles summed over all waves; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; SQ_INSTS_* wave-instructions",
  "_derived": "VALU instructions per output element = (SQ_INSTS_VALU - SQ_INSTS_MFMA) * 64 / (8192 * 3072)"
 }

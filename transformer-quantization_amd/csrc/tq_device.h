@@ -262,8 +262,9 @@ __device__ __forceinline__ uint32_t f32_to_bits(float f) { return __builtin_bit_
 // h(v) = Q(act(v)) - zero_point of a <= 8-bit quantizer is a step function of the fp32 pre-activation v with at most 255
 // steps.  csrc/tq_stair.hip tabulates it over uniform bins of v that hold at most ONE step each; a consumer (the integer
 // Linear's epilogue) then needs one fma + clamp + convert for the bin, one 8-byte table read, one compare and a select
-// instead of evaluating the activation and the quantizer's quotient: ~14 instead of ~30 issue slots per output with
-// GELU.  Table: [StairHdr | nb entries {T, packed}], packed = bf16(h right of T) << 16 | bf16(h left of T) (|h| <= 256
+// instead of evaluating the activation and the quantizer's quotient (with GELU: ~69 instead of ~100 issue cycles per
+// output-instruction, profiles/r04/valu_probe2.txt; 26.7 -> 21.6 VALU instructions per output over the whole kernel).
+// Table: [StairHdr | nb entries {T, packed}], packed = bf16(h right of T) << 16 | bf16(h left of T) (|h| <= 256
 // is exact in bf16), h(v) = v >= T ? right : left inside the bin.  `stair_bin` is THE bin map: the builder derives
 // every bin's fp32 interval from this very function, so builder and consumers agree on every input bit pattern.
 struct StairHdr {

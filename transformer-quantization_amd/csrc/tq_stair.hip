@@ -1,8 +1,9 @@
 // Activation + output quantizer of an integer Linear as a staircase table (round 4).
 //
 // The fused Linear + GELU + quantizer epilogue (reference hijacker.py:66-116 behind autoquant_utils.py:16-21: F.linear ->
-// nn.GELU() -> activation quantizer) spent ~30 VALU issue slots per output on the erf fit and the quantizer's exact
-// quotient, and on CDNA4 that VALU time ADDS to the matrix-core time (tools/tuning/mfma_valu_overlap.hip).  But
+// nn.GELU() -> activation quantizer) spent ~18 VALU instructions (most of them packed, i.e. double-cost) per output on the
+// erf fit and the quantizer's exact quotient, and on CDNA4 that VALU time ADDS to the matrix-core time
+// (tools/tuning/mfma_valu_overlap.hip).  But
 //     h(v) = clamp(rne(RN32(GELU(v)) / scale) + zp, lo, hi) - zp
 // is a step function of the fp32 pre-activation v with at most 255 steps, so it can be tabulated exactly.  This file
 // builds the table on the device (no host read of the range buffers: hipGraph-capturable like every other launch):
