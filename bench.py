@@ -671,6 +671,25 @@ def main():
                            'M_elems_s': round(xs.numel() / ms_small / 1e3, 1),
                            'GBps': round(xs.numel() * BYTES_PER_ELEM / ms_small / 1e6, 1),
                            'note': 'HIP-event span of 200 back-to-back calls / 200 (launch boundaries included)'}
+    # ... and the same 161 sites as ONE multi-tensor call (tq_fake_quant_multi_fwd: 40 tensors per launch): what independent
+    # sites cost when they do not pay a launch each (a forward's sites depend on each other; a model's 102 weight tensors
+    # do not -- quantization.autoquant_utils.prequantize_weights)
+    try:
+        from quantization import _hip as _tq_hip
+        q_small = qa.activation_quantizer.quantizer
+        sites = [xs.clone() for _ in range(161)]
+        plan = _tq_hip.backend().fake_quant_multi_plan(
+            [(t, q_small._delta, q_small._zero_float, None, q_small.n_bits, False, False, q_small.eps, 1, 1) for t in sites])
+        for _ in range(3):
+            _tq_hip.backend().fake_quant_multi_launch(plan)
+        _, ms_multi = timed_region(lambda: _tq_hip.backend().fake_quant_multi_launch(plan), 20, False)
+        out['config_shape']['batched_161_sites'] = {
+            'us_per_site': round(ms_multi * 1e3 / 161, 3), 'ms_per_call': round(ms_multi, 4),
+            'GBps': round(161 * xs.numel() * BYTES_PER_ELEM / ms_multi / 1e6, 1),
+            'note': '161 independent [8,128,768] tensors, one C call = 5 launches of <= 40 tensors'}
+        del sites, plan
+    except Exception as e:       # noqa: BLE001 -- optional figure
+        out['config_shape']['batched_161_sites'] = {'error': repr(e)[:300]}
 
     if args.sweep and rank == 0:
         sweep = []

@@ -81,6 +81,20 @@ const char* tq_last_error(void);
 int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtype, uint64_t n, int dtype,
                       const tq_quantizer* q, tq_stream_t stream);
 
+/* The same for MANY independent tensors in one launch (40 per launch; more are split): what a model does with its weight
+ * tensors once per range state -- the reference quantizes and caches them one by one in eval mode (quantization/
+ * hijacker.py:52-64, base_quantized_classes.py:62-75).  Every item has its own quantizer (per-tensor, or n_params rows
+ * of `inner` elements with inner a multiple of a 16-byte vector: per-output-channel weights); all items share `dtype`.
+ * `items` is a HOST array, read during the call (the table travels as a kernel argument: no upload, hipGraph-capturable).
+ * Bit-identical to n_items calls of tq_fake_quant_fwd.                                                                */
+typedef struct tq_fq_item {
+  const void*  x;
+  void*        y;            /* same dtype and size as x */
+  uint64_t     n;            /* elements; 0 = skipped    */
+  tq_quantizer q;
+} tq_fq_item;
+int tq_fake_quant_multi_fwd(const tq_fq_item* items, uint32_t n_items, int dtype, tq_stream_t stream);
+
 /* Fused NoNorm + output quantizer (MobileBERT; reference models/quantized_mobilebert.py:58-72,
  * QuantNoNorm.forward followed by quantize_activations): y = Q(x * w[col] + b[col]) for x viewed
  * as [n / d, d]; w, b fp32 [d] (the already fake-quantized affine parameters); per-tensor output

@@ -868,6 +868,75 @@ static int launch_bwd(const void* x, const void* gy, void* gx, float* g_delta, f
   return TQ_OK;
 }
 
+
+// ------------------------------------------------------------------------------ many independent tensors, one launch
+// The 102 weight tensors of a BERT-base are quantized once per range state, one launch each when done lazily by the
+// layers (reference hijacker.py:52-64: get_params caches them in eval mode).  Independent sites can share a launch: every
+// block finds its tensor in a table that travels as a kernel argument (no upload, capturable), then runs the same element
+// arithmetic as the single-tensor kernels (IEEE-division form: bit-identical to all of them).  Per-tensor and
+// per-row (per-output-channel weight) parameters; rows must be whole 16-byte vectors.
+constexpr int kMultiMax = 40;          // items per launch: the argument block stays below the 4 KB kernarg limit
+struct FqMultiArgs {
+  const void* x[kMultiMax];
+  void* y[kMultiMax];
+  uint64_t n[kMultiMax];
+  tq_quantizer q[kMultiMax];
+  uint32_t first_block[kMultiMax + 1];
+  uint32_t count;
+};
+
+static_assert(sizeof(FqMultiArgs) <= 4096, "the table must fit the kernel-argument segment");
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void fq_multi_k(FqMultiArgs a) {
+  constexpr int V = Store<DT>::kVec;
+  typedef typename Store<DT>::elem_t E;
+  uint32_t t = 0;
+  while (t + 1 < a.count && blockIdx.x >= a.first_block[t + 1]) ++t;      // wave-uniform
+  const uint32_t b = blockIdx.x - a.first_block[t], nblk = a.first_block[t + 1] - a.first_block[t];
+  const tq_quantizer q = a.q[t];
+  const u32x4* x = static_cast<const u32x4*>(a.x[t]);
+  u32x4* y = static_cast<u32x4*>(a.y[t]);
+  const uint64_t n = a.n[t], n_vec = n / V;
+  if (q.n_params == 1) {
+    const QP p = make_qp(q, 0);
+    for (uint64_t i = (uint64_t)b * kBlock + threadIdx.x; i < n_vec; i += (uint64_t)nblk * kBlock)
+      y[i] = fq_vec<DT, false>(x[i], p, nullptr, TQ_IDX_NONE, 0);
+    if (b == 0 && n_vec * V + threadIdx.x < n) {
+      const uint64_t k = n_vec * V + threadIdx.x;
+      Store<DT>::store1(reinterpret_cast<E*>(y) + k, q_dequant(q_index(Store<DT>::load1(reinterpret_cast<const E*>(x) + k), p), p));
+    }
+  } else {
+    const uint64_t vec_per_row = q.inner / V;                              // host: inner % V == 0, n % (n_params * inner) == 0
+    for (uint64_t i = (uint64_t)b * kBlock + threadIdx.x; i < n_vec; i += (uint64_t)nblk * kBlock) {
+      const QP p = make_qp(q, (i / vec_per_row) % q.n_params);
+      y[i] = fq_vec<DT, false>(x[i], p, nullptr, TQ_IDX_NONE, 0);
+    }
+  }
+}
+
+template <int DT>
+static int launch_fq_multi(const tq_fq_item* items, uint32_t n_items, hipStream_t st) {
+  constexpr int V = Store<DT>::kVec;
+  for (uint32_t i0 = 0; i0 < n_items; i0 += kMultiMax) {
+    FqMultiArgs a{};
+    uint32_t blocks = 0;
+    for (uint32_t i = i0; i < n_items && i < i0 + kMultiMax; ++i) {
+      const tq_fq_item& it = items[i];
+      if (it.n == 0) continue;
+      const uint32_t s = a.count++;
+      a.x[s] = it.x; a.y[s] = it.y; a.n[s] = it.n; a.q[s] = it.q;
+      a.first_block[s] = blocks;
+      blocks += (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(it.n / V, (uint64_t)kBlock * 4), 1), 2048);
+    }
+    if (a.count == 0) continue;
+    a.first_block[a.count] = blocks;
+    hipLaunchKernelGGL((fq_multi_k<DT>), dim3(blocks), dim3(kBlock), 0, st, a);
+    if (int e = check_launch("fq_multi_k")) return e;
+  }
+  return TQ_OK;
+}
+
 }  // namespace tq
 
 using namespace tq;
@@ -887,6 +956,29 @@ extern "C" int tq_fake_quant_fwd(const void* x, void* y, void* idx, int idx_dtyp
     case TQ_F32: return has_idx ? launch_fq<TQ_F32, true>(x, y, idx, idx_dtype, n, *q, st) : launch_fq<TQ_F32, false>(x, y, idx, idx_dtype, n, *q, st);
     case TQ_BF16: return has_idx ? launch_fq<TQ_BF16, true>(x, y, idx, idx_dtype, n, *q, st) : launch_fq<TQ_BF16, false>(x, y, idx, idx_dtype, n, *q, st);
     default: return has_idx ? launch_fq<TQ_F16, true>(x, y, idx, idx_dtype, n, *q, st) : launch_fq<TQ_F16, false>(x, y, idx, idx_dtype, n, *q, st);
+  }
+}
+
+extern "C" int tq_fake_quant_multi_fwd(const tq_fq_item* items, uint32_t n_items, int dtype, tq_stream_t stream) {
+  if (n_items == 0) return TQ_OK;
+  TQ_REQUIRE(items != nullptr, "tq_fake_quant_multi_fwd: items is NULL");
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_fake_quant_multi_fwd: bad dtype %d", dtype);
+  const uint64_t V = dtype == TQ_F32 ? 4 : 8;
+  for (uint32_t i = 0; i < n_items; ++i) {
+    const tq_fq_item& it = items[i];
+    if (it.n == 0) continue;
+    TQ_REQUIRE(it.x != nullptr && it.y != nullptr, "tq_fake_quant_multi_fwd: item %u has a NULL tensor", i);
+    TQ_REQUIRE(aligned16(it.x) && aligned16(it.y), "tq_fake_quant_multi_fwd: item %u: 16-byte alignment required", i);
+    if (int e = check_quantizer(&it.q, it.n, "tq_fake_quant_multi_fwd")) return e;
+    if (it.q.n_params > 1 && it.q.inner % V != 0)
+      return set_error(TQ_EUNSUPPORTED, "tq_fake_quant_multi_fwd: item %u: rows of %llu elements are not whole 16-byte vectors "
+                       "(use tq_fake_quant_fwd)", i, (unsigned long long)it.q.inner);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case TQ_F32: return launch_fq_multi<TQ_F32>(items, n_items, st);
+    case TQ_BF16: return launch_fq_multi<TQ_BF16>(items, n_items, st);
+    default: return launch_fq_multi<TQ_F16>(items, n_items, st);
   }
 }
 

@@ -35,6 +35,10 @@ class tq_quantizer(C.Structure):
                 ('eps', C.c_float), ('n_params', C.c_uint64), ('inner', C.c_uint64)]
 
 
+class tq_fq_item(C.Structure):          # one tensor of tq_fake_quant_multi_fwd
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('n', C.c_uint64), ('q', tq_quantizer)]
+
+
 class tq_quantizer_f64(C.Structure):
     _fields_ = [('delta', C.c_void_p), ('zero_float', C.c_void_p), ('signed_flag', C.c_void_p),
                 ('n_bits', C.c_int32), ('symmetric', C.c_int32), ('log_domain', C.c_int32),
@@ -46,6 +50,7 @@ _QP = C.POINTER(tq_quantizer)
 _QPD = C.POINTER(tq_quantizer_f64)
 
 # name -> (restype, argtypes); must list every symbol include/tq_hip.h declares
+
 SIGNATURES = {
     'tq_fake_quant_fwd_f64': (_int, [_vp, _vp, _vp, _u64, _QPD, _vp]),
     'tq_fake_quant_bwd_f64_workspace_bytes': (_sz, [_u64, _u64, _u64]),
@@ -60,6 +65,7 @@ SIGNATURES = {
     'tq_abi_version': (_int, []),
     'tq_last_error': (C.c_char_p, []),
     'tq_fake_quant_fwd': (_int, [_vp, _vp, _vp, _int, _u64, _int, _QP, _vp]),
+    'tq_fake_quant_multi_fwd': (_int, [C.POINTER(tq_fq_item), C.c_uint32, _int, _vp]),
     'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
     'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
     'tq_residual_nonorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _QP, _vp]),
@@ -375,6 +381,37 @@ class HipBackend:
                                         x.numel(), _dtype_code(x, 'fake_quant'), C.byref(q), _stream())
         _check(rc, self.lib)
         return y, idx
+
+    def fake_quant_multi_plan(self, items):
+        """(C item table, outputs, inputs kept alive, dtype code) for `fake_quant_multi_launch`: build once, launch many
+        times (the outputs are overwritten in place)."""
+        arr = (tq_fq_item * max(len(items), 1))()
+        ys, keep = [], []
+        dtype = items[0][0].dtype if items else torch.float32
+        for k, (x, delta, zf, signed, n_bits, symmetric, log_domain, eps, n_params, inner) in enumerate(items):
+            _need_device(x, 'fake_quant_multi')
+            if x.dtype != dtype:
+                raise TQError('fake_quant_multi: all tensors must share one dtype')
+            x = x.contiguous()
+            y = torch.empty_like(x)
+            keep.append((x, delta, zf, signed))
+            ys.append(y)
+            arr[k].x, arr[k].y, arr[k].n = x.data_ptr(), y.data_ptr(), x.numel()
+            arr[k].q = tq_quantizer(_ptr(delta), _ptr(zf), _ptr(signed), int(n_bits), int(bool(symmetric)),
+                                    int(bool(log_domain)), float(eps), int(n_params), int(inner))
+        return arr, ys, keep, (_dtype_code(items[0][0], 'fake_quant_multi') if items else 0)
+
+    def fake_quant_multi_launch(self, plan):
+        arr, ys, _, code = plan
+        if ys:
+            _check(self.lib.tq_fake_quant_multi_fwd(arr, len(ys), code, _stream()), self.lib)
+        return ys
+
+    def fake_quant_multi(self, items):
+        """Fake-quantize many independent tensors of ONE dtype in one launch (40 per launch, more are split).
+        items: [(x, delta, zero_float, signed, n_bits, symmetric, log_domain, eps, n_params, inner), ...] -> [y, ...];
+        bit-identical to `fake_quant` on each item.  Per-row parameters need rows of whole 16-byte vectors."""
+        return self.fake_quant_multi_launch(self.fake_quant_multi_plan(items)) if items else []
 
     def fixed_quant_plan(self, delta, zero_float, signed, n_bits, symmetric, log_domain, eps):
         """Launch plan of a fixed-range per-tensor quantizer for QuantizationManager's fast path: the memoised C

@@ -33,6 +33,59 @@ def _fixed_per_tensor_manager(mgr):
             and mgr.quantizer.is_initialized and mgr.quantizer._delta.numel() == 1)
 
 
+def prequantize_weights(model):
+    """Fill the eval-mode parameter cache of every quantized layer below `model` whose weight range is FIXED with ONE
+    multi-tensor launch per 40 tensors (`tq_fake_quant_multi_fwd`) instead of one launch per layer on its first eval
+    forward.  The reference quantizes and caches the weights layer by layer (hijacker.py:52-64 `get_params`: 102 weight
+    tensors in a BERT-base); this is the same computation on the same inputs -- `cached_params` ends up bit-identical
+    -- batched over independent sites.  Layers that do not qualify (training mode, caching off, a cache already
+    present, weights not quantized, ranges not fixed / learnable / not initialised, rows that are not whole 16-byte
+    vectors, float64) are left to the lazy path.  -> number of layers served."""
+    from quantization.quantization_manager import Qstates
+    from quantization.quantizers import AsymmetricUniformQuantizer, SymmetricUniformQuantizer, param_layout
+    be = _hip.backend()
+    if not hasattr(be, 'fake_quant_multi'):
+        return 0
+    groups = {}                     # (device, dtype) -> [(module, weight, bias, item)]
+    for m in model.modules():
+        if not isinstance(m, QuantizationHijacker) or m.training or not m._caching or m.cached_params or not m._quant_w:
+            continue
+        mgr = m._modules.get('weight_quantizer')
+        if not isinstance(mgr, QuantizationManager) or mgr.state != Qstates.fix_ranges:
+            continue
+        if mgr._forward_hooks or mgr._forward_pre_hooks:
+            continue
+        q = mgr.quantizer
+        if type(q) not in (AsymmetricUniformQuantizer, SymmetricUniformQuantizer) or not q.is_initialized:
+            continue
+        if q._forward_hooks or q._forward_pre_hooks:
+            continue
+        weight, bias = m.get_weight_bias()
+        delta = q._delta
+        if (not weight.is_cuda or weight.dtype not in (torch.float32, torch.bfloat16, torch.float16)
+                or delta.requires_grad or delta.device != weight.device):
+            continue
+        try:
+            n_params, inner = param_layout(weight, delta.numel(), q.axis, q.per_channel, tuple(delta.shape))
+        except (ValueError, RuntimeError):
+            continue                # the lazy path raises the reference's error
+        vec = 4 if weight.dtype == torch.float32 else 8
+        if n_params > 1 and inner % vec:
+            continue
+        item = (weight.detach(), delta, None if q.symmetric else q._zero_float, getattr(q, '_signed', None), q.n_bits,
+                q.symmetric, q.scale_domain == 'log', q.eps, n_params, inner)
+        groups.setdefault((weight.device, weight.dtype), []).append((m, bias, item))
+    served = 0
+    for (device, _), entries in groups.items():
+        with torch.cuda.device(device):
+            ys = be.fake_quant_multi([e[2] for e in entries])
+        for (m, bias, _), y in zip(entries, ys):
+            # exactly what get_params caches: detached fp32 copies resident in HBM
+            m.cached_params = (y.detach().to(torch.float32), None if bias is None else bias.detach().to(torch.float32))
+            served += 1
+    return served
+
+
 def int8_stair_status(model):
     """{QuantLinear name: {n_bins: table accepted by its builder?}} for every integer Linear below `model` that has built a
     GELU staircase table so far.  Reads the tables' headers (a host synchronisation): diagnostics, not the data path."""

@@ -299,6 +299,11 @@ def run(config, args):
     agree = total = 0
     with torch.no_grad():
         model.eval()
+        if config.quant.weight_quant and not config.quant.dynamic:
+            # fixed weight ranges: fill every layer's eval-mode parameter cache in one multi-tensor launch instead of one
+            # launch per layer on its first forward (same values; layers it cannot serve keep the lazy path)
+            from quantization.autoquant_utils import prequantize_weights
+            report['prequantized_weight_tensors'] = prequantize_weights(model)
 
         fwd = model
         if args.hip_graph and not config.quant.dynamic:
