@@ -63,7 +63,8 @@ def prequantize_weights(model):
         weight, bias = m.get_weight_bias()
         delta = q._delta
         if (not weight.is_cuda or weight.dtype not in (torch.float32, torch.bfloat16, torch.float16)
-                or delta.requires_grad or delta.device != weight.device):
+                or delta.requires_grad or delta.device != weight.device or not weight.is_contiguous()
+                or weight.data_ptr() % 16):
             continue
         try:
             n_params, inner = param_layout(weight, delta.numel(), q.axis, q.per_channel, tuple(delta.shape))
