@@ -46,7 +46,7 @@ def settle(seconds=0.4):
         torch.cuda.synchronize()
 
 
-def run(family, label, pattern, fn, unit_per_launch, bound, reps=30, note=''):
+def run(family, label, pattern, fn, unit_per_launch, bound, reps=30, note='', patterns=None):
     settle()
     for _ in range(3):
         fn()
@@ -64,7 +64,7 @@ def run(family, label, pattern, fn, unit_per_launch, bound, reps=30, note=''):
                      'unit_per_launch': unit_per_launch, 'unit': 'bytes' if bound == 'hbm' else 'ops',
                      'peak': peak, 'peak_unit': 'GB/s' if bound == 'hbm' else 'GOP/s',
                      'event_us': round(ms * 1e3, 2), 'event_achieved': round(ach, 1),
-                     'event_frac': round(ach / peak, 4), 'note': note})
+                     'event_frac': round(ach / peak, 4), 'note': note, **({'patterns': patterns} if patterns else {})})
     print(f'{family:8s} {label:46s} {ms * 1e3:9.1f} us  {ach:10.1f} {"GB/s" if bound == "hbm" else "GOP/s"}'
           f'  {100 * ach / peak:5.1f} %', flush=True)
 
@@ -93,6 +93,20 @@ def fam_fq():
         run('stats', f'K4 mm_rows per-tensor {name}', f'mm_rows<{code}', lambda: be.minmax(x, 1, 1), es * n, 'hbm')
         run('stats', f'K5 mm_cols per-embedding {name}', f'mm_cols<{code}', lambda: be.minmax(x, D, 1), es * n, 'hbm')
         del gy
+        # per-token ranges (`--per-token`: axis = 1, reference main.py:359-376): one (scale, zero-point) per token position
+        dT, zT = torch.full((S,), 0.03, device=dev), torch.full((S,), 128.0, device=dev)
+        run('fq', f'K2r fq_rows_wave per-token {name} [1024,512,768]', 'fq_rows_wave', lambda: be.fake_quant(
+            x, dT, zT, None, 8, False, False, 1e-8, S, D), 2 * es * n, 'hbm', note=f'dtype code {code}')
+        run('stats', f'K4r mm_rows_wave per-token {name}', 'mm_rows_wave', lambda: be.minmax(x, S, D), es * n, 'hbm')
+        # dynamic per-token step (`--dynamic --per-token`): statistics -> estimator -> parameters -> quantize, every call;
+        # x is read twice (3 x es bytes per element); the row sums the two streaming kernels of the call, the two
+        # parameter-sized launches between them (mm_final, calib_update_k) show in the HIP-event column
+        run('dyn', f'dynamic per-token estimate+quantize {name} [1024,512,768]', None, lambda: be.calibrate_minmax(
+            x, S, D, _hip.EST_CURRENT, None, None, 0.9, 0, None, 8, False, 1e-8, False), 3 * es * n, 'hbm',
+            patterns=['mm_rows_wave', 'fq_rows_wave'], note='tq_calibrate_minmax: 4 launches')
+        run('dyn', f'dynamic per-tensor estimate+quantize {name} [1024,512,768]', None, lambda: be.calibrate_minmax(
+            x, 1, 1, _hip.EST_CURRENT, None, None, 0.9, 0, None, 8, False, 1e-8, False), 3 * es * n, 'hbm',
+            patterns=['calib_partials_k', 'fq_tensor_calib'], note='tq_calibrate_tensor: 2 launches')
 
 
 def fam_tails():

@@ -22,31 +22,43 @@ def kernel_table(out_dir, dest_dir):
         disp.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     disp.sort()
     cursor = defaultdict(int)       # per pattern: how many matching dispatches earlier manifest rows consumed
+
+    def patterns_of(row):
+        return row.get('patterns') or [row['pattern']]
+
     rows = []
     for m in man:
-        pat = m['pattern']
-        match = [d for d in disp if pat in d[2]]
-        per_run = None
-        # each run() = 3 warm + reps timed launches of its kernel; rows sharing a pattern follow each other in time
-        same = [x for x in man if x['pattern'] == pat]
-        per_run = len(match) // len(same) if same else 0
-        mine = match[cursor[pat]:cursor[pat] + per_run]
-        cursor[pat] += per_run
-        timed = mine[3:] if len(mine) > 3 else mine
-        if not timed:
+        # each run() = 3 warm + reps timed launches of its kernel(s); rows sharing a pattern follow each other in time.
+        # A composite row (`patterns`: several kernels per call, e.g. the dynamic estimate + quantize step) sums the
+        # averages of its kernels.
+        total_avg, total_min, total_max, n_disp, outliers_all, names = 0.0, 0, 0, None, 0, []
+        for pat in patterns_of(m):
+            match = [d for d in disp if pat in d[2]]
+            same = [x for x in man if pat in patterns_of(x)]
+            per_run = len(match) // len(same) if same else 0
+            mine = match[cursor[pat]:cursor[pat] + per_run]
+            cursor[pat] += per_run
+            timed = mine[3:] if len(mine) > 3 else mine
+            if not timed:
+                n_disp = 0
+                break
+            ns = [e - s for s, e, _ in timed]
+            # a dispatch that is pre-empted (another client of the box, a clock transition) shows up as one launch of
+            # 10-20x the others; such outliers (> 3x the median) are left out of the average and counted in the table
+            med = sorted(ns)[len(ns) // 2]
+            keep = [v for v in ns if v <= 3 * med]
+            outliers_all += len(ns) - len(keep)
+            total_avg += sum(keep) / len(keep)
+            total_min += min(keep)
+            total_max += max(keep)
+            n_disp = len(timed)
+            names.append(timed[0][2].split('(')[0][:80])
+        if not n_disp:
             continue
-        ns = [e - s for s, e, _ in timed]
-        # a dispatch that is pre-empted (another client of the box, a clock transition) shows up as one launch of 10-20x
-        # the others; such outliers (> 3x the median) are left out of the average and counted in the table
-        med = sorted(ns)[len(ns) // 2]
-        keep = [v for v in ns if v <= 3 * med]
-        outliers = len(ns) - len(keep)
-        ns = keep
-        avg = sum(ns) / len(ns)
-        ach = m['unit_per_launch'] / avg          # bytes/ns = GB/s ; ops/ns = GOP/s
-        rows.append({**m, 'kernel_name': timed[0][2].split('(')[0][:80], 'dispatches': len(timed),
-                     'rocprof_avg_ns': round(avg, 1), 'rocprof_min_ns': min(ns), 'rocprof_max_ns': max(ns),
-                     'outliers_excluded': outliers,
+        ach = m['unit_per_launch'] / total_avg          # bytes/ns = GB/s ; ops/ns = GOP/s
+        rows.append({**m, 'kernel_name': ' + '.join(names), 'dispatches': n_disp,
+                     'rocprof_avg_ns': round(total_avg, 1), 'rocprof_min_ns': total_min, 'rocprof_max_ns': total_max,
+                     'outliers_excluded': outliers_all,
                      'achieved': round(ach, 1), 'frac': round(ach / m['peak'], 4)})
     os.makedirs(dest_dir, exist_ok=True)
     json.dump(rows, open(os.path.join(dest_dir, 'kernel_table.json'), 'w'), indent=1)

@@ -23,6 +23,21 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    config.addinivalue_line('markers', "default_route: runs with the product's default options.INT8_LINEAR ('auto')")
+
+
+@pytest.fixture(autouse=True)
+def _pin_the_route_under_test(request):
+    """The product default is options.INT8_LINEAR = 'auto': with autograd off, fixed-range forwards take the exact-integer /
+    fused route (quantization/options.py).  Almost every parity test here is a statement about ONE route -- the layered
+    module chain against the oracle / the reference fixtures, or the integer route (switched on explicitly) against the
+    integer oracle -- so each test starts from the layered route (False) and the tests of the DEFAULT are marked
+    `default_route`.  The switch is restored after every test whatever it did."""
+    from quantization import options
+    before = options.INT8_LINEAR
+    options.INT8_LINEAR = 'auto' if request.node.get_closest_marker('default_route') else False
+    yield
+    options.INT8_LINEAR = before
 
 
 def _has_gpu():

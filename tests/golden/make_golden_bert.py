@@ -89,7 +89,7 @@ def inputs():
 def main(recipe='default'):
     torch.set_num_threads(8)
     hf = build_hf(2 if recipe == 'double' else None)
-    if recipe in ('default', 'double'):
+    if recipe in ('default', 'double', 'hidden'):
         qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8,
                   n_bits_act=8, weight_range_method=RangeEstimators.current_minmax,
                   act_range_method=RangeEstimators.running_minmax, quant_dict={})
@@ -120,14 +120,16 @@ def main(recipe='default'):
             if hasattr(m, fn) and not isinstance(m, QuantizationManager):
                 getattr(m, fn)()
 
-    def forward(ids):
+    def forward(ids, hidden=None):
         mask = torch.zeros(ids.shape[0], 1, 1, ids.shape[1])          # all-ones attention mask
         h = emb(input_ids=ids)
-        for L in layers:
+        for k, L in enumerate(layers):
             att = L.attention
             ctx = att.self(h, mask)[0]
             a_out = att.output(ctx, h)
             h = L.output(L.intermediate(a_out), a_out)
+            if hidden is not None:
+                hidden[k + 1] = h
         pooled = hf.dropout(pooler(h))
         return classifier(pooled)
 
@@ -150,6 +152,8 @@ def main(recipe='default'):
             if isinstance(m, QuantizationManager) and m.quantizer.is_initialized:
                 m.fix_ranges()
         logits = forward(ids)
+        if recipe == 'hidden':
+            return save_hidden(forward, layers, ids, logits)
 
     act, wts = [], []
     for name, m in blocks.named_modules():
@@ -171,6 +175,33 @@ def main(recipe='default'):
         versions=np.array(f'torch {torch.__version__} transformers {transformers.__version__}'),
         first_weight_sum=np.array(float(hf.bert.encoder.layer[0].attention.self.query.weight.double().sum())),
         weight_check_sum=np.array(weight_check_sum(hf)))
+
+
+def save_hidden(forward, layers, ids, logits):
+    """`python tests/golden/make_golden_bert.py hidden` -> bert_base_w8a8_hidden.npz: the SAME calibrated model as
+    bert_base_w8a8.npz (asserted on the logits), with what a route comparison needs to be statistically meaningful --
+    the grid indices of the encoder output after layers 1, 6 and 12 ([8, 128, 768] uint8 each: 786 432 samples instead of
+    16 logits) and the reference's logits on three further evaluation batches (fixed ranges)."""
+    z = np.load(os.path.join(OUT, 'bert_base_w8a8.npz'))
+    assert np.array_equal(z['logits'], logits.numpy()) and np.array_equal(z['input_ids'], ids.numpy())
+    hidden = {}
+    assert torch.equal(forward(ids, hidden), logits)
+    data = {}
+    for k in (1, 6, 12):
+        q = layers[k - 1].output.LayerNorm.activation_quantizer.quantizer
+        idx = q.to_integer_forward(hidden[k])
+        assert torch.equal(q(hidden[k]), hidden[k])                      # the layer output lies on its quantizer's grid
+        data[f'hidden_idx_L{k}'] = idx.numpy().astype(np.uint8)
+        assert np.array_equal(data[f'hidden_idx_L{k}'].astype(np.float32), idx.numpy())
+        data[f'hidden_delta_L{k}'] = q._delta.numpy().reshape(()).copy()
+        data[f'hidden_zero_float_L{k}'] = q._zero_float.numpy().reshape(()).copy()
+    g = torch.Generator().manual_seed(SEED + 1)
+    extra = torch.randint(0, 30522, (3, 8, 128), generator=g)
+    data['input_ids_extra'] = extra.numpy()
+    data['logits_extra'] = np.stack([forward(extra[i]).numpy() for i in range(3)])
+    data['logits'] = logits.numpy()
+    np.savez_compressed(os.path.join(OUT, 'bert_base_w8a8_hidden.npz'), **data)
+    print('hidden-state fixture written; extra logits', data['logits_extra'][:, :2])
 
 
 def gen_nonorm():
@@ -213,6 +244,8 @@ if __name__ == '__main__':
         main('double')
     elif len(sys.argv) > 1 and sys.argv[1] == 'readme':
         main('readme')
+    elif len(sys.argv) > 1 and sys.argv[1] == 'hidden':
+        main('hidden')
     else:
         main()
         gen_nonorm()

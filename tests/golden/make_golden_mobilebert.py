@@ -91,7 +91,7 @@ class RefLayer(torch.nn.Module):
         return self.output(self.intermediate(a), a, h)
 
 
-def main():
+def main(hidden=False):
     torch.set_num_threads(8)
     torch.manual_seed(SEED)
     hf = fill_from_numpy_stream(MobileBertForSequenceClassification(MobileBertConfig(num_labels=2)).eval(), SEED)
@@ -112,11 +112,13 @@ def main():
             if hasattr(m, fn) and not isinstance(m, QuantizationManager):
                 getattr(m, fn)()
 
-    def forward(ids):
+    def forward(ids, keep=None):
         mask = torch.zeros(ids.shape[0], 1, 1, ids.shape[1])
         h = emb(input_ids=ids)
-        for L in layers:
+        for k, L in enumerate(layers):
             h = L(h, mask)
+            if keep is not None:
+                keep[k + 1] = h
         return classifier(hf.dropout(pooler(h)))
 
     blocks.eval()
@@ -129,6 +131,8 @@ def main():
             if isinstance(m, QuantizationManager) and m.quantizer.is_initialized:
                 m.fix_ranges()
         logits = forward(ids)
+        if hidden:
+            return save_hidden(forward, layers, ids, logits)
 
     act, wts = [], []
     for name, m in blocks.named_modules():
@@ -151,5 +155,32 @@ def main():
         weight_check_sum=np.array(weight_check_sum(hf)))
 
 
+def save_hidden(forward, layers, ids, logits):
+    """`python tests/golden/make_golden_mobilebert.py hidden` -> mobilebert_w4a4_hidden.npz: the SAME calibrated model as
+    mobilebert_w4a4.npz (asserted on the logits): grid indices of the encoder output ([8, 128, 512], 4-bit) after layers
+    1, 6, 12 and 24 -- 524 288 samples per layer for the route comparison instead of 16 logits -- and the reference's
+    logits on three further evaluation batches."""
+    z = np.load(os.path.join(OUT, 'mobilebert_w4a4.npz'))
+    assert np.array_equal(z['logits'], logits.numpy()) and np.array_equal(z['input_ids'], ids.numpy())
+    keep = {}
+    assert torch.equal(forward(ids, keep), logits)
+    data = {}
+    for k in (1, 6, 12, 24):
+        q = layers[k - 1].output.bottleneck.LayerNorm.activation_quantizer.quantizer
+        idx = q.to_integer_forward(keep[k])
+        assert torch.equal(q(keep[k]), keep[k])
+        data[f'hidden_idx_L{k}'] = idx.numpy().astype(np.uint8)
+        assert np.array_equal(data[f'hidden_idx_L{k}'].astype(np.float32), idx.numpy())
+        data[f'hidden_delta_L{k}'] = q._delta.numpy().reshape(()).copy()
+        data[f'hidden_zero_float_L{k}'] = q._zero_float.numpy().reshape(()).copy()
+    g = torch.Generator().manual_seed(SEED + 1)
+    extra = torch.randint(0, 30522, (3, 8, 128), generator=g)
+    data['input_ids_extra'] = extra.numpy()
+    data['logits_extra'] = np.stack([forward(extra[i]).numpy() for i in range(3)])
+    data['logits'] = logits.numpy()
+    np.savez_compressed(os.path.join(OUT, 'mobilebert_w4a4_hidden.npz'), **data)
+    print('hidden-state fixture written')
+
+
 if __name__ == '__main__':
-    main()
+    main(hidden=len(sys.argv) > 1 and sys.argv[1] == 'hidden')

@@ -1,0 +1,149 @@
+"""Per-token (`--per-token`: axis = 1 on [B, T, d] / [B, T, D]) and dynamic (`--dynamic`) activation quantization at
+BERT-base shapes against tests/golden/per_token.npz -- outputs of the REFERENCE's QuantizationManager
+(tests/golden/make_golden_per_token.py; reference main.py:359-376, utils/per_embd_quant_utils.py:54-68,
+quantization_manager.py:99-106).  Dynamic mode is the one mode where estimate + quantize run on every inference call.
+
+* CPU: the oracle backend through the drop-in manager reproduces all 18 cases bit for bit (ranges, parameters, SHA-256
+  of the index tensor and of the output, first / last token rows in full).
+* GPU: the same through the HIP kernels (`mm_rows_wave`, `fq_rows_wave`, the fused `tq_calibrate_minmax`), both
+  calibration routes; plus ragged / multi-slice launch shapes against the oracle.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import GOLDEN
+
+
+def make_input(seed, shape, outlier_dims=(308, 381), scale=20.0):
+    """== tests/golden/make_golden_per_token.py::make_input (numpy MT19937 stream: build independent)."""
+    rs = np.random.RandomState(seed)
+    x = rs.standard_normal(size=shape).astype(np.float32)
+    for d in outlier_dims:
+        if d < shape[-1]:
+            x[..., d] *= scale
+    x *= (1.0 + np.arange(shape[1], dtype=np.float32) / shape[1])[None, :, None]
+    return x
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _fixture():
+    z = np.load(os.path.join(GOLDEN, 'per_token.npz'))
+    return z, json.loads(str(z['meta']))
+
+
+def _run_case(m, z, device):
+    from quantization.quantization_manager import QuantizationManager
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+    k, shape = m['k'], tuple(m['shape'])
+    dt = torch.bfloat16 if m['io'] == 'bf16' else torch.float32
+    x = torch.from_numpy(make_input(m['seed'], shape)).to(dt).to(device)
+    mgr = QuantizationManager(qmethod=QMethods.asymmetric_uniform, init=RangeEstimators.current_minmax,
+                              qparams=dict(n_bits=m['n_bits']))
+    set_act_quant_axis_and_groups(mgr, axis=1, n_groups=None)
+    if m['mode'] == 'fixed':
+        y0 = mgr(x)
+        mgr.fix_ranges()
+        y = mgr(x)
+        assert torch.equal(y, y0), m
+    else:
+        mgr(torch.from_numpy(make_input(m['seed'] + 500, shape)).to(dt).to(device))
+        y = mgr(x)                                   # dynamic: still estimating, ranges follow THIS input
+    q = mgr.quantizer
+    est = mgr.range_estimator
+    assert y.dtype == dt
+    assert np.array_equal(est.current_xmin.cpu().numpy().reshape(-1), z[f'p{k}_xmin']), m
+    assert np.array_equal(est.current_xmax.cpu().numpy().reshape(-1), z[f'p{k}_xmax']), m
+    assert np.array_equal(q._delta.cpu().numpy().reshape(-1), z[f'p{k}_delta']), m
+    assert np.array_equal(q._zero_float.cpu().numpy().reshape(-1), z[f'p{k}_zero_float']), m
+    idx = q.to_integer_forward(x).cpu().numpy()
+    idx_u8 = idx.astype(np.uint8)
+    assert np.array_equal(idx_u8.astype(np.float32), idx), m
+    y_out = y.cpu().view(torch.int16).numpy() if m['io'] == 'bf16' else y.cpu().numpy()
+    T = shape[1]
+    assert np.array_equal(idx_u8[:, [0, T - 1], :], z[f'p{k}_idx_rows']), m
+    assert np.array_equal(y_out[:, [0, T - 1], :], z[f'p{k}_y_rows']), m
+    assert sha(idx_u8) == m['idx_sha256'], m
+    assert sha(y_out) == m['y_sha256'], m
+
+
+def test_per_token_and_dynamic_cpu_oracle_equals_reference():
+    from quantization import _hip
+    from tests._oracle_backend import OracleBackend
+    z, meta = _fixture()
+    assert len(meta) == 18
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        for m in meta:
+            _run_case(m, z, 'cpu')
+    finally:
+        _hip.set_backend(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fused', [True, False], ids=['fused-calibration', 'layered-calibration'])
+def test_per_token_and_dynamic_gpu_equals_reference(fused):
+    from quantization import _hip, quantization_manager as qm
+    assert _hip.backend().name == 'hip'
+    z, meta = _fixture()
+    prev = qm.FUSED_CALIBRATION
+    qm.FUSED_CALIBRATION = fused
+    try:
+        for m in meta:
+            _run_case(m, z, 'cuda')
+    finally:
+        qm.FUSED_CALIBRATION = prev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape,axis', [
+    ((8, 128, 768), 1), ((8, 128, 3072), 1),        # BERT-base [B, T, d] and [B, T, D] per token
+    ((9, 4096, 16), 1),                             # 2 slices of the outer index: the 4-row batches AND their remainder
+    ((70, 128, 64), 1),                             # 64 slices, some with two rows
+    ((5, 40, 24), 1), ((3, 7, 8), 1),               # ragged: rows shorter than a wave
+    ((3072, 768), 0),                               # per-channel weight layout (outer = 1)
+    ((4, 6, 4104), 1),                              # rows longer than the wave kernels take: the block-per-row kernels
+])
+def test_row_parameter_launch_shapes_vs_oracle(dtype, shape, axis):
+    """Statistics, parameters, indices and outputs for row-parameter layouts through the wave-per-(parameter, slice)
+    kernels and their neighbours, against the oracle on the same tensor."""
+    from oracle import tq_oracle as O
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(sum(shape) + axis)
+    x = (torch.randn(*shape, generator=g) * torch.linspace(0.5, 4, shape[axis]).view(
+        [-1 if i == axis else 1 for i in range(len(shape))])).to(dtype)
+    xf = x.float()
+    inner = int(np.prod(shape[axis + 1:]))
+    xd = x.cuda()
+    mn, mx = be.minmax(xd, shape[axis], inner)
+    rmn, rmx = O.minmax_axis(xf, axis)
+    assert torch.equal(mn.cpu(), rmn) and torch.equal(mx.cpu(), rmx)
+    for n_bits in (8, 4):
+        delta, zf = O.asym_params_from_range(rmn, rmx, n_bits)
+        d2, z2 = be.set_range_asym(mn, mx, n_bits, 1e-8, False)
+        assert torch.equal(d2.cpu(), delta) and torch.equal(z2.cpu(), zf)
+        ref_idx, ref_y = O.fake_quant_lowp(x, delta, zf, n_bits, False, axis=axis)
+        y, idx = be.fake_quant(xd, d2, z2, None, n_bits, False, False, 1e-8, shape[axis], inner, idx_dtype=torch.float32)
+        assert torch.equal(idx.cpu(), ref_idx)
+        assert torch.equal(y.cpu(), ref_y)
+        y8, idx8 = be.fake_quant(xd, d2, z2, None, n_bits, False, False, 1e-8, shape[axis], inner, idx_dtype=torch.uint8)
+        assert torch.equal(idx8.cpu().float(), ref_idx) and torch.equal(y8.cpu(), ref_y)
+    # NaN in one row poisons that row's range only (torch.min / torch.max semantics)
+    xn = xd.clone()
+    xn.view(-1)[inner * 2 + 1] = float('nan')
+    mn2, mx2 = be.minmax(xn, shape[axis], inner)
+    rmn2, rmx2 = O.minmax_axis(xn.float().cpu(), axis)
+    assert torch.equal(torch.isnan(mn2.cpu()), torch.isnan(rmn2)) and torch.equal(torch.isnan(mx2.cpu()), torch.isnan(rmx2))
+    ok = ~torch.isnan(rmn2)
+    assert torch.equal(mn2.cpu()[ok], rmn2[ok]) and torch.equal(mx2.cpu()[ok], rmx2[ok])

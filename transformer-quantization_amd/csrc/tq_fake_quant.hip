@@ -509,6 +509,61 @@ __global__ __launch_bounds__(kBlock) void fq_rows(const u32x4* __restrict__ x, u
   }
 }
 
+// ------------------------------------------------------------------------------ short rows
+// x viewed as [outer, n_params, inner], rows of at most kWaveRowMaxVec vectors (per-token ranges of a [B, T, d]
+// activation, reference main.py:359-376; per-channel weights).  fq_rows gives every row a 256-thread block (96 lanes
+// busy for d = 768 bf16) and derives the parameters once per row in every lane.  Here wave (p, s) owns the rows
+// o = s, s + S, ... of parameter p: the parameters are derived ONCE per wave (wave-uniform), the body is the per-tensor
+// one, and at any time the resident waves sweep one contiguous window of S x n_params rows (see mm_rows_wave).
+template <int DT, bool HAS_IDX, bool NT, bool FAST>
+__device__ __forceinline__ void fq_rows_wave_body(const u32x4* __restrict__ x, u32x4* __restrict__ y, void* __restrict__ idx,
+                                                  int idx_dtype, uint64_t outer, uint32_t vpr, uint32_t n_params, uint32_t S,
+                                                  uint32_t p_at, uint32_t s, const QP& p, const QF& qf) {
+  constexpr int V = Store<DT>::kVec;
+  constexpr int U = 4;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint64_t row_stride = (uint64_t)n_params * vpr;
+  const uint64_t base = (uint64_t)p_at * vpr;
+  uint64_t o = s;
+  for (; o + (uint64_t)(U - 1) * S < outer; o += (uint64_t)U * S) {
+    for (uint32_t i = lane; i < vpr; i += kWave) {
+      u32x4 v[U];
+      uint64_t at[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        at[u] = base + (o + (uint64_t)u * S) * row_stride + i;
+        v[u] = NT ? ld_stream(x + at[u]) : x[at[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const u32x4 r = fq_vec<DT, HAS_IDX, FAST>(v[u], p, idx, idx_dtype, at[u] * V, &qf);
+        if (y) { if (NT) st_stream(y + at[u], r); else y[at[u]] = r; }
+      }
+    }
+  }
+  for (; o < outer; o += S) {
+    for (uint32_t i = lane; i < vpr; i += kWave) {
+      const uint64_t at = base + o * row_stride + i;
+      const u32x4 r = fq_vec<DT, HAS_IDX, FAST>(x[at], p, idx, idx_dtype, at * V, &qf);
+      if (y) y[at] = r;
+    }
+  }
+}
+
+template <int DT, bool HAS_IDX, bool NT>
+__global__ __launch_bounds__(kBlock) void fq_rows_wave(const u32x4* __restrict__ x, u32x4* __restrict__ y,
+                                                       void* __restrict__ idx, int idx_dtype, uint64_t outer, uint32_t vpr,
+                                                       uint32_t S, tq_quantizer q) {
+  const uint32_t n_params = (uint32_t)q.n_params;
+  const uint64_t gw = (uint64_t)blockIdx.x * (kBlock / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  if (gw >= (uint64_t)n_params * S) return;
+  const uint32_t p_at = (uint32_t)(gw % n_params), s = (uint32_t)(gw / n_params);
+  const QP p = make_qp(q, p_at);
+  const QF qf = make_qf(p);
+  if (qf.ok) fq_rows_wave_body<DT, HAS_IDX, NT, true>(x, y, idx, idx_dtype, outer, vpr, n_params, S, p_at, s, p, qf);
+  else fq_rows_wave_body<DT, HAS_IDX, NT, false>(x, y, idx, idx_dtype, outer, vpr, n_params, S, p_at, s, p, qf);
+}
+
 // ------------------------------------------------------------------------------ fallback
 template <int DT, bool HAS_IDX>
 __global__ __launch_bounds__(kBlock) void fq_scalar(const void* __restrict__ x, void* __restrict__ y,
@@ -589,6 +644,17 @@ static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t 
     else     { if (nt) TQ_LAUNCH_AXIS(true, 1) else TQ_LAUNCH_AXIS(false, 1) }
 #undef TQ_LAUNCH_AXIS
     return check_launch("fq_axis");
+  }
+  if (vec_ok && q.n_params > 1 && q.inner > 1 && q.inner % V == 0 && q.inner / V <= kWaveRowMaxVec &&
+      q.n_params <= (1u << 24) && n % (q.n_params * q.inner) == 0) {
+    const uint64_t outer = n / (q.n_params * q.inner);
+    const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(kWaveRowTarget, q.n_params), outer));
+    const unsigned gx = (unsigned)ceil_div(q.n_params * S, (uint64_t)(kBlock / kWave));
+    if (nt) hipLaunchKernelGGL((fq_rows_wave<DT, HAS_IDX, true>), dim3(gx), dim3(kBlock), 0, st, xv, yv, idx, idx_dtype, outer,
+                               (uint32_t)(q.inner / V), S, q);
+    else    hipLaunchKernelGGL((fq_rows_wave<DT, HAS_IDX, false>), dim3(gx), dim3(kBlock), 0, st, xv, yv, idx, idx_dtype, outer,
+                               (uint32_t)(q.inner / V), S, q);
+    return check_launch("fq_rows_wave");
   }
   if (vec_ok && q.n_params > 1 && q.inner > 1 && q.inner % V == 0) {
     const uint64_t n_rows = n / q.inner;

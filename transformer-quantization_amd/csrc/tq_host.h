@@ -17,6 +17,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 inline size_t elem_size(int dtype) { return dtype == TQ_F32 ? 4 : 2; }
 
+// Row-parameter layouts ([outer, n_params, inner]: per-token ranges, per-channel weights) with short rows: one wave per
+// (parameter, slice of the outer index) -- mm_rows_wave (tq_stats.hip), fq_rows_wave (tq_fake_quant.hip)
+constexpr uint64_t kWaveRowMaxVec = 512;    // rows of up to 512 16-byte vectors (8 KB)
+constexpr uint64_t kWaveRowTarget = 8192;   // waves wanted in flight: 256 CUs x 4 SIMDs x 8
+
 inline int tuning(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;

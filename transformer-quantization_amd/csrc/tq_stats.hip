@@ -154,6 +154,57 @@ __global__ __launch_bounds__(kBlock) void mm_rows(const void* __restrict__ x, ui
   }
 }
 
+// ------------------------------------------------------------------------------ short rows, one wave per (parameter, slice)
+// x viewed as [outer, n_params, inner] with rows of at most a few KB (per-token ranges of a [B, T, d] activation:
+// n_params = T, inner = d, reference main.py:359-376 `--per-token`; per-channel weights).  mm_rows gives such a row a
+// whole 256-thread block (96 of 256 lanes loading for d = 768 bf16, two barriers per row).  Here wave (p, s) owns the
+// rows o = s, s + S, s + 2 S, ... of parameter p, keeps lane-local running statistics over ALL of them and reduces
+// across the wave once at the end; consecutive waves own consecutive parameters of the same `o`, so that at any time the
+// resident waves sweep one contiguous window of S x n_params rows.  No LDS, no barrier.
+// partial layout (mm_final's): ws[s * 2 * n_params + {0,1} * n_params + p]
+template <int DT>
+__global__ __launch_bounds__(kBlock) void mm_rows_wave(const u32x4* __restrict__ x, uint64_t outer, uint32_t vpr,
+                                                       uint32_t n_params, uint32_t S, float* __restrict__ ws) {
+  constexpr int V = Store<DT>::kVec;
+  constexpr int U = 4;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint64_t gw = (uint64_t)blockIdx.x * (kBlock / kWave) + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  if (gw >= (uint64_t)n_params * S) return;
+  const uint32_t p = (uint32_t)(gw % n_params), s = (uint32_t)(gw / n_params);
+  const uint64_t row_stride = (uint64_t)n_params * vpr;         // vectors between two rows of one parameter
+  const u32x4* base = x + (uint64_t)p * vpr;
+  MinMax acc;
+  uint64_t o = s;
+  for (; o + (uint64_t)(U - 1) * S < outer; o += (uint64_t)U * S) {
+    for (uint32_t i = lane; i < vpr; i += kWave) {
+      u32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = ld_stream(base + (o + (uint64_t)u * S) * row_stride + i);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float f[V];
+        Store<DT>::unpack(v[u], f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc.add(f[j]);
+      }
+    }
+  }
+  for (; o < outer; o += S) {
+    for (uint32_t i = lane; i < vpr; i += kWave) {
+      float f[V];
+      Store<DT>::unpack(ld_stream(base + o * row_stride + i), f);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc.add(f[j]);
+    }
+  }
+  const float mn = wave_min(acc.lo()), mx = wave_max(acc.hi());
+  if (lane == 0) {
+    float* out = ws + (uint64_t)s * 2 * n_params;
+    out[p] = mn;
+    out[n_params + p] = mx;
+  }
+}
+
 // ------------------------------------------------------------------------------ finalize
 // ws [P][2][n_params] -> out_min[n_params], out_max[n_params].  block = (cx, sy): cx adjacent
 // parameters, sy slices of P.
@@ -204,6 +255,7 @@ __global__ void mm_final(const float* __restrict__ ws, uint64_t P, uint64_t n_pa
 
 struct MMPlan {
   bool cols;          // mm_cols path
+  bool wave;          // mm_rows_wave path (S = P slices of the outer index)
   unsigned bx, by, gx, gy;
   uint64_t P;         // number of partial records of 2*n_params floats
 };
@@ -220,6 +272,14 @@ static MMPlan plan_minmax(uint64_t n, uint64_t n_params, uint64_t inner, int V, 
     const uint64_t want = std::max<uint64_t>(1, (uint64_t)kMaxGrid / 2 / pl.gx);
     pl.gy = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, ceil_div(rows, (uint64_t)pl.by * 8)));
     pl.P = pl.gy;
+    return pl;
+  }
+  if (n_params > 1 && inner > 1 && inner % V == 0 && aligned && inner / V <= kWaveRowMaxVec && n_params <= (1u << 24) &&
+      n % (n_params * inner) == 0) {
+    const uint64_t outer = n / (n_params * inner);
+    pl.wave = true;
+    pl.P = std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(kWaveRowTarget, n_params), outer));
+    pl.gx = (unsigned)ceil_div(n_params * pl.P, (uint64_t)(kBlock / kWave));
     return pl;
   }
   const uint64_t eff_inner = n_params == 1 ? n : inner;
@@ -248,6 +308,9 @@ static int launch_minmax(const void* x, uint64_t n, uint64_t n_params, uint64_t 
     const size_t lds = (size_t)pl.by * 2 * pl.bx * V * sizeof(float);
     hipLaunchKernelGGL((mm_cols<DT>), dim3(pl.gx, pl.gy), dim3(pl.bx, pl.by), lds, st,
                        static_cast<const u32x4*>(x), n / n_params, (uint32_t)n_params, ws);
+  } else if (pl.wave) {
+    hipLaunchKernelGGL((mm_rows_wave<DT>), dim3(pl.gx), dim3(kBlock), 0, st, static_cast<const u32x4*>(x),
+                       n / (n_params * inner), (uint32_t)(inner / V), (uint32_t)n_params, (uint32_t)pl.P, ws);
   } else {
     const uint64_t eff_inner = n_params == 1 ? n : inner;
     const uint64_t n_rows = n_params == 1 ? 1 : n / inner;

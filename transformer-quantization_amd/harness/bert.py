@@ -18,6 +18,7 @@ import math
 import torch
 from torch import nn
 
+from quantization import options
 from quantization.autoquant_utils import quantize_model
 from quantization.base_quantized_classes import QuantizedActivation
 from quantization.base_quantized_model import QuantizedModel
@@ -62,10 +63,10 @@ class QSelfAttention(QuantizedModel):
         B, T, _ = x.shape
         return x.view(B, T, self.heads, self.head_dim).permute(0, 2, 1, 3)
 
-    fuse = False   # set True: scores-quant -> scale -> mask -> softmax -> probs-quant as one kernel
+    fuse = None    # set True: scores-quant -> scale -> mask -> softmax -> probs-quant as one kernel
 
     def forward(self, h, mask):
-        if self.fuse:
+        if options.fuse_on(self.fuse, self):
             from quantization.fused import quantized_self_attention
             ctx = quantized_self_attention(h, self.query, self.key, self.value, mask, self.heads,
                                            self.attn_scores_act_quantizer, self.attn_probs_act_quantizer,
@@ -73,7 +74,7 @@ class QSelfAttention(QuantizedModel):
             if ctx is not None:                  # stacked QKV projection + attention core: 2 integer kernels
                 return ctx
         qo, ko, vo = self.query(h), self.key(h), self.value(h)
-        if self.fuse:
+        if options.fuse_on(self.fuse, self):
             from quantization.fused import quantized_attention
             ctx = quantized_attention(qo, ko, vo, mask, self.heads, self.attn_scores_act_quantizer,
                                       self.attn_probs_act_quantizer, self.context_act_quantizer)
@@ -81,7 +82,7 @@ class QSelfAttention(QuantizedModel):
                 return ctx
         q, k, v = self._split(qo), self._split(ko), self._split(vo)
         raw = torch.matmul(q, k.transpose(-1, -2))
-        if self.fuse:
+        if options.fuse_on(self.fuse, self):
             from quantization.fused import scores_softmax_quant
             probs = scores_softmax_quant(self.attn_scores_act_quantizer, self.attn_probs_act_quantizer, raw,
                                          mask, math.sqrt(self.head_dim))
@@ -105,10 +106,10 @@ class QResidualBlock(QuantizedModel):
         self.res_act_quantizer = QuantizedActivation(**qp)
         self.LayerNorm = quantize_model(hf.LayerNorm, **qp)
 
-    fuse = False   # set True to run the fixed-range tail as one kernel (quantization/fused.py)
+    fuse = None    # set True to run the fixed-range tail as one kernel (quantization/fused.py)
 
     def forward(self, h, residual):
-        if self.fuse:
+        if options.fuse_on(self.fuse, self):
             from quantization.fused import residual_layernorm_quant
             return residual_layernorm_quant(self.dense, self.res_act_quantizer, self.LayerNorm, h, residual)
         return self.LayerNorm(self.res_act_quantizer(self.dense(h) + residual))
@@ -122,12 +123,12 @@ class QLayer(QuantizedModel):
         self.intermediate = quantize_model(nn.Sequential(hf.intermediate.dense, nn.GELU()), **qp)
         self.output = QResidualBlock(hf.output, **qp)
 
-    fuse_ffn = False   # set True (with options.INT8_LINEAR): intermediate runs index-only, its [B, T, 3072] fp32 output is
+    fuse_ffn = None    # set True (with options.INT8_LINEAR): intermediate runs index-only, its [B, T, 3072] fp32 output is
                        # never stored (quantization/fused.py quantized_bert_ffn)
 
     def forward(self, h, mask):
         a = self.attention_output(self.attention_self(h, mask), h)
-        if self.fuse_ffn:
+        if options.fuse_on(self.fuse_ffn, self):
             from quantization.fused import quantized_bert_ffn
             out = self.output
             return quantized_bert_ffn(self.intermediate[0], out.dense, out.res_act_quantizer, out.LayerNorm, a, a)

@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from quantization import options
 from quantization.autoquant_utils import QuantNoNorm, quantize_model
 from quantization.base_quantized_classes import FP32Acts, QuantizedActivation
 from quantization.base_quantized_model import QuantizedModel
@@ -84,10 +85,10 @@ class QBottleneckLayer(QuantizedModel):
         self.dense = quantize_model(hf.dense, **qp)
         self.LayerNorm = QuantNoNorm(hf.LayerNorm, **qp)
 
-    fuse = False   # set True: dense + NoNorm + both quantizers as one integer launch (quantization/fused.py)
+    fuse = None    # set True: dense + NoNorm + both quantizers as one integer launch (quantization/fused.py)
 
     def forward(self, h):
-        if self.fuse:
+        if options.fuse_on(self.fuse, self):
             from quantization.fused import linear_nonorm_quant
             return linear_nonorm_quant(self.dense, self.LayerNorm, h)
         return self.LayerNorm(self.dense(h))
@@ -119,11 +120,11 @@ class QMobileSelfAttention(QuantizedModel):
         B, T, _ = x.shape
         return x.view(B, T, self.heads, self.head_dim).permute(0, 2, 1, 3)
 
-    fuse = False   # set True to run the fixed-range attention core as one integer kernel (quantization/fused.py)
+    fuse = None    # set True to run the fixed-range attention core as one integer kernel (quantization/fused.py)
 
     def forward(self, q_in, k_in, v_in, mask):
         qo, ko, vo = self.query(q_in), self.key(k_in), self.value(v_in)
-        if self.fuse:
+        if options.fuse_on(self.fuse, self):
             # Q K^T -> quantizer -> / sqrt(d) + mask -> softmax -> quantizer -> P V -> quantizer (per-tensor, so "per head
             # before the merge" and "after the merge" coincide) on the i8 matrix cores; None = layered modules
             from quantization.fused import quantized_attention
@@ -147,7 +148,7 @@ class QResidualNoNorm(QuantizedModel):
     OutputBottleneck all have this shape.  `fuse = True` runs the fixed-range tail as ONE kernel
     (tq_residual_nonorm_quant_fwd, quantization/fused.py)."""
 
-    fuse = False
+    fuse = None
 
     def __init__(self, hf, site_on=True, **qp):
         super().__init__()
@@ -156,7 +157,7 @@ class QResidualNoNorm(QuantizedModel):
         self.LayerNorm = QuantNoNorm(hf.LayerNorm, **qp)
 
     def forward(self, h, residual):
-        if self.fuse:
+        if options.fuse_on(self.fuse, self):
             from quantization.fused import residual_layernorm_quant
             return residual_layernorm_quant(self.dense, self.res_act_quantizer, self.LayerNorm, h, residual)
         return self.LayerNorm(self.res_act_quantizer(self.dense(h) + residual))
@@ -169,10 +170,10 @@ class QFFN(QuantizedModel):
         self.intermediate = quantize_model(nn.Sequential(hf.intermediate.dense, nn.ReLU()), **qp)
         self.output = QResidualNoNorm(hf.output, sites['res_ffn_output'], **qp)
 
-    fuse = False   # set True: intermediate + output + NoNorm tail as one integer launch (quantization/fused.py quantized_ffn)
+    fuse = None    # set True: intermediate + output + NoNorm tail as one integer launch (quantization/fused.py quantized_ffn)
 
     def forward(self, h):
-        if self.fuse:
+        if options.fuse_on(self.fuse, self):
             return _ffn(self.intermediate, self.output, h)
         return self.output(self.intermediate(h), h)
 
@@ -197,7 +198,7 @@ class QMobileLayer(QuantizedModel):
         self.output = QResidualNoNorm(hf.output, sites['res_output'], **qp)
         self.output_bottleneck = QResidualNoNorm(hf.output.bottleneck, sites['res_output_bottleneck'], **qp)
 
-    fuse_ffn = False   # set True: the last feed-forward block (intermediate + output) as one integer launch, like QFFN.fuse
+    fuse_ffn = None    # set True: the last feed-forward block (intermediate + output) as one integer launch, like QFFN.fuse
 
     def forward(self, h, mask):
         layer_input = self.bottleneck_input(h)                    # [B, T, 128] residual of the attention block
@@ -205,7 +206,7 @@ class QMobileLayer(QuantizedModel):
         a = self.attention_output(self.attention_self(shared, shared, h, mask), layer_input)
         for f in self.ffn:
             a = f(a)
-        o = _ffn(self.intermediate, self.output, a) if self.fuse_ffn else self.output(self.intermediate(a), a)
+        o = _ffn(self.intermediate, self.output, a) if options.fuse_on(self.fuse_ffn, self) else self.output(self.intermediate(a), a)
         return self.output_bottleneck(o, h)                       # back to 512, residual = the layer's input
 
 

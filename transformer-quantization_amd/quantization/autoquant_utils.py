@@ -27,6 +27,12 @@ INT8_STATS = {'kernel_calls': 0, 'autograd_calls': 0, 'unsigned_weight_fallbacks
 _ACT_CODES = {type(None): _hip.ACT_NONE, nn.ReLU: _hip.ACT_RELU, nn.GELU: _hip.ACT_GELU, nn.Tanh: _hip.ACT_TANH}
 
 
+def _hooked(*modules):
+    """Does any of these modules carry forward (pre-)hooks?  The integer / fused routes evaluate whole module chains in
+    one launch without calling the modules, so a hook on any of them would silently stop firing."""
+    return any(m is not None and isinstance(m, nn.Module) and (m._forward_hooks or m._forward_pre_hooks) for m in modules)
+
+
 def _fixed_per_tensor_manager(mgr):
     from quantization.quantization_manager import Qstates
     return (isinstance(mgr, QuantizationManager) and mgr.state == Qstates.fix_ranges
@@ -110,7 +116,7 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         return F.linear(x.contiguous(), weight.contiguous(), bias=bias)
 
     def forward(self, x, offsets=None):
-        if options.INT8_LINEAR:
+        if options.int8_active() and (options.INT8_LINEAR is True or not self.training):
             y = self._int8_forward(x)
             if y is not None:
                 return y
@@ -144,6 +150,9 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         (per-tensor or per-output-channel), weights quantized, nothing recording this layer's activations."""
         from quantization.quantization_manager import Qstates
         wmgr = self.weight_quantizer
+        if _hooked(wmgr, getattr(wmgr, 'quantizer', None), self._modules.get('activation_quantizer'),
+                   getattr(self._modules.get('activation_quantizer'), 'quantizer', None), self.activation_function):
+            return False                 # somebody observes a stage the fused launch would skip: layered route
         return bool(self._quant_w and self.activation_save_target is None
                     and isinstance(wmgr, QuantizationManager) and wmgr.quantizer.is_initialized
                     and wmgr.quantizer.symmetric and wmgr.quantizer.n_bits <= 8
@@ -372,7 +381,7 @@ class QuantNoNorm(QuantizationHijacker):
         if self._fusable(x):
             q = self.activation_quantizer.quantizer
             # feeding integer Linears (MobileBERT's bottlenecks -> query / key): emit the int8 indices in the same launch
-            want_idx = (options.INT8_LINEAR and not q.symmetric and q.n_bits <= 8 and q.scale_domain == 'linear'
+            want_idx = (options.int8_active() and not q.symmetric and q.n_bits <= 8 and q.scale_domain == 'linear'
                         and _hip.on_device(x) and x.dtype == torch.float32)
             out = _hip.backend().affine_fake_quant(
                 x, weight, bias, q._delta, q._zero_float, getattr(q, '_signed', None), q.n_bits,

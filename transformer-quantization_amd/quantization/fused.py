@@ -27,10 +27,18 @@ def _fixed_per_tensor(enabled, mgr):
     if not isinstance(mgr, QuantizationManager) or mgr.state != Qstates.fix_ranges:
         return 'no'
     q = mgr.quantizer
+    if mgr._forward_hooks or mgr._forward_pre_hooks or q._forward_hooks or q._forward_pre_hooks:
+        return 'no'                      # an observer on a stage the fused launch would skip: layered route
     if not q.is_initialized or q._delta.numel() != 1:
         return 'no'
     return (q._delta, q._zero_float, getattr(q, '_signed', None), q.n_bits, q.symmetric,
             q.scale_domain == 'log', q.eps)
+
+
+def _hooked(*modules):
+    """forward (pre-)hooks on modules a fused launch would not call"""
+    return any(m is not None and isinstance(m, torch.nn.Module) and (m._forward_hooks or m._forward_pre_hooks)
+               for m in modules)
 
 
 def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual, _gemm=None):
@@ -50,7 +58,8 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual, _gem
                and layer_norm.activation_function is None and _hip.on_device(x) and x.dtype != torch.float64
                and not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad))
                and (is_nonorm or len(layer_norm.normalized_shape) == 1)
-               and dense.activation_save_target is None and layer_norm.activation_save_target is None)
+               and dense.activation_save_target is None and layer_norm.activation_save_target is None
+               and not _hooked(dense, res_quantizer, layer_norm))
     if not fusable:
         if _gemm is not None:
             raise RuntimeError('residual_layernorm_quant: pre-computed GEMM handed to a tail that is not fusable')
@@ -60,7 +69,7 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual, _gem
         if y is not None:
             return y
     gemm = _gemm
-    if gemm is None and options.INT8_LINEAR and hasattr(dense, '_int8_forward'):
+    if gemm is None and options.int8_active() and hasattr(dense, '_int8_forward'):
         gemm = dense._int8_forward(x, with_output_quantizer=False)     # exact integer GEMM (MFMA i8)
     if gemm is None:
         w, b = dense.get_params()
@@ -72,7 +81,7 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual, _gem
         ln_w, ln_b = layer_norm.get_params()                # fake-quantized (cached in eval) affine
     arg = lambda q: None if q == 'off' else q
     oq = layer_norm.activation_quantizer.quantizer if q3 != 'off' else None
-    want_idx = (options.INT8_LINEAR and oq is not None and not oq.symmetric and oq.n_bits <= 8
+    want_idx = (options.int8_active() and oq is not None and not oq.symmetric and oq.n_bits <= 8
                 and gemm.dtype == torch.float32)
     out = _hip.backend().residual_layernorm_quant(gemm, residual, arg(q1), arg(q2), ln_w, ln_b,
                                                   None if is_nonorm else layer_norm.eps, arg(q3), want_idx=want_idx)
@@ -96,9 +105,10 @@ def quantized_bert_ffn(intermediate, dense, res_quantizer, layer_norm, x, residu
     def separate():
         return residual_layernorm_quant(dense, res_quantizer, layer_norm, intermediate(x), residual)
 
-    if (not options.INT8_LINEAR or not hasattr(intermediate, '_int8_plan') or not hasattr(dense, '_int8_plan_from')
+    if (not options.int8_active() or not hasattr(intermediate, '_int8_plan') or not hasattr(dense, '_int8_plan_from')
             or not _hip.on_device(x) or x.dtype != torch.float32 or dense.activation_function is not None
-            or _needs_autograd(intermediate, dense, layer_norm, x, residual)):
+            or _needs_autograd(intermediate, dense, layer_norm, x, residual)
+            or _hooked(intermediate, dense, res_quantizer, layer_norm)):
         return separate()
     from quantization.autoquant_utils import QuantNoNorm
     q1 = _fixed_per_tensor(dense._quant_a, dense.activation_quantizer)
@@ -147,7 +157,7 @@ def _linear_nonorm_i8(dense, layer_norm, x, residual, q1, q2, q3):
     """Integer Linear -> (+ residual -> Q_sum) -> NoNorm -> Q_out in one launch (tq_linear_i8_nonorm_fwd), or None when
     the integer path does not apply to `dense` / `x` (then the caller runs GEMM and tail separately).  Bit-identical to
     that two-launch form: same integer contraction, same element arithmetic."""
-    if not options.INT8_LINEAR or not hasattr(dense, '_int8_plan') or (residual is not None and (
+    if not options.int8_active() or not hasattr(dense, '_int8_plan') or (residual is not None and (
             residual.dtype != torch.float32 or not _hip.on_device(residual))) or _needs_autograd(dense, layer_norm, x, residual):
         return None
     plan = dense._int8_plan(x, with_output_quantizer=False)
@@ -177,7 +187,7 @@ def linear_nonorm_quant(dense, layer_norm, x):
     if (isinstance(layer_norm, QuantNoNorm) and _hip.on_device(x) and x.dtype == torch.float32
             and dense.activation_function is None and layer_norm.activation_function is None
             and dense.activation_save_target is None and layer_norm.activation_save_target is None
-            and not _needs_autograd(dense, layer_norm, x)):
+            and not _needs_autograd(dense, layer_norm, x) and not _hooked(dense, layer_norm)):
         q1 = _fixed_per_tensor(dense._quant_a, dense.activation_quantizer)
         q3 = _fixed_per_tensor(layer_norm._quant_a, layer_norm.activation_quantizer)
         if 'no' not in (q1, q3):
@@ -201,11 +211,12 @@ def quantized_ffn(intermediate, dense, res_quantizer, layer_norm, x):
 
     from quantization.autoquant_utils import INT8_STATS, QuantNoNorm
     be = _hip.backend()
-    if (not options.INT8_LINEAR or not hasattr(be, 'ffn_i8_nonorm') or not isinstance(layer_norm, QuantNoNorm)
+    if (not options.int8_active() or not hasattr(be, 'ffn_i8_nonorm') or not isinstance(layer_norm, QuantNoNorm)
             or not hasattr(intermediate, '_int8_plan') or not hasattr(dense, '_int8_weight_side_ok')
             or not _hip.on_device(x) or x.dtype != torch.float32 or _needs_autograd(intermediate, dense, layer_norm, x)
             or dense.activation_function is not None or layer_norm.activation_function is not None
-            or layer_norm.activation_save_target is not None or not dense._int8_weight_side_ok()):
+            or layer_norm.activation_save_target is not None or not dense._int8_weight_side_ok()
+            or _hooked(intermediate, dense, res_quantizer, layer_norm)):
         return separate()
     K1, N1, N2 = intermediate.in_features, intermediate.out_features, dense.out_features
     if (K1, N1, N2) not in be.FFN_SHAPES or dense.in_features != N1 or (x.numel() // K1) % 32:
@@ -252,7 +263,7 @@ def scores_softmax_quant(scores_quantizer, probs_quantizer, scores, mask, denom)
                                and mask.shape[0] == scores.shape[0] and mask.shape[3] == Tk)
     if ('no' in (q1, q2) or not _hip.on_device(scores) or scores.dtype != torch.float32 or scores.dim() != 4
             or not ok_mask or Tk not in (32, 64, 128, 256, 512, 1024)
-            or (torch.is_grad_enabled() and scores.requires_grad)):
+            or (torch.is_grad_enabled() and scores.requires_grad) or _hooked(scores_quantizer, probs_quantizer)):
         s = scores_quantizer(scores) / denom
         if mask is not None:
             s = s + mask
@@ -285,7 +296,8 @@ def quantized_attention(query, key, value, mask, num_heads, scores_quantizer, pr
     carry their int8 grid indices, every quantizer involved is fixed, per-tensor (asymmetric <= 8 bit
     for Q, K, V and the probabilities), T a multiple of 64 up to 512 and d in (32, 64).  Returns None otherwise: the
     caller then runs the layered modules."""
-    if not options.INT8_LINEAR or query.dim() != 3 or not _hip.on_device(query):
+    if (not options.int8_active() or query.dim() != 3 or not _hip.on_device(query)
+            or _hooked(scores_quantizer, probs_quantizer, context_quantizer)):
         return None
     if torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad):
         return None
@@ -352,7 +364,9 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
     when any of that does not hold (run the layered modules then)."""
     from quantization.autoquant_utils import QuantLinear, _fixed_per_tensor_manager
     layers = (query, key, value)
-    if not options.INT8_LINEAR or x.dim() != 3 or not _hip.on_device(x) or x.dtype != torch.float32:
+    if (not options.int8_active() or x.dim() != 3 or not _hip.on_device(x) or x.dtype != torch.float32
+            or _hooked(query, key, value, scores_quantizer, probs_quantizer, context_quantizer,
+                       *(getattr(l, 'weight_quantizer', None) for l in layers))):
         return None
     if torch.is_grad_enabled() and (x.requires_grad or any(l.weight.requires_grad for l in layers)):
         return None

@@ -1,13 +1,22 @@
-"""Process-wide opt-in switches of the MI355X path (extensions beyond the reference's behaviour)."""
+"""Process-wide switches of the MI355X path (extensions beyond the reference's behaviour)."""
+import torch
 
-# Run eval-mode quantized Linears with fixed ranges as exact integer GEMMs on the i8 matrix cores with
-# bias / activation / output quantizer fused into the epilogue (tq_linear_i8_fwd); quantizers with a
-# fixed per-tensor range then also emit their int8 grid indices in the same launch so that the GEMM
-# can consume them directly.  Off by default: the default path reproduces the reference's fp32
-# simulation; the integer path evaluates the same numbers exactly and therefore differs from the
-# simulation by the simulation's own fp32 accumulation error (~1e-6 relative), which can move an
-# output that sits on a rounding boundary by one grid step.
-INT8_LINEAR = False
+# Run quantized Linears with fixed ranges as exact integer GEMMs on the i8 matrix cores with bias / activation / output
+# quantizer fused into the epilogue (tq_linear_i8_fwd); quantizers with a fixed per-tensor range then also emit their int8
+# grid indices in the same launch so that the GEMM can consume them directly, and the harness models run their fused
+# fixed-range tails / attention cores.
+#   'auto' (default): whenever autograd is off (torch.no_grad() / inference_mode) -- the fixed-range EVALUATION forward.
+#           Calibration (ranges not fixed: every plan declines), training and anything with forward hooks on the modules
+#           involved keep the layered route (one launch per quantizer around torch's fp32 GEMM, the reference's module chain).
+#   True:   also under autograd (QAT forward on the matrix cores, straight-through backward).
+#   False:  never -- the layered route everywhere.
+# Why 'auto' is the default (round 5, profiles/r05/int_vs_reference.json, tests/test_bert_e2e.py / test_mobilebert_e2e.py
+# `..._default_route_...`): against the REFERENCE's own outputs the integer route is as close as the layered GPU route --
+# the layered route's hipBLASLt GEMMs differ from the reference's CPU GEMMs by fp32 round-off just as the exact integer
+# contraction does, and through 12-24 quantized layers either difference is amplified the same way (BERT-base W8A8,
+# reference ranges installed: 24.53 % vs 24.56 % of the last layer's 786 432 outputs on the reference's grid point, mean
+# deviation 1.289 vs 1.291 steps) -- while it is deterministic, exact arithmetic and 3-4x faster (3.26 -> 0.84 ms).
+INT8_LINEAR = 'auto'
 
 # Integer Linears with a GELU: evaluate activation + output quantizer through a staircase table built on the device from
 # the quantizer's range (csrc/tq_stair.hip, one extra launch per range state) instead of the erf fit + exact quotient in
@@ -37,6 +46,24 @@ GRAPH_ADAROUND = True
 # (int8 weight indices, NoNorm parameters, stacked QKV operands, provenance records) sees a new key:
 # QuantizerBase.range_state_key() includes it.
 CACHE_EPOCH = 0
+
+
+def int8_active():
+    """Is the integer / fused fixed-range route on for the call being made right now?  (see INT8_LINEAR)"""
+    m = INT8_LINEAR
+    if m is True:
+        return True
+    if not m:
+        return False
+    return not torch.is_grad_enabled()
+
+
+def fuse_on(flag, module=None):
+    """Tri-state `fuse` switches of the harness models: True / False force it, None (default) follows INT8_LINEAR for
+    modules in eval mode."""
+    if flag is None:
+        return int8_active() and not (module is not None and module.training)
+    return bool(flag)
 
 
 def invalidate_derived_caches():

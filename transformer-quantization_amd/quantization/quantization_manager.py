@@ -230,7 +230,7 @@ class QuantizationManager(nn.Module):
         ~0.6 us of the ~7 us a launch-bound quantizer call costs on the host.  Anything out of the ordinary (hooks on
         this manager, global module hooks, the integer path, PEG range collection, an ineligible quantizer) takes
         `self(x)`."""
-        if (self.state is Qstates.fix_ranges and FAST_FIXED_FORWARD and not options.INT8_LINEAR
+        if (self.state is Qstates.fix_ranges and FAST_FIXED_FORWARD and (x.dtype is not torch.float32 or not options.int8_active())
                 and not (self._forward_hooks or self._forward_pre_hooks or _GLOBAL_FWD_HOOKS or _GLOBAL_FWD_PRE_HOOKS)):
             mods = self._modules
             est = mods.get('range_estimator')
@@ -327,12 +327,15 @@ class QuantizationManager(nn.Module):
         return plan
 
     def _fixed_forward(self, x, q):
-        if not options.INT8_LINEAR:
+        if not options.int8_active():
             y = self._fixed_fast(x, q) if FAST_FIXED_FORWARD else None
             return q(x) if y is None else y
         y = self._fixed_forward_with_indices(x)
         if y is None:
-            y = q(x)
+            # no index output for this tensor (bf16 / fp16 storage, > 8 bits, per-axis ranges, ...): the plain launch
+            y = self._fixed_fast(x, q) if FAST_FIXED_FORWARD else None
+            if y is None:
+                y = q(x)
         # provenance record: lets a consumer (the fused integer Linear, also under autograd in QAT) recover the
         # exact grid indices of this tensor from the quantizer that produced it (quantization/provenance.py);
         # only the integer fast paths consume it

@@ -116,7 +116,11 @@ def build_parser():
     g.add_argument('--seed', type=int, default=1000)
     g.add_argument('--device', default='cuda')
     g.add_argument('--fast-inference', action='store_true',
-                   help='Evaluate with the opt-in fused fixed-range paths (fused LN tails / attention, int8 MFMA Linears).')
+                   help='Force the fused fixed-range paths (fused LN tails / attention, int8 MFMA Linears) for the evaluation; '
+                        "they are the default already when eligible (quantization.options.INT8_LINEAR = 'auto').")
+    g.add_argument('--layered-inference', action='store_true',
+                   help="Evaluate through the layered module chain (one launch per quantizer around torch's fp32 GEMMs), "
+                        'the route calibration and training always take.')
     g.add_argument('--hip-graph', action='store_true',
                    help='Replay calibration batches 2..N and the evaluation forward as hipGraphs (quantization/graphs.py).')
     g.add_argument('--output-dir', default=None)
@@ -292,9 +296,18 @@ def run(config, args):
             os.makedirs(args.output_dir, exist_ok=True)
             torch.save(model.state_dict(), os.path.join(args.output_dir, 'state_dict_adaround.pth'))
 
+    route_before = (QResidualBlock.fuse, QSelfAttention.fuse, options.INT8_LINEAR)
+    if args.fast_inference and args.layered_inference:
+        raise SystemExit('--fast-inference and --layered-inference exclude each other')
     if args.fast_inference:
         QResidualBlock.fuse = QSelfAttention.fuse = True
         options.INT8_LINEAR = True
+    elif args.layered_inference:
+        QResidualBlock.fuse = QSelfAttention.fuse = False
+        options.INT8_LINEAR = False
+    report['inference_route'] = ('fused/integer (forced)' if args.fast_inference else
+                                 'layered (forced)' if args.layered_inference else
+                                 f'options.INT8_LINEAR = {options.INT8_LINEAR!r}')
     sig = noise = 0.0
     agree = total = 0
     with torch.no_grad():
@@ -320,7 +333,10 @@ def run(config, args):
                 noise += float(((ref - out).double() ** 2).sum())
                 agree += int((ref.argmax(-1) == out.argmax(-1)).sum())
                 total += ids.shape[0]
-        _, t = _timed(evaluate)
+        try:
+            _, t = _timed(evaluate)
+        finally:
+            QResidualBlock.fuse, QSelfAttention.fuse, options.INT8_LINEAR = route_before      # process-wide switches
     report['timings_s']['evaluation_incl_fp32_reference'] = t
     import math
     report['fidelity_vs_fp32'] = {'logit_sqnr_db': (10 * math.log10(sig / noise)) if noise > 0 else float('inf'),
