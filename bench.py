@@ -135,19 +135,45 @@ def cpu_baseline(budget_s=14.0):
 PMC_TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
+KERNEL_SOURCES = ('csrc/tq_fake_quant.hip', 'csrc/tq_device.h', 'csrc/tq_host.h')      # what tq::fq_tensor is built from
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the dominant kernel, as recorded in profiles/pmc_traffic.json by
+    scripts/summarize_profiles.py when the PMC passes were collected."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, 'transformer-quantization_amd', rel), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(n_elems):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes).
-    None when no PMC summary exists for this exact workload size."""
+    """(bytes, note): HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes).  The profile is REFUSED
+    (bytes = None, the note says why) when it was collected for another workload size, for another kernel symbol than the
+    one this run measures, or from kernel sources that differ from the ones the shipped library was built from."""
     path = PMC_TRAFFIC_JSON
     try:
         with open(path) as f:
             t = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, 'no committed PMC profile (profiles/pmc_traffic.json)'
     if t.get('workload_elems') != n_elems:
-        return None
-    return t.get('traffic_bytes_per_launch')
+        return None, 'committed PMC profile is for another workload size'
+    if 'tq::fq_tensor<1,' not in str(t.get('kernel', '')):
+        return None, 'committed PMC profile is for another kernel: ' + str(t.get('kernel'))[:80]
+    try:
+        now = kernel_source_hash()
+    except OSError:
+        now = None
+    if t.get('kernel_source_sha256') != now:
+        return None, ('STALE: committed PMC profile was collected from other kernel sources (%s..., now %s...) -- re-run '
+                      'scripts/profile_gpu.sh' % (str(t.get('kernel_source_sha256'))[:12], str(now)[:12]))
+    return t.get('traffic_bytes_per_launch'), (
+        'committed profile, NOT a counter of this run: bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc '
+        'passes of this same command, gfx950 FETCH_SIZE x2 correction), kernel symbol and source hash match the built library')
 
 
 def _cpu_model():
@@ -383,19 +409,25 @@ def calibration_model_block(device, rank, world, use_dist, wd):
         model.fix_ranges()
         # the calibrated model's fixed-range forward at the config shape (collective-free: configs[1]'s inference pass)
         wd.stage = 'calibration_model: fixed-range forward'
-        fx = {'per_rank_batch': [8, 128]}
-        fx_eager = _wall_ms(lambda: model(ids_weak), 20, 3, use_dist)
-        fx_graph = None
-        try:
-            with tq_dist.suspended():
-                gf = GraphedForward(model, ids_weak)
-            fx_graph = _wall_ms(lambda: gf(ids_weak), 30, 3, use_dist)
-            del gf
-        except Exception as e:       # noqa: BLE001
-            fx['hipgraph_error'] = repr(e)[:300]
-        fx_eager, fx_graph = _max_over_ranks([fx_eager, fx_graph if fx_graph is not None else -1.0], device, use_dist)
-        fx['eager_ms'] = round(fx_eager, 4)
-        fx['hipgraph_ms'] = round(fx_graph, 4) if fx_graph >= 0 else None
+        # (both evaluation routes: the layered module chain -- what calibration above ran -- and the product's default for a
+        # no-grad fixed-range forward, options.INT8_LINEAR = 'auto': exact-integer GEMMs + fused tails / attention core)
+        from harness.routes import Route
+        fx = {'per_rank_batch': [8, 128],
+              'default_route': "options.INT8_LINEAR = 'auto' -> integer / fused ('fused_*' keys); 'layered_*' = options.INT8_LINEAR = False"}
+        for tag, route in (('layered', 'layered'), ('fused', 'default')):
+            with Route(model, route):
+                e_ms = _wall_ms(lambda: model(ids_weak), 20, 3, use_dist)
+                g_ms = None
+                try:
+                    with tq_dist.suspended():
+                        gf = GraphedForward(model, ids_weak)
+                    g_ms = _wall_ms(lambda: gf(ids_weak), 30, 3, use_dist)
+                    del gf
+                except Exception as e:       # noqa: BLE001
+                    fx[tag + '_hipgraph_error'] = repr(e)[:300]
+            e_ms, g_ms = _max_over_ranks([e_ms, g_ms if g_ms is not None else -1.0], device, use_dist)
+            fx[tag + '_eager_ms'] = round(e_ms, 4)
+            fx[tag + '_hipgraph_ms'] = round(g_ms, 4) if g_ms >= 0 else None
         blk['fixed_range_forward'] = fx
     # ---- per-exchange latency on the transport in use, measured (not assumed) -------------------------------------------
     wd.stage = 'calibration_model: exchange latency'
@@ -649,10 +681,8 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4),
-            'traffic': pmc_traffic(n_elems),
-            'traffic_source': 'committed profile, NOT a counter of this run: bytes per launch from '
-                              'profiles/pmc_traffic.json (rocprofv3 --pmc passes of this same command, gfx950 '
-                              'FETCH_SIZE x2 correction); null if not collected for this workload size',
+            'traffic': pmc_traffic(n_elems)[0],
+            'traffic_source': pmc_traffic(n_elems)[1],
             'kernel': 'tq::fq_tensor<bf16>',
             'kernel_ms': round(ev_ms, 4),
             'algorithmic_bytes_per_launch': n_elems * BYTES_PER_ELEM,

@@ -101,11 +101,17 @@ def test_bert_base_w8a8_gpu():
 
     # ---- every site, on the tensor it actually saw: HIP kernel == CPU oracle, bit for bit --------
     seen = []
+    # the 13 sites of ONE encoder layer are compared as WHOLE tensors (attention scores / probabilities [8,12,128,128], the
+    # [8,128,3072] intermediate and the ten [8,128,768] sites: a tail bug would hide behind a slab); the first 256 rows
+    # of every other site
+    whole = {id(m) for n, m in act if n.startswith('layers.0.')}
+    assert len(whole) == 13
 
     def hook(mod, inp, out):
         x = inp[0]
-        sl = x.reshape(-1, x.shape[-1])[:256]                    # element-wise op: a slab suffices
-        seen.append((mod, sl.detach().cpu(), out.reshape(-1, out.shape[-1])[:256].detach().cpu(),
+        rows = x.shape[0] * x.numel() if id(mod) in whole else 256
+        sl = x.reshape(-1, x.shape[-1])[:rows]
+        seen.append((mod, sl.detach().cpu(), out.reshape(-1, out.shape[-1])[:rows].detach().cpu(),
                      float(x.min()), float(x.max())))
 
     handles = [m.register_forward_hook(hook) for _, m in act]
@@ -117,6 +123,7 @@ def test_bert_base_w8a8_gpu():
     for h in handles:
         h.remove()
     assert len(seen) == 161
+    assert sum(x.numel() for mod, x, _, _, _ in seen if id(mod) in whole) == 2 * 8 * 12 * 128 * 128 + 8 * 128 * (3072 + 10 * 768)
     for mod, x, y, xmin, xmax in seen:
         q = mod.quantizer
         assert float(mod.range_estimator.current_xmin) == xmin   # K4 == torch's own reduction
@@ -212,3 +219,70 @@ def test_bert_base_readme_recipe_gpu_weight_deltas_bit_exact():
     assert rel[:-1].max() <= 0.10 and np.median(rel) <= 0.01, (rel.max(), np.median(rel))
     lspan = float(z['logits'].max() - z['logits'].min())
     assert np.abs(logits.cpu().numpy() - z['logits']).max() <= 0.10 * lspan
+
+
+# ---------------------------------------------------------------------------------------------------
+# Which route is the default?    options.INT8_LINEAR = 'auto': with autograd off a fixed-range forward
+# runs the exact-integer / fused route.  Justified against the REFERENCE's outputs, not against the layered GPU route:
+# tests/golden/bert_base_w8a8_hidden.npz (make_golden_bert.py hidden) holds the reference's grid indices of the encoder
+# output after layers 1 / 6 / 12 (786 432 samples each) and its logits on four evaluation batches.
+@pytest.mark.gpu
+@pytest.mark.default_route
+def test_bert_base_default_route_is_the_integer_route_and_no_further_from_the_reference():
+    import os
+    from harness.routes import Route, compare_routes, install_reference_ranges
+    from quantization import options
+    from quantization.autoquant_utils import INT8_STATS
+    from tests.harness_bert import quantizer_census
+    assert options.INT8_LINEAR == 'auto'                           # the product default (tests/conftest.py keeps it for this test)
+    z = _fixture()
+    zh = np.load(os.path.join(GOLDEN, 'bert_base_w8a8_hidden.npz'))
+    model, hf = _build('cuda')
+    _check_weights_reproduced(hf, z)
+    ids = torch.from_numpy(z['input_ids'])
+    _calibrate_and_run(model, ids)                                 # calibration: layered route whatever the switch says
+    act, _ = quantizer_census(model)
+    report = {}
+    for leg in ('own_ranges', 'reference_ranges'):
+        if leg == 'reference_ranges':
+            install_reference_ranges([m for _, m in act], list(zip(z['act_min'], z['act_max'])))
+        report[leg] = r = compare_routes(model, ids, zh, (1, 6, 12), routes=('layered', 'integer', 'default'))
+        lay, itg, dfl = r['layered'], r['integer'], r['default']
+        print(leg, {k: {L: round(v['hidden'][L]['mean_abs_dev_steps'], 4) for L in v['hidden']} for k, v in r.items()},
+              {k: round(v['logits_4_batches']['mean_abs'], 5) for k, v in r.items()})
+        # the default IS the integer route, bit for bit, and it is not the layered one
+        assert torch.equal(dfl['logits'], itg['logits'])
+        assert not torch.equal(dfl['logits'], lay['logits'])
+        # distance to the reference: the integer route within 10 % of the layered route's on every hidden-state measure
+        # (measured, reference ranges: 0.00813 / 0.7001 / 1.2895 steps against 0.00808 / 0.6988 / 1.2913; own ranges
+        # 0.0116 / 0.8673 / 1.5242 against 0.0107 / 0.8672 / 1.5225) ...
+        for L in ('L1', 'L6', 'L12'):
+            a, b = itg['hidden'][L], lay['hidden'][L]
+            assert a['mean_abs_dev_steps'] <= 1.10 * b['mean_abs_dev_steps'] + 1e-3, (leg, L, a, b)
+            assert a['same_grid_point_frac'] >= b['same_grid_point_frac'] - 0.01, (leg, L, a, b)
+        # ... and on the 64 logits of four batches (a noisy statistic: mean within 25 %, same decisions)
+        assert itg['logits_4_batches']['mean_abs'] <= 1.25 * lay['logits_4_batches']['mean_abs'], (leg, itg, lay)
+        assert itg['logits_4_batches']['argmax_agree'] >= lay['logits_4_batches']['argmax_agree']
+    # what the routes agree on with the reference at all: the first layer (99 % of 786 432 outputs on the same grid point)
+    assert report['reference_ranges']['integer']['hidden']['L1']['same_grid_point_frac'] >= 0.98
+    # the default route really runs integer launches, stays off under autograd, and yields to observers
+    with torch.no_grad():
+        before = INT8_STATS['kernel_calls']
+        model(ids.cuda())
+        assert INT8_STATS['kernel_calls'] - before >= 12 * 3       # attention-output + 2 FFN Linears per layer (+ grouped QKV, not counted)
+        seen = []
+        site = model.layers[3].output.dense.activation_quantizer
+        h = site.register_forward_hook(lambda m, i, o: seen.append(1))
+        try:
+            model(ids.cuda())
+        finally:
+            h.remove()
+        assert seen, 'a forward hook on a quantizer site must keep that site on the layered route'
+    before = INT8_STATS['kernel_calls']
+    with torch.enable_grad():
+        model(ids.cuda())
+    assert INT8_STATS['kernel_calls'] == before                    # 'auto' = autograd off only
+    with Route(model, 'layered'), torch.no_grad():
+        before = INT8_STATS['kernel_calls']
+        model(ids.cuda())
+        assert INT8_STATS['kernel_calls'] == before

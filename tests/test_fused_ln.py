@@ -1,8 +1,11 @@
-"""(f2) fused residual-add -> quant -> LayerNorm -> quant.  LayerNorm statistics are fp32 sums whose
-order differs between any two implementations (torch CPU, torch GPU, this kernel), so outputs that sit
-within round-off of a rounding boundary of the LAST quantizer may land one grid step apart; the bar:
->= 99.9 % of elements bit-identical to the CPU oracle chain, all others exactly one step away, and the
-un-quantized LayerNorm output within 1e-5 relative."""
+"""(f2) fused residual-add -> quant -> LayerNorm -> quant.  Two statements:
+
+* EXACT: against the oracle chain whose LayerNorm sums its fp32 statistics in the kernel's order (oracle/ln_sum.py ->
+  oracle/tq_ln_oracle.c, one correctly rounded operation per step): every output equal, bit for bit.
+* TOLERANCE against the reference's own op: torch.nn.functional.layer_norm leaves the summation order to the backend
+  (torch CPU, torch GPU and this kernel all differ), so outputs that sit within round-off of a rounding boundary of the
+  LAST quantizer may land one grid step apart: >= 99.9 % of elements identical to the torch-CPU chain, all others exactly
+  one step away, and the un-quantized LayerNorm output within 1e-5 relative."""
 import numpy as np
 import pytest
 import torch
@@ -12,15 +15,54 @@ from oracle import tq_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_chain(a, r, q1, q2, w, b, eps, q3):
+def _oracle_chain(a, r, q1, q2, w, b, eps, q3, kernel_order=False):
     def q(v, p):
         if p is None:
             return v
         delta, zf, n_bits, sym, sgn = p
         return O.fake_quant(v, delta, zf, n_bits, sym, sgn)[1]
     u = q(q(a.float(), q1) + r.float(), q2)
-    v = torch.nn.functional.layer_norm(u, (u.shape[-1],), w, b, eps)
+    if kernel_order:
+        from oracle.ln_sum import layer_norm_kernel_order
+        v = layer_norm_kernel_order(u, w, b, eps, a.dtype)
+    else:
+        v = torch.nn.functional.layer_norm(u, (u.shape[-1],), w, b, eps)
     return q(v, q3), v
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('d', [768, 3072, 512, 128, 1024, 256, 2048])
+def test_fused_chain_equals_kernel_order_oracle(dtype, d):
+    """Bit for bit against the chain whose LayerNorm statistics follow the kernel's summation order (every (lanes per row,
+    vectors per lane) instantiation of launch_res_ln is hit by one of these widths)."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(d + 7)
+    rows = 515                                               # not a multiple of the rows a block handles
+    a = (torch.randn(rows, d, generator=g) * 2).to(dtype)
+    r = (torch.randn(rows, d, generator=g) * 1.5).to(dtype)
+    r[:, 5] *= 12
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    b = 0.05 * torch.randn(d, generator=g)
+    d1, z1 = O.asym_params_from_range(-7.0, 7.5, 8)
+    d2, z2 = O.asym_params_from_range(-20.0, 22.0, 8)
+    d3, z3 = O.asym_params_from_range(-6.0, 11.0, 8)
+    dev = lambda t: t.cuda()
+    for use in ((1, 1, 1), (0, 1, 1), (1, 0, 0), (0, 0, 0), (1, 1, 0)):
+        q1 = (d1, z1, 8, False, False) if use[0] else None
+        q2 = (d2, z2, 8, False, False) if use[1] else None
+        q3 = (d3, z3, 8, False, False) if use[2] else None
+        ref, _ = _oracle_chain(a, r, q1, q2, w, b, 1e-12, q3, kernel_order=True)
+        k = lambda q: None if q is None else (dev(q[0]), dev(q[1]), None, 8, False, False, 1e-8)
+        out = be.residual_layernorm_quant(dev(a), dev(r), k(q1), k(q2), dev(w), dev(b), 1e-12, k(q3),
+                                          want_idx=q3 is not None and dtype == torch.float32)
+        y = (out[0] if isinstance(out, tuple) else out).cpu()
+        assert y.dtype == dtype
+        assert torch.equal(y, ref.to(dtype)), (use, float((y.float() - ref.to(dtype).float()).abs().max()),
+                                               float((y != ref.to(dtype)).float().mean()))
+        if isinstance(out, tuple):
+            ref_idx = O.fake_quant(_oracle_chain(a, r, q1, q2, w, b, 1e-12, None, kernel_order=True)[0], d3, z3, 8, False)[0]
+            assert torch.equal(out[1].cpu().float() + 128, ref_idx), use
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

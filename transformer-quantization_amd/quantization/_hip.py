@@ -268,6 +268,16 @@ def _device_guarded(fn):
                     idx = i
                 elif i != idx:
                     raise TQError(f'{fn.__name__}: operands live on different devices (cuda:{idx} and cuda:{i})')
+        if idx < 0:
+            # no top-level tensor operand: quantizer tuples (delta, zero_float, ...) carry the device (act_stair)
+            for a in args:
+                if isinstance(a, (tuple, list)):
+                    for b in a:
+                        if isinstance(b, _Tensor) and b.get_device() >= 0:
+                            idx = b.get_device()
+                            break
+                    if idx >= 0:
+                        break
         if idx < 0 or idx == _cur():
             return fn(self, *args, **kwargs)
         with torch.cuda.device(idx):

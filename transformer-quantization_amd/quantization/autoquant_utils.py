@@ -93,6 +93,44 @@ def prequantize_weights(model):
     return served
 
 
+def precalibrate_weights(model):
+    """Golden-section weight ranges of every layer below `model` in ONE lock-step search
+    (`range_estimators.golden_section_lockstep`) instead of one scipy search -- with a host round trip per loss
+    evaluation -- per layer on its first calibrating forward.  The README's standard recipe (reference README.md:149-157:
+    `--weight-quant-method MSE --weight-opt-method golden_section`) runs 102 such searches of ~35 evaluations each on a
+    BERT-base; the weights do not depend on the data, so the searches are independent and advance together: ~35 rounds of
+    102 queued launches and one device->host copy each.  Every estimator keeps the thresholds and a memo of the tensor they
+    were found for; the calibrating forward that follows (`pass_data_for_range_estimation`) finds them there and
+    launches nothing for the search.  Same scipy calls on the same fp32 loss values: `_delta` is bit-identical
+    (tests/test_bert_e2e.py::test_bert_base_readme_recipe_*).  Layers that do not qualify (other estimators, per-channel
+    ranges, weights not quantized, not in an estimating state, sharded calibration) keep the lazy path.
+    -> {'searches', 'rounds', 'evaluations'}"""
+    from quantization.range_estimators import golden_section_lockstep, lockstep_eligible
+    jobs, devices = [], set()
+    for m in model.modules():
+        if not isinstance(m, QuantizationHijacker) or not m._quant_w:
+            continue
+        mgr = m._modules.get('weight_quantizer')
+        if not isinstance(mgr, QuantizationManager) or not mgr._estimating() or _hooked(mgr, mgr.range_estimator):
+            continue
+        weight, _ = m.get_weight_bias()
+        if torch.is_tensor(weight) and lockstep_eligible(mgr.range_estimator, weight):
+            jobs.append((mgr.range_estimator, weight))
+            devices.add(weight.device)
+    if len(jobs) < 2 or len(devices) != 1:
+        return {'searches': 0, 'rounds': 0, 'evaluations': 0}
+    with torch.cuda.device(next(iter(devices))) if next(iter(devices)).type == 'cuda' else _null():
+        return golden_section_lockstep(jobs)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def int8_stair_status(model):
     """{QuantLinear name: {n_bins: table accepted by its builder?}} for every integer Linear below `model` that has built a
     GELU staircase table so far.  Reads the tables' headers (a host synchronisation): diagnostics, not the data path."""
@@ -221,7 +259,12 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
                 or not hasattr(be, 'act_stair')):
             return None
         n_bins = be.stair_bins_for(rows, self.out_features) if hasattr(be, 'stair_bins_for') else None
-        key = self.activation_quantizer.quantizer.range_state_key()
+        oq = self.activation_quantizer.quantizer
+        # the table bakes in delta, zero_float, the grid ends and eps: every one of them is part of the key (an in-place
+        # `zero_float.fill_()` moves neither `_range_gen` nor `_delta._version`)
+        zf, sg = oq._buffers.get('_zero_float'), oq._buffers.get('_signed')
+        key = (oq.range_state_key(), None if zf is None else zf._version, None if sg is None else sg._version, oq.eps,
+               oq.symmetric)
         if self._int8_stair is None:
             self._int8_stair = {}
         cached = self._int8_stair.get(n_bins)           # one table per bin count (two call shapes may alternate)

@@ -24,6 +24,15 @@ INT8_LINEAR = 'auto'
 # arithmetic epilogue stays in place for grids the table cannot hold (decided on the device).
 INT8_ACT_STAIR = True
 
+# README recipe (MSE / golden-section weight ranges): run the searches of all weight tensors in lock step before the first
+# calibrating forward (autoquant_utils.precalibrate_weights: one scipy instance per tensor in its own thread, one queue of
+# launches and ONE device->host copy per round instead of one per loss evaluation; bit-identical thresholds).  OFF by
+# default because it is SLOWER on one MI355X (measured, tests/test_lockstep.py, BERT-base: 102 searches, 2 096 evaluations:
+# layer by layer 150-153 ms = 73 us per evaluation incl. its host round trip; lock step 249-271 ms in 26 rounds): the
+# sequential path is kernel-bound, not sync-bound, and waking 102 Python threads per round costs more than the ~2 000
+# synchronisations it saves.  Kept for hosts where a device->host round trip is expensive (remote / virtualised GPUs).
+LOCKSTEP_WEIGHT_SEARCH = False
+
 # Estimator state (current_xmin / current_xmax) and quantizer parameters (_delta / _zero_float / _signed)
 # are rebound to FRESH tensors on every calibrating forward, like the reference does.  With this switch
 # the fused calibration step updates the existing buffers IN PLACE once they exist (same values, same

@@ -159,6 +159,8 @@ def _percentile_rows(rows, q):
     fp32 by ``torch.Tensor(...)`` -- bit-identical to numpy on the same values.  (A -0.0 / +0.0 tie may come out with
     the other sign than numpy's sort would leave at that position; the values compare equal.)"""
     rows = rows.detach()
+    if rows.dtype == torch.float64:
+        rows = rows.float()          # --double: the selection kernel is fp32 (the round-3 sort path cast the same way)
     n = rows.shape[-1]
     plan = []
     for p in q:

@@ -81,12 +81,14 @@ def agree(store, key, rank, world, ok, message='', timeout_s=None):
 class RawRcclComm:
     """One RCCL communicator over all ranks of the job, bound to this process's current device.
 
-    Bring-up is a two-phase commit over the rendezvous store (`agree`), so that a failure on ONE rank can never leave the
-    ranks on different transports or blocked inside ncclCommInitRank:
+    Bring-up is a two-phase commit over the rendezvous store (`agree`), so that a LOCAL failure on one rank (library
+    missing, bad id, device error) never leaves the ranks on different transports or some of them blocked inside
+    ncclCommInitRank.  (A rank that dies inside ncclCommInitRank itself still leaves its peers to RCCL's own timeout.)
 
     1. *prepare* (local, no peer involved): bind librccl (`tq_comm_load`), rank 0 makes the unique id.  Every rank then
        publishes ok / failed and reads everybody's verdict; unless all are ok, all ranks raise `RawSetupFailed` -- nobody
-       has entered a collective call yet.
+       has entered a collective call yet.  1b: every rank fetches the id, checks its length and drains its device, and a
+       second round agrees on THAT: phase 2 then contains nothing that can fail locally before the collective.
     2. *commit*: `ncclCommInitRank` on every rank, the communicator's own rank / size are compared with the job's, and
        a second round agrees the outcome; on any failure every rank that holds a communicator aborts it
        (`tq_comm_abort`, which does not wait for peers) and all raise `RawSetupFailed`.
@@ -133,15 +135,27 @@ class RawRcclComm:
         if failed:
             raise RawSetupFailed('prepare', failed) from err
 
-        # ---- phase 2: commit (collective) ---------------------------------------------------------------------------
+        # ---- phase 1b: everything else that can fail LOCALLY (id fetch and length, draining the device) ------------------
+        # agreed on separately so that phase 2 holds nothing but the collective: a rank that fails here has not entered
+        # ncclCommInitRank, and no peer enters it before every rank has reported
+        buf = None
         try:
             raw = uid if self.rank == 0 else bytes(store.get(key + '/uid'))
             if len(raw) != nb:
                 raise _hip.TQError(f'ncclUniqueId of {len(raw)} bytes, expected {nb}')
             buf = (C.c_ubyte * nb).from_buffer_copy(raw)
-            comm = C.c_void_p()
             if self.device.type == 'cuda':
                 torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001
+            err = e
+        failed = agree(store, key + '/fetched', self.rank, self.world, err is None, repr(err) if err else '', agree_timeout_s)
+        if failed:
+            raise RawSetupFailed('prepare', failed) from err
+
+        # ---- phase 2: commit (collective) ---------------------------------------------------------------------------
+        # (a rank that dies INSIDE ncclCommInitRank still leaves its peers to RCCL's own timeout: nothing a caller can do)
+        try:
+            comm = C.c_void_p()
             _hip._check(self.lib.tq_comm_init(buf, self.rank, self.world, C.byref(comm)), self.lib)
             self.handle = comm.value
             got = self.rank_world()

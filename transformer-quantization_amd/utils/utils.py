@@ -65,6 +65,12 @@ def pass_data_for_range_estimation(loader, model, act_quant, weight_quant, max_n
         _install_cross_entropy_estimator(model, cross_entropy_layer)
 
     device = next(model.parameters()).device
+    from quantization import options
+    if weight_quant and options.LOCKSTEP_WEIGHT_SEARCH:
+        # weight ranges do not depend on the data: the golden-section searches of all layers (README recipe) in lock step
+        from quantization.autoquant_utils import precalibrate_weights
+        with torch.no_grad():
+            precalibrate_weights(model)
     for i, data in enumerate(loader):
         try:
             if isinstance(data, (tuple, list)):
