@@ -25,6 +25,34 @@ from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
 dev = 'cuda'
 out = {}
 
+# The stages below switch the fast paths on ONE BY ONE, starting from the layered route: pin every switch to "off" first
+# (the product default is options.INT8_LINEAR = 'auto' with the harness models' `fuse` switches following it; the default
+# route is timed at the end of each whole-model block as `fixed_range_forward_default_route_*`).
+from harness import bert as _hb, mobilebert as _hm
+from quantization import options
+options.INT8_LINEAR = False
+_SWITCHES = [(_hb.QSelfAttention, 'fuse'), (_hb.QResidualBlock, 'fuse'), (_hb.QLayer, 'fuse_ffn'), (_hm.QBottleneckLayer, 'fuse'),
+             (_hm.QMobileSelfAttention, 'fuse'), (_hm.QResidualNoNorm, 'fuse'), (_hm.QFFN, 'fuse'), (_hm.QMobileLayer, 'fuse_ffn')]
+for _c, _a in _SWITCHES:
+    setattr(_c, _a, False)
+
+
+def default_route_ms(model, ids, c):
+    """hipGraph time of the product's default fixed-range forward (options.INT8_LINEAR = 'auto', fuse = None)."""
+    from harness.routes import Route
+    with Route(model, 'default'):
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                model(ids)
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            model(ids)
+        c['fixed_range_forward_default_route_hipgraph_ms'] = wall(lambda: g.replay(), n=30)
+        c['fixed_range_forward_default_route_eager_ms'] = wall(lambda: model(ids), n=20)
+
 
 def wall(fn, n=10, w=2):
     for _ in range(w):
@@ -108,11 +136,51 @@ with torch.no_grad():
     QResidualBlock.fuse = QSelfAttention.fuse = False
     options.INT8_LINEAR = False
     c['logit_span'] = float(o.max() - o.min())
+    default_route_ms(model, ids, c)
 c['activation_elems_per_forward'] = 172234768
 c['reference_cpu_8thr_ms'] = {'fp32': 239, 'fixed_range': 368, 'calibrating': 5100,
                               'source': 'BASELINE.md section 2 (survey container, 8 vCPU)'}
 out['config0_1_bert_base_w8a8_b8_t128'] = c
 del model, hf
+
+# ---- configs[0] README recipe: the 102 golden-section weight searches, layer by layer vs in lock step ----
+from harness.bert import build_bert_base
+from quantization.autoquant_utils import precalibrate_weights
+from quantization.hijacker import QuantizationHijacker
+rm_, _ = build_bert_base(seed=1000, method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8,
+                         n_bits_act=8, weight_range_method=RangeEstimators.MSE,
+                         weight_range_options=dict(opt_method=OptMethod.golden_section),
+                         act_range_method=RangeEstimators.current_minmax)
+rm_ = rm_.to(dev).eval()
+rm_.set_quant_state(True, True)
+mods_ = [(m.weight_quantizer, m.weight) for m in rm_.modules() if isinstance(m, QuantizationHijacker)]
+c = {'weight_tensors': len(mods_)}
+with torch.no_grad():
+    for rep in range(2):
+        for mg, _ in mods_:
+            mg.range_estimator.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for mg, w_ in mods_:
+            mg.range_estimator(w_)
+        torch.cuda.synchronize()
+        c['layer_by_layer_ms'] = (time.perf_counter() - t0) * 1e3
+    seq_ = [(mg.range_estimator.current_xmin.clone(), mg.range_estimator.current_xmax.clone()) for mg, _ in mods_]
+    for mg, _ in mods_:
+        mg.range_estimator.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st_ = precalibrate_weights(rm_)
+    torch.cuda.synchronize()
+    c['lock_step_ms'] = (time.perf_counter() - t0) * 1e3
+    c['lock_step'] = st_
+    c['same_ranges'] = all(torch.equal(mg.range_estimator.current_xmin, a) and torch.equal(mg.range_estimator.current_xmax, b)
+                           for (mg, _), (a, b) in zip(mods_, seq_))
+    c['us_per_evaluation_layer_by_layer'] = c['layer_by_layer_ms'] * 1e3 / max(st_['evaluations'], 1)
+    c['note'] = ('lock step (options.LOCKSTEP_WEIGHT_SEARCH) is off by default: the sequential path is kernel-bound, not '
+                 'sync-bound, and 102 thread wake-ups per round cost more than the host round trips they save')
+out['config0_readme_recipe_weight_calibration'] = c
+del rm_, mods_
 
 # ---- config 2: per-tensor running min/max, [8,128,768] and [1024,512,768] --------------------------
 c = {}
@@ -135,11 +203,16 @@ out['config2_per_tensor_running_minmax'] = c
 c = {}
 for shape in ((8, 128), (256, 512)):
     x = hidden(*shape)
-    for layout in ('per_embd', 'ng6', 'ngp6'):
+    for layout in ('per_embd', 'ng6', 'ngp6', 'per_token'):
         mgr = QuantizationManager(qmethod=QMethods.asymmetric_uniform, init=RangeEstimators.current_minmax,
                                   qparams=dict(n_bits=8))
-        set_act_quant_axis_and_groups(mgr, axis=2, n_groups=None if layout == 'per_embd' else 6,
-                                      permute=layout == 'ngp6')
+        if layout == 'per_token':
+            # `--per-token` (axis = 1; reference main.py:359-376); its estimate_plus_quantize time is the per-call cost of
+            # `--dynamic` mode, where the ranges follow every inference batch
+            set_act_quant_axis_and_groups(mgr, axis=1, n_groups=None)
+        else:
+            set_act_quant_axis_and_groups(mgr, axis=2, n_groups=None if layout == 'per_embd' else 6,
+                                          permute=layout == 'ngp6')
         if layout == 'ngp6':
             mgr(x)
             mgr.range_estimator.per_group_range_estimation = False
@@ -316,6 +389,7 @@ with torch.no_grad():
     QMobileSelfAttention.fuse = False
     options.INT8_LINEAR = False
     QResidualNoNorm.fuse = False
+    default_route_ms(mb, ids_mb, c)
     # how far the integer evaluation moves the W4A4 network from the fp32 simulation (the reference's contract), per
     # encoder layer: output-index flip rate on the SAME input and free-running (harness/divergence.py)
     from harness.divergence import encoder_flip_rates

@@ -33,11 +33,20 @@ def _pin_the_route_under_test(request):
     module chain against the oracle / the reference fixtures, or the integer route (switched on explicitly) against the
     integer oracle -- so each test starts from the layered route (False) and the tests of the DEFAULT are marked
     `default_route`.  The switch is restored after every test whatever it did."""
+    from harness import bert, mobilebert
     from quantization import options
+    switches = [(bert.QSelfAttention, 'fuse'), (bert.QResidualBlock, 'fuse'), (bert.QLayer, 'fuse_ffn'),
+                (mobilebert.QBottleneckLayer, 'fuse'), (mobilebert.QMobileSelfAttention, 'fuse'),
+                (mobilebert.QResidualNoNorm, 'fuse'), (mobilebert.QFFN, 'fuse'), (mobilebert.QMobileLayer, 'fuse_ffn')]
     before = options.INT8_LINEAR
-    options.INT8_LINEAR = 'auto' if request.node.get_closest_marker('default_route') else False
+    default = request.node.get_closest_marker('default_route') is not None
+    options.INT8_LINEAR = 'auto' if default else False
+    for cls, attr in switches:
+        setattr(cls, attr, None if default else False)      # the harness models' tri-state switches (None: follow the option)
     yield
     options.INT8_LINEAR = before
+    for cls, attr in switches:
+        setattr(cls, attr, None)
 
 
 def _has_gpu():

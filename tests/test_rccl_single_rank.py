@@ -113,7 +113,7 @@ def test_bench_distributed_control_flow_over_rccl():
     assert 'raw RCCL' in cm['transport'], cm
     for leg in ('weak', 'strong'):
         assert cm[leg]['collectives_per_forward'] == 161 and cm[leg]['eager_ms'] > 0 and cm[leg]['hipgraph_ms'] > 0, cm[leg]
-    assert cm['strong']['per_rank_batch'] == [128, 128] and cm['fixed_range_forward']['hipgraph_ms'] > 0
+    assert cm['strong']['per_rank_batch'] == [128, 128] and cm['fixed_range_forward']['fused_hipgraph_ms'] > 0 and cm['fixed_range_forward']['layered_hipgraph_ms'] > 0
     assert set(cm['exchange_latency_us']) == {'8B', '6KB', '103KB', '9.4MB'} and all(v > 0 for v in cm['exchange_latency_us'].values())
     assert out['adaround_dp']['gradient_allreduce_bytes'] == 3072 * 768 * 4 and out['adaround_dp']['ms_per_iter'] > 0
     q = out['qat_dp']

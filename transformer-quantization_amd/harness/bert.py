@@ -66,7 +66,8 @@ class QSelfAttention(QuantizedModel):
     fuse = None    # set True: scores-quant -> scale -> mask -> softmax -> probs-quant as one kernel
 
     def forward(self, h, mask):
-        if options.fuse_on(self.fuse, self):
+        fused = options.fuse_on(self.fuse, self, self.attn_probs_act_quantizer)
+        if fused:
             from quantization.fused import quantized_self_attention
             ctx = quantized_self_attention(h, self.query, self.key, self.value, mask, self.heads,
                                            self.attn_scores_act_quantizer, self.attn_probs_act_quantizer,
@@ -74,7 +75,7 @@ class QSelfAttention(QuantizedModel):
             if ctx is not None:                  # stacked QKV projection + attention core: 2 integer kernels
                 return ctx
         qo, ko, vo = self.query(h), self.key(h), self.value(h)
-        if options.fuse_on(self.fuse, self):
+        if fused:
             from quantization.fused import quantized_attention
             ctx = quantized_attention(qo, ko, vo, mask, self.heads, self.attn_scores_act_quantizer,
                                       self.attn_probs_act_quantizer, self.context_act_quantizer)
@@ -82,7 +83,7 @@ class QSelfAttention(QuantizedModel):
                 return ctx
         q, k, v = self._split(qo), self._split(ko), self._split(vo)
         raw = torch.matmul(q, k.transpose(-1, -2))
-        if options.fuse_on(self.fuse, self):
+        if fused:
             from quantization.fused import scores_softmax_quant
             probs = scores_softmax_quant(self.attn_scores_act_quantizer, self.attn_probs_act_quantizer, raw,
                                          mask, math.sqrt(self.head_dim))
@@ -109,7 +110,7 @@ class QResidualBlock(QuantizedModel):
     fuse = None    # set True to run the fixed-range tail as one kernel (quantization/fused.py)
 
     def forward(self, h, residual):
-        if options.fuse_on(self.fuse, self):
+        if options.fuse_on(self.fuse, self, self.res_act_quantizer):
             from quantization.fused import residual_layernorm_quant
             return residual_layernorm_quant(self.dense, self.res_act_quantizer, self.LayerNorm, h, residual)
         return self.LayerNorm(self.res_act_quantizer(self.dense(h) + residual))
@@ -128,7 +129,7 @@ class QLayer(QuantizedModel):
 
     def forward(self, h, mask):
         a = self.attention_output(self.attention_self(h, mask), h)
-        if options.fuse_on(self.fuse_ffn, self):
+        if options.fuse_on(self.fuse_ffn, self, self.output.res_act_quantizer):
             from quantization.fused import quantized_bert_ffn
             out = self.output
             return quantized_bert_ffn(self.intermediate[0], out.dense, out.res_act_quantizer, out.LayerNorm, a, a)

@@ -88,7 +88,7 @@ class QBottleneckLayer(QuantizedModel):
     fuse = None    # set True: dense + NoNorm + both quantizers as one integer launch (quantization/fused.py)
 
     def forward(self, h):
-        if options.fuse_on(self.fuse, self):
+        if options.fuse_on(self.fuse, self, self.LayerNorm):
             from quantization.fused import linear_nonorm_quant
             return linear_nonorm_quant(self.dense, self.LayerNorm, h)
         return self.LayerNorm(self.dense(h))
@@ -124,7 +124,7 @@ class QMobileSelfAttention(QuantizedModel):
 
     def forward(self, q_in, k_in, v_in, mask):
         qo, ko, vo = self.query(q_in), self.key(k_in), self.value(v_in)
-        if options.fuse_on(self.fuse, self):
+        if options.fuse_on(self.fuse, self, self.attn_probs_act_quantizer):
             # Q K^T -> quantizer -> / sqrt(d) + mask -> softmax -> quantizer -> P V -> quantizer (per-tensor, so "per head
             # before the merge" and "after the merge" coincide) on the i8 matrix cores; None = layered modules
             from quantization.fused import quantized_attention
@@ -157,7 +157,7 @@ class QResidualNoNorm(QuantizedModel):
         self.LayerNorm = QuantNoNorm(hf.LayerNorm, **qp)
 
     def forward(self, h, residual):
-        if options.fuse_on(self.fuse, self):
+        if options.fuse_on(self.fuse, self, self.LayerNorm):
             from quantization.fused import residual_layernorm_quant
             return residual_layernorm_quant(self.dense, self.res_act_quantizer, self.LayerNorm, h, residual)
         return self.LayerNorm(self.res_act_quantizer(self.dense(h) + residual))
@@ -173,7 +173,7 @@ class QFFN(QuantizedModel):
     fuse = None    # set True: intermediate + output + NoNorm tail as one integer launch (quantization/fused.py quantized_ffn)
 
     def forward(self, h):
-        if options.fuse_on(self.fuse, self):
+        if options.fuse_on(self.fuse, self, self.output.LayerNorm):
             return _ffn(self.intermediate, self.output, h)
         return self.output(self.intermediate(h), h)
 
@@ -206,7 +206,7 @@ class QMobileLayer(QuantizedModel):
         a = self.attention_output(self.attention_self(shared, shared, h, mask), layer_input)
         for f in self.ffn:
             a = f(a)
-        o = _ffn(self.intermediate, self.output, a) if options.fuse_on(self.fuse_ffn, self) else self.output(self.intermediate(a), a)
+        o = _ffn(self.intermediate, self.output, a) if options.fuse_on(self.fuse_ffn, self, self.output.LayerNorm) else self.output(self.intermediate(a), a)
         return self.output_bottleneck(o, h)                       # back to 512, residual = the layer's input
 
 
