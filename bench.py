@@ -17,7 +17,7 @@ in the fixed-range forward).  The calibration phase before the timed region DOES
 fused MAX all-reduce of [-min; max] per quantizer call; its throughput at N ranks is reported under
 "calibration" (the north-star's 1/2/4/8-GPU calibration throughput).
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json

@@ -106,7 +106,8 @@ def fam_fq():
             patterns=['mm_rows_wave', 'fq_rows_wave'], note='tq_calibrate_minmax: 4 launches')
         run('dyn', f'dynamic per-tensor estimate+quantize {name} [1024,512,768]', None, lambda: be.calibrate_minmax(
             x, 1, 1, _hip.EST_CURRENT, None, None, 0.9, 0, None, 8, False, 1e-8, False), 3 * es * n, 'hbm',
-            patterns=['calib_partials_k', 'fq_tensor_calib'], note='tq_calibrate_tensor: 2 launches')
+            patterns=[f'mm_rows<{code}', f'fq_tensor<{code}, false, true'],
+            note='tq_calibrate_minmax with one range: statistics, update, quantize (the same kernels as the K4 / K1 rows)')
 
 
 def fam_tails():

@@ -68,8 +68,12 @@ def test_flag_cross_checks_match_the_reference():
     ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--num-est-batches', '2', '--double'],
     ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--per-embd', '--double',
      '--weight-quant-method', 'MSE', '--weight-opt-method', 'golden_section', '--act-quant-method', 'current_minmax'],
+    # `--per-token` (axis = 1 on every [B, T, d] site, reference main.py:359-376) implies `--dynamic` (main.py:249: no range
+    # estimation pass, ranges follow every batch): estimate + quantize on every inference call (mm_rows_wave / fq_rows_wave)
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--per-token', '--act-quant-method',
+     'current_minmax'],
 ], ids=['w8a8', 'peg6-permute-fp-logits', 'per-embd-mixed-precision', 'w4a8-adaround', 'w4a8-adaround-all-layers',
-        'w8a8-double', 'per-embd-mse-double'])
+        'w8a8-double', 'per-embd-mse-double', 'per-token-dynamic'])
 def test_end_to_end_on_two_layers(flags, tmp_path, capsys):
     layers = '1' if 'all' in flags else '2'      # 'all' also walks embeddings (incl. the [1, T] position ids) and LayerNorms
     rep = V.main(flags + ['--num-layers', layers, '--num-eval-batches', '2', '--output-dir', str(tmp_path)])
@@ -82,6 +86,10 @@ def test_end_to_end_on_two_layers(flags, tmp_path, capsys):
         assert f['logit_sqnr_db'] > 3.0
         assert all(v.dtype == torch.float64 for k, v in sd.items() if k.endswith('activation_quantizer.quantizer._delta'))
     assert any(k.endswith('activation_quantizer.quantizer._delta') for k in sd)
+    if '--per-token' in flags:
+        assert rep['timings_s'].get('range_estimation') is None            # dynamic: no calibration pass
+        per_token = [v for k, v in sd.items() if k.endswith('res_act_quantizer.activation_quantizer.quantizer._delta')]
+        assert per_token and all(v.numel() == 128 for v in per_token)        # one range per token position
     assert any(k.endswith('weight_quantizer.range_estimator.quantizer._delta') for k in sd)
     if '--adaround' in flags:
         sda = torch.load(os.path.join(tmp_path, 'state_dict_adaround.pth'))

@@ -1,4 +1,4 @@
-// Do i8 MFMAs and VALU work share a SIMD's time?  (lab note for DESIGN.md section 8, integer GEMM)
+// Do i8 MFMAs and VALU work share a SIMD's time?  (lab note for docs/history/DESIGN_rounds_1-4.md section 8, integer GEMM)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/tuning/mfma_valu_overlap.hip -o tools/tuning/mfma_valu_overlap
 // Round 4's first probe (i8_v4.hip: overlap_probe) found MFMA waves + VALU waves exactly additive -- but its "VALU" loop
 // had been SLP-packed by hipcc into v_pk_fma_f32, which the microarchitecture guide lists as an anti-lever beside MFMAs.

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(kBlock) void linear_i8_k(LinArgs p) {
 // 4 x 16 lane grouping (rows of equal parity share a 256-byte bank row; the swizzle spreads the 8 of them over its
 // 8 chunk slots).  Double-buffered: the next slab's loads are in flight while the current slab's 2 * NI * MI MFMAs
 // run; one barrier per slab.  A 4-stage ring of 64-byte slabs with counted vmcnt waits was slower (tools/tuning/
-// i8_glds.hip: more barriers per MFMA).  What bounds the loop was measured in round 4 (tools/tuning/i8_v4.hip):
+// i8_glds.hip: more barriers per MFMA).  What bounds the loop was measured in round 4 (tools/tuning/i8_v4.hip, docs/history/DESIGN_rounds_1-4.md section 8):
 // the operand DMA path (~56 B/clk/CU through L1/TA, one 1 KB piece per ~150 cycles and wave) and the per-slab barrier,
 // NOT the LDS (ds_read_b128 peaks at 256 B/clk/CU and these fragment reads are conflict-free).  M, N % BT == 0, K % 128 == 0.
 // Wait for this wave's LDS-DMA loads explicitly before the barrier that publishes them.  hipcc usually puts an
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
   const uint32_t nk = p.K / 128;
 
   // One block per output tile.  (Round 3 tried persistent blocks working through runs of tiles -- parameters loaded
-  // once per run, no per-tile dispatch: +3 % for +50 VGPRs, dropped; see DESIGN.md 8 for what bounds the loop.)
+  // once per run, no per-tile dispatch: +3 % for +50 VGPRs, dropped; see docs/history/DESIGN_rounds_1-4.md section 8 for what bounds the loop.)
   {
     const uint32_t tile = blockIdx.x;
     const uint32_t n0 = (tile / tiles_m) * BT, m0 = (tile % tiles_m) * BT;

@@ -1,4 +1,4 @@
-// Activation + output quantizer of an integer Linear as a staircase table (round 4).
+// Activation + output quantizer of an integer Linear as a staircase table (round 4; docs/history/DESIGN_rounds_1-4.md section 3.4).
 //
 // The fused Linear + GELU + quantizer epilogue (reference hijacker.py:66-116 behind autoquant_utils.py:16-21: F.linear ->
 // nn.GELU() -> activation quantizer) spent ~18 VALU instructions (most of them packed, i.e. double-cost) per output on the

@@ -230,12 +230,18 @@ class QuantizationManager(nn.Module):
         ~0.6 us of the ~7 us a launch-bound quantizer call costs on the host.  Anything out of the ordinary (hooks on
         this manager, global module hooks, the integer path, PEG range collection, an ineligible quantizer) takes
         `self(x)`."""
-        if (self.state is Qstates.fix_ranges and FAST_FIXED_FORWARD and (x.dtype is not torch.float32 or not options.int8_active())
+        if (self.state is Qstates.fix_ranges and FAST_FIXED_FORWARD
                 and not (self._forward_hooks or self._forward_pre_hooks or _GLOBAL_FWD_HOOKS or _GLOBAL_FWD_PRE_HOOKS)):
             mods = self._modules
             est = mods.get('range_estimator')
             if est is None or not est.per_group_range_estimation:
-                y = self._fixed_fast(x, mods['quantizer'])
+                q = mods['quantizer']
+                if x.dtype is not torch.float32 or not options.int8_active():
+                    y = self._fixed_fast(x, q)
+                elif type(q) is AsymmetricUniformQuantizer and q.n_bits <= 8 and q.scale_domain == 'linear':
+                    y = self._fixed_fast(x, q, with_idx=True)      # integer route: y and its int8 indices, tagged
+                else:
+                    y = None
                 if y is not None:
                     return y
         return self(x)
@@ -266,7 +272,7 @@ class QuantizationManager(nn.Module):
         state['_fast_plan'] = None
         return state
 
-    def _fixed_fast(self, x, q):
+    def _fixed_fast(self, x, q, with_idx=False):
         """Fixed per-tensor range, plain ROCm tensor, no autograd: torch.empty_like + one foreign call.  Bit-identical to
         q(x) -- it IS the same entry point with the same descriptor, minus the Python of the generic route (module
         dispatch, argument marshalling, layout checks) per call.  Returns None whenever anything is out of the ordinary
@@ -298,12 +304,21 @@ class QuantizationManager(nn.Module):
             return None
         y = torch.empty_like(x)
         ref = plan[10]
+        if with_idx:
+            # the integer route's producers: the same launch also writes int8(index - 128) for the consuming integer GEMM
+            # (fp32 tensors on <= 8-bit asymmetric linear-domain grids only: the caller checked)
+            idx = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+            ip, it = idx.data_ptr(), _hip.IDX_I8_M128
+        else:
+            idx, ip, it = None, 0, 0
         if type(ref) is tuple:          # CPython stub (csrc_py/tq_fastcall.c): (entry address, descriptor address)
-            rc = call(ref[0], x.data_ptr(), y.data_ptr(), 0, 0, x.numel(), _FAST_DTYPES[x.dtype], ref[1], _raw_stream(dev))
+            rc = call(ref[0], x.data_ptr(), y.data_ptr(), ip, it, x.numel(), _FAST_DTYPES[x.dtype], ref[1], _raw_stream(dev))
         else:                           # ctypes: the same entry point, marshalled
-            rc = call(x.data_ptr(), y.data_ptr(), None, 0, x.numel(), _FAST_DTYPES[x.dtype], ref, _raw_stream(dev))
+            rc = call(x.data_ptr(), y.data_ptr(), ip or None, it, x.numel(), _FAST_DTYPES[x.dtype], ref, _raw_stream(dev))
         if rc != 0:
             _hip._check(rc, plan[12])
+        if with_idx:
+            provenance.tag(y, q, idx)
         return y
 
     def _make_fast_plan(self, q):
@@ -330,7 +345,15 @@ class QuantizationManager(nn.Module):
         if not options.int8_active():
             y = self._fixed_fast(x, q) if FAST_FIXED_FORWARD else None
             return q(x) if y is None else y
-        y = self._fixed_forward_with_indices(x)
+        y = None
+        wants_idx = (type(q) is AsymmetricUniformQuantizer and q.n_bits <= 8 and x.dtype is torch.float32
+                     and q.scale_domain == 'linear')
+        if wants_idx and FAST_FIXED_FORWARD:
+            y = self._fixed_fast(x, q, with_idx=True)      # launch plan of the plain fixed-range call + the index pointer
+            if y is not None:
+                return y                                   # (tagged with its indices inside)
+        if wants_idx:
+            y = self._fixed_forward_with_indices(x)
         if y is None:
             # no index output for this tensor (bf16 / fp16 storage, > 8 bits, per-axis ranges, ...): the plain launch
             y = self._fixed_fast(x, q) if FAST_FIXED_FORWARD else None

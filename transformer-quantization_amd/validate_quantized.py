@@ -255,6 +255,10 @@ def run(config, args):
             pass_data_for_range_estimation(est[:1], model, config.quant.act_quant, config.quant.weight_quant, 1)
             missing = model.load_state_dict(torch.load(args.load_state_dict, map_location=dev), strict=False)
             report['load_state_dict'] = {'missing': list(missing.missing_keys), 'unexpected': list(missing.unexpected_keys)}
+        elif config.quant.dynamic:
+            # reference main.py:247-262: no range-estimation pass in dynamic mode -- every quantizer stays in its estimating
+            # state and follows the batch it is given (estimate + quantize on every call)
+            report['dynamic'] = True
         else:
             if config.quant.per_groups_permute or config.quant.per_groups_permute_shared_h:
                 _, t = _timed(lambda: estimate_permutation_ranges(model, est, config.quant.per_groups_permute_shared_h))
