@@ -147,3 +147,51 @@ def test_row_parameter_launch_shapes_vs_oracle(dtype, shape, axis):
     assert torch.equal(torch.isnan(mn2.cpu()), torch.isnan(rmn2)) and torch.equal(torch.isnan(mx2.cpu()), torch.isnan(rmx2))
     ok = ~torch.isnan(rmn2)
     assert torch.equal(mn2.cpu()[ok], rmn2[ok]) and torch.equal(mx2.cpu()[ok], rmx2[ok])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('init', ['current_minmax', 'running_minmax', 'allminmax'])
+@pytest.mark.parametrize('shape', [(8, 128, 768), (3, 40, 24), (2, 5, 8), (21, 16, 768), (8, 16, 3072)])
+def test_one_pass_dynamic_step_equals_the_separate_launches(dtype, init, shape):
+    """`tq_calibrate_minmax` runs row-parameter layouts whose per-parameter data fits in a block's registers as ONE launch
+    (calib_rows_onepass_k: statistics, estimator rule, parameters, quantization, one read of x).  Three batches through the
+    manager on the fused route against the layered route (tq_minmax -> tq_range_update -> tq_set_range_asym ->
+    tq_fake_quant_fwd): estimator state, parameters and outputs equal bit for bit after every batch -- incl. a NaN in one
+    token's rows (that token's range turns NaN, the others do not), shapes at both sides of the one-pass limit, and the
+    in-place state of options.INPLACE_CALIBRATION_STATE."""
+    from quantization import options, quantization_manager as qm
+    from quantization.quantization_manager import QuantizationManager
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+    if init == 'allminmax':
+        pytest.skip('AllMinMax ignores the axis upstream (quirk q5): per-tensor statistics, not this kernel')
+    xs = [torch.from_numpy(make_input(900 + i, shape, outlier_dims=(3, 5))).to(dtype).cuda() * (1 + 0.5 * i) for i in range(3)]
+    xs[2].view(-1)[shape[-1] * 2 + 1] = float('nan')               # row of token 2 (batch entry 0)
+
+    def run(fused, inplace):
+        prev, prev_inp = qm.FUSED_CALIBRATION, options.INPLACE_CALIBRATION_STATE
+        qm.FUSED_CALIBRATION, options.INPLACE_CALIBRATION_STATE = fused, inplace
+        try:
+            mgr = QuantizationManager(qmethod=QMethods.asymmetric_uniform, init=RangeEstimators[init], qparams=dict(n_bits=8))
+            set_act_quant_axis_and_groups(mgr, axis=1, n_groups=None)
+            out = []
+            for x in xs:
+                y = mgr(x)
+                out.append((y.clone(), mgr.range_estimator.current_xmin.clone().reshape(-1), mgr.range_estimator.current_xmax.clone().reshape(-1),
+                            mgr.quantizer._delta.clone().reshape(-1), mgr.quantizer._zero_float.clone().reshape(-1)))
+            return out
+        finally:
+            qm.FUSED_CALIBRATION, options.INPLACE_CALIBRATION_STATE = prev, prev_inp
+
+    ref = run(False, False)
+    for inplace in (False, True):
+        got = run(True, inplace)
+        for b, (r, g) in enumerate(zip(ref, got)):
+            for k, (rt, gt) in enumerate(zip(r, g)):
+                same = torch.equal(rt.view(torch.int16 if rt.element_size() == 2 else torch.int32),
+                                   gt.view(torch.int16 if gt.element_size() == 2 else torch.int32))
+                nan_same = torch.equal(torch.isnan(rt), torch.isnan(gt)) and torch.equal(rt[~torch.isnan(rt)], gt[~torch.isnan(gt)])
+                assert same or nan_same, (init, shape, dtype, inplace, b, k)
+    assert torch.isnan(ref[2][1]).sum() == 1                        # exactly one token position poisoned

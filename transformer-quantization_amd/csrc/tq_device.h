@@ -399,4 +399,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+
+// ------------------------------------------------------------------ running min / max
+constexpr float kInf = __builtin_huge_valf();
+
+// Branch-free running min/max with torch's NaN propagation: the compares ignore NaN, a third
+// lane-local word remembers the largest |bits| seen (> 0x7f800000 <=> some input was NaN).
+struct MinMax {
+  float mn = kInf, mx = -kInf;
+  uint32_t top = 0;
+  __device__ __forceinline__ void add(float x) {
+    mn = x < mn ? x : mn;
+    mx = x > mx ? x : mx;
+    const uint32_t a = f32_to_bits(x) & 0x7fffffffu;
+    top = a > top ? a : top;
+  }
+  __device__ __forceinline__ float lo() const { return top > 0x7f800000u ? __builtin_nanf("") : mn; }
+  __device__ __forceinline__ float hi() const { return top > 0x7f800000u ? __builtin_nanf("") : mx; }
+};
+
 }  // namespace tq

@@ -696,6 +696,106 @@ int launch_fq_from_stats(const void* x, void* y, uint64_t n, int dtype, const Ca
   }
 }
 
+// ------------------------------------------------------------------------------ dynamic step, one pass
+// Block p owns parameter p of an [outer, n_params, inner] tensor whose outer * inner / V vectors fit in the block's
+// registers (MAXV per lane): load once, block min / max (torch's NaN propagation), estimator rule and range -> parameters in
+// the operation order of calib_update_k (tq_stats.hip; reference range_estimators.py:83-216, quantizers.py:258-259, 276-277),
+// make_qp on the STORED values, quantize from registers, store.  1 read + 1 write of x instead of 2 reads + 1 write, one
+// launch instead of four: `--dynamic --per-token` (reference main.py:249, 359-376) runs this on every inference call.
+template <int DT, int MAXV>
+__global__ __launch_bounds__(kBlock) void calib_rows_onepass_k(const u32x4* __restrict__ x, u32x4* __restrict__ y,
+                                                               uint32_t outer, uint32_t vpr, RowsOnePassArgs a) {
+  constexpr int V = Store<DT>::kVec;
+  const uint32_t p = blockIdx.x, n_params = (uint32_t)a.n_params;
+  const uint32_t total = outer * vpr;
+  u32x4 v[MAXV];
+  uint64_t at[MAXV];
+  MinMax acc;
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    const uint32_t j = threadIdx.x + u * kBlock;
+    if (j < total) {
+      const uint32_t o = j / vpr, i = j - o * vpr;
+      at[u] = ((uint64_t)o * n_params + p) * vpr + i;
+      v[u] = x[at[u]];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    if (threadIdx.x + u * kBlock < total) {
+      float f[V];
+      Store<DT>::unpack(v[u], f);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc.add(f[k]);
+    }
+  }
+  __shared__ float s_mm[2][kBlock / kWave];
+  float mn = wave_min(acc.lo()), mx = wave_max(acc.hi());
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_mm[0][threadIdx.x / kWave] = mn; s_mm[1][threadIdx.x / kWave] = mx; }
+  __syncthreads();
+  float ea = s_mm[0][0], eb = s_mm[1][0];
+#pragma unroll
+  for (int k = 1; k < kBlock / kWave; ++k) { ea = min_nanprop(ea, s_mm[0][k]); eb = max_nanprop(eb, s_mm[1][k]); }
+  if (!(a.mode == TQ_EST_CURRENT || a.prev_min == nullptr)) {
+    const float pa = a.prev_min[p], pb = a.prev_max[p];
+    if (a.mode == TQ_EST_ALL) { ea = min_nanprop(pa, ea); eb = max_nanprop(pb, eb); }
+    else { ea = a.om * ea + a.mom * pa; eb = a.om * eb + a.mom * pb; }
+  }
+  const float lo = min_nanprop(ea, 0.0f), hi = max_nanprop(eb, a.eps);
+  const float top = grid_top(a.n_bits);
+  const float d = (hi - lo) / top;
+  const float zf_store = (-lo) / d;
+  const float d_store = a.log_domain ? logf(d) : d;
+  QP qp;
+  qp.lo = 0.0f;
+  qp.hi = top;
+  qp.zp = clamp_nanprop(rintf(zf_store), qp.lo, qp.hi);
+  qp.scale = a.log_domain ? expf(d_store) : (d_store < a.eps ? a.eps : d_store);
+  __syncthreads();                       // every thread has read prev_* (the state may be updated in place)
+  if (threadIdx.x == 0) {
+    a.cur_min[p] = ea;
+    a.cur_max[p] = eb;
+    a.delta[p] = d_store;
+    a.zero_float[p] = zf_store;
+  }
+  const QF qf = make_qf(qp);
+#pragma unroll
+  for (int u = 0; u < MAXV; ++u) {
+    if (threadIdx.x + u * kBlock < total) {
+      const u32x4 r = qf.ok ? fq_vec<DT, false, true>(v[u], qp, nullptr, TQ_IDX_NONE, 0, &qf)
+                            : fq_vec<DT, false, false>(v[u], qp, nullptr, TQ_IDX_NONE, 0, &qf);
+      y[at[u]] = r;
+    }
+  }
+}
+
+int launch_calib_rows_onepass(const void* x, void* y, int dtype, const RowsOnePassArgs& a, hipStream_t st) {
+  static const int enabled = tuning("TQ_DYN_ONEPASS", 1);
+  const uint64_t V = dtype == TQ_F32 ? 4 : 8;
+  constexpr int MAXV = 8;
+  if (!enabled || a.n_params < 2 || a.inner < 2 || a.inner % V || !aligned16(x) || !aligned16(y) || a.n_params > (1u << 20))
+    return -1;
+  const uint64_t vpr = a.inner / V, total = a.outer * vpr;
+  if (total > (uint64_t)kBlock * MAXV || a.outer > 0xffffu) return -1;
+  const auto xv = static_cast<const u32x4*>(x);
+  auto yv = static_cast<u32x4*>(y);
+#define TQ_GO(DTV, MV)                                                                                          \
+  hipLaunchKernelGGL((calib_rows_onepass_k<DTV, MV>), dim3((unsigned)a.n_params), dim3(kBlock), 0, st, xv, yv,  \
+                     (uint32_t)a.outer, (uint32_t)vpr, a)
+#define TQ_PICK(DTV)                                                            \
+  if (total <= (uint64_t)kBlock * 2) TQ_GO(DTV, 2);                             \
+  else if (total <= (uint64_t)kBlock * 4) TQ_GO(DTV, 4);                        \
+  else TQ_GO(DTV, 8)
+  switch (dtype) {
+    case TQ_F32: TQ_PICK(TQ_F32); break;
+    case TQ_BF16: TQ_PICK(TQ_BF16); break;
+    default: TQ_PICK(TQ_F16); break;
+  }
+#undef TQ_PICK
+#undef TQ_GO
+  return check_launch("calib_rows_onepass_k");
+}
+
 // ------------------------------------------------------------------------------ STE backward
 // dx = ((g * scale) * mask) / scale      (autograd of mul / clamp / STE-round / div in order)
 // d_delta, d_zero_float (per-tensor only): chain rule through scale = clamp(delta, eps),

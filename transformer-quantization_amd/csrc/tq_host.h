@@ -52,6 +52,20 @@ struct CalibApplyArgs {
 };
 int launch_fq_from_stats(const void* x, void* y, uint64_t n, int dtype, const CalibApplyArgs& c, hipStream_t st);
 
+// Dynamic / calibrating step for row-parameter layouts whose per-parameter data fits in one block's registers (per-token
+// ranges at inference batch sizes: [8, 128, 768] -> 8 rows x 768 per token position): statistics, estimator rule, range ->
+// parameters and the fake-quant itself in ONE launch with ONE read of x (tq_fake_quant.hip; arithmetic of calib_update_k +
+// make_qp, so the result is bit-identical to the statistics / update / quantize launches).  -> -1 when the shape does not
+// qualify (the caller runs the separate launches), else a TQ_* code.
+struct RowsOnePassArgs {
+  uint64_t outer, n_params, inner;
+  int mode, n_bits, log_domain;
+  const float *prev_min, *prev_max;
+  float *cur_min, *cur_max, *delta, *zero_float;
+  float eps, om, mom;
+};
+int launch_calib_rows_onepass(const void* x, void* y, int dtype, const RowsOnePassArgs& a, hipStream_t st);
+
 // halves of the one-call sharded steps (tq_stats.hip); `stats` scratch of >= 4 floats
 int calibrate_stats_for_exchange(const void* x, uint64_t n, int dtype, uint64_t n_params, uint64_t inner, float* stats,
                                  void* workspace, size_t workspace_bytes, uint32_t* counter, const float* prev_min,

@@ -15,23 +15,6 @@
 
 namespace tq {
 
-constexpr float kInf = __builtin_huge_valf();
-
-// Branch-free running min/max with torch's NaN propagation: the compares ignore NaN, a third
-// lane-local word remembers the largest |bits| seen (> 0x7f800000 <=> some input was NaN).
-struct MinMax {
-  float mn = kInf, mx = -kInf;
-  uint32_t top = 0;
-  __device__ __forceinline__ void add(float x) {
-    mn = x < mn ? x : mn;
-    mx = x > mx ? x : mx;
-    const uint32_t a = f32_to_bits(x) & 0x7fffffffu;
-    top = a > top ? a : top;
-  }
-  __device__ __forceinline__ float lo() const { return top > 0x7f800000u ? __builtin_nanf("") : mn; }
-  __device__ __forceinline__ float hi() const { return top > 0x7f800000u ? __builtin_nanf("") : mx; }
-};
-
 // ------------------------------------------------------------------------------ last axis
 // blockDim = (CX, RY): CX lanes side by side cover CX 16-byte vectors of a row, RY rows at a time.
 // grid = (col_chunks, row_blocks).  partial layout: ws[(row_block) * 2 * d + {0,1} * d + col]
@@ -715,6 +698,16 @@ extern "C" int tq_calibrate_minmax(const void* x, uint64_t n, int dtype, uint64_
              (unsigned long long)n_params, kCalibMaxN);
   TQ_REQUIRE(n_groups == 0 || n_params % n_groups == 0, "tq_calibrate_minmax: n_params %% n_groups != 0");
   TQ_REQUIRE(n_bits >= 1 && n_bits <= 24, "tq_calibrate_minmax: n_bits=%d", n_bits);
+  TQ_REQUIRE(x != nullptr && n > 0, "tq_calibrate_minmax: NULL / empty input");
+  TQ_REQUIRE(dtype == TQ_F32 || dtype == TQ_BF16 || dtype == TQ_F16, "tq_calibrate_minmax: bad dtype %d", dtype);
+  if (y != nullptr && !symmetric && n_groups == 0 && n_params > 1 && inner > 1 && n % (n_params * inner) == 0) {
+    // per-parameter data small enough for one block's registers: statistics, update, parameters and quantization in ONE
+    // launch with one read of x (tq_fake_quant.hip, calib_rows_onepass_k); -1 = shape does not qualify
+    const RowsOnePassArgs a{n / (n_params * inner), n_params, inner, mode, n_bits, log_domain, prev_min, prev_max, cur_min, cur_max,
+                            delta, zero_float, eps, (float)(1.0 - momentum), (float)momentum};
+    const int rc = launch_calib_rows_onepass(x, y, dtype, a, static_cast<hipStream_t>(stream));
+    if (rc >= 0) return rc;
+  }
   const size_t stats_bytes = (2 * n_params * sizeof(float) + 255) / 256 * 256;
   TQ_REQUIRE(workspace && workspace_bytes >= stats_bytes, "tq_calibrate_minmax: workspace too small");
   float* stats = static_cast<float*>(workspace);
