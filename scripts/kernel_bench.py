@@ -110,6 +110,18 @@ def fam_fq():
             note='tq_calibrate_minmax with one range: statistics, update, quantize (the same kernels as the K4 / K1 rows)')
 
 
+def fam_dyn_small():
+    # `--dynamic --per-token` at the BASELINE batch (B = 8, T = 128): the per-token data of one position (8 rows x d) fits a
+    # block's registers -> statistics, estimator, parameters and quantization as ONE launch with one read of x
+    for d in (768,):
+        for dt, es, code in ((torch.bfloat16, 2, 1), (torch.float32, 4, 0)):
+            x = torch.randn(8, 128, d, device=dev).to(dt)
+            name = str(dt)[6:]
+            run('dyn', f'dynamic per-token ONE PASS {name} [8,128,{d}]', f'calib_rows_onepass_k<{code}', lambda: be.calibrate_minmax(
+                x, 128, d, _hip.EST_CURRENT, None, None, 0.9, 0, None, 8, False, 1e-8, False), 2 * es * x.numel(), 'hbm',
+                note='launch-latency bound at this size (1.5 / 3 MB); was 4 launches')
+
+
 def fam_tails():
     for rows, d in ((131072, 768), (131072, 512)):
         for dt, es, code in ((torch.bfloat16, 2, 1), (torch.float32, 4, 0)):
@@ -232,7 +244,7 @@ def fam_ada():
     run('ada', 'K13 reconstruction loss [64,128,3072]', 'sqdiff', lambda: be.recon_loss(a, b), 8 * a.numel(), 'hbm')
 
 
-FAMILIES = {'fq': fam_fq, 'tails': fam_tails, 'mse': fam_mse, 'i8': fam_i8, 'ada': fam_ada}
+FAMILIES = {'fq': fam_fq, 'dyn_small': fam_dyn_small, 'tails': fam_tails, 'mse': fam_mse, 'i8': fam_i8, 'ada': fam_ada}
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

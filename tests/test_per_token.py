@@ -113,6 +113,7 @@ def test_per_token_and_dynamic_gpu_equals_reference(fused):
     ((5, 40, 24), 1), ((3, 7, 8), 1),               # ragged: rows shorter than a wave
     ((3072, 768), 0),                               # per-channel weight layout (outer = 1)
     ((4, 6, 4104), 1),                              # rows longer than the wave kernels take: the block-per-row kernels
+    ((131, 500, 136), 1),                           # 17 / 34 vectors per row: the flat U-row batches with ragged last iteration
 ])
 def test_row_parameter_launch_shapes_vs_oracle(dtype, shape, axis):
     """Statistics, parameters, indices and outputs for row-parameter layouts through the wave-per-(parameter, slice)

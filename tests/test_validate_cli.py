@@ -88,7 +88,7 @@ def test_end_to_end_on_two_layers(flags, tmp_path, capsys):
     assert any(k.endswith('activation_quantizer.quantizer._delta') for k in sd)
     if '--per-token' in flags:
         assert rep['timings_s'].get('range_estimation') is None            # dynamic: no calibration pass
-        per_token = [v for k, v in sd.items() if k.endswith('res_act_quantizer.activation_quantizer.quantizer._delta')]
+        per_token = [v for k, v in sd.items() if k.endswith('.res_act_quantizer.activation_quantizer.quantizer._delta')]
         assert per_token and all(v.numel() == 128 for v in per_token)        # one range per token position
     assert any(k.endswith('weight_quantizer.range_estimator.quantizer._delta') for k in sd)
     if '--adaround' in flags:

@@ -7,7 +7,8 @@ from harness.bert import QResidualBlock, QSelfAttention
 from quantization import options
 z = _fixture(); model, _ = _build('cuda'); ids = torch.from_numpy(z['input_ids']).cuda()
 _calibrate_and_run(model, ids)
-QResidualBlock.fuse = QSelfAttention.fuse = True; options.INT8_LINEAR = True
+from harness.bert import QLayer
+QResidualBlock.fuse = QSelfAttention.fuse = QLayer.fuse_ffn = None; options.INT8_LINEAR = 'auto'      # the default route
 with torch.no_grad():
     for _ in range(5): model(ids)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -16,4 +17,5 @@ with torch.no_grad():
     pr = cProfile.Profile(); pr.enable()
     for _ in range(20): model(ids)
     torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(22); print(s.getvalue()[:4500])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(40); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45); print(s.getvalue()[:9000])

@@ -525,6 +525,8 @@ __device__ __forceinline__ void fq_rows_wave_body(const u32x4* __restrict__ x, u
   const uint64_t row_stride = (uint64_t)n_params * vpr;
   const uint64_t base = (uint64_t)p_at * vpr;
   uint64_t o = s;
+  // (tried in round 5 and slower, profiles/r05/fq_rows_seq_ab.txt: the U rows of a batch as one flat index space over the
+  // lanes -- all lanes busy, 6-8 loads in flight: 59 % against 66 %; sequential tiles with an LDS parameter table: 60 %)
   for (; o + (uint64_t)(U - 1) * S < outer; o += (uint64_t)U * S) {
     for (uint32_t i = lane; i < vpr; i += kWave) {
       u32x4 v[U];
