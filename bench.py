@@ -176,6 +176,40 @@ def pmc_traffic(n_elems):
         'passes of this same command, gfx950 FETCH_SIZE x2 correction), kernel symbol and source hash match the built library')
 
 
+def per_token_block(x, device, n_elems, B, S):
+    """Per-token ranges (`--per-token`: axis = 1, reference main.py:359-376) and the dynamic step (`--dynamic`: estimate +
+    quantize on EVERY call, quantization_manager.py:99-106) -- the one mode where the estimators are on the inference path."""
+    from quantization.quantization_manager import QuantizationManager
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from utils.per_embd_quant_utils import set_act_quant_axis_and_groups
+
+    def run(xin, dynamic, n_timed):
+        m = QuantizationManager(qmethod=QMethods.asymmetric_uniform, init=RangeEstimators.current_minmax, qparams=dict(n_bits=8))
+        set_act_quant_axis_and_groups(m, axis=1, n_groups=None)
+        with torch.no_grad():
+            m(xin)
+            if not dynamic:
+                m.fix_ranges()
+            for _ in range(3):
+                m(xin)
+            _, ms = timed_region(lambda: m(xin), n_timed, False)
+        return ms
+    fixed_ms, dyn_ms = run(x, False, 20), run(x, True, 20)
+    small = make_hidden(8, 128, device, seed=7)
+    return {
+        'shape': [B, S, 768], 'storage_dtype': 'bf16',
+        'fixed_range': {'kernel_ms': round(fixed_ms, 4), 'GBps': round(n_elems * BYTES_PER_ELEM / fixed_ms / 1e6, 1),
+                        'frac': round(n_elems * BYTES_PER_ELEM / fixed_ms / 1e6 / HBM_PEAK_GBS, 4), 'bytes_per_elem': BYTES_PER_ELEM},
+        'dynamic': {'step_ms': round(dyn_ms, 4), 'GBps': round(n_elems * 6 / dyn_ms / 1e6, 1),
+                    'frac': round(n_elems * 6 / dyn_ms / 1e6 / HBM_PEAK_GBS, 4), 'bytes_per_elem': 6,
+                    'note': 'statistics + estimator + parameters + quantize per call: x is read twice (2 + 2 + 2 B per bf16 element)'},
+        'dynamic_config_shape': {'shape': [8, 128, 768], 'call_us': round(run(small, True, 200) * 1e3, 2),
+                                 'note': "ONE launch, one read of x (calib_rows_onepass_k: a token position's 8 x 768 values fit a "
+                                         "block's registers); host-bound"},
+    }
+
+
 def _cpu_model():
     try:
         with open('/proc/cpuinfo') as f:
@@ -720,6 +754,12 @@ def main():
         del sites, plan
     except Exception as e:       # noqa: BLE001 -- optional figure
         out['config_shape']['batched_161_sites'] = {'error': repr(e)[:300]}
+
+    if not args.headline_only:
+        try:
+            out['per_token'] = per_token_block(x, device, n_elems, B, S)
+        except Exception as e:       # noqa: BLE001 -- optional figures
+            out['per_token'] = {'error': repr(e)[:300]}
 
     if args.sweep and rank == 0:
         sweep = []
