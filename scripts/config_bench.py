@@ -182,6 +182,33 @@ with torch.no_grad():
 out['config0_readme_recipe_weight_calibration'] = c
 del rm_, mods_
 
+# ---- dynamic per-token BERT-base (`--per-token` implies `--dynamic`, reference main.py:249, 359-376): every one of the 123
+# per-token sites (and the 38 per-tensor ones) estimates and quantizes on EVERY forward -------------------------------------------
+from harness.bert import apply_activation_granularity
+from quantization.graphs import GraphedForward as _GF
+dm, _ = build_bert_base(seed=1000, method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8,
+                        n_bits_act=8, weight_range_method=RangeEstimators.current_minmax,
+                        act_range_method=RangeEstimators.current_minmax)
+dm = dm.to(dev).eval()
+c = {'per_token_sites': apply_activation_granularity(dm, per_token=True)}
+dm.set_quant_state(True, True)
+ids_d = torch.randint(1000, 30000, (8, 128), device=dev)
+with torch.no_grad():
+    dm(ids_d)
+    c['dynamic_forward_eager_ms'] = wall(lambda: dm(ids_d), n=10)
+    options.INPLACE_CALIBRATION_STATE = True
+    try:
+        dm(ids_d)
+        ref_ = dm(ids_d).clone()
+        gd = _GF(dm, ids_d)
+        c['dynamic_forward_hipgraph_ms'] = wall(lambda: gd(ids_d), n=30)
+        c['graph_equals_eager'] = bool(torch.equal(gd(ids_d), ref_))
+        del gd
+    finally:
+        options.INPLACE_CALIBRATION_STATE = False
+out['bert_base_dynamic_per_token_b8_t128'] = c
+del dm
+
 # ---- config 2: per-tensor running min/max, [8,128,768] and [1024,512,768] --------------------------
 c = {}
 for shape in ((8, 128), (1024, 512)):

@@ -107,6 +107,12 @@ def test_state_dict_round_trip_and_fast_inference(tmp_path, capsys):
     assert abs(a['fidelity_vs_fp32']['logit_sqnr_db'] - b['fidelity_vs_fp32']['logit_sqnr_db']) < 1e-6
     d = V.main(base + ['--hip-graph'])                       # graph-replayed calibration + evaluation: same numbers
     assert abs(a['fidelity_vs_fp32']['logit_sqnr_db'] - d['fidelity_vs_fp32']['logit_sqnr_db']) < 1e-6
+    # dynamic per-token inference (estimate + quantize at every site on every call) replays as ONE hipGraph, too
+    dyn = base + ['--per-token', '--act-quant-method', 'current_minmax']
+    e = V.main(dyn)
+    g = V.main(dyn + ['--hip-graph'])
+    assert e.get('dynamic') and g.get('dynamic')
+    assert abs(e['fidelity_vs_fp32']['logit_sqnr_db'] - g['fidelity_vs_fp32']['logit_sqnr_db']) < 1e-6
     c = V.main(base + ['--load-state-dict', os.path.join(tmp_path, 'state_dict.pth'), '--fast-inference'])
     assert abs(a['fidelity_vs_fp32']['logit_sqnr_db'] - c['fidelity_vs_fp32']['logit_sqnr_db']) < 3.0
     from harness.bert import QResidualBlock, QSelfAttention

@@ -323,8 +323,15 @@ def run(config, args):
             report['prequantized_weight_tensors'] = prequantize_weights(model)
 
         fwd = model
-        if args.hip_graph and not config.quant.dynamic:
+        inplace_before = options.INPLACE_CALIBRATION_STATE
+        if args.hip_graph:
             from quantization.graphs import GraphedForward
+            if config.quant.dynamic:
+                # dynamic mode = a calibrating forward on every call: with the estimator state and the quantizer parameters
+                # updated IN PLACE it is one recorded graph like a fixed-range forward (one eager batch first, so that every
+                # state buffer exists); per-token sites run as one launch each (calib_rows_onepass_k)
+                options.INPLACE_CALIBRATION_STATE = True
+                model(evalb[0][0].to(dev))
             fwd = GraphedForward(model, evalb[0][0].to(dev))
 
         def evaluate():
@@ -341,6 +348,7 @@ def run(config, args):
             _, t = _timed(evaluate)
         finally:
             QResidualBlock.fuse, QSelfAttention.fuse, options.INT8_LINEAR = route_before      # process-wide switches
+            options.INPLACE_CALIBRATION_STATE = inplace_before
     report['timings_s']['evaluation_incl_fp32_reference'] = t
     import math
     report['fidelity_vs_fp32'] = {'logit_sqnr_db': (10 * math.log10(sig / noise)) if noise > 0 else float('inf'),
