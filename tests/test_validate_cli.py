@@ -119,3 +119,32 @@ def test_state_dict_round_trip_and_fast_inference(tmp_path, capsys):
     from quantization import options
     QResidualBlock.fuse = QSelfAttention.fuse = False
     options.INT8_LINEAR = False
+
+
+@pytest.mark.gpu
+@pytest.mark.default_route
+@pytest.mark.parametrize('flags', [
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform'],
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--per-embd', '--act-quant-method', 'current_minmax'],
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--n-bits', '4', '--n-bits-act', '8',
+     '--quant-setup', 'FP_logits'],
+    ['--qmethod', 'symmetric_uniform', '--per-channel'],
+], ids=['w8a8', 'per-embd', 'w4a8-fp-logits', 'symmetric-acts-per-channel-weights'])
+def test_default_route_against_the_layered_route(flags, capsys):
+    """The product default (options.INT8_LINEAR = 'auto') on configurations where the integer route applies fully (W8A8),
+    partly (per-embedding sites keep per-axis ranges: only the softmax chain fuses; FP32 logits) or nowhere (symmetric
+    activation grids): the evaluation must run, report the route, and stay within a dB of the layered route's fidelity."""
+    from quantization import options
+    assert options.INT8_LINEAR == 'auto'
+    base = flags + ['--num-layers', '2', '--num-eval-batches', '2']
+    auto = V.main(base)
+    layered = V.main(base + ['--layered-inference'])
+    assert auto['inference_route'] == "options.INT8_LINEAR = 'auto'" and layered['inference_route'] == 'layered (forced)'
+    a, b = auto['fidelity_vs_fp32'], layered['fidelity_vs_fp32']
+    assert a['samples'] == b['samples'] == 16
+    assert abs(a['logit_sqnr_db'] - b['logit_sqnr_db']) < 1.5, (a, b)
+    if '--qmethod-act' not in flags:
+        # symmetric activation quantizers: no integer plan, no fused tail eligible for an int8 index output -- but the fused
+        # LayerNorm tail / softmax chain still apply (fp32 kernels), so equality is not expected, closeness is
+        assert a['argmax_agreement'] >= b['argmax_agreement'] - 0.13
+    assert options.INT8_LINEAR == 'auto'                    # the CLI restores the process-wide switches

@@ -26,6 +26,7 @@ ranges of the concatenated batch.
 """
 import math
 import threading
+import weakref
 from collections import namedtuple
 from enum import Enum
 
@@ -518,17 +519,18 @@ class MSE_Estimator(RangeEstimatorBase):
         self.current_xmax = xmax.to(data.device)
         self.current_xmin = xmin.to(data.device)
 
-    @staticmethod
-    def _input_key(data):
-        return (data.data_ptr(), data._version, tuple(data.shape), data.dtype, data.device)
+    def _memoise(self, data):
+        """Remember the thresholds just found for THIS tensor object in THIS state (identity through a weak reference +
+        the version counter: an address can be recycled by another tensor, an object cannot)."""
+        self._memo = (weakref.ref(data), data._version, (self.current_xmin, self.current_xmax))
 
     def forward(self, data):
         memo = self._memo
         if memo is not None:
             # the golden-section search is a pure function of (input, search range): the thresholds a lock-step search
             # (golden_section_lockstep) found for THIS tensor are what running it again would return
-            if memo[0] == self._input_key(data) and self.opt_method == OptMethod.golden_section:
-                self.current_xmin, self.current_xmax = memo[1]
+            if memo[0]() is data and memo[1] == data._version and self.opt_method == OptMethod.golden_section:
+                self.current_xmin, self.current_xmax = memo[2]
                 return self.current_xmin, self.current_xmax
             self._memo = None
         if self._loss_dev is None:
@@ -647,6 +649,7 @@ def golden_section_lockstep(jobs):
     if not jobs:
         return {'searches': 0, 'rounds': 0, 'evaluations': 0}
     be = _hip.backend()
+    originals = [data for _, data in jobs]           # the memo is keyed on the object the caller will pass again
     jobs = [(est, data.detach()) for est, data in jobs]
     # ---- search ranges: every tensor's (min, max) with ONE host copy -------------------------------------------------------
     fresh = [k for k, (est, _) in enumerate(jobs) if est._loss_dev is None]
@@ -666,7 +669,7 @@ def golden_section_lockstep(jobs):
         try:
             with torch.no_grad():
                 est.optimization_method(data)
-            est._memo = (est._input_key(data), (est.current_xmin, est.current_xmax))
+            est._memoise(originals[slot])
         except BaseException as e:               # noqa: BLE001 -- re-raised by the caller below
             errors.append(e)
         finally:
