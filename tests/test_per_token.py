@@ -196,3 +196,34 @@ def test_one_pass_dynamic_step_equals_the_separate_launches(dtype, init, shape):
                 nan_same = torch.equal(torch.isnan(rt), torch.isnan(gt)) and torch.equal(rt[~torch.isnan(rt)], gt[~torch.isnan(gt)])
                 assert same or nan_same, (init, shape, dtype, inplace, b, k)
     assert torch.isnan(ref[2][1]).sum() == 1                        # exactly one token position poisoned
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_misaligned_and_odd_row_lengths_take_the_fallback_kernels(dtype):
+    """The wave / one-pass kernels need 16-byte aligned tensors and rows that are whole 16-byte vectors; anything else must
+    fall back (scalar / block-per-row kernels, separate launches) and give the SAME statistics, parameters and outputs as
+    an aligned copy of the same values."""
+    from quantization import _hip
+    be = _hip.backend()
+    for shape in ((8, 16, 24), (4, 10, 7), (3, 5, 33)):
+        n = int(np.prod(shape))
+        g = torch.Generator().manual_seed(n)
+        vals = (torch.randn(n, generator=g) * 3).to(dtype)
+        aligned = vals.clone().cuda().view(shape)
+        holder = torch.empty(n + 1, dtype=dtype, device='cuda')
+        holder[1:] = vals.cuda()
+        skewed = holder[1:].view(shape)                       # same values, data_ptr % 16 != 0
+        assert skewed.data_ptr() % 16 != 0 and skewed.is_contiguous()
+        T, inner = shape[1], shape[2]
+        ref = be.calibrate_minmax(aligned, T, inner, _hip.EST_CURRENT, None, None, 0.9, 0, None, 8, False, 1e-8, False)
+        got = be.calibrate_minmax(skewed, T, inner, _hip.EST_CURRENT, None, None, 0.9, 0, None, 8, False, 1e-8, False)
+        for r, t in zip(ref, got):
+            if r is not None:
+                assert torch.equal(r, t), shape
+        mn_a, mx_a = be.minmax(aligned, T, inner)
+        mn_s, mx_s = be.minmax(skewed, T, inner)
+        assert torch.equal(mn_a, mn_s) and torch.equal(mx_a, mx_s)
+        ya, ia = be.fake_quant(aligned, ref[2], ref[3], None, 8, False, False, 1e-8, T, inner, idx_dtype=torch.uint8)
+        ys, is_ = be.fake_quant(skewed, ref[2], ref[3], None, 8, False, False, 1e-8, T, inner, idx_dtype=torch.uint8)
+        assert torch.equal(ya, ys) and torch.equal(ia, is_) and torch.equal(ya, ref[5])
