@@ -129,7 +129,11 @@ def test_state_dict_round_trip_and_fast_inference(tmp_path, capsys):
     ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--n-bits', '4', '--n-bits-act', '8',
      '--quant-setup', 'FP_logits'],
     ['--qmethod', 'symmetric_uniform', '--per-channel'],
-], ids=['w8a8', 'per-embd', 'w4a8-fp-logits', 'symmetric-acts-per-channel-weights'])
+    # AdaRound collects its layer inputs / outputs through forward hooks on the optimised layer (adaround/utils.py): the
+    # hooked layer must stay on the layered route while they are registered, whatever the switch says
+    ['--qmethod', 'symmetric_uniform', '--qmethod-act', 'asymmetric_uniform', '--n-bits', '4', '--n-bits-act', '8',
+     '--adaround', 'layers.0.output.dense,layers.1.intermediate.0', '--adaround-iters', '30', '--adaround-num-samples', '16'],
+], ids=['w8a8', 'per-embd', 'w4a8-fp-logits', 'symmetric-acts-per-channel-weights', 'w4a8-adaround'])
 def test_default_route_against_the_layered_route(flags, capsys):
     """The product default (options.INT8_LINEAR = 'auto') on configurations where the integer route applies fully (W8A8),
     partly (per-embedding sites keep per-axis ranges: only the softmax chain fuses; FP32 logits) or nowhere (symmetric
@@ -142,7 +146,9 @@ def test_default_route_against_the_layered_route(flags, capsys):
     assert auto['inference_route'] == "options.INT8_LINEAR = 'auto'" and layered['inference_route'] == 'layered (forced)'
     a, b = auto['fidelity_vs_fp32'], layered['fidelity_vs_fp32']
     assert a['samples'] == b['samples'] == 16
-    assert abs(a['logit_sqnr_db'] - b['logit_sqnr_db']) < 1.5, (a, b)
+    assert abs(a['logit_sqnr_db'] - b['logit_sqnr_db']) < (3.0 if '--adaround' in flags else 1.5), (a, b)
+    if '--adaround' in flags:
+        assert 'adaround' in auto['timings_s'] and 'adaround' in layered['timings_s']
     if '--qmethod-act' not in flags:
         # symmetric activation quantizers: no integer plan, no fused tail eligible for an int8 index output -- but the fused
         # LayerNorm tail / softmax chain still apply (fp32 kernels), so equality is not expected, closeness is
