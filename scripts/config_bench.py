@@ -177,8 +177,8 @@ with torch.no_grad():
     c['same_ranges'] = all(torch.equal(mg.range_estimator.current_xmin, a) and torch.equal(mg.range_estimator.current_xmax, b)
                            for (mg, _), (a, b) in zip(mods_, seq_))
     c['us_per_evaluation_layer_by_layer'] = c['layer_by_layer_ms'] * 1e3 / max(st_['evaluations'], 1)
-    c['note'] = ('lock step (options.LOCKSTEP_WEIGHT_SEARCH) is off by default: the sequential path is kernel-bound, not '
-                 'sync-bound, and 102 thread wake-ups per round cost more than the host round trips they save')
+    c['note'] = ('lock step (options.LOCKSTEP_WEIGHT_SEARCH, default): scipy\'s bounded Brent as a resumable generator, prepared '
+                 'launches, one device->host copy per round; bit-identical ranges')
 out['config0_readme_recipe_weight_calibration'] = c
 del rm_, mods_
 

@@ -36,7 +36,7 @@ def _check_lockstep_equals_sequential(device):
         par = _estimators(symmetric, n_bits, len(xs))
         stats = golden_section_lockstep(list(zip(par, xs)))
         assert stats['searches'] == len(xs) and stats['evaluations'] > stats['rounds'] >= 10, stats
-        # nested searches (asymmetric two-sided) run ~35 x 35 evaluations per tensor; rounds = the longest search
+        # nested searches (asymmetric two-sided) run ~20 x 20 evaluations per tensor; rounds = the longest search
         assert stats['rounds'] * len(xs) >= stats['evaluations'] > 2 * stats['rounds'], stats
         for e, p, (rmin, rmax) in zip(seq, par, ref):
             assert torch.equal(p.current_xmin.cpu(), rmin.cpu()) and torch.equal(p.current_xmax.cpu(), rmax.cpu())
@@ -76,10 +76,51 @@ def test_lockstep_equals_sequential_cpu_oracle():
         _hip.set_backend(prev)
 
 
-def test_lockstep_propagates_a_failing_search():
-    """One search raising (here: the backend fails on its tensor) ends the whole lock-step run with that error; no thread
-    is left waiting."""
-    import threading
+def test_restated_bounded_brent_is_scipys():
+    """`range_estimators._bounded_brent` (scipy's `minimize_scalar(method='Bounded')` as a resumable generator) against
+    scipy itself: abscissa, value, evaluation count AND the numpy scalar types of the result on 2 000 random fp32-valued
+    objectives -- smooth, kinked, noisy, with plateaus (quantization losses are piecewise smooth), flat, and with NaN."""
+    from scipy.optimize import minimize_scalar
+    from quantization.range_estimators import _bounded_brent
+    rs = np.random.RandomState(0)
+
+    def run(f, bounds):
+        g = _bounded_brent(bounds)
+        x = next(g)
+        try:
+            while True:
+                x = g.send(f(x))
+        except StopIteration as stop:
+            return stop.value
+
+    for t in range(2000):
+        c, k, n, noise = rs.uniform(0.05, 3), rs.uniform(0.1, 5), rs.randint(2, 6), rs.uniform(0, 1e-3)
+        lo = rs.uniform(0.001, 0.05)
+        hi = lo + rs.uniform(0.5, 4)
+        kind = t % 5
+
+        def f(x):
+            if kind == 3:
+                return np.float32(1.25)                                    # flat
+            if kind == 4 and x > 0.5 * (lo + hi):
+                return np.float32('nan')
+            return np.float32(k * abs(x - c) ** (n / 2.0) + noise * np.sin(1000 * x) + (0.3 * np.floor(8 * x) / 8 if kind == 2 else 0))
+        ref = minimize_scalar(f, bounds=(lo, hi), method='Bounded')
+        got = run(f, (lo, hi))
+        assert type(got.x) is type(ref.x) and type(got.fun) is type(ref.fun), t
+        same_x = got.x == ref.x or (np.isnan(got.x) and np.isnan(ref.x))
+        same_f = got.fun == ref.fun or (np.isnan(got.fun) and np.isnan(ref.fun))
+        assert same_x and same_f and got.nfev == ref.nfev and got.status == ref.status and got.success == ref.success, (t, got, ref)
+    # float64 objective values (--double)
+    for t in range(200):
+        c = rs.uniform(0.1, 2)
+        f = lambda x: np.float64((x - c) ** 2 + 0.01 * np.abs(np.sin(50 * x)))
+        ref = minimize_scalar(f, bounds=(0.01, 3.0), method='Bounded')
+        got = run(f, (0.01, 3.0))
+        assert got.x == ref.x and got.fun == ref.fun and got.nfev == ref.nfev
+
+
+def test_lockstep_propagates_a_failing_evaluation():
     from quantization import _hip
     from quantization.range_estimators import golden_section_lockstep
     from tests._oracle_backend import OracleBackend
@@ -96,11 +137,9 @@ def test_lockstep_propagates_a_failing_search():
                 raise RuntimeError('injected failure')
             return orig(x, *a, **k)
         be.mse_candidates_ordered = flaky
-        before = threading.active_count()
         with pytest.raises(RuntimeError, match='injected failure'):
             golden_section_lockstep(list(zip(est, xs)))
-        assert threading.active_count() == before
-        assert all(e._lockstep is None for e in est)
+        assert all(e._memo is None for e in est)
     finally:
         _hip.set_backend(prev)
 
@@ -138,21 +177,22 @@ def _check_precalibrate(device):
         return [m.quantizer._delta.detach().cpu().clone() for n, m in model.named_modules()
                 if isinstance(m, QuantizationManager) and n.endswith('weight_quantizer')]
 
-    # (a) with options.LOCKSTEP_WEIGHT_SEARCH the calibration driver runs the lock-step search by itself ...
+    # (a) the calibration driver runs the lock-step search by itself (options.LOCKSTEP_WEIGHT_SEARCH, on by default) ...
     from quantization import options
+    assert options.LOCKSTEP_WEIGHT_SEARCH is True
     m1 = _toy(device)
-    options.LOCKSTEP_WEIGHT_SEARCH = True
-    try:
-        with torch.no_grad():
-            pass_data_for_range_estimation([(x,)], m1, act_quant=True, weight_quant=True, max_num_batches=1)
-    finally:
-        options.LOCKSTEP_WEIGHT_SEARCH = False
+    with torch.no_grad():
+        pass_data_for_range_estimation([(x,)], m1, act_quant=True, weight_quant=True, max_num_batches=1)
     assert all(m.range_estimator._memo is not None for n, m in m1.named_modules()
                if isinstance(m, QuantizationManager) and n.endswith('weight_quantizer'))
     # (b) ... and finds what layer-by-layer searches find
     m2 = _toy(device)
-    with torch.no_grad():
-        pass_data_for_range_estimation([(x,)], m2, act_quant=True, weight_quant=True, max_num_batches=1)
+    options.LOCKSTEP_WEIGHT_SEARCH = False
+    try:
+        with torch.no_grad():
+            pass_data_for_range_estimation([(x,)], m2, act_quant=True, weight_quant=True, max_num_batches=1)
+    finally:
+        options.LOCKSTEP_WEIGHT_SEARCH = True
     assert all(m.range_estimator._memo is None for n, m in m2.named_modules()
                if isinstance(m, QuantizationManager) and n.endswith('weight_quantizer'))
     d1, d2 = deltas(m1), deltas(m2)
@@ -186,10 +226,9 @@ def test_lockstep_equals_sequential_gpu():
 @pytest.mark.gpu
 def test_readme_recipe_weight_calibration_wall_time():
     """The 102 weight searches of the README recipe on BERT-base: layer by layer (2 096 evaluations,
-    each with its own device->host copy) against the lock-step search (26 rounds): the SAME 102 ranges, wall time of both
-    printed.  Measured: 150-153 ms layer by layer (73 us per evaluation) against 249-271 ms in lock step -- the sequential
-    path is kernel-bound, and 102 thread wake-ups per round cost more than the synchronisations they save; hence
-    options.LOCKSTEP_WEIGHT_SEARCH = False.  The assertion is parity; the times are evidence, not a bar."""
+    each with its own device->host copy) against the lock-step search (26 rounds, one copy each): the SAME 102 ranges,
+    wall time of both printed.  Measured: 148-156 ms layer by layer (71-75 us per evaluation) against 64.5 ms in lock step
+    (2.3x; the kernels alone are ~38 ms -- a first, thread-per-search version took 250-290 ms)."""
     from harness.bert import build_bert_base
     from quantization.autoquant_utils import precalibrate_weights
     from quantization.quantizers import QMethods
@@ -223,4 +262,4 @@ def test_readme_recipe_weight_calibration_wall_time():
         assert torch.equal(mgr.range_estimator.current_xmin, mn) and torch.equal(mgr.range_estimator.current_xmax, mx)
     print(f'README-recipe weight calibration: layer by layer {t_seq * 1e3:.1f} ms, lock step {t_par * 1e3:.1f} ms '
           f'({t_seq / t_par:.1f}x), {st}')
-    assert t_seq < 1.0 and t_par < 2.0          # sanity: neither path is pathologically slow
+    assert t_par < t_seq                        # measured 2.0-2.3x; any win at all is the bar

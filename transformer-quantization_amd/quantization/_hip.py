@@ -999,6 +999,35 @@ class HipBackend:
         _check(rc, self.lib)
         return loss, f32
 
+    def mse_ordered_plans(self, tensors):
+        """Prepared single-candidate launches of `mse_candidates_ordered` for tensors that are evaluated MANY times (the
+        lock-step golden-section search: ~20 rounds x 102 weight tensors): shapes, dtype codes, pointers and ONE shared
+        workspace (the launches run back to back on one stream) resolved once.  -> (plans, keepalive) or None when a
+        tensor needs the generic route (float64, empty, another device)."""
+        if not tensors:
+            return None
+        dev = tensors[0].device
+        plans, keep, need = [], [], 0
+        for t in tensors:
+            if t.dtype == torch.float64 or t.numel() == 0 or t.device != dev or not t.is_cuda:
+                return None
+            x = t.detach().contiguous()
+            rows = x.shape[0] if x.dim() > 0 else 1
+            row_len = x.numel() // max(rows, 1)
+            need = max(need, int(self.lib.tq_mse_ordered_workspace_bytes(rows, row_len, 1)))
+            plans.append((x.data_ptr(), rows, row_len, _dtype_code(x, 'mse_ordered_plans')))
+            keep.append(x)
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        keep.append(ws)
+        return [(p + (ws.data_ptr(), ws.numel())) for p in plans], keep
+
+    def mse_ordered_launch(self, plan, cand_ptr, loss_ptr, stream):
+        """One candidate (the 4 floats at cand_ptr) for a prepared tensor; its fp32 loss is ADDED to the fp64 cell at loss_ptr."""
+        rc = self.lib.tq_mse_candidates_ordered(plan[0], plan[1], plan[2], plan[3], cand_ptr, 1, 1, loss_ptr, None,
+                                                plan[4], plan[5], stream)
+        if rc != 0:
+            _check(rc, self.lib)
+
     def mse_candidates_grouped(self, x, n_groups, cand, loss):
         """loss[n_groups, C] += per-group (of the LAST axis) squared quantisation error per candidate."""
         _need_device(x, 'mse_candidates_grouped')

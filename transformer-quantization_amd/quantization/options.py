@@ -24,14 +24,15 @@ INT8_LINEAR = 'auto'
 # arithmetic epilogue stays in place for grids the table cannot hold (decided on the device).
 INT8_ACT_STAIR = True
 
-# README recipe (MSE / golden-section weight ranges): run the searches of all weight tensors in lock step before the first
-# calibrating forward (autoquant_utils.precalibrate_weights: one scipy instance per tensor in its own thread, one queue of
-# launches and ONE device->host copy per round instead of one per loss evaluation; bit-identical thresholds).  OFF by
-# default because it is SLOWER on one MI355X (measured, tests/test_lockstep.py, BERT-base: 102 searches, 2 096 evaluations:
-# layer by layer 150-153 ms = 73 us per evaluation incl. its host round trip; lock step 249-271 ms in 26 rounds): the
-# sequential path is kernel-bound, not sync-bound, and waking 102 Python threads per round costs more than the ~2 000
-# synchronisations it saves.  Kept for hosts where a device->host round trip is expensive (remote / virtualised GPUs).
-LOCKSTEP_WEIGHT_SEARCH = False
+# README recipe (MSE / golden-section weight ranges, reference README.md:149-157): run the searches of ALL weight tensors in
+# lock step before the first calibrating forward (autoquant_utils.precalibrate_weights -> range_estimators.
+# golden_section_lockstep): every search is scipy's bounded Brent restated as a resumable generator (pinned against scipy,
+# tests/test_lockstep.py), each round evaluates the pending candidate of every live search with prepared launches queued
+# back to back and ONE device->host copy.  Bit-identical ranges; BERT-base (102 tensors, 2 096 evaluations in 26 rounds):
+# 148-156 ms layer by layer (71-75 us per evaluation: 11 us of kernels, 17 us of synchronisation, ~25 us of Python) ->
+# 64.5 ms (2.3x; the kernels alone are ~38 ms).  (A first version with one scipy instance per search in its own THREAD was
+# slower than layer by layer -- 250-290 ms: 102 thread wake-ups per round -- and is gone.)
+LOCKSTEP_WEIGHT_SEARCH = True
 
 # Estimator state (current_xmin / current_xmax) and quantizer parameters (_delta / _zero_float / _signed)
 # are rebound to FRESH tensors on every calibrating forward, like the reference does.  With this switch

@@ -18,14 +18,14 @@ arguments, ``current_xmin`` / ``current_xmax`` buffers, ``per_group_range_estima
 * golden-section search keeps ``scipy.optimize.minimize_scalar`` as the owner of the iterate
   sequence (reference :321, :429, :449, :458); each loss evaluation is one kernel launch.  K INDEPENDENT searches
   (the 102 weight tensors of a BERT-base under the README recipe) advance in lock step (`golden_section_lockstep`):
-  one scipy instance per search, one queue of launches + ONE device->host copy per round instead of per evaluation.
+  scipy's bounded Brent restated as a resumable generator (pinned against scipy), one queue of launches + ONE
+  device->host copy per round instead of per evaluation.
 
 When ``quantization.distributed`` is enabled, the per-rank statistics (min/max, candidate
 losses) are all-reduced over RCCL before the state update, so every rank ends up with the
 ranges of the concatenated batch.
 """
 import math
-import threading
 import weakref
 from collections import namedtuple
 from enum import Enum
@@ -288,7 +288,6 @@ class MSE_Estimator(RangeEstimatorBase):
         self._thr_dev = None       # fp32 [2, n_cand]
         self._cand_shape = None
         self._memo = None          # (input key, thresholds) left by golden_section_lockstep
-        self._lockstep = None      # (coordinator, slot) while a lock-step search runs this estimator
 
     # ---- reference-visible state ---------------------------------------------------------
     @property
@@ -372,10 +371,6 @@ class MSE_Estimator(RangeEstimatorBase):
         if not (neg_thr or pos_thr):
             # quirk q7 (reference :292): both thresholds falsy -> the quantizer's current range
             neg_thr, pos_thr = float(self.quantizer.x_min), float(self.quantizer.x_max)
-        ls = self._lockstep
-        if ls is not None and not per_channel_loss:
-            # lock-step search: post the candidate, block until the round's single device->host copy delivered its loss
-            return ls[0].request(ls[1], neg_thr, pos_thr)
         be = _hip.backend()
         cand = be.candidate_table(self._cand_table([neg_thr], [pos_thr]), data.device)
         rows = len(data) if per_channel_loss else 1
@@ -564,93 +559,161 @@ class CrossEntropyEstimator(MSE_Estimator):
 # --------------------------------------------------------------------------------------
 # K independent golden-section searches in lock step
 # --------------------------------------------------------------------------------------
-class _LockStepRounds:
-    """Coordinator of K scipy searches running in K threads.  `request` (called by MSE_Estimator.loss_fx in a worker)
-    posts one candidate and blocks; when every live search has posted, the coordinator evaluates the whole round --
-    one candidate table upload, one launch sequence per tensor queued back to back on the stream, ONE device->host copy --
-    and hands every search its fp32 loss: the value `loss_fx` would have computed for it alone, so scipy's iterates, and
-    therefore the thresholds, are the ones of the sequential searches."""
+def _bounded_brent(bounds, xatol=1e-5, maxiter=500):
+    """scipy.optimize.minimize_scalar(method='Bounded') as a RESUMABLE search: a generator that yields the next abscissa
+    and is sent the function value there; returns an OptimizeResult.  Restates scipy's `_minimize_scalar_bounded`
+    (scipy/optimize/_optimize.py, 1.15: Brent's fminbound, the routine behind the reference's golden-section option,
+    range_estimators.py:321, 429, 449, 458) expression by expression INCLUDING the numpy scalar types scipy's code
+    produces on the way (np.abs / np.sign / np.maximum return numpy scalars, the function values are fp32 numpy
+    scalars, the bounds Python floats: mixed expressions promote exactly as they do there), so the iterates are
+    scipy's bit for bit -- pinned against scipy itself by tests/test_lockstep.py on random objectives."""
+    from math import sqrt
+    from scipy.optimize import OptimizeResult
+    x1, x2 = bounds
+    flag = 0
+    sqrt_eps = sqrt(2.2e-16)
+    golden_mean = 0.5 * (3.0 - sqrt(5.0))
+    a, b = x1, x2
+    fulc = a + golden_mean * (b - a)
+    nfc, xf = fulc, fulc
+    rat = e = 0.0
+    x = xf
+    fx = yield x
+    num = 1
+    fu = np.inf
+    ffulc = fnfc = fx
+    xm = 0.5 * (a + b)
+    tol1 = sqrt_eps * np.abs(xf) + xatol / 3.0
+    tol2 = 2.0 * tol1
+    while np.abs(xf - xm) > (tol2 - 0.5 * (b - a)):
+        golden = 1
+        if np.abs(e) > tol1:                      # try a parabola through the three best points
+            golden = 0
+            r = (xf - nfc) * (fx - ffulc)
+            q = (xf - fulc) * (fx - fnfc)
+            p = (xf - fulc) * q - (xf - nfc) * r
+            q = 2.0 * (q - r)
+            if q > 0.0:
+                p = -p
+            q = np.abs(q)
+            r = e
+            e = rat
+            if (np.abs(p) < np.abs(0.5 * q * r)) and (p > q * (a - xf)) and (p < q * (b - xf)):
+                rat = (p + 0.0) / q
+                x = xf + rat
+                if ((x - a) < tol2) or ((b - x) < tol2):
+                    si = np.sign(xm - xf) + ((xm - xf) == 0)
+                    rat = tol1 * si
+            else:
+                golden = 1
+        if golden:                                # golden-section step into the larger part
+            e = a - xf if xf >= xm else b - xf
+            rat = golden_mean * e
+        si = np.sign(rat) + (rat == 0)
+        x = xf + si * np.maximum(np.abs(rat), tol1)
+        fu = yield x
+        num += 1
+        if fu <= fx:
+            if x >= xf:
+                a = xf
+            else:
+                b = xf
+            fulc, ffulc = nfc, fnfc
+            nfc, fnfc = xf, fx
+            xf, fx = x, fu
+        else:
+            if x < xf:
+                a = x
+            else:
+                b = x
+            if (fu <= fnfc) or (nfc == xf):
+                fulc, ffulc = nfc, fnfc
+                nfc, fnfc = x, fu
+            elif (fu <= ffulc) or (fulc == xf) or (fulc == nfc):
+                fulc, ffulc = x, fu
+        xm = 0.5 * (a + b)
+        tol1 = sqrt_eps * np.abs(xf) + xatol / 3.0
+        tol2 = 2.0 * tol1
+        if num >= maxiter:
+            flag = 1
+            break
+    if np.isnan(xf) or np.isnan(fx) or np.isnan(fu):
+        flag = 2
+    return OptimizeResult(fun=fx, status=flag, success=(flag == 0),
+                          message={0: 'Solution found.', 1: 'Maximum number of function calls reached.',
+                                   2: 'NaN result encountered.'}.get(flag, ''), x=xf, nfev=num, nit=num)
 
-    def __init__(self, jobs):
-        self.jobs = jobs
-        self.cv = threading.Condition()
-        self.pending = {}
-        self.results = {}
-        self.finished = 0
-        self.rounds = 0
-        self.evaluations = 0
 
-    def request(self, slot, neg_thr, pos_thr):
-        with self.cv:
-            self.pending[slot] = (neg_thr, pos_thr)
-            self.cv.notify_all()
-            while slot not in self.results:
-                self.cv.wait()
-            value = self.results.pop(slot)
-        if isinstance(value, BaseException):
-            raise value
+def _minimize_bounded(bounds, evaluate):
+    """Drive `_bounded_brent` with an objective that is itself a generator (it may yield loss requests, or run a nested
+    search): -> OptimizeResult."""
+    g = _bounded_brent(bounds)
+    x = next(g)
+    while True:
+        fx = yield from evaluate(x)
+        try:
+            x = g.send(fx)
+        except StopIteration as stop:
+            return stop.value
+
+
+def _search_program(est):
+    """The golden-section search of ONE estimator (one range per tensor) as a generator: yields (neg_thr, pos_thr)
+    requests, is sent their fp32 losses, leaves the estimator in the state `_golden_section_symmetric /
+    _golden_section_asymmetric` leave (reference range_estimators.py:296-327, 422-470) and returns (xmin, xmax)."""
+    def loss(neg_thr, pos_thr):
+        assert neg_thr or pos_thr, 'both thresholds falsy: the search range never contains it'
+        value = yield (neg_thr, pos_thr)
         return value
 
-    def done(self):
-        with self.cv:
-            self.finished += 1
-            self.cv.notify_all()
+    lo, hi = 0.01 * est.max_search_range, est.max_search_range
+    if est._one_dimensional:
+        def sym(r):
+            return (yield from loss(0 if est.one_sided_dist else -r, r))
+        est.result = yield from _minimize_bounded((lo, hi), sym)
+        xmin, xmax = torch.zeros(est.channel_groups), torch.zeros(est.channel_groups)      # fp32 [1], as the sequential search
+        xmax[0] = torch.tensor(est.result.x)
+        xmin[0] = torch.tensor(0.0) if est.one_sided_dist else -xmax[0]
+        return xmin, xmax
 
-    def _evaluate(self, batch):
-        be = _hip.backend()
-        slots = sorted(batch)
-        device = self.jobs[slots[0]][1].device
-        table = np.concatenate([self.jobs[i][0]._cand_table([batch[i][0]], [batch[i][1]]) for i in slots], axis=0)
-        cand = be.candidate_table(table, device)
-        loss = be.zeros_f64((len(slots), 1), device)
-        for j, i in enumerate(slots):
-            be.mse_candidates_ordered(self.jobs[i][1], cand[j:j + 1], loss[j:j + 1], per_row=False)
-        host = loss.cpu().numpy()                         # the round's one synchronisation
-        self.rounds += 1
-        self.evaluations += len(slots)
-        out = {}
-        for j, i in enumerate(slots):
-            v = host[j, 0]
-            out[i] = v if self.jobs[i][1].dtype == torch.float64 else np.float32(v)    # exact: the cell holds one fp32 value
-        return out
+    def shift_search(r):
+        temp_delta = 2 * r / (2 ** est.quantizer.n_bits - 1)
+        max_shift = temp_delta * est.max_int_skew
 
-    def run(self, workers):
-        for w in workers:
-            w.start()
-        try:
-            while True:
-                with self.cv:
-                    self.cv.wait_for(lambda: len(self.pending) + self.finished >= len(self.jobs))
-                    if self.finished >= len(self.jobs) and not self.pending:
-                        break
-                    batch = dict(self.pending)
-                    self.pending.clear()
-                try:
-                    out = self._evaluate(batch)
-                except BaseException as e:       # noqa: BLE001 -- delivered to every waiting search, which re-raises it
-                    out = {i: e for i in batch}
-                with self.cv:
-                    self.results.update(out)
-                    self.cv.notify_all()
-        finally:
-            for w in workers:
-                w.join()
+        def shifted(shift):
+            return (yield from loss(-r + shift, r + shift))
+        return (yield from _minimize_bounded((-max_shift, max_shift), shifted))
+
+    def range_loss(r):
+        return (yield from shift_search(r)).fun
+    est.result = yield from _minimize_bounded((lo, hi), range_loss)
+    est.final_range = est.result.x
+    est.subresult = yield from shift_search(est.final_range)
+    est.final_shift = est.subresult.x
+    xmin, xmax = torch.zeros(est.channel_groups), torch.zeros(est.channel_groups)
+    xmax[0] = torch.tensor(est.final_range + est.final_shift)
+    xmin[0] = torch.tensor(-est.final_range + est.final_shift)
+    return xmin, xmax
 
 
 def golden_section_lockstep(jobs):
-    """Run the golden-section range searches of `jobs` = [(MSE_Estimator, tensor), ...] together.
+    """Run the golden-section range searches of `jobs` = [(MSE_Estimator, tensor), ...] together, in lock step.
 
-    Each estimator ends in the state `estimator(tensor)` leaves (thresholds, `result` / `subresult`, search range) plus a
-    memo of the tensor it saw, so that the estimating forward that follows finds its answer without launching anything.
-    Requirements (checked by `lockstep_eligible`): plain MSE_Estimator, opt_method golden_section, one range per tensor,
-    device tensors on ONE device, calibration not sharded.  Reference: range_estimators.py:296-327, 422-470 run once per
-    weight tensor with a host round trip per loss evaluation (~35 per search; 102 searches under README.md:149-157).
-    -> {'searches', 'rounds', 'evaluations'}"""
+    Every search is a resumable program (`_search_program`: scipy's bounded Brent restated as a generator, nested for
+    the asymmetric two-sided case).  Per ROUND the pending candidate of every live search is evaluated: one candidate-table
+    upload, the launches of all tensors queued back to back, ONE device->host copy; each search is then sent the fp32 loss
+    `loss_fx` would have computed for it alone -- same objective values, same iterates, same thresholds, bit for bit.
+    Each estimator ends in the state `estimator(tensor)` leaves plus a memo of the tensor it saw, so that the estimating
+    forward that follows finds its answer without launching anything.  Requirements (`lockstep_eligible`): plain
+    MSE_Estimator, opt_method golden_section, one range per tensor, tensors on ONE device, calibration not sharded.
+    Reference: range_estimators.py:296-327, 422-470 run once per weight tensor with a host round trip per loss evaluation
+    (~20 per search; 102 searches under README.md:149-157).  -> {'searches', 'rounds', 'evaluations'}"""
     if not jobs:
         return {'searches': 0, 'rounds': 0, 'evaluations': 0}
     be = _hip.backend()
     originals = [data for _, data in jobs]           # the memo is keyed on the object the caller will pass again
     jobs = [(est, data.detach()) for est, data in jobs]
+    device = jobs[0][1].device
     # ---- search ranges: every tensor's (min, max) with ONE host copy -------------------------------------------------------
     fresh = [k for k, (est, _) in enumerate(jobs) if est._loss_dev is None]
     if fresh:
@@ -660,26 +723,45 @@ def golden_section_lockstep(jobs):
             if est.one_sided_dist is None:
                 est.one_sided_dist = bool(float(row[0]) >= 0)
             est._define_search_range(data, stats=(row[0], row[1]))
-    rounds = _LockStepRounds(jobs)
-    errors = []
-
-    def work(slot):
-        est, data = jobs[slot]
-        est._lockstep = (rounds, slot)
-        try:
-            with torch.no_grad():
-                est.optimization_method(data)
-            est._memoise(originals[slot])
-        except BaseException as e:               # noqa: BLE001 -- re-raised by the caller below
-            errors.append(e)
-        finally:
-            est._lockstep = None
-            rounds.done()
-
-    rounds.run([threading.Thread(target=work, args=(k,), daemon=True) for k in range(len(jobs))])
-    if errors:
-        raise errors[0]
-    return {'searches': len(jobs), 'rounds': rounds.rounds, 'evaluations': rounds.evaluations}
+    # prepared launches (shapes, pointers, one shared workspace resolved once) where the backend offers them
+    prepared = be.mse_ordered_plans([data for _, data in jobs]) if hasattr(be, 'mse_ordered_plans') else None
+    programs = {k: _search_program(est) for k, (est, _) in enumerate(jobs)}
+    pending = {k: next(g) for k, g in programs.items()}            # every search starts with one evaluation
+    rounds = evaluations = 0
+    with torch.no_grad():
+        while pending:
+            slots = sorted(pending)
+            cfgs = {(jobs[k][0].quantizer.n_bits, jobs[k][0].quantizer.symmetric, jobs[k][0].quantizer.eps,
+                     jobs[k][0].quantizer.scale_domain) for k in slots}
+            if len(cfgs) == 1:                   # the usual case (one recipe for all layers): ONE vectorised table build
+                table = jobs[slots[0]][0]._cand_table([pending[k][0] for k in slots], [pending[k][1] for k in slots])
+            else:
+                table = np.concatenate([jobs[k][0]._cand_table([pending[k][0]], [pending[k][1]]) for k in slots], axis=0)
+            cand = be.candidate_table(table, device)
+            loss = be.zeros_f64((len(slots), 1), device)
+            if prepared is not None:
+                c0, l0, st = cand.data_ptr(), loss.data_ptr(), _hip._stream()
+                for j, k in enumerate(slots):
+                    be.mse_ordered_launch(prepared[0][k], c0 + 16 * j, l0 + 8 * j, st)
+            else:
+                for j, k in enumerate(slots):
+                    be.mse_candidates_ordered(jobs[k][1], cand[j:j + 1], loss[j:j + 1], per_row=False)
+            host = loss.cpu().numpy()                              # the round's one synchronisation
+            rounds += 1
+            evaluations += len(slots)
+            nxt = {}
+            for j, k in enumerate(slots):
+                est, data = jobs[k]
+                v = host[j, 0]
+                v = v if data.dtype == torch.float64 else np.float32(v)      # exact: the cell holds one fp32 value
+                try:
+                    nxt[k] = programs[k].send(v)
+                except StopIteration as stop:
+                    xmin, xmax = stop.value
+                    est.current_xmin, est.current_xmax = xmin.to(data.device), xmax.to(data.device)
+                    est._memoise(originals[k])
+            pending = nxt
+    return {'searches': len(jobs), 'rounds': rounds, 'evaluations': evaluations}
 
 
 def lockstep_eligible(est, data):
