@@ -548,3 +548,40 @@ def test_bench_refuses_a_stale_pmc_profile(tmp_path, monkeypatch):
     assert bench.pmc_traffic(n // 2)[0] is None
     path.unlink()
     assert bench.pmc_traffic(n)[0] is None
+
+
+def test_inference_mode_keeps_the_layered_route_and_never_raises():
+    """torch.inference_mode() tensors carry no version counter: the integer route ('auto' or forced) must stand down there
+    instead of failing in its bookkeeping (provenance records, range-state keys, the golden-section memo)."""
+    from quantization import _hip, options, provenance
+    from quantization.base_quantized_classes import QuantizedActivation
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import OptMethod, RangeEstimators
+    from tests._oracle_backend import OracleBackend
+    prev = _hip.set_backend(OracleBackend())
+    before = options.INT8_LINEAR
+    try:
+        for mode in ('auto', True):
+            options.INT8_LINEAR = mode
+            with torch.no_grad():
+                assert options.int8_active()
+            with torch.inference_mode():
+                assert not options.int8_active()
+                qa = QuantizedActivation(act_method=QMethods.asymmetric_uniform, n_bits_act=8,
+                                         act_range_method=RangeEstimators.current_minmax)
+                qa.quantized_acts()
+                x = torch.randn(4, 8, 16)
+                y0 = qa(x)                                   # estimating: ranges are set from inference tensors
+                qa.activation_quantizer.fix_ranges()
+                y = qa(x)
+                assert torch.equal(y, y0)
+                assert provenance.of(y) is None
+                assert provenance.tag(y, qa.activation_quantizer.quantizer) is y and provenance.of(y) is None
+                qa.activation_quantizer.quantizer.range_state_key()
+                est = RangeEstimators.MSE.cls(quantizer=QMethods.symmetric_uniform.cls(n_bits=8), opt_method=OptMethod.golden_section)
+                est(x)
+                est._memoise(x)
+                assert est._memo is None
+    finally:
+        options.INT8_LINEAR = before
+        _hip.set_backend(prev)

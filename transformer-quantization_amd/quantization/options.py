@@ -61,10 +61,15 @@ CACHE_EPOCH = 0
 def int8_active():
     """Is the integer / fused fixed-range route on for the call being made right now?  (see INT8_LINEAR)"""
     m = INT8_LINEAR
-    if m is True:
-        return True
     if not m:
         return False
+    # torch.inference_mode(): tensors created there carry no version counter, so an in-place change of an activation between
+    # the quantizer that produced it and the integer Linear that consumes its indices could not be noticed (provenance.py):
+    # the layered route runs there, whatever the switch says.  torch.no_grad() keeps the counters and is what 'auto' is for.
+    if torch.is_inference_mode_enabled():
+        return False
+    if m is True:
+        return True
     return not torch.is_grad_enabled()
 
 

@@ -21,9 +21,22 @@ import weakref
 _records = {}
 
 
+def version_of(tensor):
+    """The tensor's in-place modification counter, or None where torch does not keep one (inference tensors)."""
+    try:
+        return tensor._version
+    except RuntimeError:
+        return None
+
+
 def tag(tensor, quantizer, idx=None):
-    """Record that `tensor` was produced by `quantizer` (fixed range); returns the tensor."""
+    """Record that `tensor` was produced by `quantizer` (fixed range); returns the tensor.  A tensor without a version
+    counter (created under torch.inference_mode()) gets NO record: an in-place change could not be detected later, so its
+    consumers take the layered path."""
     key = id(tensor)
+    if version_of(tensor) is None:
+        _records.pop(key, None)
+        return tensor
 
     def _drop(_ref, key=key):
         _records.pop(key, None)
@@ -41,7 +54,7 @@ def of(tensor):
     rec = _records.get(id(tensor))
     if rec is None or rec[0]() is not tensor:
         return None
-    if tensor._version != rec[3] or _range_state(rec[1]) != rec[4]:
+    if version_of(tensor) != rec[3] or _range_state(rec[1]) != rec[4]:
         return None                          # modified in place / producer's grid changed since the record was made
     return rec[1], rec[2]
 

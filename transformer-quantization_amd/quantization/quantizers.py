@@ -140,7 +140,11 @@ class QuantizerBase(nn.Module):
     def range_state_key(self):
         """Changes whenever the quantization grid of this quantizer may have changed (rebinding or in-place update)."""
         d = self._buffers.get('_delta', None) if '_delta' in self._buffers else getattr(self, '_delta', None)
-        return (self._range_gen, None if d is None else d._version, self.n_bits, options.CACHE_EPOCH)
+        try:
+            ver = None if d is None else d._version
+        except RuntimeError:                 # a range set under torch.inference_mode(): no counter -- rebinding still bumps _range_gen
+            ver = -1
+        return (self._range_gen, ver, self.n_bits, options.CACHE_EPOCH)
 
     @property
     def is_initialized(self):

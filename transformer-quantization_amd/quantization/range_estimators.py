@@ -39,6 +39,13 @@ from quantization import _hip
 from quantization import distributed as tq_dist
 
 
+def _hip_version(t):
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 class NoDataPassedError(Exception):
     """Raised data has been passed inot the Range Estimator."""
 
@@ -517,14 +524,17 @@ class MSE_Estimator(RangeEstimatorBase):
     def _memoise(self, data):
         """Remember the thresholds just found for THIS tensor object in THIS state (identity through a weak reference +
         the version counter: an address can be recycled by another tensor, an object cannot)."""
-        self._memo = (weakref.ref(data), data._version, (self.current_xmin, self.current_xmax))
+        try:
+            self._memo = (weakref.ref(data), data._version, (self.current_xmin, self.current_xmax))
+        except RuntimeError:                 # inference tensor: no version counter, no memo
+            self._memo = None
 
     def forward(self, data):
         memo = self._memo
         if memo is not None:
             # the golden-section search is a pure function of (input, search range): the thresholds a lock-step search
             # (golden_section_lockstep) found for THIS tensor are what running it again would return
-            if memo[0]() is data and memo[1] == data._version and self.opt_method == OptMethod.golden_section:
+            if memo[0]() is data and memo[1] == _hip_version(data) and self.opt_method == OptMethod.golden_section:
                 self.current_xmin, self.current_xmax = memo[2]
                 return self.current_xmin, self.current_xmax
             self._memo = None
