@@ -22,6 +22,11 @@ INT8_LINEAR = 'auto'
 # the quantizer's range (csrc/tq_stair.hip, one extra launch per range state) instead of the erf fit + exact quotient in
 # the epilogue.  The table is the correctly rounded GELU followed by the reference quantizer, exact by construction; the
 # arithmetic epilogue stays in place for grids the table cannot hold (decided on the device).
+# Reproducibility note: the table evaluates the CORRECTLY ROUNDED GELU, the arithmetic epilogue a degree-7 erfc fit; they
+# agree on all but <= 2e-5 of the outputs, where the index differs by ONE grid step.  Which of the two a launch uses depends
+# on the tile kernel (call shape: M, N), on the room for the table and on the builder's verdict -- so the same layer with
+# the same ranges can differ in those few indices between batch sizes.  Every launch is deterministic; set
+# INT8_ACT_STAIR = False for one definition (the fit) at every shape.
 INT8_ACT_STAIR = True
 
 # README recipe (MSE / golden-section weight ranges, reference README.md:149-157): run the searches of ALL weight tensors in
