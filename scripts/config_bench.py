@@ -31,7 +31,8 @@ out = {}
 from harness import bert as _hb, mobilebert as _hm
 from quantization import options
 options.INT8_LINEAR = False
-_SWITCHES = [(_hb.QSelfAttention, 'fuse'), (_hb.QResidualBlock, 'fuse'), (_hb.QLayer, 'fuse_ffn'), (_hm.QBottleneckLayer, 'fuse'),
+_SWITCHES = [(_hb.QSelfAttention, 'fuse'), (_hb.QResidualBlock, 'fuse'), (_hb.QLayer, 'fuse_ffn'), (_hb.QEmbeddings, 'fuse'),
+             (_hm.QBottleneckLayer, 'fuse'),
              (_hm.QMobileSelfAttention, 'fuse'), (_hm.QResidualNoNorm, 'fuse'), (_hm.QFFN, 'fuse'), (_hm.QMobileLayer, 'fuse_ffn')]
 for _c, _a in _SWITCHES:
     setattr(_c, _a, False)
@@ -124,6 +125,10 @@ with torch.no_grad():
     from tests.harness_bert import QLayer
     QLayer.fuse_ffn = True
     graphed('fixed_range_forward_all_fused_index_only_ffn')
+    # + the embedding block (3 look-ups, 2 quantizers, LayerNorm + quantizer) as one launch
+    _hb.QEmbeddings.fuse = True
+    graphed('fixed_range_forward_all_fused_incl_embeddings')
+    _hb.QEmbeddings.fuse = False
     c['index_only_ffn_equal_to_separate_launches'] = bool(torch.equal(model(ids), o_fast))
     from quantization.autoquant_utils import int8_stair_status
     st = int8_stair_status(model)

@@ -35,7 +35,7 @@ def _pin_the_route_under_test(request):
     `default_route`.  The switch is restored after every test whatever it did."""
     from harness import bert, mobilebert
     from quantization import options
-    switches = [(bert.QSelfAttention, 'fuse'), (bert.QResidualBlock, 'fuse'), (bert.QLayer, 'fuse_ffn'),
+    switches = [(bert.QSelfAttention, 'fuse'), (bert.QResidualBlock, 'fuse'), (bert.QLayer, 'fuse_ffn'), (bert.QEmbeddings, 'fuse'),
                 (mobilebert.QBottleneckLayer, 'fuse'), (mobilebert.QMobileSelfAttention, 'fuse'),
                 (mobilebert.QResidualNoNorm, 'fuse'), (mobilebert.QFFN, 'fuse'), (mobilebert.QMobileLayer, 'fuse_ffn')]
     before = options.INT8_LINEAR

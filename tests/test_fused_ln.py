@@ -258,3 +258,88 @@ def test_fused_tails_special_values(dtype):
             same = (y[ok] == ref[ok]).float().mean().item()
             assert same >= 0.999
             assert not (y[ok].view(torch.int32) == -2 ** 31).any()                      # no -0.0
+
+
+@pytest.mark.parametrize('d', [768, 1024, 128, 512])
+def test_fused_embeddings_equal_kernel_order_oracle(d):
+    """BERT's embedding block as ONE launch (tq_embeddings_layernorm_quant_fwd: word + token-type look-up, Q1, + position
+    look-up, Q2, LayerNorm, Q3; reference models/quantized_bert.py:75-111) against the oracle chain with the LayerNorm
+    statistics in the kernel's order: every output and int8 index equal, bit for bit -- incl. repeated ids, the clamped
+    out-of-range ids and the quantizer subsets."""
+    from oracle.ln_sum import layer_norm_kernel_order
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(d)
+    B, T, V_, P_ = 5, 37, 211, 64
+    word = torch.randn(V_, d, generator=g) * 0.8
+    typ = torch.randn(2, d, generator=g) * 0.3
+    pos = torch.randn(P_, d, generator=g) * 0.5
+    word[:, 3] *= 9
+    ids = torch.randint(0, V_, (B, T), generator=g)
+    ids[0, :4] = ids[0, 0]
+    tok = torch.randint(0, 2, (B, T), generator=g)
+    pid = torch.arange(T).unsqueeze(0).expand(B, T).contiguous()
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    b = 0.05 * torch.randn(d, generator=g)
+    p1, p2, p3 = (O.asym_params_from_range(lo, hi, 8) for lo, hi in ((-8.0, 9.0), (-9.0, 10.0), (-5.0, 7.0)))
+
+    def q(v, p):
+        return v if p is None else O.fake_quant(v, p[0], p[1], 8, False)[1]
+    k = lambda p: None if p is None else (p[0].cuda(), p[1].cuda(), None, 8, False, False, 1e-8)
+    for use in ((1, 1, 1), (0, 1, 1), (1, 1, 0), (0, 0, 0)):
+        q1, q2, q3 = (p if u else None for p, u in zip((p1, p2, p3), use))
+        u2 = q(q(word[ids] + typ[tok], q1) + pos[pid], q2).reshape(-1, d)
+        v = layer_norm_kernel_order(u2, w, b, 1e-12, torch.float32)
+        ref = q(v, q3)
+        out = be.embeddings_layernorm_quant(word.cuda(), ids.cuda(), typ.cuda(), tok.cuda(), pos.cuda(), pid.cuda(), k(q1), k(q2),
+                                            w.cuda(), b.cuda(), 1e-12, k(q3), want_idx=q3 is not None)
+        y = (out[0] if q3 is not None else out).cpu()
+        assert torch.equal(y, ref), (use, float((y - ref).abs().max()))
+        if q3 is not None:
+            assert torch.equal(out[1].cpu().float() + 128, O.fake_quant(v, q3[0], q3[1], 8, False)[0]), use
+    # ids outside their table are clamped (the layered route's F.embedding raises): no fault, the edge rows are used
+    bad = ids.clone()
+    bad[1, 1], bad[2, 2] = V_ + 5, -3
+    y_bad = be.embeddings_layernorm_quant(word.cuda(), bad.cuda(), typ.cuda(), tok.cuda(), pos.cuda(), pid.cuda(), k(p1), k(p2),
+                                          w.cuda(), b.cuda(), 1e-12, k(p3)).cpu()
+    y_cl = be.embeddings_layernorm_quant(word.cuda(), bad.clamp(0, V_ - 1).cuda(), typ.cuda(), tok.cuda(), pos.cuda(), pid.cuda(),
+                                         k(p1), k(p2), w.cuda(), b.cuda(), 1e-12, k(p3)).cpu()
+    assert torch.equal(y_bad, y_cl)
+
+
+def test_fused_embeddings_in_bert_harness():
+    """QEmbeddings.fuse: the block of the harness model as one launch -- used (one backend call per forward), >= 99.9 %
+    of the outputs identical to the layered modules (torch's LayerNorm sums in another order), the rest one step away; the
+    layered path runs while ranges are being estimated and under a forward hook on any of the modules involved."""
+    from tests.test_bert_e2e import _build, _fixture, _calibrate_and_run
+    from harness.bert import QEmbeddings
+    from quantization import _hip
+    z = _fixture()
+    model, _ = _build('cuda')
+    ids = torch.from_numpy(z['input_ids']).cuda()
+    _calibrate_and_run(model, ids)
+    emb = model.embeddings
+    be = _hip.backend()
+    calls = []
+    orig = be.embeddings_layernorm_quant
+    be.embeddings_layernorm_quant = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            layered = emb(ids)
+            QEmbeddings.fuse = True
+            fused = emb(ids)
+            assert len(calls) == 1
+            step = float(emb.LayerNorm.activation_quantizer.quantizer._delta)
+            diff = (fused - layered).abs()
+            assert float((diff == 0).float().mean()) >= 0.999 and float(diff.max()) <= step * 1.01
+            h = emb.sum_pos_embd_act_quantizer.register_forward_hook(lambda m, i, o: None)
+            try:
+                assert torch.equal(emb(ids), layered) and len(calls) == 1          # an observer: layered modules
+            finally:
+                h.remove()
+            model.estimate_ranges()
+            emb(ids)
+            assert len(calls) == 1                                                 # estimating: layered modules
+    finally:
+        QEmbeddings.fuse = False
+        be.__dict__.pop('embeddings_layernorm_quant', None)

@@ -90,12 +90,22 @@ __device__ __forceinline__ f32x2 apply_f2(f32x2 v, const FusedF& q) { return q.o
 // on bf16 rows (3.1-3.3 TB/s).  NaN: an unordered input pair poisons its element before the statistics (so a LayerNorm
 // row turns NaN as a whole, like the reference) and a NaN pre-quantizer value is passed through at the end.  FAST = false
 // is the division path (scales outside [2^-100, 2^100], grids of 2^22+ steps); IDX also emits int8(index - 128).
-template <int DT, int LPR, int NV, bool IDX, bool FAST, bool ALLON, bool AFF>
+// BERT's embedding block through the same body (EMB): the "dense output" row is word[word_ids[row]] + type[type_ids[row]]
+// (one fp32 addition, like the reference's `inputs_embeds + token_type_embeddings`, models/quantized_bert.py:95-111), the
+// "residual" row is pos[pos_ids[row]]; ids are clamped to the tables (the layered route's F.embedding raises instead).
+struct EmbArgs {
+  const int64_t *a_rows, *a2_rows, *r_rows;
+  const u32x4* a2;
+  uint64_t a_n, a2_n, r_n;        // rows of the three tables
+};
+
+template <int DT, int LPR, int NV, bool IDX, bool FAST, bool ALLON, bool AFF, bool EMB>
 __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
                                             u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                             float ln_eps, const tq_quantizer& q1, const tq_quantizer& q2,
-                                            const tq_quantizer& q3, int on1_, int on2_, int on3_, int nt, uint32_t iters) {
+                                            const tq_quantizer& q3, int on1_, int on2_, int on3_, int nt, uint32_t iters,
+                                            const EmbArgs& emb) {
   // AFF (NoNorm: affine map only, no statistics) is a compile-time property: as a run-time flag every NaN rule of BOTH
   // variants was evaluated per element and selected (4-5 v_cndmask / v_cmp per element of ~29 VALU instructions on the
   // bf16 LayerNorm rows, found in the ISA in round 4)
@@ -126,9 +136,22 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
   // fp32 5.4 / 5.8 / 5.4 / 5.2 -> 8 for 2-byte storage, 2 for fp32 (launch_res_ln).
   const uint64_t row0 = (uint64_t)blockIdx.x * RPB * iters + sub;
   u32x4 va[NV], vr[NV], na[NV], nr[NV];
+  u32x4 va2[EMB ? NV : 1], na2[EMB ? NV : 1];
   // streaming hints only for tensors that cannot stay in L2 / MALL anyway: in a model forward the inputs were just
   // written by the GEMM and the output is read by the next layer.  ONE uniform branch per group of loads / stores.
-  auto load_row = [&](uint64_t row, u32x4 (&pa)[NV], u32x4 (&pr)[NV]) {
+  auto load_row = [&](uint64_t row, u32x4 (&pa)[NV], u32x4 (&pr)[NV], u32x4 (&pa2)[EMB ? NV : 1]) {
+    if (EMB) {
+      auto pick = [](const int64_t* ids, uint64_t row_, uint64_t n) {
+        const int64_t id = ids[row_];
+        return id < 0 ? (uint64_t)0 : ((uint64_t)id >= n ? n - 1 : (uint64_t)id);
+      };
+      const uint64_t oa = pick(emb.a_rows, row, emb.a_n) * (d / V) + lane;
+      const uint64_t o2 = pick(emb.a2_rows, row, emb.a2_n) * (d / V) + lane;
+      const uint64_t orr = pick(emb.r_rows, row, emb.r_n) * (d / V) + lane;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) { pa[v] = a[oa + v * LPR]; pa2[v] = emb.a2[o2 + v * LPR]; pr[v] = r[orr + v * LPR]; }
+      return;
+    }
     const uint64_t o = row * (d / V) + lane;
     if (nt) {
 #pragma unroll
@@ -138,13 +161,13 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
       for (int v = 0; v < NV; ++v) { pa[v] = a[o + v * LPR]; pr[v] = r[o + v * LPR]; }
     }
   };
-  if (row0 < rows) load_row(row0, va, vr);
+  if (row0 < rows) load_row(row0, va, vr, va2);
   for (uint32_t it = 0; it < iters; ++it) {
     const uint64_t row = row0 + (uint64_t)it * RPB;
     if (row >= rows) break;
     const uint64_t base = row * (d / V);
     const uint64_t nrow = row + RPB;
-    if (it + 1 < iters && nrow < rows) load_row(nrow, na, nr);
+    if (it + 1 < iters && nrow < rows) load_row(nrow, na, nr, na2);
     f32x2 u[NV][H];
     f32x2 s2 = {0.f, 0.f}, s2b = {0.f, 0.f};      // two chains for the row sum (LayerNorm only)
     bool lane_nan = false;
@@ -153,6 +176,12 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
       float fa[V], fr[V];
       Store<DT>::unpack(va[v], fa);
       Store<DT>::unpack(vr[v], fr);
+      if (EMB) {                                    // word row + token-type row: ONE fp32 addition in front of Q1
+        float f2[V];
+        Store<DT>::unpack(va2[v], f2);
+#pragma unroll
+        for (int k = 0; k < V; ++k) fa[k] = fa[k] + f2[k];
+      }
       if (FAST) {
         // the H pairs of this 16-byte vector move through the stages side by side (qf_*_n)
         f32x2 t[H];
@@ -292,32 +321,37 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) { va[v] = na[v]; vr[v] = nr[v]; }
+    if (EMB) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) va2[v] = na2[v];
+    }
   }
 }
 
-template <int DT, int LPR, int NV, bool IDX, bool AFF>
+template <int DT, int LPR, int NV, bool IDX, bool AFF, bool EMB = false>
 __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
                                                          u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          float ln_eps, tq_quantizer q1, tq_quantizer q2, tq_quantizer q3,
-                                                         int on1, int on2, int on3, int nt, uint32_t iters) {
+                                                         int on1, int on2, int on3, int nt, uint32_t iters, EmbArgs emb) {
   // wave-uniform: every enabled quantizer admits the branch-free exact path (tq_device.h, QF)
   bool fast = true;
   if (on1) fast = fast && make_qf(make_qp(q1, 0)).ok;
   if (on2) fast = fast && make_qf(make_qp(q2, 0)).ok;
   if (on3) fast = fast && make_qf(make_qp(q3, 0)).ok;
   if (fast && on1 && on2 && on3)
-    res_ln_body<DT, LPR, NV, IDX, true, true, AFF>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, 1, 1, 1, nt, iters);
+    res_ln_body<DT, LPR, NV, IDX, true, true, AFF, EMB>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, 1, 1, 1, nt, iters, emb);
   else if (fast)
-    res_ln_body<DT, LPR, NV, IDX, true, false, AFF>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, nt, iters);
+    res_ln_body<DT, LPR, NV, IDX, true, false, AFF, EMB>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, nt, iters, emb);
   else
-    res_ln_body<DT, LPR, NV, IDX, false, false, AFF>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, nt, iters);
+    res_ln_body<DT, LPR, NV, IDX, false, false, AFF, EMB>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, nt, iters, emb);
 }
 
 template <int DT>
 static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, uint64_t rows, uint64_t d, const float* w, const float* b,
                          float eps, const tq_quantizer* q1, const tq_quantizer* q2, const tq_quantizer* q3, int affine_only,
-                         hipStream_t st) {
+                         hipStream_t st, const EmbArgs* emb_in = nullptr) {
+  const EmbArgs emb = emb_in ? *emb_in : EmbArgs{};
   constexpr int V = Store<DT>::kVec;
   const tq_quantizer none{};
   const tq_quantizer &c1 = q1 ? *q1 : none, &c2 = q2 ? *q2 : none, &c3 = q3 ? *q3 : none;
@@ -328,12 +362,19 @@ static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, u
   const int nt = rows * d * elem_size(DT) >= (64ull << 20);
 #define TQ_LN_GO(LPR, NV, IDXV, AFFV)                                                                           \
   hipLaunchKernelGGL((res_ln_quant_k<DT, LPR, NV, IDXV, AFFV>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, \
-                     eps, c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, nt, iters)
+                     eps, c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, nt, iters, emb)
 #define TQ_LN(LPR, NV)                                                                                          \
   if (vpr == (uint64_t)(LPR) * (NV)) {                                                                          \
     const unsigned rpb = kBlock / (LPR);                                                                        \
     const uint32_t iters = (uint32_t)std::max<int>(1, std::min<uint64_t>(tuning("TQ_TAIL_ITERS", DT == TQ_F32 ? 2 : 8), ceil_div(rows, (uint64_t)rpb * 2048))); \
     const unsigned grid = (unsigned)std::max<uint64_t>(ceil_div(rows, (uint64_t)rpb * iters), 1);               \
+    if (DT == TQ_F32 && emb_in != nullptr) {                                                                    \
+      if (y_idx != nullptr) hipLaunchKernelGGL((res_ln_quant_k<TQ_F32, LPR, NV, true, false, true>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, \
+                                               eps, c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, 0, iters, emb); \
+      else hipLaunchKernelGGL((res_ln_quant_k<TQ_F32, LPR, NV, false, false, true>), dim3(grid), dim3(kBlock), 0, st, av, rv, yv, y_idx, rows, w, b, \
+                              eps, c1, c2, c3, q1 != nullptr, q2 != nullptr, q3 != nullptr, 0, iters, emb);   \
+      return check_launch("res_ln_quant_k (embeddings)");                                                       \
+    }                                                                                                           \
     if (y_idx != nullptr && affine_only)      TQ_LN_GO(LPR, NV, true, true);                                    \
     else if (y_idx != nullptr)                TQ_LN_GO(LPR, NV, true, false);                                   \
     else if (affine_only)                     TQ_LN_GO(LPR, NV, false, true);                                   \
@@ -570,6 +611,30 @@ extern "C" int tq_residual_layernorm_quant_fwd(const void* dense_out, const void
                                                float ln_eps, const tq_quantizer* q_out, tq_stream_t stream) {
   return residual_tail("tq_residual_layernorm_quant_fwd", dense_out, residual, y, y_idx, rows, d, dtype, q_dense, q_sum, ln_weight,
                        ln_bias, ln_eps, q_out, 0, stream);
+}
+
+extern "C" int tq_embeddings_layernorm_quant_fwd(const float* word_table, uint64_t word_rows, const int64_t* word_ids,
+                                                 const float* type_table, uint64_t type_rows, const int64_t* type_ids,
+                                                 const float* pos_table, uint64_t pos_rows, const int64_t* pos_ids, float* y,
+                                                 int8_t* y_idx, uint64_t rows, uint64_t d, const tq_quantizer* q_sum1,
+                                                 const tq_quantizer* q_sum2, const float* ln_weight, const float* ln_bias,
+                                                 float ln_eps, const tq_quantizer* q_out, tq_stream_t stream) {
+  const char* who = "tq_embeddings_layernorm_quant_fwd";
+  if (rows == 0) return TQ_OK;
+  TQ_REQUIRE(word_table && type_table && pos_table && word_ids && type_ids && pos_ids && y && ln_weight && ln_bias, "%s: NULL pointer", who);
+  TQ_REQUIRE(word_rows >= 1 && type_rows >= 1 && pos_rows >= 1, "%s: empty table", who);
+  TQ_REQUIRE(aligned16(word_table) && aligned16(type_table) && aligned16(pos_table) && aligned16(y), "%s: 16-byte alignment required", who);
+  TQ_REQUIRE(d % 4 == 0, "%s: row length %llu is not a whole number of 16-byte vectors", who, (unsigned long long)d);
+  TQ_REQUIRE(y_idx == nullptr || (q_out != nullptr && !q_out->symmetric && q_out->n_bits <= 8 && (reinterpret_cast<uintptr_t>(y_idx) & 7u) == 0),
+             "%s: y_idx needs an asymmetric <= 8-bit output quantizer and 8-byte alignment", who);
+  for (const tq_quantizer* q : {q_sum1, q_sum2, q_out})
+    if (q != nullptr) {
+      if (int e = check_quantizer(q, rows * d, who)) return e;
+      TQ_REQUIRE(q->n_params == 1, "%s: per-tensor quantizers only", who);
+    }
+  const EmbArgs emb{word_ids, type_ids, pos_ids, reinterpret_cast<const u32x4*>(type_table), word_rows, type_rows, pos_rows};
+  return launch_res_ln<TQ_F32>(word_table, pos_table, y, y_idx, rows, d, ln_weight, ln_bias, ln_eps, q_sum1, q_sum2, q_out, 0,
+                               static_cast<hipStream_t>(stream), &emb);
 }
 
 extern "C" int tq_residual_nonorm_quant_fwd(const void* dense_out, const void* residual, void* y, int8_t* y_idx, uint64_t rows,

@@ -70,8 +70,9 @@ class QMobileEmbeddings(QuantizedModel):
                            F.pad(e[:, :-1], [0, 0, 1, 0, 0, 0], value=0.0)], dim=2)   # [B, T, 384]
         if self.trigram_input or self.embedding_size != self.hidden_size:
             e = self.embedding_transformation(e)                                   # [B, T, 512]
-        pos = torch.arange(T, device=input_ids.device).unsqueeze(0)
-        tok = torch.zeros_like(input_ids)
+        from harness.bert import constant
+        pos = constant('positions', 1, T, input_ids.device)
+        tok = constant('token_type', input_ids.shape[0], T, input_ids.device)
         x = self.sum_input_pos_embd_act_quantizer(e + self.position_embeddings(pos))
         x = self.sum_token_type_embd_act_quantizer(x + self.token_type_embeddings(tok))
         return self.LayerNorm(x)
@@ -230,7 +231,8 @@ class QMobileBertForSequenceClassification(QuantizedModel):
         if attention_mask is not None:
             mask = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
         else:
-            mask = torch.zeros(input_ids.shape[0], 1, 1, input_ids.shape[1], device=input_ids.device)
+            from harness.bert import constant
+            mask = constant('mask', input_ids.shape[0], input_ids.shape[1], input_ids.device)
         h = self.embeddings(input_ids)
         for layer in self.layers:
             h = layer(h, mask)

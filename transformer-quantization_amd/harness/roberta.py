@@ -40,7 +40,8 @@ class QRobertaForSequenceClassification(QuantizedModel):
         if attention_mask is not None:
             mask = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
         else:
-            mask = torch.zeros(input_ids.shape[0], 1, 1, input_ids.shape[1], device=input_ids.device)
+            from harness.bert import constant
+            mask = constant('mask', input_ids.shape[0], input_ids.shape[1], input_ids.device)
         h = self.embeddings(input_ids)
         for layer in self.layers:
             h = layer(h, mask)

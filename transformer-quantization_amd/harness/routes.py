@@ -32,7 +32,7 @@ class Route:
             self.integer = [(mobilebert.QBottleneckLayer, 'fuse'), (mobilebert.QFFN, 'fuse'),
                             (mobilebert.QMobileSelfAttention, 'fuse'), (mobilebert.QMobileLayer, 'fuse_ffn')]
         else:
-            self.tails = [(bert.QResidualBlock, 'fuse'), (bert.QSelfAttention, 'fuse')]
+            self.tails = [(bert.QResidualBlock, 'fuse'), (bert.QSelfAttention, 'fuse'), (bert.QEmbeddings, 'fuse')]
             self.integer = [(bert.QLayer, 'fuse_ffn')]
 
     def __enter__(self):

@@ -69,6 +69,8 @@ SIGNATURES = {
     'tq_affine_fake_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _vp]),
     'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
     'tq_residual_nonorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _QP, _vp]),
+    'tq_embeddings_layernorm_quant_fwd': (_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _u64, _u64, _QP, _QP,
+                                                _vp, _vp, C.c_float, _QP, _vp]),
     'tq_attention_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u64, _u64, _vp, _f, _QP, _QP, _QP, _QP, _QP, _QP, _vp]),
     'tq_linear_i8_grouped_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _f, _int,
                                         _u64, C.POINTER(_QP), _vp]),
@@ -470,6 +472,29 @@ class HipBackend:
             rc = self.lib.tq_residual_layernorm_quant_fwd(
                 _ptr(a), _ptr(r), _ptr(y), _ptr(idx), a.numel() // d, d, _dtype_code(a, 'residual_layernorm_quant'),
                 refs[0], refs[1], _ptr(w32), _ptr(b32), float(ln_eps), refs[2], _stream())
+        _check(rc, self.lib)
+        return (y, idx) if want_idx else y
+
+    def embeddings_layernorm_quant(self, word, word_ids, type_tab, type_ids, pos_tab, pos_ids, q_sum1, q_sum2, ln_weight,
+                                   ln_bias, ln_eps, q_out, want_idx=False):
+        """y [rows, d] = Q_out(LN(Q_sum2(Q_sum1(word[word_ids] + type[type_ids]) + pos[pos_ids]))); tables fp32 [n, d]
+        (already fake-quantized), ids int64 [rows]; each q_* None or a per-tensor 7-tuple.  -> y (, int8 indices)."""
+        _need_device(word, 'embeddings_layernorm_quant')
+        _need_f32('embeddings_layernorm_quant', word, type_tab, pos_tab)
+        tabs = [t.detach().contiguous() for t in (word, type_tab, pos_tab)]
+        ids = [i.reshape(-1).contiguous() for i in (word_ids, type_ids, pos_ids)]
+        rows, d = ids[0].numel(), tabs[0].shape[-1]
+        if any(i.numel() != rows or i.dtype != torch.int64 for i in ids) or any(t.shape[-1] != d for t in tabs):
+            raise TQError('embeddings_layernorm_quant: ids must be int64 of one length, tables of one width')
+        y = torch.empty((rows, d), dtype=torch.float32, device=word.device)
+        idx = torch.empty((rows, d), dtype=torch.int8, device=word.device) if want_idx else None
+        descs = [None if q is None else self._qdesc(*q, 1, 1) for q in (q_sum1, q_sum2, q_out)]
+        refs = [None if dsc is None else C.byref(dsc) for dsc in descs]
+        w32, b32 = ln_weight.detach().float().contiguous(), ln_bias.detach().float().contiguous()
+        rc = self.lib.tq_embeddings_layernorm_quant_fwd(
+            _ptr(tabs[0]), tabs[0].shape[0], _ptr(ids[0]), _ptr(tabs[1]), tabs[1].shape[0], _ptr(ids[1]), _ptr(tabs[2]),
+            tabs[2].shape[0], _ptr(ids[2]), _ptr(y), _ptr(idx), rows, d, refs[0], refs[1], _ptr(w32), _ptr(b32), float(ln_eps),
+            refs[2], _stream())
         _check(rc, self.lib)
         return (y, idx) if want_idx else y
 

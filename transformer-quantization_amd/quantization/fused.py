@@ -91,6 +91,56 @@ def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual, _gem
     return y
 
 
+_LN_VECTORS = (16, 32, 64, 96, 128, 192, 256, 384, 512, 768)      # 16-byte vectors per row the tail kernels are built for
+
+
+def embeddings_layernorm_quant(word_emb, type_emb, pos_emb, sum1, sum2, layer_norm, input_ids, type_ids, pos_ids):
+    """BERT's embedding block (reference models/quantized_bert.py:75-111):
+
+        layer_norm( sum2( sum1( word_emb(input_ids) + type_emb(type_ids) ) + pos_emb(pos_ids) ) )
+
+    with three QuantEmbeddings (no output quantizer), two QuantizedActivations and a QuantLayerNorm, as ONE launch
+    (tq_embeddings_layernorm_quant_fwd: the 13 launches of the layered modules read and write [B, T, d] nine times) when
+    every range involved is fixed and per-tensor.  Returns None otherwise: the caller runs the layered modules."""
+    from quantization.autoquant_utils import QuantEmbedding, QuantLayerNorm
+    be = _hip.backend()
+    embs = (word_emb, type_emb, pos_emb)
+    if (not hasattr(be, 'embeddings_layernorm_quant') or not _hip.on_device(input_ids) or input_ids.dim() != 2
+            or input_ids.dtype != torch.int64 or type(layer_norm) is not QuantLayerNorm
+            or layer_norm.activation_function is not None or len(layer_norm.normalized_shape) != 1
+            or layer_norm.activation_save_target is not None or layer_norm.training
+            or _needs_autograd(word_emb, type_emb, pos_emb, layer_norm) or _hooked(*embs, sum1, sum2, layer_norm)):
+        return None
+    for e in embs:
+        if (type(e) is not QuantEmbedding or e.training or e.max_norm is not None or e.activation_save_target is not None
+                or not isinstance(e.activation_quantizer, FP32Acts) or _hooked(e._modules.get('weight_quantizer'))):
+            return None
+    q1 = _fixed_per_tensor(getattr(sum1, '_quant_a', False), getattr(sum1, 'activation_quantizer', sum1))
+    q2 = _fixed_per_tensor(getattr(sum2, '_quant_a', False), getattr(sum2, 'activation_quantizer', sum2))
+    q3 = _fixed_per_tensor(layer_norm._quant_a, layer_norm.activation_quantizer)
+    if 'no' in (q1, q2, q3):
+        return None
+    tables = [e.get_params()[0] for e in embs]                  # fake-quantized (cached in eval mode) fp32 tables
+    d = tables[0].shape[-1]
+    if (any(t.dtype != torch.float32 or t.shape[-1] != d or not _hip.on_device(t) for t in tables) or d % 4
+            or d // 4 not in _LN_VECTORS):
+        return None
+    B, T = input_ids.shape
+    if pos_ids.shape[-1] != T or type_ids.shape != input_ids.shape:
+        return None
+    pos_full = pos_ids.expand(B, T) if pos_ids.shape[0] != B else pos_ids
+    ln_w, ln_b = layer_norm.get_params()
+    arg = lambda q: None if q == 'off' else q
+    oq = layer_norm.activation_quantizer.quantizer if q3 != 'off' else None
+    want_idx = options.int8_active() and oq is not None and not oq.symmetric and oq.n_bits <= 8
+    out = be.embeddings_layernorm_quant(tables[0], input_ids, tables[1], type_ids, tables[2], pos_full, arg(q1), arg(q2),
+                                        ln_w, ln_b, layer_norm.eps, arg(q3), want_idx=want_idx)
+    y = (out[0] if want_idx else out).view(B, T, d)
+    if oq is not None:
+        provenance.tag(y, oq, out[1].view(B, T, d) if want_idx else None)
+    return y
+
+
 def quantized_bert_ffn(intermediate, dense, res_quantizer, layer_norm, x, residual):
     """BERT feed-forward block (reference models/quantized_bert.py:252-280 behind hijacker.py:66-116):
 

@@ -300,14 +300,15 @@ def run(config, args):
             os.makedirs(args.output_dir, exist_ok=True)
             torch.save(model.state_dict(), os.path.join(args.output_dir, 'state_dict_adaround.pth'))
 
-    route_before = (QResidualBlock.fuse, QSelfAttention.fuse, options.INT8_LINEAR)
+    from harness.bert import QEmbeddings
+    route_before = (QResidualBlock.fuse, QSelfAttention.fuse, options.INT8_LINEAR, QEmbeddings.fuse)
     if args.fast_inference and args.layered_inference:
         raise SystemExit('--fast-inference and --layered-inference exclude each other')
     if args.fast_inference:
-        QResidualBlock.fuse = QSelfAttention.fuse = True
+        QResidualBlock.fuse = QSelfAttention.fuse = QEmbeddings.fuse = True
         options.INT8_LINEAR = True
     elif args.layered_inference:
-        QResidualBlock.fuse = QSelfAttention.fuse = False
+        QResidualBlock.fuse = QSelfAttention.fuse = QEmbeddings.fuse = False
         options.INT8_LINEAR = False
     report['inference_route'] = ('fused/integer (forced)' if args.fast_inference else
                                  'layered (forced)' if args.layered_inference else
@@ -347,7 +348,7 @@ def run(config, args):
         try:
             _, t = _timed(evaluate)
         finally:
-            QResidualBlock.fuse, QSelfAttention.fuse, options.INT8_LINEAR = route_before      # process-wide switches
+            QResidualBlock.fuse, QSelfAttention.fuse, options.INT8_LINEAR, QEmbeddings.fuse = route_before      # process-wide switches
             options.INPLACE_CALIBRATION_STATE = inplace_before
     report['timings_s']['evaluation_incl_fp32_reference'] = t
     import math
