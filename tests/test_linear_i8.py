@@ -96,6 +96,55 @@ def test_linear_i8_vs_fp32_simulation(shape, cfg):
     assert torch.equal(yb, y.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize('shape', [(1024, 768, 768), (1024, 768, 3072), (64, 64, 256), (128, 192, 512), (256, 256, 1024),
+                                   (64, 128, 1280), (128, 64, 2048), (1024, 1024, 1792), (64, 64, 16384)])
+@pytest.mark.parametrize('act', ['none', 'gelu'])
+def test_ring_kernel_equals_the_double_buffered_kernel(shape, act):
+    """Launches of at most one 64 x 64 tile per CU with K >= 1024 run the 8-stage slab ring (csrc/tq_linear_i8.hip,
+    NS = 8): same integer contraction, same epilogue -- bit-identical to the double-buffered kernel
+    (TQ_I8_RING_MAX_GRID=0), for K of fewer / as many / more slabs than the ring holds (TQ_I8_RING_MIN_K=256 sends the
+    short K through the ring as well)."""
+    from quantization import _hip
+    be = _hip.backend()
+    M, N, K = shape
+    p = _problem(M, N, K, 8, 8, True, seed=K + N)
+    dev = lambda t: t.cuda()
+    x_i8 = be.quantize_to_int8(dev(p['x_q']), dev(p['xd']), dev(p['xz']), None, 8, False, False, 1e-8, 1, 1, minus_128=True)
+    w_i8 = be.quantize_to_int8(dev(p['w_q']), dev(p['wd']), None, dev(torch.tensor(True)), 8, True, False, 1e-8, N, K,
+                               minus_128=False)
+    rs = be.rowsum_i8(w_i8)
+    xq = (dev(p['xd']), dev(p['xz']), 8, 1e-8)
+    a = _hip.ACT_GELU if act == 'gelu' else _hip.ACT_NONE
+    pre = torch.nn.functional.linear(p['x_q'], p['w_q'], p['b'])
+    pre = torch.nn.functional.gelu(pre) if act == 'gelu' else pre
+    od, oz = O.asym_params_from_range(pre.min(), pre.max(), 8)
+    q_out = (dev(od), dev(oz), None, 8, False, False, 1e-8)
+
+    def run():
+        y0 = be.linear_i8(x_i8, w_i8, rs, dev(p['b']), xq, dev(p['wd']).reshape(-1), 1e-8, a, None, torch.float32)
+        y1, i1 = be.linear_i8(x_i8, w_i8, rs, dev(p['b']), xq, dev(p['wd']).reshape(-1), 1e-8, a, q_out, torch.float32,
+                              want_idx=True)
+        return y0.cpu(), y1.cpu(), i1.cpu()
+    os.environ['TQ_I8_RING_MIN_K'] = '256'
+    try:
+        ring = run()
+    finally:
+        del os.environ['TQ_I8_RING_MIN_K']
+    os.environ['TQ_I8_RING_MAX_GRID'] = '0'
+    try:
+        plain = run()
+    finally:
+        del os.environ['TQ_I8_RING_MAX_GRID']
+    for r, q in zip(ring, plain):
+        assert torch.equal(r, q)
+    # and against the exact integer contraction
+    acc = p['x_idx'].double() @ p['w_idx'].double().t()
+    zx = O.effective_zero_point(p['xz'], 8)
+    exact = (acc - zx * p['w_idx'].double().sum(1)) * (p['xd'].double() * p['wd'].double().reshape(1, -1)) + p['b'].double()
+    if act == 'none':
+        assert (ring[0].double() - exact).abs().max().item() <= 4e-7 * exact.abs().max().item() + 1e-7
+
+
 def test_bert_forward_with_integer_linears():
     """Whole BERT-base fixed-range forward with every eligible Linear on the i8 matrix cores (and the
     fused layer tails): logits stay within the same envelope as CPU-vs-GPU GEMM round-off."""

@@ -152,12 +152,18 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
     }
   }
 
-  const QP pq = make_qp(p.qq, 0), pk = make_qp(p.qk, 0), pv = make_qp(p.qv, 0), pp = make_qp(p.q_probs, 0);
+  // the raw buffers of all six quantizers as ONE batch of independent loads (tq_device.h load_qraw; quantizer by
+  // quantizer, delta -> zero_float, this was ~10 dependent scalar round trips: 3-4 us of a 10 us launch at BERT-base's
+  // inference batch), pinned behind the V / Q / K loads
+  QRaw wq = load_qraw(p.qq, 0, p.qq.delta), wk = load_qraw(p.qk, 0, p.qq.delta), wv = load_qraw(p.qv, 0, p.qq.delta);
+  QRaw wp = load_qraw(p.q_probs, 0, p.qq.delta), ws = load_qraw(p.q_scores, 0, p.qq.delta), wc = load_qraw(p.q_ctx, 0, p.qq.delta);
+  qraw_arrived(wq); qraw_arrived(wk); qraw_arrived(wv); qraw_arrived(wp); qraw_arrived(ws); qraw_arrived(wc);
+  const QP pq = qp_from_raw(p.qq, wq), pk = qp_from_raw(p.qk, wk), pv = qp_from_raw(p.qv, wv), pp = qp_from_raw(p.q_probs, wp);
   const int cq = 128 - (int)pq.zp, ck = 128 - (int)pk.zp, cv = 128 - (int)pv.zp, cp = 128 - (int)pp.zp;
   const float s_qk = pq.scale * pk.scale, s_pv = pp.scale * pv.scale;
   QP ps = {1.f, 0.f, 0.f, 0.f}, pc = {1.f, 0.f, 0.f, 0.f};
-  if (p.has_scores) ps = make_qp(p.q_scores, 0);
-  if (p.has_ctx) pc = make_qp(p.q_ctx, 0);
+  if (p.has_scores) ps = qp_from_raw(p.q_scores, ws);
+  if (p.has_ctx) pc = qp_from_raw(p.q_ctx, wc);
   const float rcp_s = guarded_rcp(ps.scale), rcp_p = guarded_rcp(pp.scale);   // rne(x / scale), tq_device.h
 
   // denom = 2^k (normal range): the division is an exact scaling

@@ -57,6 +57,62 @@ __device__ __forceinline__ QP make_qp(const tq_quantizer& q, uint64_t p) {
   return r;
 }
 
+// The same in two halves, for kernels whose run time is their PROLOGUE (the fused launches of a model forward at
+// inference batch sizes: a few microseconds in all).  make_qp reads delta, then -- behind the branches on the quantizer
+// kind -- zero_float or the signed flag: two dependent memory round trips per quantizer, and a kernel with three
+// quantizers that also derives its code path from them spent ~12 round trips (~3 us) before its first data load.
+// load_qraw issues every read of one quantizer unconditionally (an absent buffer reads `safe` instead, any valid device
+// address), so that the loads of ALL quantizers of a kernel -- and its first data loads -- are in flight together;
+// qp_from_raw is make_qp's arithmetic on the values.  Same results as make_qp for every input.
+struct QRaw {
+  float d, z;
+  uint32_t s;
+};
+
+__device__ __forceinline__ QRaw load_qraw(const tq_quantizer& q, uint64_t p, const float* safe) {
+  const float* dp = q.delta != nullptr ? q.delta + p : safe;
+  const float* zp = q.zero_float != nullptr ? q.zero_float + p : safe;
+  const uint8_t* sp = q.signed_flag != nullptr ? q.signed_flag : reinterpret_cast<const uint8_t*>(safe);
+  QRaw r;
+  r.d = *dp;
+  r.z = *zp;
+  r.s = *sp;
+  return r;
+}
+
+// Call on every QRaw of the kernel AFTER all of them (and the first data loads) were issued: pins the values to this point
+// of the program.  Without it the compiler sinks each (single-use) load into the branch of qp_from_raw that consumes it,
+// which brings back the dependent round trips one by one.
+// (Wave-uniform parameters only: the values are moved to scalar registers.)
+__device__ __forceinline__ float pinned_uniform(float v) {
+  uint32_t b = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, v));
+  asm volatile("" : "+s"(b));
+  return __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ void qraw_arrived(QRaw& w) {
+  w.d = pinned_uniform(w.d);
+  w.z = pinned_uniform(w.z);
+  uint32_t s = __builtin_amdgcn_readfirstlane(w.s);
+  asm volatile("" : "+s"(s));
+  w.s = s;
+}
+
+__device__ __forceinline__ QP qp_from_raw(const tq_quantizer& q, const QRaw& w) {
+  QP r;
+  r.scale = q.log_domain ? expf(w.d) : (w.d < q.eps ? q.eps : w.d);
+  if (q.symmetric) {
+    const bool sgn = q.signed_flag != nullptr && w.s != 0;
+    r.zp = 0.0f;
+    r.lo = sgn ? -(float)ldexp(1.0, q.n_bits - 1) : 0.0f;
+    r.hi = grid_top(q.n_bits - (sgn ? 1 : 0));
+  } else {
+    r.lo = 0.0f;
+    r.hi = grid_top(q.n_bits);
+    r.zp = clamp_nanprop(rintf(w.z), r.lo, r.hi);
+  }
+  return r;
+}
+
 // ------------------------------------------------------------------ rne(x / scale) without the division
 // The IEEE fp32 division is 10 of the ~19 VALU instructions of a fake-quant element and makes the bf16
 // per-embedding and the candidate-search kernels VALU-bound.  Only rne(x / scale) is needed, so:

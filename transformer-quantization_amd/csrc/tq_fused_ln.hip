@@ -26,11 +26,12 @@ struct FusedQ {
   float rcp;     // guarded_rcp(p.scale): three quantizers per element make these kernels VALU-bound with the division
 };
 
-__device__ __forceinline__ FusedQ make_fq(const tq_quantizer& q, int on) {
+__device__ __forceinline__ FusedQ make_fq(const QP& p, int on) {
   FusedQ f = {QP{1.f, 0.f, 0.f, 0.f}, on, 1.f};
-  if (on) { f.p = make_qp(q, 0); f.rcp = guarded_rcp(f.p.scale); }
+  if (on) { f.p = p; f.rcp = guarded_rcp(f.p.scale); }
   return f;
 }
+__device__ __forceinline__ FusedQ make_fq(const tq_quantizer& q, int on) { return make_fq(on ? make_qp(q, 0) : QP{1.f, 0.f, 0.f, 0.f}, on); }
 
 // x_int of v under q (bit-identical to q_index: rne_quot1 falls back to the division near ties)
 __device__ __forceinline__ float index_q(float v, const FusedQ& q) {
@@ -77,10 +78,10 @@ struct FusedF {
   QF f;
   int on;
 };
-__device__ __forceinline__ FusedF make_ff(const tq_quantizer& q, int on) {
+__device__ __forceinline__ FusedF make_ff(const QP& p, int on) {
   FusedF r;
   r.on = on;
-  r.f = make_qf(on ? make_qp(q, 0) : QP{1.f, 0.f, 0.f, 1.f});
+  r.f = make_qf(on ? p : QP{1.f, 0.f, 0.f, 1.f});
   return r;
 }
 __device__ __forceinline__ f32x2 apply_f2(f32x2 v, const FusedF& q) { return q.on ? qf_fake_quant2(v, q.f) : v; }
@@ -99,13 +100,47 @@ struct EmbArgs {
   uint64_t a_n, a2_n, r_n;        // rows of the three tables
 };
 
+// One row's 16-byte vectors of this lane (dense output, residual, and the token-type row in EMB mode) -> registers.
+// Streaming hints only for tensors that cannot stay in L2 / MALL anyway: in a model forward the inputs were just written by
+// the GEMM and the output is read by the next layer.  ONE uniform branch per group of loads.
+template <int DT, int LPR, int NV, bool EMB>
+__device__ __forceinline__ void ln_load_row(const u32x4* __restrict__ a, const u32x4* __restrict__ r, const EmbArgs& emb, int nt,
+                                            int lane, uint64_t row, u32x4 (&pa)[NV], u32x4 (&pr)[NV], u32x4 (&pa2)[EMB ? NV : 1]) {
+  constexpr int V = Store<DT>::kVec;
+  constexpr uint32_t d = LPR * NV * V;
+  if (EMB) {
+    auto pick = [](const int64_t* ids, uint64_t row_, uint64_t n) {
+      const int64_t id = ids[row_];
+      return id < 0 ? (uint64_t)0 : ((uint64_t)id >= n ? n - 1 : (uint64_t)id);
+    };
+    const uint64_t oa = pick(emb.a_rows, row, emb.a_n) * (d / V) + lane;
+    const uint64_t o2 = pick(emb.a2_rows, row, emb.a2_n) * (d / V) + lane;
+    const uint64_t orr = pick(emb.r_rows, row, emb.r_n) * (d / V) + lane;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { pa[v] = a[oa + v * LPR]; pa2[v] = emb.a2[o2 + v * LPR]; pr[v] = r[orr + v * LPR]; }
+    return;
+  }
+  const uint64_t o = row * (d / V) + lane;
+  if (nt) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { pa[v] = ld_stream(a + o + v * LPR); pr[v] = ld_stream(r + o + v * LPR); }
+  } else {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { pa[v] = a[o + v * LPR]; pr[v] = r[o + v * LPR]; }
+  }
+}
+
+// The three quantizers as the kernel entry derived them (once, from one batch of loads: tq_device.h load_qraw).
+struct TailQ {
+  QP p1, p2, p3;
+};
+
 template <int DT, int LPR, int NV, bool IDX, bool FAST, bool ALLON, bool AFF, bool EMB>
 __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u32x4* __restrict__ r,
                                             u32x4* __restrict__ y, int8_t* __restrict__ y_idx, uint64_t rows,
-                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                            float ln_eps, const tq_quantizer& q1, const tq_quantizer& q2,
-                                            const tq_quantizer& q3, int on1_, int on2_, int on3_, int nt, uint32_t iters,
-                                            const EmbArgs& emb) {
+                                            const float* s_w, const float* s_b,
+                                            float ln_eps, const TailQ& tq, int on1_, int on2_, int on3_, int nt, uint32_t iters,
+                                            const EmbArgs& emb, u32x4 (&va)[NV], u32x4 (&vr)[NV], u32x4 (&va2)[EMB ? NV : 1]) {
   // AFF (NoNorm: affine map only, no statistics) is a compile-time property: as a run-time flag every NaN rule of BOTH
   // variants was evaluated per element and selected (4-5 v_cndmask / v_cmp per element of ~29 VALU instructions on the
   // bf16 LayerNorm rows, found in the ISA in round 4)
@@ -117,51 +152,24 @@ __device__ __forceinline__ void res_ln_body(const u32x4* __restrict__ a, const u
   constexpr int H = V / 2;                          // register pairs per 16-byte vector
   constexpr int RPB = kBlock / LPR;                 // rows per block iteration
   constexpr uint32_t d = LPR * NV * V;
-  const FusedF f1 = make_ff(q1, on1), f2 = make_ff(q2, on2), f3 = make_ff(q3, on3);
-  const FusedQ g1 = make_fq(q1, on1), g2 = make_fq(q2, on2), g3 = make_fq(q3, on3);     // division path (FAST = false)
+  const FusedF f1 = make_ff(tq.p1, on1), f2 = make_ff(tq.p2, on2), f3 = make_ff(tq.p3, on3);
+  const FusedQ g1 = make_fq(tq.p1, on1), g2 = make_fq(tq.p2, on2), g3 = make_fq(tq.p3, on3);     // division path (FAST = false)
   const int lane = threadIdx.x % LPR;
   const int sub = threadIdx.x / LPR;
   const float inv_d = 1.0f / (float)d;
-
-  // affine parameters: staged once per block in LDS, read as 8-byte pairs where they are used (keeping this lane's
-  // 2 x d / LPR values in registers cost 48 VGPRs on bf16 rows and with them half the occupancy)
-  __shared__ __attribute__((aligned(16))) float s_w[d], s_b[d];
-  for (uint32_t c = threadIdx.x; c < d; c += kBlock) { s_w[c] = ln_w[c]; s_b[c] = ln_b[c]; }
-  __syncthreads();
 
   // A block owns `iters` consecutive groups of RPB rows (one-shot tiles in row order: the resident blocks sweep one
   // contiguous window of HBM); the loads of group i + 1 are issued before group i is computed, and the affine
   // parameters / quantizer constants are set up once per block instead of once per RPB rows.  Measured on
   // [131072, 768] (tools/tuning/tail_sweep.py): bf16 LayerNorm 3.6 / 4.6 / 4.9 / 4.9 TB/s for iters = 1 / 2 / 4 / 8,
-  // fp32 5.4 / 5.8 / 5.4 / 5.2 -> 8 for 2-byte storage, 2 for fp32 (launch_res_ln).
+  // fp32 5.4 / 5.8 / 5.4 / 5.2 -> 8 for 2-byte storage, 2 for fp32 (launch_res_ln).  The first group's loads were issued by
+  // the kernel entry, ahead of everything else.
   const uint64_t row0 = (uint64_t)blockIdx.x * RPB * iters + sub;
-  u32x4 va[NV], vr[NV], na[NV], nr[NV];
-  u32x4 va2[EMB ? NV : 1], na2[EMB ? NV : 1];
-  // streaming hints only for tensors that cannot stay in L2 / MALL anyway: in a model forward the inputs were just
-  // written by the GEMM and the output is read by the next layer.  ONE uniform branch per group of loads / stores.
+  u32x4 na[NV], nr[NV];
+  u32x4 na2[EMB ? NV : 1];
   auto load_row = [&](uint64_t row, u32x4 (&pa)[NV], u32x4 (&pr)[NV], u32x4 (&pa2)[EMB ? NV : 1]) {
-    if (EMB) {
-      auto pick = [](const int64_t* ids, uint64_t row_, uint64_t n) {
-        const int64_t id = ids[row_];
-        return id < 0 ? (uint64_t)0 : ((uint64_t)id >= n ? n - 1 : (uint64_t)id);
-      };
-      const uint64_t oa = pick(emb.a_rows, row, emb.a_n) * (d / V) + lane;
-      const uint64_t o2 = pick(emb.a2_rows, row, emb.a2_n) * (d / V) + lane;
-      const uint64_t orr = pick(emb.r_rows, row, emb.r_n) * (d / V) + lane;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) { pa[v] = a[oa + v * LPR]; pa2[v] = emb.a2[o2 + v * LPR]; pr[v] = r[orr + v * LPR]; }
-      return;
-    }
-    const uint64_t o = row * (d / V) + lane;
-    if (nt) {
-#pragma unroll
-      for (int v = 0; v < NV; ++v) { pa[v] = ld_stream(a + o + v * LPR); pr[v] = ld_stream(r + o + v * LPR); }
-    } else {
-#pragma unroll
-      for (int v = 0; v < NV; ++v) { pa[v] = a[o + v * LPR]; pr[v] = r[o + v * LPR]; }
-    }
+    ln_load_row<DT, LPR, NV, EMB>(a, r, emb, nt, lane, row, pa, pr, pa2);
   };
-  if (row0 < rows) load_row(row0, va, vr, va2);
   for (uint32_t it = 0; it < iters; ++it) {
     const uint64_t row = row0 + (uint64_t)it * RPB;
     if (row >= rows) break;
@@ -334,17 +342,49 @@ __global__ __launch_bounds__(kBlock) void res_ln_quant_k(const u32x4* __restrict
                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                          float ln_eps, tq_quantizer q1, tq_quantizer q2, tq_quantizer q3,
                                                          int on1, int on2, int on3, int nt, uint32_t iters, EmbArgs emb) {
+  // At a model's inference shapes ([1024, 768]: 4 rows per block) this kernel IS its prologue, so everything it reads is
+  // requested before anything is waited for: the first row of every lane group, the affine parameters (staged in LDS,
+  // read as 8-byte pairs where they are used: keeping this lane's 2 x d / LPR values in registers cost 48 VGPRs on bf16
+  // rows and with them half the occupancy), and the raw buffers of the three quantizers -- one memory round trip where
+  // the chain rows <- affine staging <- code-path choice <- quantizer by quantizer took ~13 (7.6 -> 4.x us per launch).
+  constexpr int V = Store<DT>::kVec;
+  constexpr int RPB = kBlock / LPR;
+  constexpr uint32_t d = LPR * NV * V;
+  constexpr int NA = (d + kBlock - 1) / kBlock;
+  __shared__ __attribute__((aligned(16))) float s_w[d], s_b[d];
+  u32x4 va[NV], vr[NV];
+  u32x4 va2[EMB ? NV : 1];
+  const uint64_t row0 = (uint64_t)blockIdx.x * RPB * iters + threadIdx.x / LPR;
+  if (row0 < rows) ln_load_row<DT, LPR, NV, EMB>(a, r, emb, nt, threadIdx.x % LPR, row0, va, vr, va2);
+  float aw[NA], ab[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const uint32_t c = threadIdx.x + i * kBlock;
+    const uint32_t cc = c < d ? c : d - 1;
+    aw[i] = ln_w[cc];
+    ab[i] = ln_b[cc];
+  }
+  QRaw w1 = load_qraw(q1, 0, ln_w), w2 = load_qraw(q2, 0, ln_w), w3 = load_qraw(q3, 0, ln_w);
+  qraw_arrived(w1); qraw_arrived(w2); qraw_arrived(w3);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const uint32_t c = threadIdx.x + i * kBlock;
+    if (c < d) { s_w[c] = aw[i]; s_b[c] = ab[i]; }
+  }
+  __syncthreads();
+  const QP none = {1.f, 0.f, 0.f, 0.f};
+  const TailQ tq = {on1 ? qp_from_raw(q1, w1) : none, on2 ? qp_from_raw(q2, w2) : none, on3 ? qp_from_raw(q3, w3) : none};
   // wave-uniform: every enabled quantizer admits the branch-free exact path (tq_device.h, QF)
   bool fast = true;
-  if (on1) fast = fast && make_qf(make_qp(q1, 0)).ok;
-  if (on2) fast = fast && make_qf(make_qp(q2, 0)).ok;
-  if (on3) fast = fast && make_qf(make_qp(q3, 0)).ok;
+  if (on1) fast = fast && make_qf(tq.p1).ok;
+  if (on2) fast = fast && make_qf(tq.p2).ok;
+  if (on3) fast = fast && make_qf(tq.p3).ok;
   if (fast && on1 && on2 && on3)
-    res_ln_body<DT, LPR, NV, IDX, true, true, AFF, EMB>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, 1, 1, 1, nt, iters, emb);
+    res_ln_body<DT, LPR, NV, IDX, true, true, AFF, EMB>(a, r, y, y_idx, rows, s_w, s_b, ln_eps, tq, 1, 1, 1, nt, iters, emb, va, vr, va2);
   else if (fast)
-    res_ln_body<DT, LPR, NV, IDX, true, false, AFF, EMB>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, nt, iters, emb);
+    res_ln_body<DT, LPR, NV, IDX, true, false, AFF, EMB>(a, r, y, y_idx, rows, s_w, s_b, ln_eps, tq, on1, on2, on3, nt, iters, emb, va, vr, va2);
   else
-    res_ln_body<DT, LPR, NV, IDX, false, false, AFF, EMB>(a, r, y, y_idx, rows, ln_w, ln_b, ln_eps, q1, q2, q3, on1, on2, on3, nt, iters, emb);
+    res_ln_body<DT, LPR, NV, IDX, false, false, AFF, EMB>(a, r, y, y_idx, rows, s_w, s_b, ln_eps, tq, on1, on2, on3, nt, iters, emb, va, vr, va2);
 }
 
 template <int DT>

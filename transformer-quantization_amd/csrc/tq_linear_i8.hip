@@ -445,33 +445,88 @@ struct EpiCtx {
   float st_inv_w, st_c0, st_nbm1;
 };
 
+// In two halves (tq_device.h load_qraw): epilogue_fetch issues every read the epilogue parameters need -- input quantizer,
+// output quantizer of this block's column group, the tail's quantizers, the staircase header -- as independent loads;
+// epilogue_finish turns the values into the context.  The LDS kernel calls the first half right after issuing its first
+// operand slabs, so that parameters and operands share one memory round trip (round 5: the dependent chain
+// x_delta -> q_out.delta -> q_out.zero_float -> ... in front of the first slab was ~15 round trips, about half of the
+// 6-8 us these launches take at BERT's inference shapes).
+struct EpiRaw {
+  float dx, zx;
+  QRaw qo, q1, q2;
+  float st[4];
+  tq_quantizer qsel;             // the output quantizer of this column group (by value: stays in scalar registers)
+};
+
 template <bool WITH_TAIL>
-__device__ __forceinline__ EpiCtx epilogue_prepare(const LinArgs& p, uint32_t n0) {
+__device__ __forceinline__ EpiRaw epilogue_fetch(const LinArgs& p, uint32_t n0) {
+  EpiRaw w;
+  const uint32_t grp = p.has_q ? n0 / p.group_cols : 0;     // a block tile never straddles two groups
+  // field by field: selects between kernel-argument VALUES (a struct assignment under `if` became the selection of an
+  // ADDRESS in the argument segment and a second, dependent round of loads through it)
+#define TQ_SEL(f) w.qsel.f = grp == 0 ? p.q_out.f : (grp == 1 ? p.q_out1.f : p.q_out2.f)
+  TQ_SEL(delta); TQ_SEL(zero_float); TQ_SEL(signed_flag); TQ_SEL(n_bits); TQ_SEL(symmetric); TQ_SEL(log_domain); TQ_SEL(eps);
+  TQ_SEL(n_params); TQ_SEL(inner);
+#undef TQ_SEL
+  w.dx = p.x_delta[0];
+  w.zx = p.x_zero_float[0];
+  w.qo = load_qraw(w.qsel, 0, p.x_delta);                   // has_q == 0: reads x_delta, unused
+  w.q1 = w.q2 = w.qo;
+  if (WITH_TAIL) {
+    w.q1 = load_qraw(p.q_t1, 0, p.x_delta);
+    w.q2 = load_qraw(p.q_t2, 0, p.x_delta);
+  }
+  w.st[0] = w.st[1] = w.st[2] = w.st[3] = 0.0f;
+  if (!WITH_TAIL && p.stair != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.st[i] = p.stair[i];
+  }
+  return w;
+}
+
+// every fetched value is pinned here (see qraw_arrived): call after all loads of the prologue were issued
+template <bool WITH_TAIL>
+__device__ __forceinline__ void epilogue_arrived(EpiRaw& w) {
+  w.dx = pinned_uniform(w.dx);
+  w.zx = pinned_uniform(w.zx);
+  qraw_arrived(w.qo);
+  if (WITH_TAIL) { qraw_arrived(w.q1); qraw_arrived(w.q2); }
+  else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.st[i] = pinned_uniform(w.st[i]);
+  }
+}
+
+template <bool WITH_TAIL>
+__device__ __forceinline__ EpiCtx epilogue_finish(const LinArgs& p, const EpiRaw& w) {
   EpiCtx c;
-  const float dx = p.x_delta[0];
-  c.sx = dx < p.x_eps ? p.x_eps : dx;
-  const int zx = (int)clamp_nanprop(rintf(p.x_zero_float[0]), 0.0f, grid_top(p.x_n_bits));
+  c.sx = w.dx < p.x_eps ? p.x_eps : w.dx;
+  const int zx = (int)clamp_nanprop(rintf(w.zx), 0.0f, grid_top(p.x_n_bits));
   c.shift = 128 - zx;
   c.qo = QP{1.f, 0.f, 0.f, 0.f};
-  if (p.has_q) {
-    const uint32_t grp = n0 / p.group_cols;             // a block tile never straddles two groups
-    c.qo = make_qp(grp == 0 ? p.q_out : (grp == 1 ? p.q_out1 : p.q_out2), 0);
-  }
+  if (p.has_q) c.qo = qp_from_raw(w.qsel, w.qo);
   c.qf = make_qf(c.qo);
   c.fast = p.act != ACT_TANH && (!p.has_q || c.qf.ok) && p.fast_epi != 0;
   c.stair = false;
   c.st_inv_w = c.st_c0 = c.st_nbm1 = 0.0f;
   if (!WITH_TAIL && p.stair != nullptr && p.has_q && c.fast) {
-    c.st_inv_w = p.stair[0]; c.st_c0 = p.stair[1]; c.st_nbm1 = p.stair[2];
-    c.stair = p.stair[3] == 1.0f && c.st_nbm1 == (float)(p.stair_bins - 1);
+    c.st_inv_w = w.st[0]; c.st_c0 = w.st[1]; c.st_nbm1 = w.st[2];
+    c.stair = w.st[3] == 1.0f && c.st_nbm1 == (float)(p.stair_bins - 1);
   }
   c.qf1 = c.qf2 = c.qf;
   if (WITH_TAIL) {
-    c.qf1 = make_qf(p.on_t1 ? make_qp(p.q_t1, 0) : QP{1.f, 0.f, 0.f, 1.f});
-    c.qf2 = make_qf(p.on_t2 ? make_qp(p.q_t2, 0) : QP{1.f, 0.f, 0.f, 1.f});
+    c.qf1 = make_qf(p.on_t1 ? qp_from_raw(p.q_t1, w.q1) : QP{1.f, 0.f, 0.f, 1.f});
+    c.qf2 = make_qf(p.on_t2 ? qp_from_raw(p.q_t2, w.q2) : QP{1.f, 0.f, 0.f, 1.f});
     c.fast = c.fast && p.act == ACT_NONE && c.qf1.ok && c.qf2.ok;
   }
   return c;
+}
+
+template <bool WITH_TAIL>
+__device__ __forceinline__ EpiCtx epilogue_prepare(const LinArgs& p, uint32_t n0) {
+  EpiRaw w = epilogue_fetch<WITH_TAIL>(p, n0);
+  epilogue_arrived<WITH_TAIL>(w);
+  return epilogue_finish<WITH_TAIL>(p, w);
 }
 
 template <int NI, int MI, int YDT, bool STAGED, bool WITH_TAIL>
@@ -579,21 +634,34 @@ __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmc
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp),           \
                                    (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 
-template <int WT, int YDT, bool WITH_TAIL>
+// NS = 8 (round 5) is the same kernel with an 8-stage ring of slabs, counted waits and ONE barrier per PAIR of slabs, for
+// launches of at most one block per CU (BERT-base's attention-output and second feed-forward Linear at batch 8: 192
+// blocks).  With nothing else resident on the CU the double-buffered loop is a chain of exposed latencies -- per slab a
+// DMA round trip when the operands are cold (inside a model forward), and barrier + fragment reads (~0.17 us, measured
+// with the breakdown build: tools/tuning/i8_small_dbg.py) even when they are not: 24 slabs of K = 3072 were 8.5 us of a
+// 10-14 us launch.  Here 4-6 slabs are in flight behind the pair being multiplied and the barrier count halves.
+// (For the throughput-bound shapes a 4-stage ring was slower, see above: they keep NS = 2.)  K % 256 == 0.
+template <int N>
+__device__ __forceinline__ void lds_dma_wait_but() {                   // all but the youngest N loads of this wave have landed
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WT, int YDT, bool WITH_TAIL, int NS = 2>
 __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinArgs p) {   // 2 (128 x 128 tiles) / 4 waves per SIMD
+  static_assert(NS == 2 || NS == 8, "double buffer or the 8-stage ring");
   constexpr int BT = 2 * WT, NI = WT / 16, MI = WT / 16;
   constexpr int LPW = WT / 16;                    // 1 KB load instructions per wave, operand and slab
   constexpr int OPB = BT * 128, STB = 2 * OPB;    // bytes per operand tile / per stage
   extern __shared__ __attribute__((aligned(1024))) int8_t lds_i8[];   // [2 stages][W | X][BT rows][128 B]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform for the compiler: scalar addressing of the epilogue parameters)
   const uint32_t tiles_m = p.M / BT;
   const int wn = (wave >> 1) * WT, wm = (wave & 1) * WT;
   const int r16 = lane & 15, kg = lane >> 4;
   // reader: k chunk c = 4 s + kg of row (16-aligned base) + r16 sits in slot c ^ ((r16 >> 1) & 7)
   const int swz = (r16 >> 1) & 7;
   const int off[2] = {r16 * 128 + ((kg ^ swz) << 4), r16 * 128 + (((4 + kg) ^ swz) << 4)};
-  float* cst = reinterpret_cast<float*>(lds_i8 + 2 * STB);
-  u32x2* stab = reinterpret_cast<u32x2*>(lds_i8 + 2 * STB + 5 * BT * 4);   // staircase entries (allocated only with p.stair)
+  float* cst = reinterpret_cast<float*>(lds_i8 + NS * STB);
+  u32x2* stab = reinterpret_cast<u32x2*>(lds_i8 + NS * STB + 5 * BT * 4);   // staircase entries (allocated only with p.stair)
   const uint32_t nk = p.K / 128;
 
   // One block per output tile.  (Round 3 tried persistent blocks working through runs of tiles -- parameters loaded
@@ -612,6 +680,9 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
       xsrc[q] = p.x + (size_t)(m0 + row) * p.K + chunk * 16;
     }
     auto issue = [&](int stage, uint32_t k) {
+#ifdef TQ_I8_DBG_BUILD
+      if (p.dbg & 2) return;
+#endif
       int8_t* bw = lds_i8 + stage * STB + wave * (WT / 2) * 128;
 #pragma unroll
       for (int q = 0; q < LPW; ++q) {
@@ -626,17 +697,23 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = v4i{0, 0, 0, 0};
 
-    // everything read through pointers first, as independent loads in flight together with the first slab: the
-    // quantizers' range buffers (epilogue parameters) and the per-column scale / bias / row sum this thread turns into
-    // LDS constants [BT scale | BT bias | BT correction | BT NoNorm weight | BT NoNorm bias] (published by the loop's
-    // first barrier)
-    const EpiCtx ectx = epilogue_prepare<WITH_TAIL>(p, n0 + wn);
+    // Everything read through pointers is REQUESTED first, as independent loads -- the quantizers' range buffers
+    // (epilogue parameters; scalar loads as long as no LDS-DMA precedes them) and the per-column scale / bias / row sum
+    // this thread turns into LDS constants [BT scale | BT bias | BT correction | BT NoNorm weight | BT NoNorm bias]
+    // (published by the loop's first barrier) --, then the operand slabs go out (both stages / the ring's first NS - 2),
+    // and only then is anything waited for: one memory round trip for the lot.  The column loads sit in front of the
+    // slabs in the (in-order) vector queue, so the constants do not wait for 100 KB of operands.
+    EpiRaw eraw = epilogue_fetch<WITH_TAIL>(p, n0 + wn);
     const uint32_t ncol = n0 + (tid & (BT - 1));       // threads >= BT load duplicates and do not write
     const float ld_dw = p.w_delta[p.w_n_params == 1 ? 0 : ncol], ld_b = p.bias ? p.bias[ncol] : 0.0f;
     const int ld_rs = p.w_rowsum[ncol];
     float ld_nw = 0.0f, ld_nb = 0.0f;
     if (WITH_TAIL) { ld_nw = p.nn_w[ncol]; ld_nb = p.nn_b[ncol]; }
-    issue(0, 0);
+#pragma unroll
+    for (int s = 0; s < (NS == 2 ? 2 : NS - 2); ++s)
+      if ((uint32_t)s < nk) issue(s, s * 128);
+    epilogue_arrived<WITH_TAIL>(eraw);
+    const EpiCtx ectx = epilogue_finish<WITH_TAIL>(p, eraw);
     if (tid < BT) {
       cst[tid] = ectx.sx * (ld_dw < p.w_eps ? p.w_eps : ld_dw);
       cst[BT + tid] = ld_b;
@@ -648,15 +725,26 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
       for (uint32_t i = tid; i < p.stair_bins; i += kBlock) stab[i] = gtab[i];
     }
     for (uint32_t kb = 0; kb < nk; ++kb) {
-      lds_dma_wait_all();
-      __syncthreads();                              // slab kb landed (vmcnt(0) + barrier); slab kb - 1 is no longer read
-#ifdef TQ_I8_DBG_BUILD
-      if (kb + 1 < nk && !(p.dbg & 2)) issue((kb + 1) & 1, (kb + 1) * 128);
-#else
-      if (kb + 1 < nk) issue((kb + 1) & 1, (kb + 1) * 128);
-#endif
-      const int8_t* bw = lds_i8 + (kb & 1) * STB + wn * 128;
-      const int8_t* bx = lds_i8 + (kb & 1) * STB + OPB + wm * 128;
+      if (NS == 2) {
+        lds_dma_wait_all();
+        __syncthreads();                              // slab kb landed (vmcnt(0) + barrier); slab kb - 1 is no longer read
+        if (kb > 0 && kb + 1 < nk) issue((kb + 1) & 1, (kb + 1) * 128);     // (slab 1 went out with slab 0)
+      } else if ((kb & 1) == 0) {
+        // pair (kb, kb + 1): slabs up to min(kb + NS - 3, nk - 1) are out, those after kb + 1 may stay in flight (NS - 4
+        // of them in the steady state).  A raw s_barrier: the compiler's __syncthreads would drain the queue
+        constexpr int IPS = 2 * LPW;                  // loads per slab and wave
+        const uint32_t rest = nk - 2 - kb;
+        if (rest >= (uint32_t)(NS - 4)) lds_dma_wait_but<(NS - 4) * IPS>();
+        else if (rest == 2) lds_dma_wait_but<2 * IPS>();
+        else lds_dma_wait_but<0>();
+        asm volatile("s_barrier" ::: "memory");       // the pair landed in every wave's part; the previous pair's stages are free
+        if (kb + NS - 2 < nk) {
+          issue((kb + NS - 2) % NS, (kb + NS - 2) * 128);
+          issue((kb + NS - 1) % NS, (kb + NS - 1) * 128);
+        }
+      }
+      const int8_t* bw = lds_i8 + (kb % NS) * STB + wn * 128;
+      const int8_t* bx = lds_i8 + (kb % NS) * STB + OPB + wm * 128;
       // Fragment pipeline: the 8 LDS reads of k-step s + 1 are in flight under the 16 MFMAs of k-step s (two fragment
       // sets in registers).  Left to itself the scheduler issued one ds_read, waited for it with lgkmcnt(0), ran four
       // MFMAs, and repeated: eight exposed LDS latencies per slab, the matrix cores idle in between.
@@ -694,7 +782,7 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
     }
 #endif
     constexpr int kStageBytes = 32 * (WT * 4 + 16) + 32 * (WT + 16);
-    static_assert(4 * kStageBytes <= 2 * STB, "output staging must fit the operand stages");
+    static_assert(4 * kStageBytes <= 2 * STB, "output staging must fit the operand stages");   // (NS >= 2 of them)
     linear_epilogue<NI, MI, YDT, true, WITH_TAIL>(p, acc, n0 + wn, m0 + wm, r16, kg, ectx, lds_i8 + wave * kStageBytes, cst + wn,
                                                   2 * NI * 16, nullptr, stab);
   }
@@ -744,16 +832,38 @@ __global__ __launch_bounds__(kBlock) void ffn_i8_k(FfnArgs p) {
   constexpr int kX = 0, kH = kX + BM * 128, kW1 = kH + SL2 * BM * 128, kW1w = (N1 / 4) * 128;
   constexpr int kW2 = kW1 + 4 * kW1w, kW2w = SL2 * (N2 / 4) * 128, kC1 = kW2 + 4 * kW2w, kC2 = kC1 + 3 * N1 * 4;
   extern __shared__ __attribute__((aligned(1024))) int8_t lds_i8[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kg = lane >> 4;
   const uint32_t m0 = blockIdx.x * BM;
 
-  // ---- everything read through pointers FIRST, as independent loads in flight together (measured: written as
-  // load-use-load-use this prologue cost 3.4 us of dependent global round trips): the quantizers' range buffers, the
-  // per-column scales / biases / row sums this thread turns into LDS constants below, the residual values of epilogue 2
-  const EpiCtx ectx = epilogue_prepare<true>(p.lin2, wave * (N2 / 4));
-  const QP qm = make_qp(p.q_mid, 0);
-  const float dx_in = p.x_delta[0], zf_in = p.x_zero_float[0];
+  // ---- all operand fetches first (global_load_lds: 8 rows x 128 B per instruction, XOR chunk swizzle as above)
+  {
+    const int row8 = lane >> 3, slot = lane & 7;
+    if (wave * 8 < BM) {   // x tile: wave w brings rows [8 w, 8 w + 8)
+      const int row = wave * 8 + row8;
+      TQ_GLDS16(p.x + (size_t)(m0 + row) * K1 + ((slot ^ ((row >> 1) & 7)) << 4), lds_i8 + kX + wave * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < N1 / 4 / 8; ++q) {   // own W1 slice: rows n = wave * 128 + 8 q + row8
+      const int row = q * 8 + row8;
+      TQ_GLDS16(p.w1 + (size_t)(wave * (N1 / 4) + row) * K1 + ((slot ^ ((row >> 1) & 7)) << 4), lds_i8 + kW1 + wave * kW1w + q * 1024);
+    }
+#pragma unroll
+    for (int sl = 0; sl < SL2; ++sl)
+#pragma unroll
+      for (int q = 0; q < N2 / 4 / 8; ++q) {   // own W2 slice, slab sl: rows n = wave * 32 + 8 q + row8, k bytes [128 sl, 128 sl + 128)
+        const int row = q * 8 + row8;
+        TQ_GLDS16(p.w2 + (size_t)(wave * (N2 / 4) + row) * N1 + sl * 128 + ((slot ^ ((row >> 1) & 7)) << 4),
+                  lds_i8 + kW2 + wave * kW2w + sl * (N2 / 4) * 128 + q * 1024);
+      }
+  }
+  // ---- then everything read through pointers, as independent loads in flight together with the operands (measured:
+  // written as load-use-load-use this prologue cost 3.4 us of dependent global round trips; round 5: the quantizers'
+  // buffers, too, are fetched in one batch -- tq_device.h load_qraw): the quantizers' range buffers, the per-column
+  // scales / biases / row sums this thread turns into LDS constants below, the residual values of epilogue 2
+  EpiRaw eraw = epilogue_fetch<true>(p.lin2, wave * (N2 / 4));
+  QRaw mraw = load_qraw(p.q_mid, 0, p.x_delta);
+  float dx_in = p.x_delta[0], zf_in = p.x_zero_float[0];
   constexpr int C1 = N1 / kBlock;                    // GEMM 1 columns per thread (2)
   float ld_dw1[C1], ld_b1[C1];
   int ld_rs1[C1];
@@ -775,28 +885,13 @@ __global__ __launch_bounds__(kBlock) void ffn_i8_k(FfnArgs p) {
 #pragma unroll
     for (int j = 0; j < MI; ++j)
       res_pre[i][j] = *reinterpret_cast<const f32x4*>(l2.residual + (size_t)(m0 + j * 16 + r16) * N2 + wave * (N2 / 4) + i * 16 + kg * 4);
+  epilogue_arrived<true>(eraw);
+  qraw_arrived(mraw);
+  dx_in = pinned_uniform(dx_in);
+  zf_in = pinned_uniform(zf_in);
+  const EpiCtx ectx = epilogue_finish<true>(p.lin2, eraw);
+  const QP qm = qp_from_raw(p.q_mid, mraw);
 
-  // ---- all operand fetches up front (global_load_lds: 8 rows x 128 B per instruction, XOR chunk swizzle as above)
-  {
-    const int row8 = lane >> 3, slot = lane & 7;
-    if (wave * 8 < BM) {   // x tile: wave w brings rows [8 w, 8 w + 8)
-      const int row = wave * 8 + row8;
-      TQ_GLDS16(p.x + (size_t)(m0 + row) * K1 + ((slot ^ ((row >> 1) & 7)) << 4), lds_i8 + kX + wave * 1024);
-    }
-#pragma unroll
-    for (int q = 0; q < N1 / 4 / 8; ++q) {   // own W1 slice: rows n = wave * 128 + 8 q + row8
-      const int row = q * 8 + row8;
-      TQ_GLDS16(p.w1 + (size_t)(wave * (N1 / 4) + row) * K1 + ((slot ^ ((row >> 1) & 7)) << 4), lds_i8 + kW1 + wave * kW1w + q * 1024);
-    }
-#pragma unroll
-    for (int sl = 0; sl < SL2; ++sl)
-#pragma unroll
-      for (int q = 0; q < N2 / 4 / 8; ++q) {   // own W2 slice, slab sl: rows n = wave * 32 + 8 q + row8, k bytes [128 sl, 128 sl + 128)
-        const int row = q * 8 + row8;
-        TQ_GLDS16(p.w2 + (size_t)(wave * (N2 / 4) + row) * N1 + sl * 128 + ((slot ^ ((row >> 1) & 7)) << 4),
-                  lds_i8 + kW2 + wave * kW2w + sl * (N2 / 4) * 128 + q * 1024);
-      }
-  }
   // ---- column constants (combined scale, bias, zero-point correction; NoNorm affine) -> LDS while the fetches land
   float* c1 = reinterpret_cast<float*>(lds_i8 + kC1);
   float* c2 = reinterpret_cast<float*>(lds_i8 + kC2);
@@ -954,6 +1049,23 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
     LinArgs b = a;
     if (b.stair != nullptr && ((size_t)b.stair_bins * 8 > room || !tuning("TQ_I8_STAIR", 1))) b.stair = nullptr;
     const size_t lds = base + (b.stair != nullptr ? (size_t)b.stair_bins * 8 : 0) + (big ? (size_t)tuning("TQ_I8_LDS_PAD", 0) : 0);
+    // at most one 64 x 64 tile per CU and a long K: the 8-stage ring (up to 6 slabs = 96 KB in flight per block).  Measured
+    // inside the BERT-base forward at batch 8 (profiles/r05/bert_default_route_layer_timeline.txt): K = 3072 13.9 -> 10.6 us,
+    // K = 768 6.0 -> 6.2 us (six slabs: the double buffer already has a third of them in flight) -> from K = 1024 on
+    constexpr int kRing = 8;
+    if (!big && b.stair == nullptr && a.K % 256 == 0 && a.K >= (uint32_t)tuning("TQ_I8_RING_MIN_K", 1024) &&
+        grid <= (uint64_t)tuning("TQ_I8_RING_MAX_GRID", 256)) {
+      auto k = linear_i8_lds_k<32, YDT, WITH_TAIL, kRing>;
+      const size_t ring_lds = (size_t)kRing * 2 * 64 * 128 + 5 * 64 * 4;
+      static bool attr_set = false;                 // (per instantiation; benign if two threads both set it)
+      if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds) != hipSuccess)
+          return set_error(TQ_ELAUNCH, "linear_i8_lds_k (ring): cannot reserve %zu bytes of LDS", ring_lds);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), ring_lds, st, b);
+      return check_launch("linear_i8_lds_k (ring)");
+    }
     if (big) hipLaunchKernelGGL((linear_i8_lds_k<64, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock), lds, st, b);
     else     hipLaunchKernelGGL((linear_i8_lds_k<32, YDT, WITH_TAIL>), dim3((unsigned)grid), dim3(kBlock), lds, st, b);
     return check_launch("linear_i8_lds_k");
