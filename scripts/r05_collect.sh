@@ -7,11 +7,13 @@ O=$ROOT/gpurun_out/r05
 mkdir -p "$O"
 export TMPDIR=/tmp
 python tools/tuning/py_overhead2.py 2>&1 | grep -v amdgpu > "$O/py_overhead2.txt"
+# the PMC passes first: bench.py reads profiles/pmc_traffic.json and refuses one collected from other kernel sources
+bash scripts/profile_gpu.sh r05 > "$O/profile_gpu.log" 2>&1
+cp gpurun_out/prof_r05/pmc_traffic.json profiles/pmc_traffic.json
 python bench.py > "$O/bench_n1.json" 2> "$O/bench_n1.err"; echo "bench rc=$?"
 python bench.py --sweep --no-cpu --headline-only > "$O/bench_sweep.json" 2>> "$O/bench_n1.err"
 TQ_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 \
     bench.py --gpus 1 --no-cpu > "$O/bench_rccl1.json" 2> "$O/bench_rccl1.err"; echo "bench rccl1 rc=$?"
-bash scripts/profile_gpu.sh r05 > "$O/profile_gpu.log" 2>&1
 bash scripts/profile_kernels.sh r05 > "$O/profile_kernels.log" 2>&1
 python scripts/config_bench.py > "$O/config_bench.json" 2> "$O/config_bench.err"; echo "config_bench rc=$?"
 python scripts/int_vs_reference.py > "$O/int_vs_reference.json" 2> "$O/int_vs_reference.err"; echo "int_vs_reference rc=$?"
