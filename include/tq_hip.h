@@ -247,6 +247,15 @@ int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, const int8_t* 
                         const float* mask, float denom, const tq_quantizer* q_q,
                         const tq_quantizer* q_k, const tq_quantizer* q_v, const tq_quantizer* q_scores,
                         const tq_quantizer* q_probs, const tq_quantizer* q_ctx, tq_stream_t stream);
+/* The same with a row stride of its own for v_idx (0 = H*head_dim): MobileBERT's query and key Linears share their input
+ * (models/quantized_mobilebert.py:214-226 called with the bottlenecked shared input at :507-513) and are one grouped launch whose
+ * [B, T, 2 * H * head_dim] index buffer q_idx / k_idx point into, while the value Linear reads the layer input.        */
+int tq_attention_i8_strided_fwd(const int8_t* q_idx, const int8_t* k_idx, const int8_t* v_idx, float* ctx,
+                                int8_t* ctx_idx, uint64_t B, uint64_t T, uint64_t H, uint64_t head_dim,
+                                uint64_t qk_row_stride, uint64_t v_row_stride, const float* mask, float denom,
+                                const tq_quantizer* q_q, const tq_quantizer* q_k, const tq_quantizer* q_v,
+                                const tq_quantizer* q_scores, const tq_quantizer* q_probs, const tq_quantizer* q_ctx,
+                                tq_stream_t stream);
 
 /* Fused attention probabilities with fixed ranges (reference models/quantized_bert.py:153-198):
  *     probs = Q_probs( softmax( Q_scores(scores) / denom + mask, dim=-1 ) )

@@ -153,6 +153,57 @@ def test_stacked_qkv_projection_equals_three_linears():
     assert torch.equal(one, sep) and torch.equal(provenance.indices_of(one), provenance.indices_of(sep))
 
 
+def test_mobilebert_grouped_query_key_equals_three_linears():
+    """MobileBERT's query and key Linears read the SAME bottlenecked tensor, the value Linear the layer input:
+    quantized_self_attention((q_in, k_in, v_in), ...) runs Q | K as one grouped index-only launch, V as another, and the
+    core reads V with a row stride of its own (tq_attention_i8_strided_fwd) -- bit-identical to three integer Linears
+    followed by quantized_attention."""
+    from tests.test_mobilebert_e2e import _fixture as mb_fixture
+    from harness.mobilebert import build_mobilebert
+    from quantization import _hip, options, provenance
+    from quantization.fused import quantized_attention, quantized_self_attention
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from utils.utils import pass_data_for_range_estimation
+    z = mb_fixture()
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    model, _ = build_mobilebert(seed=1000, num_layers=2, **qp)
+    model = model.cuda().eval()
+    ids = torch.from_numpy(z['input_ids']).cuda()
+    calls = []
+    be = _hip.backend()
+    orig = be.linear_i8_grouped
+    with torch.no_grad():
+        pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
+        model.fix_ranges()
+        options.INT8_LINEAR = True
+        be.linear_i8_grouped = lambda *a, **k: (calls.append(len(a[8])), orig(*a, **k))[1]
+        try:
+            L = model.layers[0]
+            h = model.embeddings(ids)
+            assert provenance.indices_of(h) is not None
+            shared = L.bottleneck_attention(h)
+            assert provenance.indices_of(shared) is not None
+            A = L.attention_self
+            mask = torch.zeros(ids.shape[0], 1, 1, ids.shape[1], device='cuda')
+            mask[2, ..., 90:] = -10000.0
+            args = (mask, A.heads, A.attn_scores_act_quantizer, A.attn_probs_act_quantizer, A.attn_output_act_quantizer)
+            one = quantized_self_attention((shared, shared, h), A.query, A.key, A.value, *args)
+            sep = quantized_attention(A.query(shared), A.key(shared), A.value(h), *args)
+            # three different tensor objects: three launches, same result
+            shared2 = L.bottleneck_attention(h)
+            calls_before = len(calls)
+            three = quantized_self_attention((shared, shared2, h), A.query, A.key, A.value, *args)
+        finally:
+            options.INT8_LINEAR = False
+            be.__dict__.pop('linear_i8_grouped', None)
+    assert one is not None and sep is not None and three is not None
+    assert calls[:2] == [2, 1] and calls[calls_before:] == [1, 1, 1]
+    assert torch.equal(one, sep) and torch.equal(provenance.indices_of(one), provenance.indices_of(sep))
+    assert torch.equal(three, sep)
+
+
 @pytest.mark.parametrize('n_bits', [4, 6])
 def test_attention_i8_low_bit_grids(n_bits):
     """W4A4-style configurations: Q / K / V / probabilities / context on 4- and 6-bit grids (indices are

@@ -16,6 +16,9 @@ print('# One encoder layer of the DEFAULT-route BERT-base forward ([8,128], fixe
 print('# rocprofv3 --kernel-trace over tools/tuning/bert_default_prof.py; start offset / duration of every kernel between two')
 print('# consecutive attention cores (layers 11 -> 12 of the last replay; tools/tuning/layer_timeline.py).  The kernels run')
 print('# back to back: the forward is the sum of 7 latency-bound launches per layer, not launch gaps.')
+if len(sys.argv) > 2:                          # any other model: no per-kernel legend
+    WHAT = []
+    print(f'# ({sys.argv[2]})')
 for k, r in enumerate(rows[a:b + 1]):
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     name = r['Kernel_Name'].split('(')[0]

@@ -38,7 +38,8 @@ struct AttnArgs {
   int8_t* ctx_idx;            // optional int8(index - 128) of ctx (needs q_ctx)
   const float* mask;          // additive [B, T] or null
   uint32_t B, T, H;
-  uint32_t in_stride;         // elements between consecutive tokens of q / k / v (H * 64, or 3 * H * 64 inside a stacked QKV buffer)
+  uint32_t in_stride;         // elements between consecutive tokens of q / k (H * 64, or 3 * H * 64 inside a stacked QKV buffer)
+  uint32_t v_stride;          // the same for v (MobileBERT: Q | K stacked, V on its own)
   float denom;
   tq_quantizer qq, qk, qv;    // per-tensor asymmetric, n_bits <= 8
   tq_quantizer q_scores, q_probs, q_ctx;
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
   const uint32_t b = bh / p.H, h = bh % p.H;
   const size_t row_stride = p.in_stride;
   const size_t base = (size_t)b * T * row_stride + (size_t)h * DH;
+  const size_t v_stride = p.v_stride, base_v = (size_t)b * T * v_stride + (size_t)h * DH;
 
   TQ_STAMP(0);
   // ---- V tile: loads first (one work item = 4 consecutive keys x 16 head dims, four 16-byte loads) ----------------
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
       const uint32_t key4 = (c / PARTS) * 4, part = c % PARTS;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
-        raw[it][kk] = *reinterpret_cast<const v4i*>(p.v + base + (size_t)(key4 + kk) * row_stride + part * 16);
+        raw[it][kk] = *reinterpret_cast<const v4i*>(p.v + base_v + (size_t)(key4 + kk) * v_stride + part * 16);
     }
   }
 
@@ -464,6 +466,16 @@ extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, con
                                    uint64_t qkv_row_stride, const float* mask, float denom, const tq_quantizer* q_q,
                                    const tq_quantizer* q_k, const tq_quantizer* q_v, const tq_quantizer* q_scores,
                                    const tq_quantizer* q_probs, const tq_quantizer* q_ctx, tq_stream_t stream) {
+  return tq_attention_i8_strided_fwd(q_idx, k_idx, v_idx, ctx, ctx_idx, B, T, H, head_dim, qkv_row_stride, qkv_row_stride, mask,
+                                     denom, q_q, q_k, q_v, q_scores, q_probs, q_ctx, stream);
+}
+
+extern "C" int tq_attention_i8_strided_fwd(const int8_t* q_idx, const int8_t* k_idx, const int8_t* v_idx, float* ctx,
+                                           int8_t* ctx_idx, uint64_t B, uint64_t T, uint64_t H, uint64_t head_dim,
+                                           uint64_t qkv_row_stride, uint64_t v_row_stride, const float* mask, float denom,
+                                           const tq_quantizer* q_q, const tq_quantizer* q_k, const tq_quantizer* q_v,
+                                           const tq_quantizer* q_scores, const tq_quantizer* q_probs,
+                                           const tq_quantizer* q_ctx, tq_stream_t stream) {
   if (B == 0 || T == 0 || H == 0) return TQ_OK;
   TQ_REQUIRE(q_idx && k_idx && v_idx && ctx, "tq_attention_i8_fwd: NULL pointer");
   TQ_REQUIRE(head_dim == 64 || head_dim == 32, "tq_attention_i8_fwd: head_dim %llu unsupported (32, 64)", (unsigned long long)head_dim);
@@ -474,8 +486,11 @@ extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, con
              "tq_attention_i8_fwd: 16-byte alignment required");
   TQ_REQUIRE(denom != 0.0f, "tq_attention_i8_fwd: denom == 0");
   if (qkv_row_stride == 0) qkv_row_stride = H * head_dim;
+  if (v_row_stride == 0) v_row_stride = H * head_dim;
   TQ_REQUIRE(qkv_row_stride >= H * head_dim && qkv_row_stride % 16 == 0 && qkv_row_stride < (1ull << 31),
              "tq_attention_i8_fwd: bad qkv_row_stride %llu", (unsigned long long)qkv_row_stride);
+  TQ_REQUIRE(v_row_stride >= H * head_dim && v_row_stride % 16 == 0 && v_row_stride < (1ull << 31),
+             "tq_attention_i8_fwd: bad v_row_stride %llu", (unsigned long long)v_row_stride);
   TQ_REQUIRE(B * H * (T / (16 * kAttnWaves)) < (1ull << 31), "tq_attention_i8_fwd: too many tiles");
   if (int e = check_i8_grid(q_q, "query")) return e;
   if (int e = check_i8_grid(q_k, "key")) return e;
@@ -495,7 +510,7 @@ extern "C" int tq_attention_i8_fwd(const int8_t* q_idx, const int8_t* k_idx, con
   }
   AttnArgs a{};
   a.q = q_idx; a.k = k_idx; a.v = v_idx; a.ctx = ctx; a.ctx_idx = ctx_idx; a.mask = mask;
-  a.B = (uint32_t)B; a.T = (uint32_t)T; a.H = (uint32_t)H; a.in_stride = (uint32_t)qkv_row_stride; a.denom = denom;
+  a.B = (uint32_t)B; a.T = (uint32_t)T; a.H = (uint32_t)H; a.in_stride = (uint32_t)qkv_row_stride; a.v_stride = (uint32_t)v_row_stride; a.denom = denom;
   a.qq = *q_q; a.qk = *q_k; a.qv = *q_v; a.q_probs = *q_probs;
   a.has_scores = q_scores != nullptr; a.has_ctx = q_ctx != nullptr;
   a.fast_ok = tuning("TQ_ATTN_FAST", 1);

@@ -1057,11 +1057,13 @@ static int launch_linear_t(const LinArgs& a, hipStream_t st) {
         grid <= (uint64_t)tuning("TQ_I8_RING_MAX_GRID", 256)) {
       auto k = linear_i8_lds_k<32, YDT, WITH_TAIL, kRing>;
       const size_t ring_lds = (size_t)kRing * 2 * 64 * 128 + 5 * 64 * 4;
-      static bool attr_set = false;                 // (per instantiation; benign if two threads both set it)
-      if (!attr_set) {
+      static bool attr_set[64] = {};                // per instantiation and device; benign if two threads both set it
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+      if (dev < 0 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds) != hipSuccess)
           return set_error(TQ_ELAUNCH, "linear_i8_lds_k (ring): cannot reserve %zu bytes of LDS", ring_lds);
-        attr_set = true;
+        if (dev >= 0) attr_set[dev] = true;
       }
       hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), ring_lds, st, b);
       return check_launch("linear_i8_lds_k (ring)");

@@ -124,8 +124,18 @@ class QMobileSelfAttention(QuantizedModel):
     fuse = None    # set True to run the fixed-range attention core as one integer kernel (quantization/fused.py)
 
     def forward(self, q_in, k_in, v_in, mask):
+        fuse = options.fuse_on(self.fuse, self, self.attn_probs_act_quantizer)
+        if fuse:
+            # the three Linears as index-only grouped integer launches (query and key share the bottlenecked input: one
+            # launch) feeding the integer core directly; None = not eligible
+            from quantization.fused import quantized_self_attention
+            ctx = quantized_self_attention((q_in, k_in, v_in), self.query, self.key, self.value, mask, self.heads,
+                                           self.attn_scores_act_quantizer, self.attn_probs_act_quantizer,
+                                           self.attn_output_act_quantizer)
+            if ctx is not None:
+                return ctx
         qo, ko, vo = self.query(q_in), self.key(k_in), self.value(v_in)
-        if options.fuse_on(self.fuse, self, self.attn_probs_act_quantizer):
+        if fuse:
             # Q K^T -> quantizer -> / sqrt(d) + mask -> softmax -> quantizer -> P V -> quantizer (per-tensor, so "per head
             # before the merge" and "after the merge" coincide) on the i8 matrix cores; None = layered modules
             from quantization.fused import quantized_attention

@@ -72,6 +72,8 @@ SIGNATURES = {
     'tq_embeddings_layernorm_quant_fwd': (_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _u64, _u64, _QP, _QP,
                                                 _vp, _vp, C.c_float, _QP, _vp]),
     'tq_attention_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u64, _u64, _vp, _f, _QP, _QP, _QP, _QP, _QP, _QP, _vp]),
+    'tq_attention_i8_strided_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u64, _u64, _u64, _vp, _f, _QP, _QP, _QP, _QP,
+                                           _QP, _QP, _vp]),
     'tq_linear_i8_grouped_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _f, _int,
                                         _u64, C.POINTER(_QP), _vp]),
     'tq_scores_softmax_quant_fwd': (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _f, _QP, _QP, _vp]),
@@ -500,22 +502,21 @@ class HipBackend:
 
     def attention_i8(self, q_idx, k_idx, v_idx, num_heads, mask, denom, q_q, q_k, q_v, q_scores, q_probs, q_ctx,
                      want_idx=False):
-        """Quantized attention core on int8 indices [B, T, H * 64] (contiguous tensors, or the three column
-        blocks of one stacked [B, T, 3 * H * 64] buffer); every q_* is a per-tensor 7-tuple (q_scores /
-        q_ctx may be None).  -> ctx fp32 [B, T, H * 64] (, int8 indices of ctx)."""
+        """Quantized attention core on int8 indices [B, T, H * 64] (contiguous tensors, or column blocks of stacked
+        buffers: Q | K | V of one [B, T, 3 * H * 64] buffer, or Q | K of one buffer and V of another); every q_* is a
+        per-tensor 7-tuple (q_scores / q_ctx may be None).  -> ctx fp32 [B, T, H * 64] (, int8 indices of ctx)."""
         _need_device(q_idx, 'attention_i8')
         B, T, D = q_idx.shape
-        stride = q_idx.stride(1)
-        if not (q_idx.stride(2) == 1 and q_idx.stride(0) == T * stride and k_idx.stride() == q_idx.stride()
-                and v_idx.stride() == q_idx.stride()):
+        rows = lambda t: t.stride(2) == 1 and t.stride(0) == T * t.stride(1) and t.stride(1) % 16 == 0
+        if not (rows(q_idx) and rows(k_idx) and rows(v_idx) and k_idx.stride() == q_idx.stride()):
             q_idx, k_idx, v_idx = q_idx.contiguous(), k_idx.contiguous(), v_idx.contiguous()
-            stride = D
         ctx = torch.empty((B, T, D), dtype=torch.float32, device=q_idx.device)
         ctx_idx = torch.empty((B, T, D), dtype=torch.int8, device=q_idx.device) if want_idx else None
         descs = [None if q is None else self._qdesc(*q, 1, 1) for q in (q_q, q_k, q_v, q_scores, q_probs, q_ctx)]
         refs = [None if dsc is None else C.byref(dsc) for dsc in descs]
-        rc = self.lib.tq_attention_i8_fwd(_ptr(q_idx), _ptr(k_idx), _ptr(v_idx), _ptr(ctx), _ptr(ctx_idx), B, T,
-                                          num_heads, D // num_heads, stride, _ptr(mask), float(denom), *refs, _stream())
+        rc = self.lib.tq_attention_i8_strided_fwd(_ptr(q_idx), _ptr(k_idx), _ptr(v_idx), _ptr(ctx), _ptr(ctx_idx), B, T,
+                                                  num_heads, D // num_heads, q_idx.stride(1), v_idx.stride(1), _ptr(mask),
+                                                  float(denom), *refs, _stream())
         _check(rc, self.lib)
         return (ctx, ctx_idx) if want_idx else ctx
 

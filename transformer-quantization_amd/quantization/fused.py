@@ -406,31 +406,36 @@ def _stacked_qkv(layers):
 
 def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quantizer, probs_quantizer,
                              context_quantizer):
-    """Self-attention of a quantized BERT layer from the layer input: the query / key / value Linears run as
-    ONE grouped integer GEMM that only emits int8 indices (tq_linear_i8_grouped_fwd), which the integer
-    attention core consumes in place (column blocks of the stacked buffer).  Same preconditions as
-    `quantized_attention` plus: the three Linears are plain eval-mode QuantLinears without activation
-    function whose weight and output quantizers are fixed, and x carries its int8 indices.  Returns None
-    when any of that does not hold (run the layered modules then)."""
+    """Self-attention of a quantized BERT / MobileBERT layer from the inputs of its query / key / value Linears: Linears
+    that share their input run as ONE grouped integer GEMM that only emits int8 indices (tq_linear_i8_grouped_fwd:
+    no fp32 output is written), which the integer attention core consumes in place (column blocks of the stacked
+    buffers).  `x`: the one layer input (BERT: one launch for Q | K | V), or a (query_in, key_in, value_in) tuple
+    (MobileBERT, reference models/quantized_mobilebert.py:214-226 called at :507-513: query and key read the bottlenecked
+    shared input -> Q | K in one launch, V in another).  Same preconditions as `quantized_attention` plus: the three
+    Linears are plain eval-mode QuantLinears without activation function whose weight and output quantizers are fixed,
+    and the inputs carry their int8 indices.  Returns None when any of that does not hold (run the layered modules
+    then)."""
     from quantization.autoquant_utils import QuantLinear, _fixed_per_tensor_manager
     layers = (query, key, value)
-    if (not options.int8_active() or x.dim() != 3 or not _hip.on_device(x) or x.dtype != torch.float32
+    xs = tuple(x) if isinstance(x, (tuple, list)) else (x, x, x)
+    if (not options.int8_active() or len(xs) != 3
+            or any(t.dim() != 3 or not _hip.on_device(t) or t.dtype != torch.float32 for t in xs)
             or _hooked(query, key, value, scores_quantizer, probs_quantizer, context_quantizer,
                        *(getattr(l, 'weight_quantizer', None) for l in layers))):
         return None
-    if torch.is_grad_enabled() and (x.requires_grad or any(l.weight.requires_grad for l in layers)):
+    if torch.is_grad_enabled() and (any(t.requires_grad for t in xs) or any(l.weight.requires_grad for l in layers)):
         return None
-    src = _int8_source(x)
-    B, T, K = x.shape
+    B, T, _ = xs[0].shape
     D = query.out_features
-    if (src is None or D % num_heads or D // num_heads not in (32, 64) or T % 64 or T > 512 or (B * T) % 64 or K % 128
-            or K > 16384):
+    if (any(t.shape[:2] != (B, T) for t in xs) or D % num_heads or D // num_heads not in (32, 64) or T % 64 or T > 512
+            or (B * T) % 64 or D % 64):
         return None
     outs = []
-    for l in layers:
+    for l, t in zip(layers, xs):
+        K = t.shape[-1]
         if (type(l) is not QuantLinear or l.training or not l._quant_w or not l._quant_a
                 or l.activation_function is not None or l.activation_save_target is not None
-                or l.in_features != K or l.out_features != D
+                or l.in_features != K or l.out_features != D or K % 128 or K > 16384
                 or not _fixed_per_tensor_manager(l.activation_quantizer)
                 or not isinstance(l.weight_quantizer, QuantizationManager)      # e.g. replaced by FP32Acts
                 or l.weight_quantizer.state != Qstates.fix_ranges):
@@ -451,18 +456,38 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
                 and mask.shape[3] == T):
             return None
         mask = mask.reshape(B, T).float().contiguous()
-    packed = _stacked_qkv(layers)
-    if packed is None:
-        return None
-    w_idx, rowsum, bias, scales = packed
+    # consecutive Linears reading the SAME tensor object form one launch: (Q, K, V) | (Q, K), (V) | (Q), (K), (V)
+    groups = [[0]]
+    for i in (1, 2):
+        if xs[i] is xs[groups[-1][0]]:
+            groups[-1].append(i)
+        else:
+            groups.append([i])
+    srcs = {}
+    for g in groups:
+        src = _int8_source(xs[g[0]])
+        if src is None:
+            return None
+        srcs[g[0]] = src
     be = _hip.backend()
-    x_idx, xq = src
-    _, qkv = be.linear_i8_grouped(x_idx, w_idx, rowsum, bias, (xq[0], xq[1], xq[3], xq[6]), scales,
-                                  query.weight_quantizer.quantizer.eps, 0, outs, want_y=False, want_idx=True)
+    cols = [None, None, None]
+    packs = [_stacked_qkv(tuple(layers[i] for i in g)) for g in groups]
+    if any(p is None for p in packs):
+        return None
+    from quantization.autoquant_utils import INT8_STATS
+    for g, packed in zip(groups, packs):
+        INT8_STATS['kernel_calls'] += len(g)                  # counted in Linears, like the other fused launches
+        w_idx, rowsum, bias, scales = packed
+        x_idx, xq = srcs[g[0]]
+        _, buf = be.linear_i8_grouped(x_idx, w_idx, rowsum, bias, (xq[0], xq[1], xq[3], xq[6]), scales,
+                                      query.weight_quantizer.quantizer.eps, 0, [outs[i] for i in g], want_y=False,
+                                      want_idx=True)
+        for j, i in enumerate(g):
+            cols[i] = buf[..., j * D:(j + 1) * D]
     arg = lambda q: None if q == 'off' else q
     cq = context_quantizer.activation_quantizer.quantizer if qc != 'off' else None
     want_idx = cq is not None and not cq.symmetric and cq.n_bits <= 8
-    out = be.attention_i8(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], num_heads, mask, float(D // num_heads) ** 0.5,
+    out = be.attention_i8(cols[0], cols[1], cols[2], num_heads, mask, float(D // num_heads) ** 0.5,
                           outs[0], outs[1], outs[2], arg(qs), qp, arg(qc), want_idx=want_idx)
     ctx = out[0] if want_idx else out
     if cq is not None:
