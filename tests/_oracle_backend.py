@@ -121,6 +121,20 @@ class OracleBackend:
                                      nn_w=nn_w, nn_b=nn_b, q_t1=self._q7(q_sum), q_t2=self._q7(q_out))
         return (y.to(out_dtype), yi) if want_idx else y.to(out_dtype)
 
+    def linear_i8_nonorm_grouped(self, x_idx, w_idx, w_rowsum, bias, nn_w, nn_b, x_q, w_delta_rows, w_eps, q_dense, q_out,
+                                 out_dtype, want_idx=False):
+        """the two chains of the grouped launch, one after the other through the oracle"""
+        N = w_idx.shape[0]
+        ys, yis = [], []
+        for g in range(2):
+            sl = slice(g * N // 2, (g + 1) * N // 2)
+            y, yi = self.linear_i8_nonorm(x_idx, w_idx[sl], None, None if bias is None else bias[sl], None, nn_w[sl], nn_b[sl],
+                                          x_q, w_delta_rows[sl], w_eps, None if q_dense is None else q_dense[g], None,
+                                          None if q_out is None else q_out[g], out_dtype, want_idx=True)
+            ys.append(y)
+            yis.append(yi)
+        return (ys, yis) if want_idx else ys
+
     def ffn_i8_nonorm(self, x_idx, x_q, w1_idx, w1_rowsum, bias1, w1_delta, w1_eps, q_mid, w2_idx, w2_rowsum, bias2, w2_delta,
                       w2_eps, residual, nn_w, nn_b, q_dense, q_sum, q_out, out_dtype, want_idx=False):
         from oracle import int_oracle

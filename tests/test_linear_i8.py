@@ -321,6 +321,49 @@ def test_linear_i8_nonorm_tail_equals_two_launches(shape, with_res, quantizers):
     assert torch.equal(yb, ref_y.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize('shape', [(1024, 128, 512), (64, 64, 128), (4096, 128, 512), (2048, 1024, 256)])
+@pytest.mark.parametrize('quantizers', ['all', 'no_dense', 'no_out'])
+def test_grouped_linear_nonorm_pair_equals_two_launches(shape, quantizers):
+    """tq_linear_i8_nonorm_grouped_fwd: two Linear -> NoNorm chains reading the same int8 input as one launch with
+    split outputs (MobileBERT's two input bottlenecks) -- bit-identical to two tq_linear_i8_nonorm_fwd launches."""
+    from quantization import _hip
+    be = _hip.backend()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    ps = [_problem(M, N, K, 8, 8, True, seed=7 * i + N) for i in range(2)]
+    dev = lambda t: t.cuda()
+    p0 = ps[0]
+    x_i8 = be.quantize_to_int8(dev(p0['x_q']), dev(p0['xd']), dev(p0['xz']), None, 8, False, False, 1e-8, 1, 1, minus_128=True)
+    xq = (dev(p0['xd']), dev(p0['xz']), 8, 1e-8)
+    parts = []
+    for p in ps:
+        w_i8 = be.quantize_to_int8(dev(p['w_q']), dev(p['wd']), None, dev(torch.tensor(True)), 8, True, False, 1e-8, N, K,
+                                   minus_128=False)
+        nn_w = dev(torch.randn(N, generator=g) * 0.5 + 1.0)
+        nn_b = dev(torch.randn(N, generator=g) * 0.2)
+        pre = torch.nn.functional.linear(p0['x_q'], p['w_q'], p['b'])
+        dd, dz = O.asym_params_from_range(pre.min(), pre.max(), 8)
+        post = pre * nn_w.cpu() + nn_b.cpu()
+        od, oz = O.asym_params_from_range(post.min(), post.max(), 8)
+        parts.append(dict(w=w_i8, rs=be.rowsum_i8(w_i8), b=dev(p['b']), wd=dev(p['wd']).reshape(-1), nn_w=nn_w, nn_b=nn_b,
+                          qd=(dev(dd), dev(dz), None, 8, False, False, 1e-8), qo=(dev(od), dev(oz), None, 8, False, False, 1e-8)))
+    qd = None if quantizers == 'no_dense' else [q['qd'] for q in parts]
+    qo = None if quantizers == 'no_out' else [q['qo'] for q in parts]
+    want_idx = qo is not None
+    cat = lambda k: torch.cat([q[k] for q in parts]).contiguous()
+    out = be.linear_i8_nonorm_grouped(x_i8, cat('w'), cat('rs'), cat('b'), cat('nn_w'), cat('nn_b'), xq, cat('wd'), 1e-8, qd,
+                                      qo, torch.float32, want_idx=want_idx)
+    ys, idxs = out if want_idx else (out, [None, None])
+    for i, q in enumerate(parts):
+        ref = be.linear_i8_nonorm(x_i8, q['w'], q['rs'], q['b'], None, q['nn_w'], q['nn_b'], xq, q['wd'], 1e-8,
+                                  None if qd is None else q['qd'], None, None if qo is None else q['qo'], torch.float32,
+                                  want_idx=want_idx)
+        ry, ri = ref if want_idx else (ref, None)
+        assert ys[i].is_contiguous() and torch.equal(ys[i], ry), i
+        if want_idx:
+            assert torch.equal(idxs[i], ri), i
+
+
 @pytest.mark.parametrize('M', [32, 1024, 4096])
 @pytest.mark.parametrize('quantizers', ['all', 'no_dense', 'no_sum', 'no_out'])
 @pytest.mark.parametrize('per_channel', [False, True])

@@ -69,6 +69,10 @@ struct LinArgs {
   const float* nn_b;      // [N] fake-quantized NoNorm bias
   tq_quantizer q_t1, q_t2;
   int on_t1, on_t2;
+  // grouped launch WITH tail 1 (MobileBERT's two input bottlenecks read the same tensor): group 1's NoNorm output
+  // quantizer, and the outputs of group g as a tensor of their own, [M, group_cols] at y + g * M * group_cols
+  tq_quantizer q_t2b;
+  int split_out;
   // optional staircase table of act + q_out (tq_act_stair_build; LDS kernels only): replaces the activation and the
   // quantizer's quotient in the epilogue when its header says it is exact
   const float* stair;
@@ -79,6 +83,13 @@ struct StairRef {                // the table as the epilogue sees it: entries i
   const u32x2* tab;
   float inv_w, c0, nbm1;
 };
+
+// element offset of output (row, n) in y / y_idx
+__device__ __forceinline__ size_t out_at(const LinArgs& p, uint32_t row, uint32_t n) {
+  if (!p.split_out) return (size_t)row * p.N + n;
+  const uint32_t g = n / p.group_cols;
+  return (size_t)g * p.M * p.group_cols + (size_t)row * p.group_cols + (n - g * p.group_cols);
+}
 
 // ---- epilogue: zero-point correction, scales, bias, activation, output quantizer ----------------------
 // The epilogue is the expensive half of this kernel at BERT's K = 768: every output element costs one GEMM column
@@ -161,7 +172,7 @@ __device__ __forceinline__ void stage_flush(const LinArgs& p, const int8_t* ysta
       if (RPI <= PR || row < PR) {
         const u32x4 d = *reinterpret_cast<const u32x4*>(ystage + row * YP + (lane % LPR) * 16);
         __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(static_cast<int8_t*>(p.y) +
-                                                                ((size_t)(mrow0 + row) * p.N + n0) * ES + (lane % LPR) * 16));
+                                                                out_at(p, mrow0 + row, n0) * ES + (lane % LPR) * 16));
       }
     }
   }
@@ -172,7 +183,7 @@ __device__ __forceinline__ void stage_flush(const LinArgs& p, const int8_t* ysta
       const int row = t * RPI + lane / LPR;
       if (RPI <= PR || row < PR) {
         const u32x4 d = *reinterpret_cast<const u32x4*>(istage + row * IP + (lane % LPR) * 16);
-        *reinterpret_cast<u32x4*>(p.y_idx + (size_t)(mrow0 + row) * p.N + n0 + (lane % LPR) * 16) = d;
+        *reinterpret_cast<u32x4*>(p.y_idx + out_at(p, mrow0 + row, n0) + (lane % LPR) * 16) = d;
       }
     }
   }
@@ -301,7 +312,7 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
           if (want_idx) *reinterpret_cast<uint32_t*>(istage + row * IP + col) = w;
           if (p.y != nullptr) store_y4<YDT>(ystage + row * YP, col, v[2 * jj], v[2 * jj + 1]);
         } else {
-          const size_t at = (size_t)(m0 + j * 16 + r16) * p.N + n;
+          const size_t at = out_at(p, m0 + j * 16 + r16, n);
           if (want_idx) *reinterpret_cast<uint32_t*>(p.y_idx + at) = w;
           if (p.y != nullptr) store_y4<YDT>(p.y, at, v[2 * jj], v[2 * jj + 1]);
         }
@@ -398,7 +409,7 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
     }
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const size_t at = (size_t)(m0 + j * 16 + r16) * p.N + n;
+      const size_t at = out_at(p, m0 + j * 16 + r16, n), rat = (size_t)(m0 + j * 16 + r16) * p.N + n;
       float o[4];
       struct alignas(4) { int8_t e[4]; } oi4 = {{0, 0, 0, 0}};
 #pragma unroll
@@ -411,13 +422,13 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
           v = q_dequant(xi, qo);
         }
         if (p.tail == 2) {
-          v = v + p.residual[at + r];
+          v = v + p.residual[rat + r];
           if (p.on_t1) v = q_dequant(q_index(v, make_qp(p.q_t1, 0)), make_qp(p.q_t1, 0));
         }
         if (p.tail >= 1) {
           v = v * p.nn_w[n + r] + p.nn_b[n + r];
           if (p.on_t2) {
-            const QP q2 = make_qp(p.q_t2, 0);
+            const QP q2 = make_qp(p.split_out && n / p.group_cols == 1 ? p.q_t2b : p.q_t2, 0);
             const float xi = q_index(v, q2);
             oi4.e[r] = (int8_t)((int)xi - 128);
             v = q_dequant(xi, q2);
@@ -456,12 +467,13 @@ struct EpiRaw {
   QRaw qo, q1, q2;
   float st[4];
   tq_quantizer qsel;             // the output quantizer of this column group (by value: stays in scalar registers)
+  tq_quantizer t2sel;            // the tail's last quantizer of this column group
 };
 
 template <bool WITH_TAIL>
 __device__ __forceinline__ EpiRaw epilogue_fetch(const LinArgs& p, uint32_t n0) {
   EpiRaw w;
-  const uint32_t grp = p.has_q ? n0 / p.group_cols : 0;     // a block tile never straddles two groups
+  const uint32_t grp = n0 / p.group_cols;                   // (group_cols = N for a plain launch) a block tile never straddles two groups
   // field by field: selects between kernel-argument VALUES (a struct assignment under `if` became the selection of an
   // ADDRESS in the argument segment and a second, dependent round of loads through it)
 #define TQ_SEL(f) w.qsel.f = grp == 0 ? p.q_out.f : (grp == 1 ? p.q_out1.f : p.q_out2.f)
@@ -472,9 +484,11 @@ __device__ __forceinline__ EpiRaw epilogue_fetch(const LinArgs& p, uint32_t n0) 
   w.zx = p.x_zero_float[0];
   w.qo = load_qraw(w.qsel, 0, p.x_delta);                   // has_q == 0: reads x_delta, unused
   w.q1 = w.q2 = w.qo;
+  w.t2sel = p.q_t2;
   if (WITH_TAIL) {
+    if (p.split_out && grp == 1) w.t2sel = p.q_t2b;
     w.q1 = load_qraw(p.q_t1, 0, p.x_delta);
-    w.q2 = load_qraw(p.q_t2, 0, p.x_delta);
+    w.q2 = load_qraw(w.t2sel, 0, p.x_delta);
   }
   w.st[0] = w.st[1] = w.st[2] = w.st[3] = 0.0f;
   if (!WITH_TAIL && p.stair != nullptr) {
@@ -516,7 +530,7 @@ __device__ __forceinline__ EpiCtx epilogue_finish(const LinArgs& p, const EpiRaw
   c.qf1 = c.qf2 = c.qf;
   if (WITH_TAIL) {
     c.qf1 = make_qf(p.on_t1 ? qp_from_raw(p.q_t1, w.q1) : QP{1.f, 0.f, 0.f, 1.f});
-    c.qf2 = make_qf(p.on_t2 ? qp_from_raw(p.q_t2, w.q2) : QP{1.f, 0.f, 0.f, 1.f});
+    c.qf2 = make_qf(p.on_t2 ? qp_from_raw(w.t2sel, w.q2) : QP{1.f, 0.f, 0.f, 1.f});
     c.fast = c.fast && p.act == ACT_NONE && c.qf1.ok && c.qf2.ok;
   }
   return c;
@@ -1233,6 +1247,56 @@ extern "C" int tq_linear_i8_nonorm_fwd(const int8_t* x_idx, const int8_t* w_idx,
 // MobileBERT feed-forward block (intermediate Linear + ReLU + quantizer, output Linear, residual NoNorm tail) as one
 // launch: see ffn_i8_k.  Shapes: (K1, N1, N2) = (128, 512, 128), M % 32 == 0; anything else is TQ_EINVAL and the caller
 // runs tq_linear_i8_fwd + tq_linear_i8_nonorm_fwd (the results are bit-identical either way).
+extern "C" int tq_linear_i8_nonorm_grouped_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum,
+                                               const float* bias, const float* nn_weight, const float* nn_bias, void* y,
+                                               int8_t* y_idx, int y_dtype, uint64_t M, uint64_t N, uint64_t K,
+                                               const float* x_delta, const float* x_zero_float, int x_n_bits, float x_eps,
+                                               const float* w_delta, float w_eps, uint64_t n_groups,
+                                               const tq_quantizer* const* q_dense, const tq_quantizer* const* q_out,
+                                               tq_stream_t stream) {
+  if (M == 0 || N == 0) return TQ_OK;
+  TQ_REQUIRE(x_idx && w_idx && w_rowsum && y && x_delta && x_zero_float && w_delta && nn_weight && nn_bias,
+             "tq_linear_i8_nonorm_grouped_fwd: NULL pointer");
+  TQ_REQUIRE(y_dtype == TQ_F32 || y_dtype == TQ_BF16, "tq_linear_i8_nonorm_grouped_fwd: y dtype must be fp32 or bf16");
+  TQ_REQUIRE(n_groups == 2 && N % 2 == 0 && (N / 2) % 64 == 0, "tq_linear_i8_nonorm_grouped_fwd: 2 groups of a multiple of 64 output features");
+  TQ_REQUIRE(M % 64 == 0 && K % 128 == 0 && K <= 16384 && M < (1u << 31) && N < (1u << 31),
+             "tq_linear_i8_nonorm_grouped_fwd: unsupported shape M=%llu N=%llu K=%llu (M %% 64, K %% 128)", (unsigned long long)M,
+             (unsigned long long)N, (unsigned long long)K);
+  TQ_REQUIRE(x_n_bits >= 1 && x_n_bits <= 8, "tq_linear_i8_nonorm_grouped_fwd: input quantizer must have <= 8 bits");
+  TQ_REQUIRE(aligned16(x_idx) && aligned16(w_idx) && aligned16(y), "tq_linear_i8_nonorm_grouped_fwd: 16-byte alignment required");
+  LinArgs a{};
+  a.x = x_idx; a.w = w_idx; a.w_rowsum = w_rowsum; a.bias = bias; a.y = y; a.y_idx = y_idx;
+  a.M = (uint32_t)M; a.N = (uint32_t)N; a.K = (uint32_t)K;
+  a.x_delta = x_delta; a.x_zero_float = x_zero_float; a.x_eps = x_eps; a.x_n_bits = x_n_bits;
+  a.w_delta = w_delta; a.w_n_params = (uint32_t)N; a.w_eps = w_eps; a.act = ACT_NONE;
+  a.group_cols = (uint32_t)(N / 2);
+  a.split_out = 1;
+  a.tail = 1;
+  a.nn_w = nn_weight; a.nn_b = nn_bias;
+  const bool has_d = q_dense != nullptr && q_dense[0] != nullptr, has_o = q_out != nullptr && q_out[0] != nullptr;
+  TQ_REQUIRE((!has_d && (q_dense == nullptr || q_dense[1] == nullptr)) || (has_d && q_dense[1] != nullptr),
+             "tq_linear_i8_nonorm_grouped_fwd: both groups or neither need a dense-output quantizer");
+  TQ_REQUIRE((!has_o && (q_out == nullptr || q_out[1] == nullptr)) || (has_o && q_out[1] != nullptr),
+             "tq_linear_i8_nonorm_grouped_fwd: both groups or neither need an output quantizer");
+  TQ_REQUIRE(y_idx == nullptr || has_o, "tq_linear_i8_nonorm_grouped_fwd: y_idx needs output quantizers");
+  for (int g = 0; g < 2; ++g) {
+    const tq_quantizer* qs[2] = {has_d ? q_dense[g] : nullptr, has_o ? q_out[g] : nullptr};
+    for (const tq_quantizer* q : qs)
+      if (q != nullptr) {
+        if (int e = check_quantizer(q, M * N, "tq_linear_i8_nonorm_grouped_fwd")) return e;
+        TQ_REQUIRE(q->n_params == 1, "tq_linear_i8_nonorm_grouped_fwd: per-tensor quantizers only");
+      }
+    TQ_REQUIRE(y_idx == nullptr || (!q_out[g]->symmetric && q_out[g]->n_bits <= 8),
+               "tq_linear_i8_nonorm_grouped_fwd: y_idx needs asymmetric <= 8-bit output quantizers");
+  }
+  a.has_q = has_d;
+  if (has_d) { a.q_out = *q_dense[0]; a.q_out1 = *q_dense[1]; }
+  a.on_t2 = has_o;
+  if (has_o) { a.q_t2 = *q_out[0]; a.q_t2b = *q_out[1]; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return y_dtype == TQ_F32 ? launch_linear<TQ_F32>(a, st) : launch_linear<TQ_BF16>(a, st);
+}
+
 extern "C" int tq_ffn_i8_nonorm_fwd(const int8_t* x_idx, const float* x_delta, const float* x_zero_float, int x_n_bits, float x_eps,
                                     const int8_t* w1_idx, const int32_t* w1_rowsum, const float* bias1, const float* w1_delta,
                                     uint64_t w1_n_params, float w1_eps, const tq_quantizer* q_mid, const int8_t* w2_idx,

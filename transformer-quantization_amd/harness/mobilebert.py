@@ -212,8 +212,16 @@ class QMobileLayer(QuantizedModel):
     fuse_ffn = None    # set True: the last feed-forward block (intermediate + output) as one integer launch, like QFFN.fuse
 
     def forward(self, h, mask):
-        layer_input = self.bottleneck_input(h)                    # [B, T, 128] residual of the attention block
-        shared = self.bottleneck_attention(h)                     # query / key input
+        pair = None
+        if options.fuse_on(self.bottleneck_input.fuse, self.bottleneck_input, self.bottleneck_input.LayerNorm):
+            from quantization.fused import linear_nonorm_quant_pair     # both bottlenecks read h: one integer launch
+            pair = linear_nonorm_quant_pair(self.bottleneck_input.dense, self.bottleneck_input.LayerNorm,
+                                            self.bottleneck_attention.dense, self.bottleneck_attention.LayerNorm, h)
+        if pair is not None:
+            layer_input, shared = pair
+        else:
+            layer_input = self.bottleneck_input(h)                # [B, T, 128] residual of the attention block
+            shared = self.bottleneck_attention(h)                 # query / key input
         a = self.attention_output(self.attention_self(shared, shared, h, mask), layer_input)
         for f in self.ffn:
             a = f(a)

@@ -82,6 +82,8 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _QP, _QP, _QP, _vp, _vp, _int, _u64, _u64, _u64, _u64, _vp]),
     'tq_linear_i8_nonorm_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f,
                                        _vp, _u64, _f, _QP, _QP, _QP, _vp]),
+    'tq_linear_i8_nonorm_grouped_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp,
+                                               _f, _u64, C.POINTER(_QP), C.POINTER(_QP), _vp]),
     'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
                                 _int, _QP, _vp]),
     'tq_linear_i8_stair_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
@@ -643,6 +645,31 @@ class HipBackend:
             refs[2], _stream())
         _check(rc, self.lib)
         return (y, y_idx) if want_idx else y
+
+    def linear_i8_nonorm_grouped(self, x_idx, w_idx, w_rowsum, bias, nn_w, nn_b, x_q, w_delta_rows, w_eps, q_dense, q_out,
+                                 out_dtype, want_idx=False):
+        """Two Linear -> NoNorm chains reading the same int8 input in one launch (stacked operands, see include/tq_hip.h);
+        q_dense / q_out: lists of two 7-tuples or None.  -> [y_0, y_1] (, [idx_0, idx_1]), each [..., N / 2] contiguous."""
+        K = x_idx.shape[-1]
+        M = x_idx.numel() // K
+        N = w_idx.shape[0]
+        G = 2
+        y = torch.empty((G,) + tuple(x_idx.shape[:-1]) + (N // G,), dtype=out_dtype, device=x_idx.device)
+        y_idx = torch.empty(y.shape, dtype=torch.int8, device=y.device) if want_idx else None
+
+        def arr(qs):
+            if qs is None:
+                return None, None
+            descs = [self._qdesc(*q, 1, 1) for q in qs]
+            return descs, C.cast((C.POINTER(tq_quantizer) * G)(*[C.pointer(d) for d in descs]), C.POINTER(_QP))
+        keep_d, a_d = arr(q_dense)
+        keep_o, a_o = arr(q_out)
+        rc = self.lib.tq_linear_i8_nonorm_grouped_fwd(
+            _ptr(x_idx), _ptr(w_idx), _ptr(w_rowsum), _ptr(bias), _ptr(nn_w), _ptr(nn_b), _ptr(y), _ptr(y_idx),
+            _DTYPES[out_dtype], M, N, K, _ptr(x_q[0]), _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(w_delta_rows),
+            float(w_eps), G, a_d, a_o, _stream())
+        _check(rc, self.lib)
+        return ([y[0], y[1]], [y_idx[0], y_idx[1]]) if want_idx else [y[0], y[1]]
 
     FFN_SHAPES = {(128, 512, 128)}          # (K1, N1, N2) tq_ffn_i8_nonorm_fwd is built for
 

@@ -247,6 +247,77 @@ def linear_nonorm_quant(dense, layer_norm, x):
     return layer_norm(dense(x))
 
 
+def linear_nonorm_quant_pair(dense_a, layer_norm_a, dense_b, layer_norm_b, x):
+    """MobileBERT's two input bottlenecks (reference models/quantized_mobilebert.py:404-417, built at :483-488):
+
+        layer_norm_a(dense_a(x)), layer_norm_b(dense_b(x))
+
+    -- two QuantLinear -> QuantNoNorm chains reading the SAME tensor -- as ONE integer launch
+    (tq_linear_i8_nonorm_grouped_fwd) when options.INT8_LINEAR applies and every range involved is fixed and per-tensor;
+    each result is a contiguous tensor of its own, tagged with its quantizer and int8 indices.  None otherwise (the
+    caller runs the two chains separately).  Bit-identical to the separate launches."""
+    from quantization.autoquant_utils import QuantLinear, QuantNoNorm, INT8_STATS
+    be = _hip.backend()
+    pairs = ((dense_a, layer_norm_a), (dense_b, layer_norm_b))
+    if (not options.int8_active() or not hasattr(be, 'linear_i8_nonorm_grouped') or not _hip.on_device(x)
+            or x.dtype != torch.float32 or _needs_autograd(dense_a, layer_norm_a, dense_b, layer_norm_b, x)
+            or _hooked(dense_a, layer_norm_a, dense_b, layer_norm_b)):
+        return None
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = dense_a.out_features
+    if M % 64 or K % 128 or K > 16384 or N % 64 or dense_b.out_features != N:
+        return None
+    q_dense, q_out, plans = [], [], []
+    for d, ln in pairs:
+        if (type(d) is not QuantLinear or type(ln) is not QuantNoNorm or d.training or ln.training or d.in_features != K
+                or d.activation_function is not None or ln.activation_function is not None
+                or d.activation_save_target is not None or ln.activation_save_target is not None
+                or not hasattr(d, '_int8_plan') or _hooked(getattr(d, 'weight_quantizer', None))):
+            return None
+        q1 = _fixed_per_tensor(d._quant_a, d.activation_quantizer)
+        q3 = _fixed_per_tensor(ln._quant_a, ln.activation_quantizer)
+        if 'no' in (q1, q3):
+            return None
+        plan = d._int8_plan(x, with_output_quantizer=False)
+        if plan is None or plan[1] != _hip.ACT_NONE:
+            return None
+        q_dense.append(q1)
+        q_out.append(q3)
+        plans.append(plan)
+    if ((q_dense[0] == 'off') != (q_dense[1] == 'off') or (q_out[0] == 'off') != (q_out[1] == 'off')
+            or dense_a.weight_quantizer.quantizer.eps != dense_b.weight_quantizer.quantizer.eps):
+        return None
+    oqs = [ln.activation_quantizer.quantizer if q != 'off' else None for (_, ln), q in zip(pairs, q_out)]
+    want_idx = all(oq is not None and not oq.symmetric and oq.n_bits <= 8 for oq in oqs)
+    packed = _stacked_qkv((dense_a, dense_b))
+    if packed is None:
+        return None
+    w_idx, rowsum, bias, scales = packed
+    ops = dense_a._int8_operands(x, plans[0])              # the shared input's indices and quantizer
+    if ops is None:
+        return None
+    affine = [ln.quantized_params() for _, ln in pairs]    # cached with fixed ranges in inference
+    key = tuple((w.data_ptr(), b.data_ptr()) for w, b in affine)
+    hit = getattr(layer_norm_a, '_stacked_affine_cache', None)
+    if hit is None or hit[0] != key:
+        hit = (key, torch.cat([w.detach().float().reshape(-1) for w, _ in affine]).contiguous(),
+               torch.cat([b.detach().float().reshape(-1) for _, b in affine]).contiguous(), affine)   # (keeps the parts alive)
+        layer_norm_a._stacked_affine_cache = hit
+    INT8_STATS['kernel_calls'] += 2
+    out = be.linear_i8_nonorm_grouped(ops[0], w_idx, rowsum, bias, hit[1], hit[2], ops[4], scales, ops[6],
+                                      None if q_dense[0] == 'off' else q_dense, None if q_out[0] == 'off' else q_out,
+                                      torch.float32, want_idx=want_idx)
+    ys, idxs = out if want_idx else (out, [None, None])
+    res = []
+    for y, idx, oq in zip(ys, idxs, oqs):
+        y = y.view(x.shape[:-1] + (N,))
+        if oq is not None:
+            provenance.tag(y, oq, None if idx is None else idx.view(y.shape))
+        res.append(y)
+    return res
+
+
 def quantized_ffn(intermediate, dense, res_quantizer, layer_norm, x):
     """MobileBERT feed-forward block (reference models/quantized_mobilebert.py:330-352):
 
