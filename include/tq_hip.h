@@ -231,6 +231,27 @@ int tq_ffn_i8_nonorm_fwd(const int8_t* x_idx, const float* x_delta, const float*
                          int8_t* y_idx, int y_dtype, uint64_t M, uint64_t K1, uint64_t N1, uint64_t N2,
                          tq_stream_t stream);
 
+/* A CHAIN of such feed-forward blocks as ONE launch: block s + 1 reads block s's output (as GEMM input and as residual).
+ * A MobileBERT layer runs four in a row (reference models/quantized_mobilebert.py:523-529), and NoNorm has no row
+ * statistics, so a workgroup takes its 16 token rows through all of them without leaving the CU; only the last block's
+ * output is written.  x_idx / x_delta / ... / residual describe the input of block 0 (residual = its fp32 values);
+ * `stages` is a HOST array read during the call; every block but the last needs an asymmetric <= 8-bit q_out (its grid is
+ * the next block's input grid).  Same shape restriction as tq_ffn_i8_nonorm_fwd, M % 16 == 0.  Bit-identical to n_stages
+ * calls of tq_ffn_i8_nonorm_fwd.                                                                                    */
+typedef struct tq_ffn_stage {
+  const int8_t*  w1_idx;      const int32_t* w1_rowsum;  const float* bias1;   const float* w1_delta;
+  uint64_t       w1_n_params; float          w1_eps;
+  const tq_quantizer* q_mid;
+  const int8_t*  w2_idx;      const int32_t* w2_rowsum;  const float* bias2;   const float* w2_delta;
+  uint64_t       w2_n_params; float          w2_eps;
+  const float*   nn_weight;   const float*   nn_bias;
+  const tq_quantizer *q_dense, *q_sum, *q_out;
+} tq_ffn_stage;
+int tq_ffn_chain_i8_nonorm_fwd(const int8_t* x_idx, const float* x_delta, const float* x_zero_float, int x_n_bits, float x_eps,
+                               const float* residual, const tq_ffn_stage* stages, uint64_t n_stages /* 1..4 */, void* y,
+                               int8_t* y_idx, int y_dtype, uint64_t M, uint64_t K1, uint64_t N1, uint64_t N2,
+                               tq_stream_t stream);
+
 /* Several quantized Linears that share their input, as ONE launch: the weights (and row sums, biases,
  * per-row weight scales w_delta[N]) of n_groups <= 3 layers are stacked along N; group g owns output
  * columns [g N / n_groups, (g+1) N / n_groups) and has its own per-tensor output quantizer q_out[g]

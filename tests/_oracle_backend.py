@@ -143,6 +143,17 @@ class OracleBackend:
                                   self._q7(q_sum), self._q7(q_out))
         return (y.to(out_dtype), yi) if want_idx else y.to(out_dtype)
 
+    def ffn_chain_i8_nonorm(self, x_idx, x_q, residual, stages, out_dtype, want_idx=False):
+        """the blocks of the chain one after the other through the oracle"""
+        y, idx, xq = residual, x_idx, x_q
+        for g in stages:
+            y, idx = self.ffn_i8_nonorm(idx, xq, g['w1_idx'], g['w1_rowsum'], g['bias1'], g['w1_delta'], g['w1_eps'], g['q_mid'],
+                                        g['w2_idx'], g['w2_rowsum'], g['bias2'], g['w2_delta'], g['w2_eps'], y, g['nn_w'],
+                                        g['nn_b'], g['q_dense'], g['q_sum'], g['q_out'], out_dtype, want_idx=True)
+            q = g['q_out']
+            xq = (q[0], q[1], q[3], q[6])
+        return (y, idx) if want_idx else y
+
     def attention_i8(self, q_idx, k_idx, v_idx, num_heads, mask, denom, q_q, q_k, q_v, q_scores, q_probs, q_ctx,
                      want_idx=False):
         from oracle import int_oracle

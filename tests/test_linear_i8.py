@@ -421,6 +421,68 @@ def test_ffn_i8_block_equals_two_launches(M, quantizers, per_channel):
     assert torch.equal(yb, ref_y.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize('n_blocks', [2, 3, 4])
+@pytest.mark.parametrize('M', [32, 1024])
+@pytest.mark.parametrize('variant', ['all_fp32', 'mixed_fp32', 'all_bf16', 'slow_quantizer'])
+def test_ffn_chain_equals_consecutive_blocks(n_blocks, M, variant):
+    """tq_ffn_chain_i8_nonorm_fwd -- consecutive MobileBERT feed-forward blocks in ONE launch, the rows staying on the CU
+    (outputs as register residuals, their indices as the next x tile in LDS) -- against n launches of
+    tq_ffn_i8_nonorm_fwd: bit-identical y and indices.  `mixed`: blocks without dense / sum quantizer, per-channel
+    weight scales in some blocks; `slow_quantizer`: a scale outside the exact-quotient range sends one block through the
+    division epilogue."""
+    from quantization import _hip
+    be = _hip.backend()
+    K1, N1, N2 = 128, 512, 128
+    g = torch.Generator().manual_seed(M + 31 * n_blocks)
+    dt = torch.bfloat16 if variant == 'all_bf16' else torch.float32
+    x = torch.randn(M, K1, generator=g) * 1.2 + 0.2
+    xd, xz = O.asym_params_from_range(x.min(), x.max(), 8)
+    x_i8 = be.quantize_to_int8(x.cuda(), xd.cuda(), xz.cuda(), None, 8, False, False, 1e-8, 1, 1, minus_128=True)
+    xq = (xd.cuda(), xz.cuda(), 8, 1e-8)
+    res = ((x_i8.float() + 128 - O.effective_zero_point(xz, 8).cuda()) * xd.cuda()).contiguous()     # the fp32 values of the input
+
+    def q7(lo, hi, bits):
+        d, z = O.asym_params_from_range(torch.tensor(float(lo)), torch.tensor(float(hi)), bits)
+        return (d.cuda(), z.cuda(), None, bits, False, False, 1e-8)
+
+    def wq(w, bits, per_channel):
+        d, _ = O.sym_params_from_range(w.amin(1) if per_channel else w.min(), w.amax(1) if per_channel else w.max(), bits)
+        n = w.shape[0] if per_channel else 1
+        wi = be.quantize_to_int8(w.cuda(), d.cuda(), None, torch.tensor(True).cuda(), bits, True, False, 1e-8, n,
+                                 w.shape[1] if per_channel else 1, minus_128=False)
+        return wi, be.rowsum_i8(wi), d.cuda().reshape(-1)
+    stages, cur_idx, cur_q, cur_res = [], x_i8, xq, res
+    ref_y = ref_i = None
+    for k in range(n_blocks):
+        pc = variant == 'mixed_fp32' and k % 2 == 1
+        w1i, rs1, w1d = wq(torch.randn(N1, K1, generator=g) * 0.08, 8, pc)
+        w2i, rs2, w2d = wq(torch.randn(N2, N1, generator=g) * 0.06, 8, pc)
+        b1 = (torch.randn(N1, generator=g) * 0.1).cuda()
+        b2 = None if (variant == 'mixed_fp32' and k == 0) else (torch.randn(N2, generator=g) * 0.1).cuda()
+        nw, nb = (1 + 0.3 * torch.randn(N2, generator=g)).cuda(), (0.2 * torch.randn(N2, generator=g)).cuda()
+        pre = be.linear_i8(cur_idx, w1i, rs1, b1, cur_q, w1d, 1e-8, _hip.ACT_RELU, None, torch.float32)
+        q_mid = q7(0.0, 0.8 * float(pre.max()), 8)
+        _, h_idx = be.linear_i8(cur_idx, w1i, rs1, b1, cur_q, w1d, 1e-8, _hip.ACT_RELU, q_mid, torch.float32, want_idx=True)
+        lin2 = be.linear_i8(h_idx, w2i, rs2, b2, (q_mid[0], q_mid[1], 8, 1e-8), w2d, 1e-8, _hip.ACT_NONE, None, torch.float32)
+        s_ = float(lin2.abs().max()) + float(cur_res.float().abs().max())
+        q_dense = None if (variant == 'mixed_fp32' and k == 1) else q7(-0.9 * s_, 0.9 * s_, 8)
+        q_sum = None if (variant == 'mixed_fp32' and k == 2) else q7(-1.2 * s_, 1.1 * s_, 8)
+        q_out = q7(-1.6 * s_, 1.5 * s_, 8)
+        if variant == 'slow_quantizer' and k == 1:     # scale 2^110: outside the exact-quotient range -> division path
+            q_sum = (torch.tensor(2.0 ** 110).cuda(), torch.tensor(128.0).cuda(), None, 8, False, False, 1e-8)
+        st = dict(w1_idx=w1i, w1_rowsum=rs1, bias1=b1, w1_delta=w1d, w1_eps=1e-8, q_mid=q_mid, w2_idx=w2i, w2_rowsum=rs2,
+                  bias2=b2, w2_delta=w2d, w2_eps=1e-8, nn_w=nw, nn_b=nb, q_dense=q_dense, q_sum=q_sum, q_out=q_out)
+        stages.append(st)
+        ref_y, ref_i = be.ffn_i8_nonorm(cur_idx, cur_q, w1i, rs1, b1, w1d, 1e-8, q_mid, w2i, rs2, b2, w2d, 1e-8, cur_res, nw, nb,
+                                        q_dense, q_sum, q_out, dt, want_idx=True)
+        cur_idx, cur_q, cur_res = ref_i, (q_out[0], q_out[1], 8, 1e-8), ref_y
+    got_y, got_i = be.ffn_chain_i8_nonorm(x_i8, xq, res, stages, dt, want_idx=True)
+    assert torch.equal(got_i, ref_i)
+    assert torch.equal(got_y, ref_y)
+    got_only_y = be.ffn_chain_i8_nonorm(x_i8, xq, res, stages, dt)
+    assert torch.equal(got_only_y, ref_y)
+
+
 @pytest.mark.gpu
 def test_bert_ffn_with_index_only_intermediate_equals_separate_launches():
     """quantized_bert_ffn: the intermediate Linear (768 -> 3072, GELU, 8-bit quantizer) runs INDEX-ONLY

@@ -18,6 +18,7 @@
 // token: 16-byte stores.  Two kernels: LDS-staged (fast path, see below) and an LDS-free fallback for
 // shapes that are not multiples of 64 / 128.
 #include <algorithm>
+#include <type_traits>
 
 #include "tq_device.h"
 #include "tq_host.h"
@@ -84,10 +85,12 @@ struct StairRef {                // the table as the epilogue sees it: entries i
   float inv_w, c0, nbm1;
 };
 
-// element offset of output (row, n) in y / y_idx
-__device__ __forceinline__ size_t out_at(const LinArgs& p, uint32_t row, uint32_t n) {
+// Element offset of output (row, n) in y / y_idx; g = out_group(p, n0) of the wave's first column, computed ONCE per wave
+// (a tile never straddles two groups) -- with the division inside, the epilogue loops were no longer unrolled and the
+// accumulators of the 128 x 128 tile kernel moved to scratch memory.
+__device__ __forceinline__ uint32_t out_group(const LinArgs& p, uint32_t n0) { return p.split_out ? n0 / p.group_cols : 0; }
+__device__ __forceinline__ size_t out_at(const LinArgs& p, uint32_t g, uint32_t row, uint32_t n) {
   if (!p.split_out) return (size_t)row * p.N + n;
-  const uint32_t g = n / p.group_cols;
   return (size_t)g * p.M * p.group_cols + (size_t)row * p.group_cols + (n - g * p.group_cols);
 }
 
@@ -164,6 +167,7 @@ __device__ __forceinline__ void stage_flush(const LinArgs& p, const int8_t* ysta
                                             int lane, bool want_idx) {
   constexpr int ES = YDT == TQ_F32 ? 4 : 2;
   constexpr int YP = WTN * ES + 16, IP = WTN + 16;
+  const uint32_t og = out_group(p, n0);
   if (p.y != nullptr) {
     constexpr int LPR = WTN * ES / 16, RPI = 64 / LPR;   // lanes per row, rows per store instruction
 #pragma unroll
@@ -172,7 +176,7 @@ __device__ __forceinline__ void stage_flush(const LinArgs& p, const int8_t* ysta
       if (RPI <= PR || row < PR) {
         const u32x4 d = *reinterpret_cast<const u32x4*>(ystage + row * YP + (lane % LPR) * 16);
         __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(static_cast<int8_t*>(p.y) +
-                                                                out_at(p, mrow0 + row, n0) * ES + (lane % LPR) * 16));
+                                                                out_at(p, og, mrow0 + row, n0) * ES + (lane % LPR) * 16));
       }
     }
   }
@@ -183,7 +187,7 @@ __device__ __forceinline__ void stage_flush(const LinArgs& p, const int8_t* ysta
       const int row = t * RPI + lane / LPR;
       if (RPI <= PR || row < PR) {
         const u32x4 d = *reinterpret_cast<const u32x4*>(istage + row * IP + (lane % LPR) * 16);
-        *reinterpret_cast<u32x4*>(p.y_idx + out_at(p, mrow0 + row, n0) + (lane % LPR) * 16) = d;
+        *reinterpret_cast<u32x4*>(p.y_idx + out_at(p, og, mrow0 + row, n0) + (lane % LPR) * 16) = d;
       }
     }
   }
@@ -195,7 +199,9 @@ __device__ __forceinline__ void stage_flush(const LinArgs& p, const int8_t* ysta
 // instead of 16 rows x 64 B (y) or 16 rows x 16 B (indices) straight from the MFMA accumulator layout -- with
 // non-temporal stores (y is not read again by this kernel; W and X keep the L2).  Measured at M = 8192, N = 3072,
 // K = 768, fp32 y: 48.4 -> 34.5 us for the GEMM + plain store.
-template <int NI, int MI, int YDT, int ACT, bool HASQ, bool STAGED, int TAIL = 0>
+// FLUSH = false (chained feed-forward blocks): the results of the single pass stay in the wave's staging area -- y as fp32 /
+// bf16 rows of pitch YP, the int8 indices behind them -- whether or not the launch has global outputs.
+template <int NI, int MI, int YDT, int ACT, bool HASQ, bool STAGED, int TAIL = 0, bool FLUSH = true>
 __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
                                                      int kg, const QF& qf, int shift, float sx, int8_t* stage,
                                                      const float* cst, const QF& qf1 = QF{}, const QF& qf2 = QF{},
@@ -214,7 +220,10 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
   const int lane = kg * 16 + r16;
   int8_t* ystage = stage;
   int8_t* istage = stage + PR * YP;
-  const bool want_idx = fin_q && p.y_idx != nullptr;
+  static_assert(FLUSH || (STAGED && MI == JP), "results kept in the staging area: one pass");
+  const uint32_t og = out_group(p, n0);
+  const bool want_idx = fin_q && (p.y_idx != nullptr || !FLUSH);
+  const bool want_y = p.y != nullptr || !FLUSH;
 #pragma unroll
   for (int h = 0; h < MI / JP; ++h) {
 #pragma unroll
@@ -310,15 +319,15 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
         if (STAGED) {
           const int row = jj * 16 + r16, col = i * 16 + kg * 4;
           if (want_idx) *reinterpret_cast<uint32_t*>(istage + row * IP + col) = w;
-          if (p.y != nullptr) store_y4<YDT>(ystage + row * YP, col, v[2 * jj], v[2 * jj + 1]);
+          if (want_y) store_y4<YDT>(ystage + row * YP, col, v[2 * jj], v[2 * jj + 1]);
         } else {
-          const size_t at = out_at(p, m0 + j * 16 + r16, n);
+          const size_t at = out_at(p, og, m0 + j * 16 + r16, n);
           if (want_idx) *reinterpret_cast<uint32_t*>(p.y_idx + at) = w;
           if (p.y != nullptr) store_y4<YDT>(p.y, at, v[2 * jj], v[2 * jj + 1]);
         }
       }
     }
-    if (STAGED) stage_flush<WTN, PR, YDT>(p, ystage, istage, n0, m0 + h * PR, lane, want_idx);
+    if (STAGED && FLUSH) stage_flush<WTN, PR, YDT>(p, ystage, istage, n0, m0 + h * PR, lane, want_idx);
   }
 }
 
@@ -394,7 +403,10 @@ __device__ __forceinline__ void linear_epilogue_stair(const LinArgs& p, v4i (&ac
 // Generic form (tanh, quantizers outside the exact-quotient path): IEEE division, libm activation.
 template <int NI, int MI, int YDT>
 __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
-                                                     int kg, const QP& qo, int shift, float sx) {
+                                                     int kg, const QP& qo, int shift, float sx,
+                                                     const f32x4 (*res_pre)[MI] = nullptr /* residual in registers */,
+                                                     int8_t* keep = nullptr /* staging area: results stay there (MI == 1) */) {
+  const uint32_t og = out_group(p, n0);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const uint32_t n = n0 + i * 16 + kg * 4;
@@ -409,7 +421,7 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
     }
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const size_t at = out_at(p, m0 + j * 16 + r16, n), rat = (size_t)(m0 + j * 16 + r16) * p.N + n;
+      const size_t at = out_at(p, og, m0 + j * 16 + r16, n), rat = (size_t)(m0 + j * 16 + r16) * p.N + n;
       float o[4];
       struct alignas(4) { int8_t e[4]; } oi4 = {{0, 0, 0, 0}};
 #pragma unroll
@@ -422,13 +434,13 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
           v = q_dequant(xi, qo);
         }
         if (p.tail == 2) {
-          v = v + p.residual[rat + r];
+          v = v + (res_pre != nullptr ? res_pre[i][j][r] : p.residual[rat + r]);
           if (p.on_t1) v = q_dequant(q_index(v, make_qp(p.q_t1, 0)), make_qp(p.q_t1, 0));
         }
         if (p.tail >= 1) {
           v = v * p.nn_w[n + r] + p.nn_b[n + r];
           if (p.on_t2) {
-            const QP q2 = make_qp(p.split_out && n / p.group_cols == 1 ? p.q_t2b : p.q_t2, 0);
+            const QP q2 = make_qp(og == 1 ? p.q_t2b : p.q_t2, 0);
             const float xi = q_index(v, q2);
             oi4.e[r] = (int8_t)((int)xi - 128);
             v = q_dequant(xi, q2);
@@ -436,8 +448,15 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
         }
         o[r] = v;
       }
-      if (p.y_idx != nullptr) *reinterpret_cast<uint32_t*>(p.y_idx + at) = __builtin_bit_cast(uint32_t, oi4);
-      if (p.y != nullptr) store_y4<YDT>(p.y, at, f32x2{o[0], o[1]}, f32x2{o[2], o[3]});
+      if (keep != nullptr) {                      // the layout of the staged fast epilogue (16 rows, pitches YP / IP)
+        constexpr int ES = YDT == TQ_F32 ? 4 : 2, YP = NI * 16 * ES + 16, IP = NI * 16 + 16;
+        const int row = j * 16 + r16, col = i * 16 + kg * 4;
+        *reinterpret_cast<uint32_t*>(keep + 16 * YP + row * IP + col) = __builtin_bit_cast(uint32_t, oi4);
+        store_y4<YDT>(keep + row * YP, col, f32x2{o[0], o[1]}, f32x2{o[2], o[3]});
+      } else {
+        if (p.y_idx != nullptr) *reinterpret_cast<uint32_t*>(p.y_idx + at) = __builtin_bit_cast(uint32_t, oi4);
+        if (p.y != nullptr) store_y4<YDT>(p.y, at, f32x2{o[0], o[1]}, f32x2{o[2], o[3]});
+      }
     }
   }
 }
@@ -470,23 +489,29 @@ struct EpiRaw {
   tq_quantizer t2sel;            // the tail's last quantizer of this column group
 };
 
-template <bool WITH_TAIL>
+// GROUPED = false: the caller knows the launch has ONE column group (feed-forward kernels): no run-time selection
+// between the argument block's quantizer slots.
+template <bool WITH_TAIL, bool GROUPED = true>
 __device__ __forceinline__ EpiRaw epilogue_fetch(const LinArgs& p, uint32_t n0) {
   EpiRaw w;
-  const uint32_t grp = n0 / p.group_cols;                   // (group_cols = N for a plain launch) a block tile never straddles two groups
+  const uint32_t grp = GROUPED ? n0 / p.group_cols : 0;     // (group_cols = N for a plain launch) a block tile never straddles two groups
   // field by field: selects between kernel-argument VALUES (a struct assignment under `if` became the selection of an
   // ADDRESS in the argument segment and a second, dependent round of loads through it)
+  if (GROUPED) {
 #define TQ_SEL(f) w.qsel.f = grp == 0 ? p.q_out.f : (grp == 1 ? p.q_out1.f : p.q_out2.f)
-  TQ_SEL(delta); TQ_SEL(zero_float); TQ_SEL(signed_flag); TQ_SEL(n_bits); TQ_SEL(symmetric); TQ_SEL(log_domain); TQ_SEL(eps);
-  TQ_SEL(n_params); TQ_SEL(inner);
+    TQ_SEL(delta); TQ_SEL(zero_float); TQ_SEL(signed_flag); TQ_SEL(n_bits); TQ_SEL(symmetric); TQ_SEL(log_domain); TQ_SEL(eps);
+    TQ_SEL(n_params); TQ_SEL(inner);
 #undef TQ_SEL
+  } else {
+    w.qsel = p.q_out;
+  }
   w.dx = p.x_delta[0];
   w.zx = p.x_zero_float[0];
   w.qo = load_qraw(w.qsel, 0, p.x_delta);                   // has_q == 0: reads x_delta, unused
   w.q1 = w.q2 = w.qo;
   w.t2sel = p.q_t2;
   if (WITH_TAIL) {
-    if (p.split_out && grp == 1) w.t2sel = p.q_t2b;
+    if (GROUPED && p.split_out && grp == 1) w.t2sel = p.q_t2b;
     w.q1 = load_qraw(p.q_t1, 0, p.x_delta);
     w.q2 = load_qraw(w.t2sel, 0, p.x_delta);
   }
@@ -543,14 +568,14 @@ __device__ __forceinline__ EpiCtx epilogue_prepare(const LinArgs& p, uint32_t n0
   return epilogue_finish<WITH_TAIL>(p, w);
 }
 
-template <int NI, int MI, int YDT, bool STAGED, bool WITH_TAIL>
+template <int NI, int MI, int YDT, bool STAGED, bool WITH_TAIL, bool FLUSH = true>
 __device__ __forceinline__ void linear_epilogue(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
                                                 int kg, const EpiCtx& c, int8_t* stage = nullptr, const float* cst = nullptr,
                                                 int cs = 2 * NI * 16, const f32x4 (*res_pre)[MI] = nullptr,
                                                 const u32x2* stair_lds = nullptr) {
-  if (!c.fast) return linear_epilogue_generic<NI, MI, YDT>(p, acc, n0, m0, r16, kg, c.qo, c.shift, c.sx);
+  if (!c.fast) return linear_epilogue_generic<NI, MI, YDT>(p, acc, n0, m0, r16, kg, c.qo, c.shift, c.sx, res_pre, FLUSH ? nullptr : stage);
   if (WITH_TAIL) {                 // separate kernel instantiation: the plain Linear keeps its register budget
-#define TQ_EPI_T(Q, T) linear_epilogue_fast<NI, MI, YDT, ACT_NONE, Q, STAGED, T>(p, acc, n0, m0, r16, kg, c.qf, c.shift, c.sx, stage, cst, c.qf1, c.qf2, cs, res_pre)
+#define TQ_EPI_T(Q, T) linear_epilogue_fast<NI, MI, YDT, ACT_NONE, Q, STAGED, T, FLUSH>(p, acc, n0, m0, r16, kg, c.qf, c.shift, c.sx, stage, cst, c.qf1, c.qf2, cs, res_pre)
     if (p.tail == 2) { if (p.has_q) TQ_EPI_T(true, 2); else TQ_EPI_T(false, 2); }
     else             { if (p.has_q) TQ_EPI_T(true, 1); else TQ_EPI_T(false, 1); }
 #undef TQ_EPI_T
@@ -833,6 +858,107 @@ struct FfnArgs {
   uint32_t M;
 };
 
+// The three middle steps of a feed-forward block, shared by ffn_i8_k and ffn_chain_i8_k.
+// GEMM 1: [BM, K1 = 128] x [N1 / 4 (own), K1]^T
+template <int NI1, int MI>
+__device__ __forceinline__ void ffn_gemm1(v4i (&acc1)[NI1][MI], const int8_t* bw, const int8_t* bx, const int (&off)[2]) {
+#pragma unroll
+  for (int i = 0; i < NI1; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc1[i][j] = v4i{0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    v4i fx[MI];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) fx[j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s]);
+#pragma unroll
+    for (int i = 0; i < NI1; ++i) {
+      const v4i fw = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw, fx[j], acc1[i][j], 0, 0, 0);
+    }
+  }
+}
+
+// epilogue 1: scale + bias, ReLU, Q_mid -> int8(index - 128) into the intermediate's K-slab layout (slab = wave);
+// two n tiles per step so that the packed quantizer chains of 2 * IT * MI register pairs overlap
+template <int N1, int NI1, int MI, int BM>
+__device__ __forceinline__ void ffn_epilogue1(const v4i (&acc1)[NI1][MI], const QP& qm, const float* c1, int8_t* hb, int wave, int r16,
+                                              int kg) {
+  const QF qf = make_qf(qm);
+  const f32x2 zpb = {qm.zp, qm.zp};
+  constexpr int IT = 2, NP = IT * 2 * MI;
+#pragma unroll
+  for (int i0 = 0; i0 < NI1; i0 += IT) {
+    f32x2 v[NP], hq[NP];
+#pragma unroll
+    for (int ii = 0; ii < IT; ++ii) {
+      const int col = wave * (N1 / 4) + (i0 + ii) * 16 + kg * 4;
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(c1 + col);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(c1 + N1 + col);
+      const v4i r4 = *reinterpret_cast<const v4i*>(c1 + 2 * N1 + col);
+      const f32x2 sw[2] = {f32x2{s4.x, s4.y}, f32x2{s4.z, s4.w}}, bs[2] = {f32x2{b4.x, b4.y}, f32x2{b4.z, b4.w}};
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const v4i a = acc1[i0 + ii][j];
+        const f32x2 lo = {(float)(a[0] + r4.x), (float)(a[1] + r4.y)};
+        const f32x2 hi = {(float)(a[2] + r4.z), (float)(a[3] + r4.w)};
+        v[(ii * MI + j) * 2] = lo * sw[0] + bs[0];
+        v[(ii * MI + j) * 2 + 1] = hi * sw[1] + bs[1];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NP; ++e) v[e] = f32x2{v[e].x > 0.0f ? v[e].x : 0.0f, v[e].y > 0.0f ? v[e].y : 0.0f};
+    if (qf.ok) {
+      qf_round2_n<NP>(v, qf, hq);
+#pragma unroll
+      for (int e = 0; e < NP; ++e) hq[e] = hq[e] + zpb;
+    } else {
+#pragma unroll
+      for (int e = 0; e < NP; ++e) hq[e] = f32x2{q_index(v[e].x, qm), q_index(v[e].y, qm)};
+    }
+#pragma unroll
+    for (int ii = 0; ii < IT; ++ii)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const f32x2 lo = hq[(ii * MI + j) * 2], hi = hq[(ii * MI + j) * 2 + 1];
+        uint32_t w = 0;
+        w = __builtin_amdgcn_cvt_pk_u8_f32(lo.x, 0, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(lo.y, 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(hi.x, 2, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(hi.y, 3, w) ^ 0x80808080u;
+        const int m = j * 16 + r16;                    // chunk i of slab `wave`, swizzled like every operand row
+        *reinterpret_cast<uint32_t*>(hb + m * 128 + (((i0 + ii) ^ ((m >> 1) & 7)) << 4) + kg * 4) = w;
+      }
+  }
+}
+
+// GEMM 2: [BM, N1] x [N2 / 4 (own), N1]^T
+template <int NI2, int MI, int SL2, int N2, int BM>
+__device__ __forceinline__ void ffn_gemm2(v4i (&acc2)[NI2][MI], const int8_t* w2, const int8_t* hbase, const int (&off)[2]) {
+#pragma unroll
+  for (int i = 0; i < NI2; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc2[i][j] = v4i{0, 0, 0, 0};
+#pragma unroll
+  for (int sl = 0; sl < SL2; ++sl) {
+    const int8_t* bw = w2 + sl * (N2 / 4) * 128;
+    const int8_t* bh = hbase + sl * (BM * 128);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      v4i fw[NI2], fh[MI];
+#pragma unroll
+      for (int i = 0; i < NI2; ++i) fw[i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
+#pragma unroll
+      for (int j = 0; j < MI; ++j) fh[j] = *reinterpret_cast<const v4i*>(bh + j * 2048 + off[s]);
+#pragma unroll
+      for (int i = 0; i < NI2; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[i], fh[j], acc2[i][j], 0, 0, 0);
+    }
+  }
+}
+
 template <int K1, int N1, int N2, int YDT, int BM>
 __global__ __launch_bounds__(kBlock) void ffn_i8_k(FfnArgs p) {
   static_assert(K1 == 128 && N1 == 512 && N2 == 128, "instantiated for MobileBERT's feed-forward shape");
@@ -875,7 +1001,7 @@ __global__ __launch_bounds__(kBlock) void ffn_i8_k(FfnArgs p) {
   // written as load-use-load-use this prologue cost 3.4 us of dependent global round trips; round 5: the quantizers'
   // buffers, too, are fetched in one batch -- tq_device.h load_qraw): the quantizers' range buffers, the per-column
   // scales / biases / row sums this thread turns into LDS constants below, the residual values of epilogue 2
-  EpiRaw eraw = epilogue_fetch<true>(p.lin2, wave * (N2 / 4));
+  EpiRaw eraw = epilogue_fetch<true, false>(p.lin2, wave * (N2 / 4));
   QRaw mraw = load_qraw(p.q_mid, 0, p.x_delta);
   float dx_in = p.x_delta[0], zf_in = p.x_zero_float[0];
   constexpr int C1 = N1 / kBlock;                    // GEMM 1 columns per thread (2)
@@ -934,107 +1060,222 @@ __global__ __launch_bounds__(kBlock) void ffn_i8_k(FfnArgs p) {
   const int swz = (r16 >> 1) & 7;
   const int off[2] = {r16 * 128 + ((kg ^ swz) << 4), r16 * 128 + (((4 + kg) ^ swz) << 4)};
 
-  // ---- GEMM 1: [BM, K1] x [N1 / 4 (own), K1]^T
+  // ---- GEMM 1 -> epilogue 1 (intermediate indices into LDS) -> barrier -> GEMM 2
   v4i acc1[NI1][MI];
-#pragma unroll
-  for (int i = 0; i < NI1; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j) acc1[i][j] = v4i{0, 0, 0, 0};
-  {
-    const int8_t* bw = lds_i8 + kW1 + wave * kW1w;
-    const int8_t* bx = lds_i8 + kX;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      v4i fx[MI];
-#pragma unroll
-      for (int j = 0; j < MI; ++j) fx[j] = *reinterpret_cast<const v4i*>(bx + j * 2048 + off[s]);
-#pragma unroll
-      for (int i = 0; i < NI1; ++i) {
-        const v4i fw = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc1[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw, fx[j], acc1[i][j], 0, 0, 0);
-      }
-    }
-  }
-  // ---- epilogue 1: scale + bias, ReLU, Q_mid -> int8(index - 128) into the intermediate's K-slab layout (slab = wave);
-  // two n tiles per step so that the packed quantizer chains of 2 * IT * MI register pairs overlap
-  {
-    const QF qf = make_qf(qm);
-    const f32x2 zpb = {qm.zp, qm.zp};
-    int8_t* hb = lds_i8 + kH + wave * (BM * 128);
-    constexpr int IT = 2, NP = IT * 2 * MI;
-#pragma unroll
-    for (int i0 = 0; i0 < NI1; i0 += IT) {
-      f32x2 v[NP], hq[NP];
-#pragma unroll
-      for (int ii = 0; ii < IT; ++ii) {
-        const int col = wave * (N1 / 4) + (i0 + ii) * 16 + kg * 4;
-        const f32x4 s4 = *reinterpret_cast<const f32x4*>(c1 + col);
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(c1 + N1 + col);
-        const v4i r4 = *reinterpret_cast<const v4i*>(c1 + 2 * N1 + col);
-        const f32x2 sw[2] = {f32x2{s4.x, s4.y}, f32x2{s4.z, s4.w}}, bs[2] = {f32x2{b4.x, b4.y}, f32x2{b4.z, b4.w}};
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-          const v4i a = acc1[i0 + ii][j];
-          const f32x2 lo = {(float)(a[0] + r4.x), (float)(a[1] + r4.y)};
-          const f32x2 hi = {(float)(a[2] + r4.z), (float)(a[3] + r4.w)};
-          v[(ii * MI + j) * 2] = lo * sw[0] + bs[0];
-          v[(ii * MI + j) * 2 + 1] = hi * sw[1] + bs[1];
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < NP; ++e) v[e] = f32x2{v[e].x > 0.0f ? v[e].x : 0.0f, v[e].y > 0.0f ? v[e].y : 0.0f};
-      if (qf.ok) {
-        qf_round2_n<NP>(v, qf, hq);
-#pragma unroll
-        for (int e = 0; e < NP; ++e) hq[e] = hq[e] + zpb;
-      } else {
-#pragma unroll
-        for (int e = 0; e < NP; ++e) hq[e] = f32x2{q_index(v[e].x, qm), q_index(v[e].y, qm)};
-      }
-#pragma unroll
-      for (int ii = 0; ii < IT; ++ii)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-          const f32x2 lo = hq[(ii * MI + j) * 2], hi = hq[(ii * MI + j) * 2 + 1];
-          uint32_t w = 0;
-          w = __builtin_amdgcn_cvt_pk_u8_f32(lo.x, 0, w);
-          w = __builtin_amdgcn_cvt_pk_u8_f32(lo.y, 1, w);
-          w = __builtin_amdgcn_cvt_pk_u8_f32(hi.x, 2, w);
-          w = __builtin_amdgcn_cvt_pk_u8_f32(hi.y, 3, w) ^ 0x80808080u;
-          const int m = j * 16 + r16;                    // chunk i of slab `wave`, swizzled like every operand row
-          *reinterpret_cast<uint32_t*>(hb + m * 128 + (((i0 + ii) ^ ((m >> 1) & 7)) << 4) + kg * 4) = w;
-        }
-    }
-  }
+  ffn_gemm1<NI1, MI>(acc1, lds_i8 + kW1 + wave * kW1w, lds_i8 + kX, off);
+  ffn_epilogue1<N1, NI1, MI, BM>(acc1, qm, c1, lds_i8 + kH + wave * (BM * 128), wave, r16, kg);
   __syncthreads();                                   // the whole [BM, N1] intermediate is in LDS
-
-  // ---- GEMM 2: [BM, N1] x [N2 / 4 (own), N1]^T
   v4i acc2[NI2][MI];
-#pragma unroll
-  for (int i = 0; i < NI2; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j) acc2[i][j] = v4i{0, 0, 0, 0};
-#pragma unroll
-  for (int sl = 0; sl < SL2; ++sl) {
-    const int8_t* bw = lds_i8 + kW2 + wave * kW2w + sl * (N2 / 4) * 128;
-    const int8_t* bh = lds_i8 + kH + sl * (BM * 128);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      v4i fw[NI2], fh[MI];
-#pragma unroll
-      for (int i = 0; i < NI2; ++i) fw[i] = *reinterpret_cast<const v4i*>(bw + i * 2048 + off[s]);
-#pragma unroll
-      for (int j = 0; j < MI; ++j) fh[j] = *reinterpret_cast<const v4i*>(bh + j * 2048 + off[s]);
-#pragma unroll
-      for (int i = 0; i < NI2; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc2[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fw[i], fh[j], acc2[i][j], 0, 0, 0);
-    }
-  }
+  ffn_gemm2<NI2, MI, SL2, N2, BM>(acc2, lds_i8 + kW2 + wave * kW2w, lds_i8 + kH, off);
   // ---- epilogue 2: the NoNorm tail of the plain kernel; outputs staged through this wave's (now free) W1 region
   linear_epilogue<NI2, MI, YDT, true, true>(p.lin2, acc2, wave * (N2 / 4), m0, r16, kg, ectx, lds_i8 + kW1 + wave * kW1w,
                                             c2 + wave * (N2 / 4), N2, res_pre);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kMaxFfnChain = 4;
+// CHAIN of feed-forward blocks as one launch (round 5).  A MobileBERT layer runs four of them back to back (reference
+// models/quantized_mobilebert.py:330-352 three times under :523-526, then intermediate + output :528-529), each the
+// input of the next, and NoNorm has no row statistics: everything is local to a token row, so the block of ffn_i8_k that
+// owns 16 rows can take them through ALL the blocks without leaving the CU.  Per stage the same steps as ffn_i8_k (same
+// integer contractions, same element arithmetic: bit-identical to n launches); between stages
+//   * the stage's output stays in registers as the next residual, and its int8 indices go straight into the x tile of
+//     LDS in the operand layout (every wave writes its 32 columns; the barrier that opens the next stage publishes them);
+//   * the weight slices are wave-private LDS regions, so a wave refills them by itself as soon as IT is done with them:
+//     W1 of the next stage right after this stage's GEMM 1, W2 right after its GEMM 2 -- each refill has about a stage
+//     to land -- with counted vmcnt waits (each slice is 16 LDS-DMA instructions per wave) and raw barriers;
+//   * the quantizer buffers and per-column constants of ALL stages are requested at kernel start and parked in registers;
+//     every wave writes the LDS constants of its OWN columns (no cross-wave hazard with their readers).
+// (One kernel argument per stage: as members -- or worse, an array -- of ONE 2.7 KB argument struct, clang's private copy of
+// the block survived optimisation: 2.7 KB of scratch per lane.  .x / lin2.residual are read from st0 only, lin2.y / y_idx
+// belong to the last stage.)
+#ifdef TQ_FFN_PROF      // tools/tuning/ffn_chain_prof.py: 8 s_memtime stamps per stage and workgroup
+#define TQ_FSTAMP(k)                                                                                  \
+  do {                                                                                                \
+    unsigned long long t_;                                                                            \
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+    if (threadIdx.x == 0 && prof) prof[(blockIdx.x * 4 + f) * 8 + (k)] = t_;                          \
+  } while (0)
+#define TQ_FPROF_ARG , unsigned long long* prof
+#else
+#define TQ_FSTAMP(k)
+#define TQ_FPROF_ARG
+#endif
+
+template <int K1, int N1, int N2, int YDT>
+__global__ __launch_bounds__(kBlock) void ffn_chain_i8_k(FfnArgs st0, FfnArgs st1, FfnArgs st2, FfnArgs st3, int nf TQ_FPROF_ARG) {
+  static_assert(K1 == 128 && N1 == 512 && N2 == 128, "instantiated for MobileBERT's feed-forward shape (N2 == K1: chainable)");
+  constexpr int BM = 16, MI = 1;
+  constexpr int NI1 = N1 / 4 / 16, NI2 = N2 / 4 / 16, SL2 = N1 / 128;
+  constexpr int ES = YDT == TQ_F32 ? 4 : 2, YP = NI2 * 16 * ES + 16, IP = NI2 * 16 + 16;   // staging pitches of the tail
+  constexpr int kStage = 16 * YP + 16 * IP;          // per wave
+  constexpr int kX = 0, kH = kX + BM * 128, kW1 = kH + SL2 * BM * 128, kW1w = (N1 / 4) * 128;
+  constexpr int kW2 = kW1 + 4 * kW1w, kW2w = SL2 * (N2 / 4) * 128, kC1 = kW2 + 4 * kW2w, kC2 = kC1 + 3 * N1 * 4;
+  constexpr int kS = kC2 + 5 * N2 * 4;               // the tails' staging areas: the W regions are being refilled by then
+  constexpr int IW = N1 / 4 / 8;                     // LDS-DMA instructions per weight slice and wave (W1 and W2 alike)
+  static_assert(IW == SL2 * (N2 / 4 / 8) && kS + 4 * kStage <= 160 * 1024, "slices of equal size; LDS budget");
+  extern __shared__ __attribute__((aligned(1024))) int8_t lds_i8[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kg = lane >> 4;
+  const uint32_t m0 = blockIdx.x * BM;
+  const int row8 = lane >> 3, slot = lane & 7;
+  float* c1 = reinterpret_cast<float*>(lds_i8 + kC1);
+  float* c2 = reinterpret_cast<float*>(lds_i8 + kC2);
+
+  auto issue_w1 = [&](const FfnArgs& p) {     // own W1 slice: rows n = wave * 128 + 8 q + row8
+#pragma unroll
+    for (int q = 0; q < N1 / 4 / 8; ++q) {
+      const int row = q * 8 + row8;
+      TQ_GLDS16(p.w1 + (size_t)(wave * (N1 / 4) + row) * K1 + ((slot ^ ((row >> 1) & 7)) << 4), lds_i8 + kW1 + wave * kW1w + q * 1024);
+    }
+  };
+  auto issue_w2 = [&](const FfnArgs& p) {     // own W2 slice, slab sl: rows n = wave * 32 + 8 q + row8, k bytes [128 sl, 128 sl + 128)
+#pragma unroll
+    for (int sl = 0; sl < SL2; ++sl)
+#pragma unroll
+      for (int q = 0; q < N2 / 4 / 8; ++q) {
+        const int row = q * 8 + row8;
+        TQ_GLDS16(p.w2 + (size_t)(wave * (N2 / 4) + row) * N1 + sl * 128 + ((slot ^ ((row >> 1) & 7)) << 4),
+                  lds_i8 + kW2 + wave * kW2w + sl * (N2 / 4) * 128 + q * 1024);
+      }
+  };
+  // everything a stage reads through pointers, requested as independent loads and parked in registers
+  struct StageRegs {
+    EpiRaw eraw;
+    QRaw mraw;
+    float dx, zf;
+    float dw1[2], b1[2], dw2, b2, nw, nb;
+    int rs1[2], rs2;
+  };
+  auto fetch = [&](const FfnArgs& p) {
+    StageRegs g;
+    g.eraw = epilogue_fetch<true, false>(p.lin2, wave * (N2 / 4));
+    g.mraw = load_qraw(p.q_mid, 0, p.x_delta);
+    g.dx = p.x_delta[0];
+    g.zf = p.x_zero_float[0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {               // the wave's own 128 columns of GEMM 1
+      const int n = wave * (N1 / 4) + lane + t * 64;
+      g.dw1[t] = p.w1_delta[p.w1_n_params == 1 ? 0 : n];
+      g.b1[t] = p.b1 ? p.b1[n] : 0.0f;
+      g.rs1[t] = p.rs1[n];
+    }
+    const LinArgs& l2 = p.lin2;
+    const int n2 = wave * (N2 / 4) + (lane & 31);   // its own 32 columns of GEMM 2 (lanes >= 32 load duplicates)
+    g.dw2 = l2.w_delta[l2.w_n_params == 1 ? 0 : n2];
+    g.b2 = l2.bias ? l2.bias[n2] : 0.0f;
+    g.rs2 = p.rs2[n2];
+    g.nw = l2.nn_w[n2];
+    g.nb = l2.nn_b[n2];
+    return g;
+  };
+  auto arrived = [&](StageRegs& g) {
+    epilogue_arrived<true>(g.eraw);
+    qraw_arrived(g.mraw);
+    g.dx = pinned_uniform(g.dx);
+    g.zf = pinned_uniform(g.zf);
+  };
+
+  // ---- operand fetches of stage 0 first (x tile, own W1 / W2 slices: in this order, the waits below count on it); then
+  // the parameters of ALL stages and the residual rows.  With every ordinary load done up front, the only vector-memory
+  // operations in flight during the stages are the LDS-DMA refills, and the counted waits below are exact (the compiler
+  // itself waits for vmcnt(0) whenever the result of an ordinary load is needed while LDS-DMA is outstanding).
+  if (wave * 8 < BM) {
+    const int row = wave * 8 + row8;
+    TQ_GLDS16(st0.x + (size_t)(m0 + row) * K1 + ((slot ^ ((row >> 1) & 7)) << 4), lds_i8 + kX + wave * 1024);
+  }
+  issue_w1(st0);
+  issue_w2(st0);
+  StageRegs g0 = fetch(st0), g1 = g0, g2 = g0, g3 = g0;
+  if (nf > 1) g1 = fetch(st1);
+  if (nf > 2) g2 = fetch(st2);
+  if (nf > 3) g3 = fetch(st3);
+  f32x4 res[NI2][MI];
+#pragma unroll
+  for (int i = 0; i < NI2; ++i)
+    res[i][0] = *reinterpret_cast<const f32x4*>(st0.lin2.residual + (size_t)(m0 + r16) * N2 + wave * (N2 / 4) + i * 16 + kg * 4);
+  arrived(g0); arrived(g1); arrived(g2); arrived(g3);
+
+  const int swz = (r16 >> 1) & 7;
+  const int off[2] = {r16 * 128 + ((kg ^ swz) << 4), r16 * 128 + (((4 + kg) ^ swz) << 4)};
+
+  // (p / pn: this stage's and the next stage's arguments)
+  auto run_stage = [&](auto fc, const FfnArgs& p, const FfnArgs& pn, const StageRegs& cur) __attribute__((always_inline)) {
+    constexpr int f = decltype(fc)::value;
+    const LinArgs& l2 = p.lin2;
+    const bool more = f + 1 < nf;
+    TQ_FSTAMP(0);
+    // ---- this stage's parameters -> context and LDS constants (own columns only)
+    const EpiCtx ectx = epilogue_finish<true>(l2, cur.eraw);
+    const QP qm = qp_from_raw(p.q_mid, cur.mraw);
+    {
+      const float sx = cur.dx < p.x_eps ? p.x_eps : cur.dx;
+      const int zx = (int)clamp_nanprop(rintf(cur.zf), 0.0f, grid_top(p.x_n_bits));
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int n = wave * (N1 / 4) + lane + t * 64;
+        c1[n] = sx * (cur.dw1[t] < p.w1_eps ? p.w1_eps : cur.dw1[t]);
+        c1[N1 + n] = cur.b1[t];
+        reinterpret_cast<int*>(c1)[2 * N1 + n] = cur.rs1[t] * (128 - zx);
+      }
+      if (lane < 32) {
+        const int n2 = wave * (N2 / 4) + lane;
+        const int zm = (int)qm.zp;                       // lin2's input lives on Q_mid's grid
+        c2[n2] = qm.scale * (cur.dw2 < l2.w_eps ? l2.w_eps : cur.dw2);
+        c2[N2 + n2] = cur.b2;
+        reinterpret_cast<int*>(c2)[2 * N2 + n2] = cur.rs2 * (128 - zm);
+        c2[3 * N2 + n2] = cur.nw;
+        c2[4 * N2 + n2] = cur.nb;
+      }
+    }
+    // x tile (fetched, or written by the previous stage's tails) and this wave's W1 slice; its W2 slice may still be
+    // in flight.  Raw barriers: __syncthreads would drain the vector-memory queue
+    TQ_FSTAMP(1);
+    lds_dma_wait_but<IW>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TQ_FSTAMP(2);
+    v4i acc1[NI1][MI];
+    ffn_gemm1<NI1, MI>(acc1, lds_i8 + kW1 + wave * kW1w, lds_i8 + kX, off);
+    if (more) issue_w1(pn);                          // own W1 region: this wave's GEMM 1 is done with it
+    TQ_FSTAMP(3);
+    ffn_epilogue1<N1, NI1, MI, BM>(acc1, qm, c1, lds_i8 + kH + wave * (BM * 128), wave, r16, kg);
+    TQ_FSTAMP(4);
+    if (more) lds_dma_wait_but<IW>(); else lds_dma_wait_but<0>();       // this wave's W2 slice
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the whole [BM, N1] intermediate is in LDS
+    TQ_FSTAMP(5);
+    v4i acc2[NI2][MI];
+    ffn_gemm2<NI2, MI, SL2, N2, BM>(acc2, lds_i8 + kW2 + wave * kW2w, lds_i8 + kH, off);
+    if (more) issue_w2(pn);                          // own W2 region: this wave's GEMM 2 is done with it
+    TQ_FSTAMP(6);
+
+    int8_t* stage = lds_i8 + kS + wave * kStage;
+    if (!more) {                                     // last stage: the NoNorm tail of the plain kernel, out to memory
+      linear_epilogue<NI2, MI, YDT, true, true>(l2, acc2, wave * (N2 / 4), m0, r16, kg, ectx, stage, c2 + wave * (N2 / 4), N2, res);
+    } else {
+      // the same tail, results kept in the staging area: y -> the next residual (registers), indices -> the x tile
+      linear_epilogue<NI2, MI, YDT, true, true, false>(l2, acc2, wave * (N2 / 4), m0, r16, kg, ectx, stage, c2 + wave * (N2 / 4), N2,
+                                                       res);
+#pragma unroll
+      for (int i = 0; i < NI2; ++i) {
+        const int col = i * 16 + kg * 4;
+        if (YDT == TQ_F32) {
+          res[i][0] = *reinterpret_cast<const f32x4*>(stage + r16 * YP + col * 4);
+        } else {                                     // bf16 storage: the next block sees the ROUNDED value, like a separate launch
+          const u32x2 pk = *reinterpret_cast<const u32x2*>(stage + r16 * YP + col * 2);
+          res[i][0] = f32x4{__builtin_bit_cast(float, pk[0] << 16), __builtin_bit_cast(float, pk[0] & 0xffff0000u),
+                            __builtin_bit_cast(float, pk[1] << 16), __builtin_bit_cast(float, pk[1] & 0xffff0000u)};
+        }
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(stage + 16 * YP + r16 * IP + col);
+        const int chunk = wave * NI2 + i;            // 16-byte chunk of the x row these 4 columns belong to
+        *reinterpret_cast<uint32_t*>(lds_i8 + kX + r16 * 128 + ((chunk ^ ((r16 >> 1) & 7)) << 4) + kg * 4) = w;
+      }
+    }
+    TQ_FSTAMP(7);
+  };
+  run_stage(std::integral_constant<int, 0>{}, st0, st1, g0);
+  if (nf > 1) run_stage(std::integral_constant<int, 1>{}, st1, st2, g1);
+  if (nf > 2) run_stage(std::integral_constant<int, 2>{}, st2, st3, g2);
+  if (nf > 3) run_stage(std::integral_constant<int, 3>{}, st3, st3, g3);
 }
 
 // rowsum[n] = sum_k w[n, k]   (once per weight tensor)
@@ -1355,4 +1596,80 @@ extern "C" int tq_ffn_i8_nonorm_fwd(const int8_t* x_idx, const float* x_delta, c
   else                   { if (bm == 16) TQ_FFN(TQ_BF16, 16); else TQ_FFN(TQ_BF16, 32); }
 #undef TQ_FFN
   return check_launch("ffn_i8_k");
+}
+
+extern "C" int tq_ffn_chain_i8_nonorm_fwd(const int8_t* x_idx, const float* x_delta, const float* x_zero_float, int x_n_bits,
+                                          float x_eps, const float* residual, const tq_ffn_stage* stages, uint64_t n_stages,
+                                          void* y, int8_t* y_idx, int y_dtype, uint64_t M, uint64_t K1, uint64_t N1, uint64_t N2,
+                                          tq_stream_t stream) {
+  if (M == 0) return TQ_OK;
+  TQ_REQUIRE(x_idx && x_delta && x_zero_float && residual && stages && y, "tq_ffn_chain_i8_nonorm_fwd: NULL pointer");
+  TQ_REQUIRE(n_stages >= 1 && n_stages <= (uint64_t)kMaxFfnChain, "tq_ffn_chain_i8_nonorm_fwd: 1..%d feed-forward blocks", kMaxFfnChain);
+  TQ_REQUIRE(K1 == 128 && N1 == 512 && N2 == 128, "tq_ffn_chain_i8_nonorm_fwd: only the (128, 512, 128) feed-forward shape is built");
+  TQ_REQUIRE(M % 16 == 0 && M < (1u << 31), "tq_ffn_chain_i8_nonorm_fwd: M must be a multiple of 16");
+  TQ_REQUIRE(y_dtype == TQ_F32 || y_dtype == TQ_BF16, "tq_ffn_chain_i8_nonorm_fwd: y dtype must be fp32 or bf16");
+  TQ_REQUIRE(x_n_bits >= 1 && x_n_bits <= 8, "tq_ffn_chain_i8_nonorm_fwd: input quantizer must have <= 8 bits");
+  TQ_REQUIRE(aligned16(x_idx) && aligned16(y) && aligned16(residual), "tq_ffn_chain_i8_nonorm_fwd: 16-byte alignment required");
+  FfnArgs c[kMaxFfnChain] = {};
+  const int fast_epi = tuning("TQ_I8_FAST_EPI", 1);
+  for (uint64_t s = 0; s < n_stages; ++s) {
+    const tq_ffn_stage& g = stages[s];
+    const bool last = s + 1 == n_stages;
+    TQ_REQUIRE(g.w1_idx && g.w1_rowsum && g.w1_delta && g.q_mid && g.w2_idx && g.w2_rowsum && g.w2_delta && g.nn_weight && g.nn_bias,
+               "tq_ffn_chain_i8_nonorm_fwd: NULL pointer in stage %llu", (unsigned long long)s);
+    TQ_REQUIRE((g.w1_n_params == 1 || g.w1_n_params == N1) && (g.w2_n_params == 1 || g.w2_n_params == N2),
+               "tq_ffn_chain_i8_nonorm_fwd: weight scales must be per-tensor or per-output-channel");
+    TQ_REQUIRE(aligned16(g.w1_idx) && aligned16(g.w2_idx), "tq_ffn_chain_i8_nonorm_fwd: 16-byte alignment required");
+    if (int e = check_quantizer(g.q_mid, M * N1, "tq_ffn_chain_i8_nonorm_fwd")) return e;
+    TQ_REQUIRE(g.q_mid->n_params == 1 && !g.q_mid->symmetric && g.q_mid->n_bits <= 8 && !g.q_mid->log_domain,
+               "tq_ffn_chain_i8_nonorm_fwd: the intermediate quantizer must be per-tensor, asymmetric, linear, <= 8 bit");
+    const tq_quantizer* qs[3] = {g.q_dense, g.q_sum, g.q_out};
+    for (const tq_quantizer* q : qs)
+      if (q != nullptr) {
+        if (int e = check_quantizer(q, M * N2, "tq_ffn_chain_i8_nonorm_fwd")) return e;
+        TQ_REQUIRE(q->n_params == 1, "tq_ffn_chain_i8_nonorm_fwd: per-tensor quantizers only");
+      }
+    // a block's output feeds the next block's integer GEMM: it must live on an asymmetric, linear <= 8-bit grid
+    TQ_REQUIRE((last && y_idx == nullptr) || (g.q_out != nullptr && !g.q_out->symmetric && g.q_out->n_bits <= 8 && !g.q_out->log_domain),
+               "tq_ffn_chain_i8_nonorm_fwd: stage %llu needs an asymmetric, linear <= 8-bit output quantizer", (unsigned long long)s);
+    FfnArgs& f = c[s];
+    f.x = x_idx; f.w1 = g.w1_idx; f.rs1 = g.w1_rowsum; f.b1 = g.bias1; f.w1_delta = g.w1_delta;
+    f.w1_n_params = (uint32_t)g.w1_n_params; f.w1_eps = g.w1_eps;
+    if (s == 0) { f.x_delta = x_delta; f.x_zero_float = x_zero_float; f.x_eps = x_eps; f.x_n_bits = x_n_bits; }
+    else {
+      const tq_quantizer* in = stages[s - 1].q_out;
+      f.x_delta = in->delta; f.x_zero_float = in->zero_float; f.x_eps = in->eps; f.x_n_bits = in->n_bits;
+    }
+    f.q_mid = *g.q_mid; f.w2 = g.w2_idx; f.rs2 = g.w2_rowsum; f.M = (uint32_t)M;
+    LinArgs& a = f.lin2;
+    a.w_rowsum = g.w2_rowsum; a.bias = g.bias2; a.y = last ? y : nullptr; a.y_idx = last ? y_idx : nullptr;
+    a.M = (uint32_t)M; a.N = (uint32_t)N2; a.K = (uint32_t)N1;
+    a.x_delta = g.q_mid->delta; a.x_zero_float = g.q_mid->zero_float; a.x_eps = g.q_mid->eps; a.x_n_bits = g.q_mid->n_bits;
+    a.w_delta = g.w2_delta; a.w_n_params = (uint32_t)g.w2_n_params; a.w_eps = g.w2_eps; a.act = ACT_NONE;
+    a.group_cols = (uint32_t)N2; a.fast_epi = fast_epi;
+    a.tail = 2; a.residual = residual; a.nn_w = g.nn_weight; a.nn_b = g.nn_bias;
+    a.has_q = g.q_dense != nullptr;
+    if (g.q_dense) a.q_out = *g.q_dense;
+    a.on_t1 = g.q_sum != nullptr;
+    if (g.q_sum) a.q_t1 = *g.q_sum;
+    a.on_t2 = g.q_out != nullptr;
+    if (g.q_out) a.q_t2 = *g.q_out;
+  }
+  const size_t es = y_dtype == TQ_F32 ? 4 : 2;       // + the tails' staging areas: 16 rows x (32 outputs + 16 B pad), y and indices
+  const size_t lds = (size_t)16 * 128 + 4 * (size_t)16 * 128 + 4 * 128 * 128 + 4 * 4 * 32 * 128 + 3 * 512 * 4 + 5 * 128 * 4 +
+                     4 * (16 * (32 * es + 16) + 16 * (32 + 16));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(M / 16));
+  const int nf = (int)n_stages;
+#ifdef TQ_FFN_PROF
+  const char* pe = getenv("TQ_FFN_PROF_PTR");
+  unsigned long long* prof = pe ? reinterpret_cast<unsigned long long*>(strtoull(pe, nullptr, 0)) : nullptr;
+#define TQ_FPROF_PASS , prof
+#else
+#define TQ_FPROF_PASS
+#endif
+  if (y_dtype == TQ_F32) hipLaunchKernelGGL((ffn_chain_i8_k<128, 512, 128, TQ_F32>), grid, dim3(kBlock), lds, st, c[0], c[1], c[2], c[3], nf TQ_FPROF_PASS);
+  else                   hipLaunchKernelGGL((ffn_chain_i8_k<128, 512, 128, TQ_BF16>), grid, dim3(kBlock), lds, st, c[0], c[1], c[2], c[3], nf TQ_FPROF_PASS);
+#undef TQ_FPROF_PASS
+  return check_launch("ffn_chain_i8_k");
 }

@@ -210,6 +210,7 @@ class QMobileLayer(QuantizedModel):
         self.output_bottleneck = QResidualNoNorm(hf.output.bottleneck, sites['res_output_bottleneck'], **qp)
 
     fuse_ffn = None    # set True: the last feed-forward block (intermediate + output) as one integer launch, like QFFN.fuse
+    fuse_chain = True  # all feed-forward blocks of the layer as ONE launch when each of them is fused (False: one launch per block)
 
     def forward(self, h, mask):
         pair = None
@@ -223,9 +224,17 @@ class QMobileLayer(QuantizedModel):
             layer_input = self.bottleneck_input(h)                # [B, T, 128] residual of the attention block
             shared = self.bottleneck_attention(h)                 # query / key input
         a = self.attention_output(self.attention_self(shared, shared, h, mask), layer_input)
-        for f in self.ffn:
-            a = f(a)
-        o = _ffn(self.intermediate, self.output, a) if options.fuse_on(self.fuse_ffn, self, self.output.LayerNorm) else self.output(self.intermediate(a), a)
+        o = None
+        if (options.fuse_on(self.fuse_ffn, self, self.output.LayerNorm) and self.fuse_chain
+                and all(options.fuse_on(f.fuse, f, f.output.LayerNorm) for f in self.ffn)):
+            from quantization.fused import quantized_ffn_chain       # the four feed-forward blocks as ONE integer launch
+            o = quantized_ffn_chain([(f.intermediate[0], f.output.dense, f.output.res_act_quantizer, f.output.LayerNorm)
+                                     for f in self.ffn] + [(self.intermediate[0], self.output.dense,
+                                                            self.output.res_act_quantizer, self.output.LayerNorm)], a)
+        if o is None:
+            for f in self.ffn:
+                a = f(a)
+            o = _ffn(self.intermediate, self.output, a) if options.fuse_on(self.fuse_ffn, self, self.output.LayerNorm) else self.output(self.intermediate(a), a)
         return self.output_bottleneck(o, h)                       # back to 512, residual = the layer's input
 
 

@@ -47,6 +47,15 @@ class tq_quantizer_f64(C.Structure):
 
 _u64, _vp, _int, _sz, _f, _d = C.c_uint64, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double
 _QP = C.POINTER(tq_quantizer)
+
+
+class tq_ffn_stage(C.Structure):
+    """include/tq_hip.h: one block of tq_ffn_chain_i8_nonorm_fwd"""
+    _fields_ = [('w1_idx', C.c_void_p), ('w1_rowsum', C.c_void_p), ('bias1', C.c_void_p), ('w1_delta', C.c_void_p),
+                ('w1_n_params', C.c_uint64), ('w1_eps', C.c_float), ('q_mid', _QP),
+                ('w2_idx', C.c_void_p), ('w2_rowsum', C.c_void_p), ('bias2', C.c_void_p), ('w2_delta', C.c_void_p),
+                ('w2_n_params', C.c_uint64), ('w2_eps', C.c_float),
+                ('nn_weight', C.c_void_p), ('nn_bias', C.c_void_p), ('q_dense', _QP), ('q_sum', _QP), ('q_out', _QP)]
 _QPD = C.POINTER(tq_quantizer_f64)
 
 # name -> (restype, argtypes); must list every symbol include/tq_hip.h declares
@@ -82,6 +91,7 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _QP, _QP, _QP, _vp, _vp, _int, _u64, _u64, _u64, _u64, _vp]),
     'tq_linear_i8_nonorm_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f,
                                        _vp, _u64, _f, _QP, _QP, _QP, _vp]),
+    'tq_ffn_chain_i8_nonorm_fwd': (_int, [_vp, _vp, _vp, _int, _f, _vp, _vp, _u64, _vp, _vp, _int, _u64, _u64, _u64, _u64, _vp]),
     'tq_linear_i8_nonorm_grouped_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp,
                                                _f, _u64, C.POINTER(_QP), C.POINTER(_QP), _vp]),
     'tq_linear_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _u64, _u64, _vp, _vp, _int, _f, _vp, _u64, _f,
@@ -670,6 +680,43 @@ class HipBackend:
             float(w_eps), G, a_d, a_o, _stream())
         _check(rc, self.lib)
         return ([y[0], y[1]], [y_idx[0], y_idx[1]]) if want_idx else [y[0], y[1]]
+
+    def ffn_chain_i8_nonorm(self, x_idx, x_q, residual, stages, out_dtype, want_idx=False):
+        """A chain of MobileBERT feed-forward blocks in one launch (include/tq_hip.h tq_ffn_chain_i8_nonorm_fwd).  stages:
+        list of dicts with w1_idx, w1_rowsum, bias1, w1_delta, w1_eps, q_mid, w2_idx, w2_rowsum, bias2, w2_delta, w2_eps,
+        nn_w, nn_b, q_dense, q_sum, q_out (7-tuples or None).  -> y [, y_idx] of the LAST block."""
+        K1 = x_idx.shape[-1]
+        M = x_idx.numel() // K1
+        N1, N2 = stages[0]['w1_idx'].shape[0], stages[0]['w2_idx'].shape[0]
+        y = torch.empty(x_idx.shape[:-1] + (N2,), dtype=out_dtype, device=x_idx.device)
+        y_idx = torch.empty(y.shape, dtype=torch.int8, device=y.device) if want_idx else None
+        keep = []                                    # descriptors and converted tensors alive across the call
+        arr = (tq_ffn_stage * len(stages))()
+        for a, g in zip(arr, stages):
+            def qp(q):
+                if q is None:
+                    return None
+                d = self._qdesc(*q, 1, 1)
+                keep.append(d)
+                return C.pointer(d)
+
+            def f32(t):
+                t = t.detach().float().contiguous()
+                keep.append(t)
+                return t.data_ptr()
+            a.w1_idx, a.w1_rowsum, a.bias1 = _ptr(g['w1_idx']), _ptr(g['w1_rowsum']), _ptr(g['bias1'])
+            a.w1_delta, a.w1_n_params, a.w1_eps = _ptr(g['w1_delta']), g['w1_delta'].numel(), float(g['w1_eps'])
+            a.q_mid = qp(g['q_mid'])
+            a.w2_idx, a.w2_rowsum, a.bias2 = _ptr(g['w2_idx']), _ptr(g['w2_rowsum']), _ptr(g['bias2'])
+            a.w2_delta, a.w2_n_params, a.w2_eps = _ptr(g['w2_delta']), g['w2_delta'].numel(), float(g['w2_eps'])
+            a.nn_weight, a.nn_bias = f32(g['nn_w']), f32(g['nn_b'])
+            a.q_dense, a.q_sum, a.q_out = qp(g['q_dense']), qp(g['q_sum']), qp(g['q_out'])
+        res = residual.detach().float().contiguous()
+        rc = self.lib.tq_ffn_chain_i8_nonorm_fwd(_ptr(x_idx), _ptr(x_q[0]), _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(res),
+                                                 C.cast(arr, C.c_void_p), len(stages), _ptr(y), _ptr(y_idx), _DTYPES[out_dtype],
+                                                 M, K1, N1, N2, _stream())
+        _check(rc, self.lib)
+        return (y, y_idx) if want_idx else y
 
     FFN_SHAPES = {(128, 512, 128)}          # (K1, N1, N2) tq_ffn_i8_nonorm_fwd is built for
 

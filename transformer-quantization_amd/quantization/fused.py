@@ -373,6 +373,69 @@ def quantized_ffn(intermediate, dense, res_quantizer, layer_norm, x):
     return y
 
 
+def quantized_ffn_chain(blocks, x):
+    """Consecutive MobileBERT feed-forward blocks, each the input of the next (reference
+    models/quantized_mobilebert.py:523-529: three FFN layers, then intermediate + output), as ONE integer launch
+    (tq_ffn_chain_i8_nonorm_fwd: a workgroup takes its 16 token rows through all blocks; only the last output is
+    written).  blocks: [(intermediate, dense, res_quantizer, layer_norm), ...] as for `quantized_ffn`.  Same
+    preconditions as `quantized_ffn` for every block, and every block's output quantizer must be asymmetric, linear,
+    <= 8 bit (its grid is the next block's input grid).  None when not eligible (the caller runs the blocks one by one);
+    bit-identical to that."""
+    from quantization.autoquant_utils import INT8_STATS, QuantNoNorm
+    be = _hip.backend()
+    if (not options.int8_active() or not hasattr(be, 'ffn_chain_i8_nonorm') or not 2 <= len(blocks) <= 4
+            or not _hip.on_device(x) or x.dtype != torch.float32):
+        return None
+    K1 = x.shape[-1]
+    M = x.numel() // K1
+    if M % 32:
+        return None
+    arg = lambda q: None if q == 'off' else q
+    stages, src, x_ops, oq = [], None, None, None
+    for k, (intermediate, dense, res_quantizer, layer_norm) in enumerate(blocks):
+        if (not isinstance(layer_norm, QuantNoNorm) or not hasattr(intermediate, '_int8_plan')
+                or not hasattr(dense, '_int8_weight_side_ok') or _needs_autograd(intermediate, dense, layer_norm, x)
+                or dense.activation_function is not None or layer_norm.activation_function is not None
+                or layer_norm.activation_save_target is not None or dense.activation_save_target is not None
+                or intermediate.activation_save_target is not None or not dense._int8_weight_side_ok()
+                or _hooked(intermediate, dense, res_quantizer, layer_norm)
+                or (intermediate.in_features, intermediate.out_features, dense.out_features) not in be.FFN_SHAPES
+                or dense.in_features != intermediate.out_features):
+            return None
+        plan = (intermediate._int8_plan(x, with_output_quantizer=True) if k == 0
+                else intermediate._int8_plan_from(src, M, with_output_quantizer=True))
+        q1 = _fixed_per_tensor(dense._quant_a, dense.activation_quantizer)
+        q2 = _fixed_per_tensor(getattr(res_quantizer, '_quant_a', False), getattr(res_quantizer, 'activation_quantizer', res_quantizer))
+        q3 = _fixed_per_tensor(layer_norm._quant_a, layer_norm.activation_quantizer)
+        if plan is None or plan[1] != _hip.ACT_RELU or plan[2] is None or 'no' in (q1, q2, q3) or q3 == 'off':
+            return None
+        q_mid = plan[2]
+        oq = layer_norm.activation_quantizer.quantizer
+        if q_mid[4] or q_mid[5] or q_mid[3] > 8 or oq.symmetric or oq.n_bits > 8 or oq.scale_domain != 'linear':
+            return None
+        if k == 0:
+            x_ops = intermediate._int8_operands(x, plan)
+            ops = x_ops
+        else:
+            ops = intermediate._int8_operands(None, plan, x_idx=x_ops[0])     # (x_idx unused: weight side only)
+        if ops is None:
+            return None
+        w2_idx, rs2, w2_signed = dense._int8_weights()
+        if not w2_signed:
+            return None
+        ln_w, ln_b = layer_norm.quantized_params()
+        wq2 = dense.weight_quantizer.quantizer
+        stages.append(dict(w1_idx=ops[1], w1_rowsum=ops[2], bias1=ops[3], w1_delta=ops[5], w1_eps=ops[6], q_mid=q_mid,
+                           w2_idx=w2_idx, w2_rowsum=rs2, bias2=None if dense.bias is None else dense.bias.detach(),
+                           w2_delta=wq2._delta.reshape(-1), w2_eps=wq2.eps, nn_w=ln_w, nn_b=ln_b,
+                           q_dense=arg(q1), q_sum=arg(q2), q_out=q3))
+        src = oq
+    INT8_STATS['kernel_calls'] += 2 * len(blocks)
+    y, idx = be.ffn_chain_i8_nonorm(x_ops[0], x_ops[4], x, stages, torch.float32, want_idx=True)
+    provenance.tag(y, oq, idx)
+    return y
+
+
 def scores_softmax_quant(scores_quantizer, probs_quantizer, scores, mask, denom):
     """Equivalent to ``probs_quantizer(softmax(scores_quantizer(scores) / denom + mask, dim=-1))``
     (reference models/quantized_bert.py:153-198) as one kernel when both quantizers are fixed and
