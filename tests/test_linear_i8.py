@@ -424,14 +424,16 @@ def test_ffn_i8_block_equals_two_launches(M, quantizers, per_channel):
 @pytest.mark.parametrize('n_blocks', [2, 3, 4])
 @pytest.mark.parametrize('M', [32, 1024])
 @pytest.mark.parametrize('variant', ['all_fp32', 'mixed_fp32', 'all_bf16', 'slow_quantizer'])
-def test_ffn_chain_equals_consecutive_blocks(n_blocks, M, variant):
+@pytest.mark.parametrize('waves', [8, 4])
+def test_ffn_chain_equals_consecutive_blocks(n_blocks, M, variant, waves, monkeypatch):
     """tq_ffn_chain_i8_nonorm_fwd -- consecutive MobileBERT feed-forward blocks in ONE launch, the rows staying on the CU
-    (outputs as register residuals, their indices as the next x tile in LDS) -- against n launches of
+    (the output indices become the next x tile in LDS, y = scale * (index - zp) the next residual) -- against n launches of
     tq_ffn_i8_nonorm_fwd: bit-identical y and indices.  `mixed`: blocks without dense / sum quantizer, per-channel
     weight scales in some blocks; `slow_quantizer`: a scale outside the exact-quotient range sends one block through the
     division epilogue."""
     from quantization import _hip
     be = _hip.backend()
+    monkeypatch.setenv('TQ_FFN_CHAIN_WAVES', str(waves))     # 8 (default) or 4 waves share the 16 rows of a workgroup
     K1, N1, N2 = 128, 512, 128
     g = torch.Generator().manual_seed(M + 31 * n_blocks)
     dt = torch.bfloat16 if variant == 'all_bf16' else torch.float32

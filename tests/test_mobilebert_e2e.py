@@ -264,25 +264,40 @@ def test_mobilebert_linear_nonorm_tails_in_gemm_epilogue():
         try:
             separate = model(ids)
             be.linear_i8_nonorm = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            pair_calls = []
+            orig_pair = be.linear_i8_nonorm_grouped
+            be.linear_i8_nonorm_grouped = lambda *a, **k: (pair_calls.append(1), orig_pair(*a, **k))[1]
             QResidualNoNorm.fuse = QBottleneckLayer.fuse = True
             fused = model(ids)
-            # + the four feed-forward blocks of a layer as one launch each (tq_ffn_i8_nonorm_fwd)
-            ffn_calls = []
-            orig_ffn = be.ffn_i8_nonorm
+            n_single, n_pair = len(calls), len(pair_calls)
+            # + the four feed-forward blocks of a layer as one launch each (tq_ffn_i8_nonorm_fwd) ...
+            ffn_calls, chain_calls = [], []
+            orig_ffn, orig_chain = be.ffn_i8_nonorm, be.ffn_chain_i8_nonorm
             be.ffn_i8_nonorm = lambda *a, **k: (ffn_calls.append(1), orig_ffn(*a, **k))[1]
+            be.ffn_chain_i8_nonorm = lambda *a, **k: (chain_calls.append(len(a[3])), orig_chain(*a, **k))[1]
             QFFN.fuse = QMobileLayer.fuse_ffn = True
+            QMobileLayer.fuse_chain = False
             try:
                 fused_ffn = model(ids)
+                # ... and as ONE launch for all four (tq_ffn_chain_i8_nonorm_fwd, the default once every block is fused)
+                QMobileLayer.fuse_chain = True
+                fused_chain = model(ids)
             finally:
                 QFFN.fuse = QMobileLayer.fuse_ffn = False
+                QMobileLayer.fuse_chain = True
                 be.__dict__.pop('ffn_i8_nonorm', None)
+                be.__dict__.pop('ffn_chain_i8_nonorm', None)
         finally:
             QResidualNoNorm.fuse = QBottleneckLayer.fuse = False
             options.INT8_LINEAR = False
             be.__dict__.pop('linear_i8_nonorm', None)
-    assert len(calls) >= 2 * 6 - 2, len(calls)        # per layer: 2 bottlenecks + 4 residual tails (the first layer's inputs
-    assert torch.equal(fused, separate)               # come from the embeddings without int8 provenance)
-    assert len(ffn_calls) == 2 * 4 and torch.equal(fused_ffn, separate)
+            be.__dict__.pop('linear_i8_nonorm_grouped', None)
+    # per layer: the 2 input bottlenecks (one grouped launch from layer 2 on: the first layer's input comes from the
+    # embeddings without int8 provenance) + 4 residual tails
+    assert n_single + 2 * n_pair >= 2 * 6 - 2 and n_pair >= 1, (n_single, n_pair)
+    assert torch.equal(fused, separate)
+    assert len(ffn_calls) == 2 * 4 and chain_calls == [4, 4]
+    assert torch.equal(fused_ffn, separate) and torch.equal(fused_chain, separate)
 
 
 @pytest.mark.gpu

@@ -199,8 +199,8 @@ __device__ __forceinline__ void stage_flush(const LinArgs& p, const int8_t* ysta
 // instead of 16 rows x 64 B (y) or 16 rows x 16 B (indices) straight from the MFMA accumulator layout -- with
 // non-temporal stores (y is not read again by this kernel; W and X keep the L2).  Measured at M = 8192, N = 3072,
 // K = 768, fp32 y: 48.4 -> 34.5 us for the GEMM + plain store.
-// FLUSH = false (chained feed-forward blocks): the results of the single pass stay in the wave's staging area -- y as fp32 /
-// bf16 rows of pitch YP, the int8 indices behind them -- whether or not the launch has global outputs.
+// FLUSH = false (chained feed-forward blocks): the int8 indices of the single pass stay in the wave's staging area (at
+// stage + 16 * YP, rows of pitch IP; the y part is not written -- y = scale * (index - zp) exactly, rebuilt by the caller).
 template <int NI, int MI, int YDT, int ACT, bool HASQ, bool STAGED, int TAIL = 0, bool FLUSH = true>
 __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
                                                      int kg, const QF& qf, int shift, float sx, int8_t* stage,
@@ -223,7 +223,7 @@ __device__ __forceinline__ void linear_epilogue_fast(const LinArgs& p, v4i (&acc
   static_assert(FLUSH || (STAGED && MI == JP), "results kept in the staging area: one pass");
   const uint32_t og = out_group(p, n0);
   const bool want_idx = fin_q && (p.y_idx != nullptr || !FLUSH);
-  const bool want_y = p.y != nullptr || !FLUSH;
+  const bool want_y = FLUSH && p.y != nullptr;       // (FLUSH = false: y is rebuilt from the indices by the caller)
 #pragma unroll
   for (int h = 0; h < MI / JP; ++h) {
 #pragma unroll
@@ -405,7 +405,7 @@ template <int NI, int MI, int YDT>
 __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&acc)[NI][MI], uint32_t n0, uint32_t m0, int r16,
                                                      int kg, const QP& qo, int shift, float sx,
                                                      const f32x4 (*res_pre)[MI] = nullptr /* residual in registers */,
-                                                     int8_t* keep = nullptr /* staging area: results stay there (MI == 1) */) {
+                                                     int8_t* keep = nullptr /* staging area: the indices stay there (MI == 1) */) {
   const uint32_t og = out_group(p, n0);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -448,11 +448,10 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
         }
         o[r] = v;
       }
-      if (keep != nullptr) {                      // the layout of the staged fast epilogue (16 rows, pitches YP / IP)
+      if (keep != nullptr) {                      // indices only, in the layout of the staged fast epilogue (16 rows, pitch IP)
         constexpr int ES = YDT == TQ_F32 ? 4 : 2, YP = NI * 16 * ES + 16, IP = NI * 16 + 16;
         const int row = j * 16 + r16, col = i * 16 + kg * 4;
         *reinterpret_cast<uint32_t*>(keep + 16 * YP + row * IP + col) = __builtin_bit_cast(uint32_t, oi4);
-        store_y4<YDT>(keep + row * YP, col, f32x2{o[0], o[1]}, f32x2{o[2], o[3]});
       } else {
         if (p.y_idx != nullptr) *reinterpret_cast<uint32_t*>(p.y_idx + at) = __builtin_bit_cast(uint32_t, oi4);
         if (p.y != nullptr) store_y4<YDT>(p.y, at, f32x2{o[0], o[1]}, f32x2{o[2], o[3]});
@@ -692,6 +691,7 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
   constexpr int LPW = WT / 16;                    // 1 KB load instructions per wave, operand and slab
   constexpr int OPB = BT * 128, STB = 2 * OPB;    // bytes per operand tile / per stage
   extern __shared__ __attribute__((aligned(1024))) int8_t lds_i8[];   // [2 stages][W | X][BT rows][128 B]
+  prefetch_kernarg<sizeof(LinArgs)>();
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform for the compiler: scalar addressing of the epilogue parameters)
   const uint32_t tiles_m = p.M / BT;
   const int wn = (wave >> 1) * WT, wm = (wave & 1) * WT;
@@ -882,9 +882,10 @@ __device__ __forceinline__ void ffn_gemm1(v4i (&acc1)[NI1][MI], const int8_t* bw
 
 // epilogue 1: scale + bias, ReLU, Q_mid -> int8(index - 128) into the intermediate's K-slab layout (slab = wave);
 // two n tiles per step so that the packed quantizer chains of 2 * IT * MI register pairs overlap
+// (col0: the wave's first column of GEMM 1; its tiles are chunks chunk0 .. chunk0 + NI1 - 1 of the 128-byte slab at hb)
 template <int N1, int NI1, int MI, int BM>
-__device__ __forceinline__ void ffn_epilogue1(const v4i (&acc1)[NI1][MI], const QP& qm, const float* c1, int8_t* hb, int wave, int r16,
-                                              int kg) {
+__device__ __forceinline__ void ffn_epilogue1(const v4i (&acc1)[NI1][MI], const QP& qm, const float* c1, int8_t* hb, int col0,
+                                              int chunk0, int r16, int kg) {
   const QF qf = make_qf(qm);
   const f32x2 zpb = {qm.zp, qm.zp};
   constexpr int IT = 2, NP = IT * 2 * MI;
@@ -893,7 +894,7 @@ __device__ __forceinline__ void ffn_epilogue1(const v4i (&acc1)[NI1][MI], const 
     f32x2 v[NP], hq[NP];
 #pragma unroll
     for (int ii = 0; ii < IT; ++ii) {
-      const int col = wave * (N1 / 4) + (i0 + ii) * 16 + kg * 4;
+      const int col = col0 + (i0 + ii) * 16 + kg * 4;
       const f32x4 s4 = *reinterpret_cast<const f32x4*>(c1 + col);
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(c1 + N1 + col);
       const v4i r4 = *reinterpret_cast<const v4i*>(c1 + 2 * N1 + col);
@@ -928,13 +929,13 @@ __device__ __forceinline__ void ffn_epilogue1(const v4i (&acc1)[NI1][MI], const 
         w = __builtin_amdgcn_cvt_pk_u8_f32(hi.x, 2, w);
         w = __builtin_amdgcn_cvt_pk_u8_f32(hi.y, 3, w) ^ 0x80808080u;
         const int m = j * 16 + r16;                    // chunk i of slab `wave`, swizzled like every operand row
-        *reinterpret_cast<uint32_t*>(hb + m * 128 + (((i0 + ii) ^ ((m >> 1) & 7)) << 4) + kg * 4) = w;
+        *reinterpret_cast<uint32_t*>(hb + m * 128 + (((chunk0 + i0 + ii) ^ ((m >> 1) & 7)) << 4) + kg * 4) = w;
       }
   }
 }
 
-// GEMM 2: [BM, N1] x [N2 / 4 (own), N1]^T
-template <int NI2, int MI, int SL2, int N2, int BM>
+// GEMM 2: [BM, N1] x [RW (own rows of W2), N1]^T
+template <int NI2, int MI, int SL2, int RW, int BM>
 __device__ __forceinline__ void ffn_gemm2(v4i (&acc2)[NI2][MI], const int8_t* w2, const int8_t* hbase, const int (&off)[2]) {
 #pragma unroll
   for (int i = 0; i < NI2; ++i)
@@ -942,7 +943,7 @@ __device__ __forceinline__ void ffn_gemm2(v4i (&acc2)[NI2][MI], const int8_t* w2
     for (int j = 0; j < MI; ++j) acc2[i][j] = v4i{0, 0, 0, 0};
 #pragma unroll
   for (int sl = 0; sl < SL2; ++sl) {
-    const int8_t* bw = w2 + sl * (N2 / 4) * 128;
+    const int8_t* bw = w2 + sl * RW * 128;
     const int8_t* bh = hbase + sl * (BM * 128);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -972,6 +973,7 @@ __global__ __launch_bounds__(kBlock) void ffn_i8_k(FfnArgs p) {
   constexpr int kX = 0, kH = kX + BM * 128, kW1 = kH + SL2 * BM * 128, kW1w = (N1 / 4) * 128;
   constexpr int kW2 = kW1 + 4 * kW1w, kW2w = SL2 * (N2 / 4) * 128, kC1 = kW2 + 4 * kW2w, kC2 = kC1 + 3 * N1 * 4;
   extern __shared__ __attribute__((aligned(1024))) int8_t lds_i8[];
+  prefetch_kernarg<sizeof(FfnArgs)>();
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kg = lane >> 4;
   const uint32_t m0 = blockIdx.x * BM;
@@ -1063,10 +1065,10 @@ __global__ __launch_bounds__(kBlock) void ffn_i8_k(FfnArgs p) {
   // ---- GEMM 1 -> epilogue 1 (intermediate indices into LDS) -> barrier -> GEMM 2
   v4i acc1[NI1][MI];
   ffn_gemm1<NI1, MI>(acc1, lds_i8 + kW1 + wave * kW1w, lds_i8 + kX, off);
-  ffn_epilogue1<N1, NI1, MI, BM>(acc1, qm, c1, lds_i8 + kH + wave * (BM * 128), wave, r16, kg);
+  ffn_epilogue1<N1, NI1, MI, BM>(acc1, qm, c1, lds_i8 + kH + wave * (BM * 128), wave * (N1 / 4), 0, r16, kg);
   __syncthreads();                                   // the whole [BM, N1] intermediate is in LDS
   v4i acc2[NI2][MI];
-  ffn_gemm2<NI2, MI, SL2, N2, BM>(acc2, lds_i8 + kW2 + wave * kW2w, lds_i8 + kH, off);
+  ffn_gemm2<NI2, MI, SL2, N2 / 4, BM>(acc2, lds_i8 + kW2 + wave * kW2w, lds_i8 + kH, off);
   // ---- epilogue 2: the NoNorm tail of the plain kernel; outputs staged through this wave's (now free) W1 region
   linear_epilogue<NI2, MI, YDT, true, true>(p.lin2, acc2, wave * (N2 / 4), m0, r16, kg, ectx, lds_i8 + kW1 + wave * kW1w,
                                             c2 + wave * (N2 / 4), N2, res_pre);
@@ -1102,18 +1104,23 @@ constexpr int kMaxFfnChain = 4;
 #define TQ_FPROF_ARG
 #endif
 
-template <int K1, int N1, int N2, int YDT>
-__global__ __launch_bounds__(kBlock) void ffn_chain_i8_k(FfnArgs st0, FfnArgs st1, FfnArgs st2, FfnArgs st3, int nf TQ_FPROF_ARG) {
+// NW waves per workgroup (4 or 8) share the 16 rows: a wave owns N1 / NW columns of GEMM 1 and N2 / NW of GEMM 2.  A stage
+// is ALU / latency bound (phase profile, tools/tuning/ffn_chain_prof.py: ~11 500 cycles with 4 waves, the LDS-DMA refills
+// fully hidden), so 8 waves -- half the columns each, two waves per SIMD covering each other's stalls -- is the default.
+template <int K1, int N1, int N2, int YDT, int NW>
+__global__ __launch_bounds__(NW * 64) void ffn_chain_i8_k(FfnArgs st0, FfnArgs st1, FfnArgs st2, FfnArgs st3, int nf TQ_FPROF_ARG) {
   static_assert(K1 == 128 && N1 == 512 && N2 == 128, "instantiated for MobileBERT's feed-forward shape (N2 == K1: chainable)");
+  static_assert(NW == 4 || NW == 8, "waves per workgroup");
   constexpr int BM = 16, MI = 1;
-  constexpr int NI1 = N1 / 4 / 16, NI2 = N2 / 4 / 16, SL2 = N1 / 128;
+  constexpr int C1W = N1 / NW, C2W = N2 / NW;        // columns of GEMM 1 / GEMM 2 per wave
+  constexpr int NI1 = C1W / 16, NI2 = C2W / 16, SL2 = N1 / 128;
   constexpr int ES = YDT == TQ_F32 ? 4 : 2, YP = NI2 * 16 * ES + 16, IP = NI2 * 16 + 16;   // staging pitches of the tail
-  constexpr int kStage = 16 * YP + 16 * IP;          // per wave
-  constexpr int kX = 0, kH = kX + BM * 128, kW1 = kH + SL2 * BM * 128, kW1w = (N1 / 4) * 128;
-  constexpr int kW2 = kW1 + 4 * kW1w, kW2w = SL2 * (N2 / 4) * 128, kC1 = kW2 + 4 * kW2w, kC2 = kC1 + 3 * N1 * 4;
-  constexpr int kS = kC2 + 5 * N2 * 4;               // the tails' staging areas: the W regions are being refilled by then
-  constexpr int IW = N1 / 4 / 8;                     // LDS-DMA instructions per weight slice and wave (W1 and W2 alike)
-  static_assert(IW == SL2 * (N2 / 4 / 8) && kS + 4 * kStage <= 160 * 1024, "slices of equal size; LDS budget");
+  constexpr int kStage = 16 * YP + 16 * IP;          // per wave, last stage (y and indices)
+  constexpr int kX = 0, kH = kX + BM * 128, kW1 = kH + SL2 * BM * 128, kW1w = C1W * 128;
+  constexpr int kW2 = kW1 + NW * kW1w, kW2w = SL2 * C2W * 128, kC1 = kW2 + NW * kW2w, kC2 = kC1 + 3 * N1 * 4;
+  constexpr int kS = kC2 + 5 * N2 * 4;               // the inner stages' index staging: 16 rows of pitch IP per wave
+  constexpr int IW = C1W / 8;                        // LDS-DMA instructions per weight slice and wave (W1 and W2 alike)
+  static_assert(IW == SL2 * (C2W / 8) && kS + NW * 16 * IP <= 160 * 1024 && kStage <= kW2w, "slices of equal size; LDS budget");
   extern __shared__ __attribute__((aligned(1024))) int8_t lds_i8[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kg = lane >> 4;
@@ -1122,21 +1129,21 @@ __global__ __launch_bounds__(kBlock) void ffn_chain_i8_k(FfnArgs st0, FfnArgs st
   float* c1 = reinterpret_cast<float*>(lds_i8 + kC1);
   float* c2 = reinterpret_cast<float*>(lds_i8 + kC2);
 
-  auto issue_w1 = [&](const FfnArgs& p) {     // own W1 slice: rows n = wave * 128 + 8 q + row8
+  auto issue_w1 = [&](const FfnArgs& p) {     // own W1 slice: rows n = wave * C1W + 8 q + row8
 #pragma unroll
-    for (int q = 0; q < N1 / 4 / 8; ++q) {
+    for (int q = 0; q < C1W / 8; ++q) {
       const int row = q * 8 + row8;
-      TQ_GLDS16(p.w1 + (size_t)(wave * (N1 / 4) + row) * K1 + ((slot ^ ((row >> 1) & 7)) << 4), lds_i8 + kW1 + wave * kW1w + q * 1024);
+      TQ_GLDS16(p.w1 + (size_t)(wave * C1W + row) * K1 + ((slot ^ ((row >> 1) & 7)) << 4), lds_i8 + kW1 + wave * kW1w + q * 1024);
     }
   };
-  auto issue_w2 = [&](const FfnArgs& p) {     // own W2 slice, slab sl: rows n = wave * 32 + 8 q + row8, k bytes [128 sl, 128 sl + 128)
+  auto issue_w2 = [&](const FfnArgs& p) {     // own W2 slice, slab sl: rows n = wave * C2W + 8 q + row8, k bytes [128 sl, 128 sl + 128)
 #pragma unroll
     for (int sl = 0; sl < SL2; ++sl)
 #pragma unroll
-      for (int q = 0; q < N2 / 4 / 8; ++q) {
+      for (int q = 0; q < C2W / 8; ++q) {
         const int row = q * 8 + row8;
-        TQ_GLDS16(p.w2 + (size_t)(wave * (N2 / 4) + row) * N1 + sl * 128 + ((slot ^ ((row >> 1) & 7)) << 4),
-                  lds_i8 + kW2 + wave * kW2w + sl * (N2 / 4) * 128 + q * 1024);
+        TQ_GLDS16(p.w2 + (size_t)(wave * C2W + row) * N1 + sl * 128 + ((slot ^ ((row >> 1) & 7)) << 4),
+                  lds_i8 + kW2 + wave * kW2w + sl * C2W * 128 + q * 1024);
       }
   };
   // everything a stage reads through pointers, requested as independent loads and parked in registers
@@ -1144,24 +1151,24 @@ __global__ __launch_bounds__(kBlock) void ffn_chain_i8_k(FfnArgs st0, FfnArgs st
     EpiRaw eraw;
     QRaw mraw;
     float dx, zf;
-    float dw1[2], b1[2], dw2, b2, nw, nb;
-    int rs1[2], rs2;
+    float dw1[C1W / 64], b1[C1W / 64], dw2, b2, nw, nb;
+    int rs1[C1W / 64], rs2;
   };
   auto fetch = [&](const FfnArgs& p) {
     StageRegs g;
-    g.eraw = epilogue_fetch<true, false>(p.lin2, wave * (N2 / 4));
+    g.eraw = epilogue_fetch<true, false>(p.lin2, wave * C2W);
     g.mraw = load_qraw(p.q_mid, 0, p.x_delta);
     g.dx = p.x_delta[0];
     g.zf = p.x_zero_float[0];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {               // the wave's own 128 columns of GEMM 1
-      const int n = wave * (N1 / 4) + lane + t * 64;
+    for (int t = 0; t < C1W / 64; ++t) {        // the wave's own columns of GEMM 1
+      const int n = wave * C1W + lane + t * 64;
       g.dw1[t] = p.w1_delta[p.w1_n_params == 1 ? 0 : n];
       g.b1[t] = p.b1 ? p.b1[n] : 0.0f;
       g.rs1[t] = p.rs1[n];
     }
     const LinArgs& l2 = p.lin2;
-    const int n2 = wave * (N2 / 4) + (lane & 31);   // its own 32 columns of GEMM 2 (lanes >= 32 load duplicates)
+    const int n2 = wave * C2W + (lane & (C2W - 1)); // its own columns of GEMM 2 (lanes >= C2W load duplicates)
     g.dw2 = l2.w_delta[l2.w_n_params == 1 ? 0 : n2];
     g.b2 = l2.bias ? l2.bias[n2] : 0.0f;
     g.rs2 = p.rs2[n2];
@@ -1186,6 +1193,8 @@ __global__ __launch_bounds__(kBlock) void ffn_chain_i8_k(FfnArgs st0, FfnArgs st
   }
   issue_w1(st0);
   issue_w2(st0);
+  // the 2.7 KB argument block -> scalar cache while the operand fetches are on their way (tq_device.h prefetch_kernarg)
+  prefetch_kernarg<4 * sizeof(FfnArgs) + sizeof(int)>();
   StageRegs g0 = fetch(st0), g1 = g0, g2 = g0, g3 = g0;
   if (nf > 1) g1 = fetch(st1);
   if (nf > 2) g2 = fetch(st2);
@@ -1193,7 +1202,7 @@ __global__ __launch_bounds__(kBlock) void ffn_chain_i8_k(FfnArgs st0, FfnArgs st
   f32x4 res[NI2][MI];
 #pragma unroll
   for (int i = 0; i < NI2; ++i)
-    res[i][0] = *reinterpret_cast<const f32x4*>(st0.lin2.residual + (size_t)(m0 + r16) * N2 + wave * (N2 / 4) + i * 16 + kg * 4);
+    res[i][0] = *reinterpret_cast<const f32x4*>(st0.lin2.residual + (size_t)(m0 + r16) * N2 + wave * C2W + i * 16 + kg * 4);
   arrived(g0); arrived(g1); arrived(g2); arrived(g3);
 
   const int swz = (r16 >> 1) & 7;
@@ -1212,14 +1221,14 @@ __global__ __launch_bounds__(kBlock) void ffn_chain_i8_k(FfnArgs st0, FfnArgs st
       const float sx = cur.dx < p.x_eps ? p.x_eps : cur.dx;
       const int zx = (int)clamp_nanprop(rintf(cur.zf), 0.0f, grid_top(p.x_n_bits));
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int n = wave * (N1 / 4) + lane + t * 64;
+      for (int t = 0; t < C1W / 64; ++t) {
+        const int n = wave * C1W + lane + t * 64;
         c1[n] = sx * (cur.dw1[t] < p.w1_eps ? p.w1_eps : cur.dw1[t]);
         c1[N1 + n] = cur.b1[t];
         reinterpret_cast<int*>(c1)[2 * N1 + n] = cur.rs1[t] * (128 - zx);
       }
-      if (lane < 32) {
-        const int n2 = wave * (N2 / 4) + lane;
+      if (lane < C2W) {
+        const int n2 = wave * C2W + lane;
         const int zm = (int)qm.zp;                       // lin2's input lives on Q_mid's grid
         c2[n2] = qm.scale * (cur.dw2 < l2.w_eps ? l2.w_eps : cur.dw2);
         c2[N2 + n2] = cur.b2;
@@ -1238,34 +1247,43 @@ __global__ __launch_bounds__(kBlock) void ffn_chain_i8_k(FfnArgs st0, FfnArgs st
     ffn_gemm1<NI1, MI>(acc1, lds_i8 + kW1 + wave * kW1w, lds_i8 + kX, off);
     if (more) issue_w1(pn);                          // own W1 region: this wave's GEMM 1 is done with it
     TQ_FSTAMP(3);
-    ffn_epilogue1<N1, NI1, MI, BM>(acc1, qm, c1, lds_i8 + kH + wave * (BM * 128), wave, r16, kg);
+    ffn_epilogue1<N1, NI1, MI, BM>(acc1, qm, c1, lds_i8 + kH + (wave * C1W / 128) * (BM * 128), wave * C1W, (wave * C1W % 128) / 16, r16, kg);
     TQ_FSTAMP(4);
     if (more) lds_dma_wait_but<IW>(); else lds_dma_wait_but<0>();       // this wave's W2 slice
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the whole [BM, N1] intermediate is in LDS
     TQ_FSTAMP(5);
     v4i acc2[NI2][MI];
-    ffn_gemm2<NI2, MI, SL2, N2, BM>(acc2, lds_i8 + kW2 + wave * kW2w, lds_i8 + kH, off);
+    ffn_gemm2<NI2, MI, SL2, C2W, BM>(acc2, lds_i8 + kW2 + wave * kW2w, lds_i8 + kH, off);
     if (more) issue_w2(pn);                          // own W2 region: this wave's GEMM 2 is done with it
     TQ_FSTAMP(6);
 
-    int8_t* stage = lds_i8 + kS + wave * kStage;
-    if (!more) {                                     // last stage: the NoNorm tail of the plain kernel, out to memory
-      linear_epilogue<NI2, MI, YDT, true, true>(l2, acc2, wave * (N2 / 4), m0, r16, kg, ectx, stage, c2 + wave * (N2 / 4), N2, res);
+    if (!more) {     // last stage: the NoNorm tail of the plain kernel, out to memory, staged through the wave's W2 region (done with)
+      linear_epilogue<NI2, MI, YDT, true, true>(l2, acc2, wave * C2W, m0, r16, kg, ectx, lds_i8 + kW2 + wave * kW2w,
+                                                c2 + wave * C2W, N2, res);
     } else {
-      // the same tail, results kept in the staging area: y -> the next residual (registers), indices -> the x tile
-      linear_epilogue<NI2, MI, YDT, true, true, false>(l2, acc2, wave * (N2 / 4), m0, r16, kg, ectx, stage, c2 + wave * (N2 / 4), N2,
+      // the same tail with the indices kept in LDS: -> the x tile of the next stage, and y = scale * (index - zp) -- the
+      // very value the tail computes from the index -- -> the next residual (registers).  (The y part of the staging
+      // layout, 16 * YP bytes in front of the indices, is not touched: the area handed over starts that much earlier.)
+      int8_t* istage = lds_i8 + kS + wave * (16 * IP);
+      linear_epilogue<NI2, MI, YDT, true, true, false>(l2, acc2, wave * C2W, m0, r16, kg, ectx, istage - 16 * YP, c2 + wave * C2W, N2,
                                                        res);
+      const float qs = ectx.qf2.scale.x, qz = ectx.qf2.zp;
 #pragma unroll
       for (int i = 0; i < NI2; ++i) {
         const int col = i * 16 + kg * 4;
-        if (YDT == TQ_F32) {
-          res[i][0] = *reinterpret_cast<const f32x4*>(stage + r16 * YP + col * 4);
-        } else {                                     // bf16 storage: the next block sees the ROUNDED value, like a separate launch
-          const u32x2 pk = *reinterpret_cast<const u32x2*>(stage + r16 * YP + col * 2);
-          res[i][0] = f32x4{__builtin_bit_cast(float, pk[0] << 16), __builtin_bit_cast(float, pk[0] & 0xffff0000u),
-                            __builtin_bit_cast(float, pk[1] << 16), __builtin_bit_cast(float, pk[1] & 0xffff0000u)};
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(istage + r16 * IP + col);
+        const uint32_t u = w ^ 0x80808080u;          // the four grid indices 0 .. 255
+        float y4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          y4[r] = __builtin_fmaf(qs, (float)((u >> (8 * r)) & 0xffu) - qz, 0.0f);
+          if (YDT != TQ_F32) {                       // bf16 storage: the next block sees the ROUNDED value, like a separate launch
+            const f32x2 pr = {y4[r], 0.0f};
+            const uint32_t b = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2));
+            y4[r] = __builtin_bit_cast(float, b << 16);
+          }
         }
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(stage + 16 * YP + r16 * IP + col);
+        res[i][0] = f32x4{y4[0], y4[1], y4[2], y4[3]};
         const int chunk = wave * NI2 + i;            // 16-byte chunk of the x row these 4 columns belong to
         *reinterpret_cast<uint32_t*>(lds_i8 + kX + r16 * 128 + ((chunk ^ ((r16 >> 1) & 7)) << 4) + kg * 4) = w;
       }
@@ -1655,9 +1673,11 @@ extern "C" int tq_ffn_chain_i8_nonorm_fwd(const int8_t* x_idx, const float* x_de
     a.on_t2 = g.q_out != nullptr;
     if (g.q_out) a.q_t2 = *g.q_out;
   }
-  const size_t es = y_dtype == TQ_F32 ? 4 : 2;       // + the tails' staging areas: 16 rows x (32 outputs + 16 B pad), y and indices
-  const size_t lds = (size_t)16 * 128 + 4 * (size_t)16 * 128 + 4 * 128 * 128 + 4 * 4 * 32 * 128 + 3 * 512 * 4 + 5 * 128 * 4 +
-                     4 * (16 * (32 * es + 16) + 16 * (32 + 16));
+  const int nw = tuning("TQ_FFN_CHAIN_WAVES", 8);
+  TQ_REQUIRE(nw == 4 || nw == 8, "TQ_FFN_CHAIN_WAVES must be 4 or 8");
+  // x tile | intermediate | W1 | W2 | column constants | index staging of the inner stages (16 rows x (N2 / nw + 16) B per wave)
+  const size_t lds = (size_t)16 * 128 + 4 * (size_t)16 * 128 + 512 * 128 + 128 * 512 + 3 * 512 * 4 + 5 * 128 * 4 +
+                     (size_t)nw * 16 * (128 / nw + 16);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)(M / 16));
   const int nf = (int)n_stages;
@@ -1668,8 +1688,10 @@ extern "C" int tq_ffn_chain_i8_nonorm_fwd(const int8_t* x_idx, const float* x_de
 #else
 #define TQ_FPROF_PASS
 #endif
-  if (y_dtype == TQ_F32) hipLaunchKernelGGL((ffn_chain_i8_k<128, 512, 128, TQ_F32>), grid, dim3(kBlock), lds, st, c[0], c[1], c[2], c[3], nf TQ_FPROF_PASS);
-  else                   hipLaunchKernelGGL((ffn_chain_i8_k<128, 512, 128, TQ_BF16>), grid, dim3(kBlock), lds, st, c[0], c[1], c[2], c[3], nf TQ_FPROF_PASS);
+#define TQ_CHAIN(DT, W) hipLaunchKernelGGL((ffn_chain_i8_k<128, 512, 128, DT, W>), grid, dim3((W) * 64), lds, st, c[0], c[1], c[2], c[3], nf TQ_FPROF_PASS)
+  if (y_dtype == TQ_F32) { if (nw == 8) TQ_CHAIN(TQ_F32, 8); else TQ_CHAIN(TQ_F32, 4); }
+  else                   { if (nw == 8) TQ_CHAIN(TQ_BF16, 8); else TQ_CHAIN(TQ_BF16, 4); }
+#undef TQ_CHAIN
 #undef TQ_FPROF_PASS
   return check_launch("ffn_chain_i8_k");
 }
