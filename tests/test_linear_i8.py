@@ -101,9 +101,9 @@ def test_linear_i8_vs_fp32_simulation(shape, cfg):
 @pytest.mark.parametrize('act', ['none', 'gelu'])
 def test_ring_kernel_equals_the_double_buffered_kernel(shape, act):
     """Launches of at most one 64 x 64 tile per CU with K >= 1024 run the 8-stage slab ring (csrc/tq_linear_i8.hip,
-    NS = 8): same integer contraction, same epilogue -- bit-identical to the double-buffered kernel
-    (TQ_I8_RING_MAX_GRID=0), for K of fewer / as many / more slabs than the ring holds (TQ_I8_RING_MIN_K=256 sends the
-    short K through the ring as well)."""
+    NS = 8), those with a shorter K 32 x 32 tiles: same integer contraction, same epilogue -- both bit-identical to the
+    double-buffered 64 x 64 kernel (TQ_I8_RING_MAX_GRID=0, TQ_I8_SMALL_MAX_GRID=0), for K of fewer / as many / more slabs
+    than the ring holds (TQ_I8_RING_MIN_K=256 sends the short K through the ring as well)."""
     from quantization import _hip
     be = _hip.backend()
     M, N, K = shape
@@ -130,13 +130,18 @@ def test_ring_kernel_equals_the_double_buffered_kernel(shape, act):
         ring = run()
     finally:
         del os.environ['TQ_I8_RING_MIN_K']
-    os.environ['TQ_I8_RING_MAX_GRID'] = '0'
+    os.environ['TQ_I8_RING_MAX_GRID'] = '0'              # -> 32 x 32 tiles (at most one 64 x 64 tile per CU), double buffer
     try:
-        plain = run()
+        small = run()
+        os.environ['TQ_I8_SMALL_MAX_GRID'] = '0'         # -> 64 x 64 tiles, double buffer
+        try:
+            plain = run()
+        finally:
+            del os.environ['TQ_I8_SMALL_MAX_GRID']
     finally:
         del os.environ['TQ_I8_RING_MAX_GRID']
-    for r, q in zip(ring, plain):
-        assert torch.equal(r, q)
+    for r, q, t in zip(ring, plain, small):
+        assert torch.equal(r, q) and torch.equal(t, q)
     # and against the exact integer contraction
     acc = p['x_idx'].double() @ p['w_idx'].double().t()
     zx = O.effective_zero_point(p['xz'], 8)
