@@ -20,6 +20,8 @@ python scripts/int_vs_reference.py > "$O/int_vs_reference.json" 2> "$O/int_vs_re
 tools/tuning/mx_probe > "$O/mx_probe.txt" 2>&1
 rm -rf /tmp/layer_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/layer_tl -o t -- python tools/tuning/bert_default_prof.py > /dev/null 2>&1
 python tools/tuning/layer_timeline.py /tmp/layer_tl > "$O/bert_default_route_layer_timeline.txt"
+rm -rf /tmp/layer_tl_mb; rocprofv3 --kernel-trace --output-format csv -d /tmp/layer_tl_mb -o t -- python tools/tuning/mb_default_prof.py > /dev/null 2>&1
+python tools/tuning/layer_timeline.py /tmp/layer_tl_mb mobilebert > "$O/mobilebert_default_route_layer_timeline.txt"
 timeout 1500 python -m pytest tests -q -m gpu -rs > "$O/gpu_tests_full_suite.log" 2>&1; echo "suite rc=$?"
 tail -3 "$O/gpu_tests_full_suite.log"
 head -c 1200 "$O/bench_n1.json"; echo

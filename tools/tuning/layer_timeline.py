@@ -10,15 +10,20 @@ WHAT = ['attention core (QK^T, quantizers, softmax, PV)', 'attention-output Line
 t = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(t)), key=lambda r: int(r['Start_Timestamp']))
 att = [i for i, r in enumerate(rows) if 'attention_i8_k' in r['Kernel_Name']]
-a, b = att[-2], att[-1]                       # layers 11 -> 12 of the last replay
+# the layer of the last replays whose kernels ran without a profiler-induced gap: the closest pair of consecutive cores
+cand = list(zip(att[-12:-1], att[-11:]))
+a, b = min(cand, key=lambda ab: int(rows[ab[1]]['Start_Timestamp']) - int(rows[ab[0]]['Start_Timestamp']))
 t0 = int(rows[a]['Start_Timestamp'])
-print('# One encoder layer of the DEFAULT-route BERT-base forward ([8,128], fixed ranges) inside a hipGraph replay:')
-print('# rocprofv3 --kernel-trace over tools/tuning/bert_default_prof.py; start offset / duration of every kernel between two')
-print('# consecutive attention cores (layers 11 -> 12 of the last replay; tools/tuning/layer_timeline.py).  The kernels run')
-print('# back to back: the forward is the sum of 7 latency-bound launches per layer, not launch gaps.')
-if len(sys.argv) > 2:                          # any other model: no per-kernel legend
-    WHAT = []
-    print(f'# ({sys.argv[2]})')
+other = len(sys.argv) > 2
+print(f"# One encoder layer of the DEFAULT-route {'MobileBERT W4A4' if other else 'BERT-base'} forward ([8,128], fixed ranges) inside a hipGraph replay:")
+print(f"# rocprofv3 --kernel-trace over tools/tuning/{'mb' if other else 'bert'}_default_prof.py; start offset / duration of every kernel between two")
+print('# consecutive attention cores (the tightest such pair of the last replay: rocprofv3 itself opens gaps of tens of us after')
+print('# some kernels, which the un-profiled forward time does not contain; tools/tuning/layer_timeline.py).  The kernels run')
+print('# back to back: the forward is the sum of its latency-bound launches, not launch gaps.')
+if other:                                      # MobileBERT: attention core | attention output + tail | the four feed-forward
+    WHAT = ['attention core', 'attention-output Linear + residual NoNorm tail', 'the FOUR feed-forward blocks (one launch)',
+            'output bottleneck 128 -> 512 + residual NoNorm tail', 'input bottlenecks of the next layer (one grouped launch)',
+            'query | key Linears (one grouped launch, index only)', 'value Linear (index only)', '']
 for k, r in enumerate(rows[a:b + 1]):
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     name = r['Kernel_Name'].split('(')[0]
