@@ -207,13 +207,16 @@ int tq_linear_i8_nonorm_fwd(const int8_t* x_idx, const int8_t* w_idx, const int3
  * `bottleneck.attention`: two QuantizedBottleneckLayer, models/quantized_mobilebert.py:404-417, built at :483-488, both
  * 512 -> 128 from the layer input): weights, row
  * sums, biases, per-row weight scales and the NoNorm affine parameters stacked along N; q_dense[g] / q_out[g] the
- * per-tensor quantizers of group g (both groups or neither).  Group g's output is a tensor of its own: y + g * M * N/2
- * ([M, N/2] each; y_idx likewise).  Bit-identical to two tq_linear_i8_nonorm_fwd calls without residual.             */
+ * per-tensor quantizers of group g (all groups or none).  Group g's output is a tensor of its own: y + g * M * N/G
+ * ([M, N/G] each; y_idx likewise).  Bit-identical to G tq_linear_i8_nonorm_fwd calls without residual.  G = 3 takes a plain
+ * quantized Linear on the same input along (MobileBERT's value Linear, :216-226 called at :507-513) as a chain with the
+ * identity affine map and q_dense[2] == q_out[2]: the fixed-range quantizer is idempotent on its own grid, so y / y_idx
+ * of that group are exactly the Linear's quantized output and its indices.                                             */
 int tq_linear_i8_nonorm_grouped_fwd(const int8_t* x_idx, const int8_t* w_idx, const int32_t* w_rowsum, const float* bias,
                                     const float* nn_weight, const float* nn_bias, void* y, int8_t* y_idx, int y_dtype,
                                     uint64_t M, uint64_t N, uint64_t K, const float* x_delta, const float* x_zero_float,
                                     int x_n_bits, float x_eps, const float* w_delta /* [N] */, float w_eps,
-                                    uint64_t n_groups /* 2 */, const tq_quantizer* const* q_dense,
+                                    uint64_t n_groups /* 2 or 3 */, const tq_quantizer* const* q_dense,
                                     const tq_quantizer* const* q_out, tq_stream_t stream);
 
 /* MobileBERT feed-forward block as ONE launch (reference models/quantized_mobilebert.py:330-352, hijacker.py:66-116):

@@ -122,12 +122,12 @@ class OracleBackend:
         return (y.to(out_dtype), yi) if want_idx else y.to(out_dtype)
 
     def linear_i8_nonorm_grouped(self, x_idx, w_idx, w_rowsum, bias, nn_w, nn_b, x_q, w_delta_rows, w_eps, q_dense, q_out,
-                                 out_dtype, want_idx=False):
-        """the two chains of the grouped launch, one after the other through the oracle"""
-        N = w_idx.shape[0]
+                                 out_dtype, want_idx=False, n_groups=2):
+        """the chains of the grouped launch, one after the other through the oracle"""
+        N, G = w_idx.shape[0], int(n_groups)
         ys, yis = [], []
-        for g in range(2):
-            sl = slice(g * N // 2, (g + 1) * N // 2)
+        for g in range(G):
+            sl = slice(g * N // G, (g + 1) * N // G)
             y, yi = self.linear_i8_nonorm(x_idx, w_idx[sl], None, None if bias is None else bias[sl], None, nn_w[sl], nn_b[sl],
                                           x_q, w_delta_rows[sl], w_eps, None if q_dense is None else q_dense[g], None,
                                           None if q_out is None else q_out[g], out_dtype, want_idx=True)

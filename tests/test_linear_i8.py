@@ -327,7 +327,7 @@ def test_linear_i8_nonorm_tail_equals_two_launches(shape, with_res, quantizers):
 
 
 @pytest.mark.parametrize('shape', [(1024, 128, 512), (64, 64, 128), (4096, 128, 512), (2048, 1024, 256)])
-@pytest.mark.parametrize('quantizers', ['all', 'no_dense', 'no_out'])
+@pytest.mark.parametrize('quantizers', ['all', 'no_dense', 'no_out', 'all_plus_plain_linear'])
 def test_grouped_linear_nonorm_pair_equals_two_launches(shape, quantizers):
     """tq_linear_i8_nonorm_grouped_fwd: two Linear -> NoNorm chains reading the same int8 input as one launch with
     split outputs (MobileBERT's two input bottlenecks) -- bit-identical to two tq_linear_i8_nonorm_fwd launches."""
@@ -352,13 +352,30 @@ def test_grouped_linear_nonorm_pair_equals_two_launches(shape, quantizers):
         od, oz = O.asym_params_from_range(post.min(), post.max(), 8)
         parts.append(dict(w=w_i8, rs=be.rowsum_i8(w_i8), b=dev(p['b']), wd=dev(p['wd']).reshape(-1), nn_w=nn_w, nn_b=nn_b,
                           qd=(dev(dd), dev(dz), None, 8, False, False, 1e-8), qo=(dev(od), dev(oz), None, 8, False, False, 1e-8)))
+    plain = None
+    if quantizers == 'all_plus_plain_linear':
+        # third group: a plain quantized Linear on the same input (MobileBERT's value Linear) as a chain with the identity
+        # affine map and its own output quantizer twice -- must equal tq_linear_i8_fwd with that quantizer
+        p = _problem(M, N, K, 8, 8, True, seed=99 + N)
+        w_i8 = be.quantize_to_int8(dev(p['w_q']), dev(p['wd']), None, dev(torch.tensor(True)), 8, True, False, 1e-8, N, K,
+                                   minus_128=False)
+        pre = torch.nn.functional.linear(p0['x_q'], p['w_q'], p['b'])
+        vd, vz = O.asym_params_from_range(pre.min(), pre.max(), 8)
+        qv = (dev(vd), dev(vz), None, 8, False, False, 1e-8)
+        plain = dict(w=w_i8, rs=be.rowsum_i8(w_i8), b=dev(p['b']), wd=dev(p['wd']).reshape(-1), nn_w=torch.ones(N).cuda(),
+                     nn_b=torch.zeros(N).cuda(), qd=qv, qo=qv)
+        parts.append(plain)
     qd = None if quantizers == 'no_dense' else [q['qd'] for q in parts]
     qo = None if quantizers == 'no_out' else [q['qo'] for q in parts]
     want_idx = qo is not None
     cat = lambda k: torch.cat([q[k] for q in parts]).contiguous()
     out = be.linear_i8_nonorm_grouped(x_i8, cat('w'), cat('rs'), cat('b'), cat('nn_w'), cat('nn_b'), xq, cat('wd'), 1e-8, qd,
-                                      qo, torch.float32, want_idx=want_idx)
-    ys, idxs = out if want_idx else (out, [None, None])
+                                      qo, torch.float32, want_idx=want_idx, n_groups=len(parts))
+    ys, idxs = out if want_idx else (out, [None] * len(parts))
+    if plain is not None:
+        vy, vi = be.linear_i8(x_i8, plain['w'], plain['rs'], plain['b'], xq, plain['wd'], 1e-8, _hip.ACT_NONE, plain['qo'],
+                              torch.float32, want_idx=True)
+        assert torch.equal(ys[2], vy) and torch.equal(idxs[2], vi)
     for i, q in enumerate(parts):
         ref = be.linear_i8_nonorm(x_i8, q['w'], q['rs'], q['b'], None, q['nn_w'], q['nn_b'], xq, q['wd'], 1e-8,
                                   None if qd is None else q['qd'], None, None if qo is None else q['qo'], torch.float32,

@@ -70,9 +70,10 @@ struct LinArgs {
   const float* nn_b;      // [N] fake-quantized NoNorm bias
   tq_quantizer q_t1, q_t2;
   int on_t1, on_t2;
-  // grouped launch WITH tail 1 (MobileBERT's two input bottlenecks read the same tensor): group 1's NoNorm output
-  // quantizer, and the outputs of group g as a tensor of their own, [M, group_cols] at y + g * M * group_cols
-  tq_quantizer q_t2b;
+  // grouped launch WITH tail 1 (MobileBERT's two input bottlenecks -- and the value Linear -- read the same tensor): the
+  // NoNorm output quantizers of groups 1 and 2, and the outputs of group g as a tensor of their own, [M, group_cols] at
+  // y + g * M * group_cols
+  tq_quantizer q_t2b, q_t2c;
   int split_out;
   // optional staircase table of act + q_out (tq_act_stair_build; LDS kernels only): replaces the activation and the
   // quantizer's quotient in the epilogue when its header says it is exact
@@ -440,7 +441,7 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
         if (p.tail >= 1) {
           v = v * p.nn_w[n + r] + p.nn_b[n + r];
           if (p.on_t2) {
-            const QP q2 = make_qp(og == 1 ? p.q_t2b : p.q_t2, 0);
+            const QP q2 = make_qp(og == 1 ? p.q_t2b : (og == 2 ? p.q_t2c : p.q_t2), 0);
             const float xi = q_index(v, q2);
             oi4.e[r] = (int8_t)((int)xi - 128);
             v = q_dequant(xi, q2);
@@ -511,6 +512,7 @@ __device__ __forceinline__ EpiRaw epilogue_fetch(const LinArgs& p, uint32_t n0) 
   w.t2sel = p.q_t2;
   if (WITH_TAIL) {
     if (GROUPED && p.split_out && grp == 1) w.t2sel = p.q_t2b;
+    if (GROUPED && p.split_out && grp == 2) w.t2sel = p.q_t2c;
     w.q1 = load_qraw(p.q_t1, 0, p.x_delta);
     w.q2 = load_qraw(w.t2sel, 0, p.x_delta);
   }
@@ -1527,7 +1529,9 @@ extern "C" int tq_linear_i8_nonorm_grouped_fwd(const int8_t* x_idx, const int8_t
   TQ_REQUIRE(x_idx && w_idx && w_rowsum && y && x_delta && x_zero_float && w_delta && nn_weight && nn_bias,
              "tq_linear_i8_nonorm_grouped_fwd: NULL pointer");
   TQ_REQUIRE(y_dtype == TQ_F32 || y_dtype == TQ_BF16, "tq_linear_i8_nonorm_grouped_fwd: y dtype must be fp32 or bf16");
-  TQ_REQUIRE(n_groups == 2 && N % 2 == 0 && (N / 2) % 64 == 0, "tq_linear_i8_nonorm_grouped_fwd: 2 groups of a multiple of 64 output features");
+  TQ_REQUIRE((n_groups == 2 || n_groups == 3) && N % n_groups == 0 && (N / n_groups) % 64 == 0,
+             "tq_linear_i8_nonorm_grouped_fwd: 2 or 3 groups of a multiple of 64 output features");
+  const int G = (int)n_groups;
   TQ_REQUIRE(M % 64 == 0 && K % 128 == 0 && K <= 16384 && M < (1u << 31) && N < (1u << 31),
              "tq_linear_i8_nonorm_grouped_fwd: unsupported shape M=%llu N=%llu K=%llu (M %% 64, K %% 128)", (unsigned long long)M,
              (unsigned long long)N, (unsigned long long)K);
@@ -1538,17 +1542,17 @@ extern "C" int tq_linear_i8_nonorm_grouped_fwd(const int8_t* x_idx, const int8_t
   a.M = (uint32_t)M; a.N = (uint32_t)N; a.K = (uint32_t)K;
   a.x_delta = x_delta; a.x_zero_float = x_zero_float; a.x_eps = x_eps; a.x_n_bits = x_n_bits;
   a.w_delta = w_delta; a.w_n_params = (uint32_t)N; a.w_eps = w_eps; a.act = ACT_NONE;
-  a.group_cols = (uint32_t)(N / 2);
+  a.group_cols = (uint32_t)(N / n_groups);
   a.split_out = 1;
   a.tail = 1;
   a.nn_w = nn_weight; a.nn_b = nn_bias;
   const bool has_d = q_dense != nullptr && q_dense[0] != nullptr, has_o = q_out != nullptr && q_out[0] != nullptr;
-  TQ_REQUIRE((!has_d && (q_dense == nullptr || q_dense[1] == nullptr)) || (has_d && q_dense[1] != nullptr),
-             "tq_linear_i8_nonorm_grouped_fwd: both groups or neither need a dense-output quantizer");
-  TQ_REQUIRE((!has_o && (q_out == nullptr || q_out[1] == nullptr)) || (has_o && q_out[1] != nullptr),
-             "tq_linear_i8_nonorm_grouped_fwd: both groups or neither need an output quantizer");
+  for (int g = 1; g < G; ++g) {
+    TQ_REQUIRE(has_d == (q_dense != nullptr && q_dense[g] != nullptr), "tq_linear_i8_nonorm_grouped_fwd: all groups or none need a dense-output quantizer");
+    TQ_REQUIRE(has_o == (q_out != nullptr && q_out[g] != nullptr), "tq_linear_i8_nonorm_grouped_fwd: all groups or none need an output quantizer");
+  }
   TQ_REQUIRE(y_idx == nullptr || has_o, "tq_linear_i8_nonorm_grouped_fwd: y_idx needs output quantizers");
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < G; ++g) {
     const tq_quantizer* qs[2] = {has_d ? q_dense[g] : nullptr, has_o ? q_out[g] : nullptr};
     for (const tq_quantizer* q : qs)
       if (q != nullptr) {
@@ -1559,9 +1563,9 @@ extern "C" int tq_linear_i8_nonorm_grouped_fwd(const int8_t* x_idx, const int8_t
                "tq_linear_i8_nonorm_grouped_fwd: y_idx needs asymmetric <= 8-bit output quantizers");
   }
   a.has_q = has_d;
-  if (has_d) { a.q_out = *q_dense[0]; a.q_out1 = *q_dense[1]; }
+  if (has_d) { a.q_out = *q_dense[0]; a.q_out1 = *q_dense[1]; if (G == 3) a.q_out2 = *q_dense[2]; }
   a.on_t2 = has_o;
-  if (has_o) { a.q_t2 = *q_out[0]; a.q_t2b = *q_out[1]; }
+  if (has_o) { a.q_t2 = *q_out[0]; a.q_t2b = *q_out[1]; if (G == 3) a.q_t2c = *q_out[2]; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   return y_dtype == TQ_F32 ? launch_linear<TQ_F32>(a, st) : launch_linear<TQ_BF16>(a, st);
 }

@@ -123,7 +123,8 @@ class QMobileSelfAttention(QuantizedModel):
 
     fuse = None    # set True to run the fixed-range attention core as one integer kernel (quantization/fused.py)
 
-    def forward(self, q_in, k_in, v_in, mask):
+    def forward(self, q_in, k_in, v_in, mask, value_out=None):
+        """value_out: self.value(v_in) when the layer computed it along with its input bottlenecks (same input tensor)"""
         fuse = options.fuse_on(self.fuse, self, self.attn_probs_act_quantizer)
         if fuse:
             # the three Linears as index-only grouped integer launches (query and key share the bottlenecked input: one
@@ -131,10 +132,10 @@ class QMobileSelfAttention(QuantizedModel):
             from quantization.fused import quantized_self_attention
             ctx = quantized_self_attention((q_in, k_in, v_in), self.query, self.key, self.value, mask, self.heads,
                                            self.attn_scores_act_quantizer, self.attn_probs_act_quantizer,
-                                           self.attn_output_act_quantizer)
+                                           self.attn_output_act_quantizer, value_out=value_out)
             if ctx is not None:
                 return ctx
-        qo, ko, vo = self.query(q_in), self.key(k_in), self.value(v_in)
+        qo, ko, vo = self.query(q_in), self.key(k_in), (self.value(v_in) if value_out is None else value_out)
         if fuse:
             # Q K^T -> quantizer -> / sqrt(d) + mask -> softmax -> quantizer -> P V -> quantizer (per-tensor, so "per head
             # before the merge" and "after the merge" coincide) on the i8 matrix cores; None = layered modules
@@ -216,14 +217,18 @@ class QMobileLayer(QuantizedModel):
         pair = None
         if options.fuse_on(self.bottleneck_input.fuse, self.bottleneck_input, self.bottleneck_input.LayerNorm):
             from quantization.fused import linear_nonorm_quant_pair     # both bottlenecks read h: one integer launch
+            with_value = options.fuse_on(self.attention_self.fuse, self.attention_self, self.attention_self.attn_probs_act_quantizer)
             pair = linear_nonorm_quant_pair(self.bottleneck_input.dense, self.bottleneck_input.LayerNorm,
-                                            self.bottleneck_attention.dense, self.bottleneck_attention.LayerNorm, h)
+                                            self.bottleneck_attention.dense, self.bottleneck_attention.LayerNorm, h,
+                                            value=self.attention_self.value if with_value else None)
+        value_out = None
         if pair is not None:
-            layer_input, shared = pair
+            layer_input, shared = pair[0], pair[1]
+            value_out = pair[2] if len(pair) == 3 else None       # the value Linear rode along (same input)
         else:
             layer_input = self.bottleneck_input(h)                # [B, T, 128] residual of the attention block
             shared = self.bottleneck_attention(h)                 # query / key input
-        a = self.attention_output(self.attention_self(shared, shared, h, mask), layer_input)
+        a = self.attention_output(self.attention_self(shared, shared, h, mask, value_out=value_out), layer_input)
         o = None
         if (options.fuse_on(self.fuse_ffn, self, self.output.LayerNorm) and self.fuse_chain
                 and all(options.fuse_on(f.fuse, f, f.output.LayerNorm) for f in self.ffn)):

@@ -657,13 +657,14 @@ class HipBackend:
         return (y, y_idx) if want_idx else y
 
     def linear_i8_nonorm_grouped(self, x_idx, w_idx, w_rowsum, bias, nn_w, nn_b, x_q, w_delta_rows, w_eps, q_dense, q_out,
-                                 out_dtype, want_idx=False):
-        """Two Linear -> NoNorm chains reading the same int8 input in one launch (stacked operands, see include/tq_hip.h);
-        q_dense / q_out: lists of two 7-tuples or None.  -> [y_0, y_1] (, [idx_0, idx_1]), each [..., N / 2] contiguous."""
+                                 out_dtype, want_idx=False, n_groups=2):
+        """n_groups (2 or 3) Linear -> NoNorm chains reading the same int8 input in one launch (stacked operands, see
+        include/tq_hip.h); q_dense / q_out: lists of n_groups 7-tuples or None.  -> [y_g] (, [idx_g]), each [..., N / G]
+        contiguous."""
         K = x_idx.shape[-1]
         M = x_idx.numel() // K
         N = w_idx.shape[0]
-        G = 2
+        G = int(n_groups)
         y = torch.empty((G,) + tuple(x_idx.shape[:-1]) + (N // G,), dtype=out_dtype, device=x_idx.device)
         y_idx = torch.empty(y.shape, dtype=torch.int8, device=y.device) if want_idx else None
 
@@ -679,7 +680,8 @@ class HipBackend:
             _DTYPES[out_dtype], M, N, K, _ptr(x_q[0]), _ptr(x_q[1]), int(x_q[2]), float(x_q[3]), _ptr(w_delta_rows),
             float(w_eps), G, a_d, a_o, _stream())
         _check(rc, self.lib)
-        return ([y[0], y[1]], [y_idx[0], y_idx[1]]) if want_idx else [y[0], y[1]]
+        ys = [y[g] for g in range(G)]
+        return (ys, [y_idx[g] for g in range(G)]) if want_idx else ys
 
     def ffn_chain_i8_nonorm(self, x_idx, x_q, residual, stages, out_dtype, want_idx=False):
         """A chain of MobileBERT feed-forward blocks in one launch (include/tq_hip.h tq_ffn_chain_i8_nonorm_fwd).  stages:

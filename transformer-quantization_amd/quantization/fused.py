@@ -247,16 +247,20 @@ def linear_nonorm_quant(dense, layer_norm, x):
     return layer_norm(dense(x))
 
 
-def linear_nonorm_quant_pair(dense_a, layer_norm_a, dense_b, layer_norm_b, x):
+def linear_nonorm_quant_pair(dense_a, layer_norm_a, dense_b, layer_norm_b, x, value=None):
     """MobileBERT's two input bottlenecks (reference models/quantized_mobilebert.py:404-417, built at :483-488):
 
-        layer_norm_a(dense_a(x)), layer_norm_b(dense_b(x))
+        layer_norm_a(dense_a(x)), layer_norm_b(dense_b(x))        [, value(x)]
 
     -- two QuantLinear -> QuantNoNorm chains reading the SAME tensor -- as ONE integer launch
     (tq_linear_i8_nonorm_grouped_fwd) when options.INT8_LINEAR applies and every range involved is fixed and per-tensor;
-    each result is a contiguous tensor of its own, tagged with its quantizer and int8 indices.  None otherwise (the
-    caller runs the two chains separately).  Bit-identical to the separate launches."""
-    from quantization.autoquant_utils import QuantLinear, QuantNoNorm, INT8_STATS
+    each result is a contiguous tensor of its own, tagged with its quantizer and int8 indices.  `value`: the attention's
+    value QuantLinear, which reads x too (:216-226 called at :507-513): it rides along as a third group -- a chain with the
+    identity affine map whose two quantizers are the Linear's own output quantizer (idempotent on its grid: the group's
+    output IS value(x), bit for bit) -- when it has the bottlenecks' width and an asymmetric <= 8-bit fixed output
+    quantizer; a third result is returned then.  None when the pair itself is not eligible (the caller runs the chains
+    separately).  Bit-identical to the separate launches."""
+    from quantization.autoquant_utils import QuantLinear, QuantNoNorm, INT8_STATS, _fixed_per_tensor_manager
     be = _hip.backend()
     pairs = ((dense_a, layer_norm_a), (dense_b, layer_norm_b))
     if (not options.int8_active() or not hasattr(be, 'linear_i8_nonorm_grouped') or not _hip.on_device(x)
@@ -289,8 +293,29 @@ def linear_nonorm_quant_pair(dense_a, layer_norm_a, dense_b, layer_norm_b, x):
             or dense_a.weight_quantizer.quantizer.eps != dense_b.weight_quantizer.quantizer.eps):
         return None
     oqs = [ln.activation_quantizer.quantizer if q != 'off' else None for (_, ln), q in zip(pairs, q_out)]
+    layers = [dense_a, dense_b]
+    # the value Linear as a third chain: needs the same structure of quantizers as the bottlenecks (both present)
+    if (value is not None and q_dense[0] != 'off' and q_out[0] != 'off' and type(value) is QuantLinear and not value.training
+            and value.in_features == K and value.out_features == N and value.activation_function is None
+            and value.activation_save_target is None and hasattr(value, '_int8_plan') and value._quant_a
+            and _fixed_per_tensor_manager(value.activation_quantizer) and not _needs_autograd(value)
+            and not _hooked(value, getattr(value, 'weight_quantizer', None))
+            and value.weight_quantizer.quantizer.eps == dense_a.weight_quantizer.quantizer.eps):
+        vq = value.activation_quantizer.quantizer
+        vplan = value._int8_plan(x, with_output_quantizer=False)
+        if (vplan is not None and vplan[1] == _hip.ACT_NONE and not vq.symmetric and vq.n_bits <= 8
+                and vq.scale_domain == 'linear'):
+            q7 = (vq._delta, vq._zero_float, None, vq.n_bits, False, False, vq.eps)
+            layers.append(value)
+            q_dense.append(q7)
+            q_out.append(q7)
+            oqs.append(vq)
+    G = len(layers)
     want_idx = all(oq is not None and not oq.symmetric and oq.n_bits <= 8 for oq in oqs)
-    packed = _stacked_qkv((dense_a, dense_b))
+    packed = _stacked_qkv(tuple(layers))
+    if packed is None and G == 3:
+        layers, q_dense, q_out, oqs, G = layers[:2], q_dense[:2], q_out[:2], oqs[:2], 2
+        packed = _stacked_qkv(tuple(layers))
     if packed is None:
         return None
     w_idx, rowsum, bias, scales = packed
@@ -298,17 +323,21 @@ def linear_nonorm_quant_pair(dense_a, layer_norm_a, dense_b, layer_norm_b, x):
     if ops is None:
         return None
     affine = [ln.quantized_params() for _, ln in pairs]    # cached with fixed ranges in inference
-    key = tuple((w.data_ptr(), b.data_ptr()) for w, b in affine)
+    key = tuple((w.data_ptr(), b.data_ptr()) for w, b in affine) + (G,)
     hit = getattr(layer_norm_a, '_stacked_affine_cache', None)
     if hit is None or hit[0] != key:
-        hit = (key, torch.cat([w.detach().float().reshape(-1) for w, _ in affine]).contiguous(),
-               torch.cat([b.detach().float().reshape(-1) for _, b in affine]).contiguous(), affine)   # (keeps the parts alive)
+        ws = [w.detach().float().reshape(-1) for w, _ in affine]
+        bs = [b.detach().float().reshape(-1) for _, b in affine]
+        if G == 3:                                         # identity affine map of the value group
+            ws.append(torch.ones(N, dtype=torch.float32, device=x.device))
+            bs.append(torch.zeros(N, dtype=torch.float32, device=x.device))
+        hit = (key, torch.cat(ws).contiguous(), torch.cat(bs).contiguous(), affine)   # (keeps the parts alive)
         layer_norm_a._stacked_affine_cache = hit
-    INT8_STATS['kernel_calls'] += 2
+    INT8_STATS['kernel_calls'] += G
     out = be.linear_i8_nonorm_grouped(ops[0], w_idx, rowsum, bias, hit[1], hit[2], ops[4], scales, ops[6],
                                       None if q_dense[0] == 'off' else q_dense, None if q_out[0] == 'off' else q_out,
-                                      torch.float32, want_idx=want_idx)
-    ys, idxs = out if want_idx else (out, [None, None])
+                                      torch.float32, want_idx=want_idx, n_groups=G)
+    ys, idxs = out if want_idx else (out, [None] * G)
     res = []
     for y, idx, oq in zip(ys, idxs, oqs):
         y = y.view(x.shape[:-1] + (N,))
@@ -539,7 +568,7 @@ def _stacked_qkv(layers):
 
 
 def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quantizer, probs_quantizer,
-                             context_quantizer):
+                             context_quantizer, value_out=None):
     """Self-attention of a quantized BERT / MobileBERT layer from the inputs of its query / key / value Linears: Linears
     that share their input run as ONE grouped integer GEMM that only emits int8 indices (tq_linear_i8_grouped_fwd:
     no fp32 output is written), which the integer attention core consumes in place (column blocks of the stacked
@@ -547,8 +576,9 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
     (MobileBERT, reference models/quantized_mobilebert.py:214-226 called at :507-513: query and key read the bottlenecked
     shared input -> Q | K in one launch, V in another).  Same preconditions as `quantized_attention` plus: the three
     Linears are plain eval-mode QuantLinears without activation function whose weight and output quantizers are fixed,
-    and the inputs carry their int8 indices.  Returns None when any of that does not hold (run the layered modules
-    then)."""
+    and the inputs carry their int8 indices.  value_out: value(value_in) already computed by another launch
+    (linear_nonorm_quant_pair), tagged with the value Linear's output quantizer and its indices -- the value Linear is not
+    launched then.  Returns None when any of that does not hold (run the layered modules then)."""
     from quantization.autoquant_utils import QuantLinear, _fixed_per_tensor_manager
     layers = (query, key, value)
     xs = tuple(x) if isinstance(x, (tuple, list)) else (x, x, x)
@@ -597,6 +627,14 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
             groups[-1].append(i)
         else:
             groups.append([i])
+    v_src = None
+    if value_out is not None:
+        rec = provenance.of(value_out)
+        v_src = _int8_source(value_out)
+        if (rec is None or rec[0] is not value.activation_quantizer.quantizer or v_src is None
+                or value_out.shape != (B, T, D) or not value_out.is_contiguous()):
+            return None
+        groups = [g for g in ([i for i in grp if i != 2] for grp in groups) if g]
     srcs = {}
     for g in groups:
         src = _int8_source(xs[g[0]])
@@ -618,6 +656,8 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
                                       want_idx=True)
         for j, i in enumerate(g):
             cols[i] = buf[..., j * D:(j + 1) * D]
+    if v_src is not None:
+        cols[2] = v_src[0]
     arg = lambda q: None if q == 'off' else q
     cq = context_quantizer.activation_quantizer.quantizer if qc != 'off' else None
     want_idx = cq is not None and not cq.symmetric and cq.n_bits <= 8
