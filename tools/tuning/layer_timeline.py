@@ -22,8 +22,9 @@ print('# some kernels, which the un-profiled forward time does not contain; tool
 print('# back to back: the forward is the sum of its latency-bound launches, not launch gaps.')
 if other:                                      # MobileBERT: attention core | attention output + tail | the four feed-forward
     WHAT = ['attention core', 'attention-output Linear + residual NoNorm tail', 'the FOUR feed-forward blocks (one launch)',
-            'output bottleneck 128 -> 512 + residual NoNorm tail', 'input bottlenecks of the next layer (one grouped launch)',
-            'query | key Linears (one grouped launch, index only)', 'value Linear (index only)', '']
+            'output bottleneck 128 -> 512 + residual NoNorm tail',
+            'input bottlenecks + value Linear of the next layer (one grouped launch)',
+            'query | key Linears (one grouped launch, index only)', '']
 for k, r in enumerate(rows[a:b + 1]):
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     name = r['Kernel_Name'].split('(')[0]
