@@ -110,6 +110,67 @@ def test_mobilebert_w4a4_cpu_exact():
         torch.set_num_threads(1)
 
 
+@pytest.mark.default_route
+def test_mobilebert_grouped_and_chained_launches_host_logic_cpu():
+    """Host logic of the round-5 launch merging (quantization/fused.py: query | key grouped, the input bottlenecks + the
+    value Linear as one grouped launch, the four feed-forward blocks as one chain), replayed on the CPU through the
+    oracle backend -- whose grouped / chained entry points just run their parts one after the other: the operands each
+    merged call hands over (stacked weights, per-stage quantizers, the chaining of input grids, provenance of the parts)
+    must reproduce the un-merged forward bit for bit."""
+    from harness.mobilebert import QMobileLayer, build_mobilebert
+    from quantization import _hip, fused, options
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from tests._oracle_backend import OracleBackend
+    from utils.utils import pass_data_for_range_estimation
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    model, _ = build_mobilebert(seed=1000, num_layers=2, **qp)
+    model = model.eval()
+    ids = torch.randint(0, 30000, (2, 64), generator=torch.Generator().manual_seed(0))
+    be = OracleBackend()
+    prev = _hip.set_backend(be)
+    calls = {}
+    try:
+        for name in ('ffn_chain_i8_nonorm', 'linear_i8_nonorm_grouped', 'linear_i8_grouped', 'ffn_i8_nonorm'):
+            orig = getattr(be, name)
+
+            def wrap(*a, _o=orig, _n=name, **k):
+                calls.setdefault(_n, []).append(k.get('n_groups', len(a[3]) if _n == 'ffn_chain_i8_nonorm' else None))
+                return _o(*a, **k)
+            setattr(be, name, wrap)
+        with torch.no_grad():
+            pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
+            model.fix_ranges()
+            assert options.INT8_LINEAR == 'auto'
+            merged = model(ids)
+            seen = {k: list(v) for k, v in calls.items()}
+            calls.clear()
+            keep = fused.linear_nonorm_quant_pair, fused.quantized_self_attention
+            QMobileLayer.fuse_chain = False
+            fused.linear_nonorm_quant_pair = lambda *a, **k: None
+            fused.quantized_self_attention = lambda *a, **k: None
+            try:
+                plain = model(ids)
+            finally:
+                fused.linear_nonorm_quant_pair, fused.quantized_self_attention = keep
+                QMobileLayer.fuse_chain = True
+            options.INT8_LINEAR = False
+            try:
+                layered = model(ids)
+            finally:
+                options.INT8_LINEAR = 'auto'
+    finally:
+        _hip.set_backend(prev)
+    assert seen['ffn_chain_i8_nonorm'] == [4, 4]                      # one chain of four blocks per layer
+    assert seen['linear_i8_nonorm_grouped'] == [3, 3]                 # bottleneck pair + value Linear
+    assert len(seen['linear_i8_grouped']) == 2                        # query | key
+    assert 'ffn_chain_i8_nonorm' not in calls and 'linear_i8_nonorm_grouped' not in calls and len(calls['ffn_i8_nonorm']) == 8
+    assert torch.equal(merged, plain)
+    span = float(layered.max() - layered.min())
+    assert float((merged - layered).abs().max()) <= 0.05 * span      # the integer route itself: close to the layered one
+
+
 @pytest.mark.gpu
 def test_mobilebert_w4a4_gpu():
     from oracle import tq_oracle as O
