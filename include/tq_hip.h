@@ -251,7 +251,7 @@ typedef struct tq_ffn_stage {
   const tq_quantizer *q_dense, *q_sum, *q_out;
 } tq_ffn_stage;
 int tq_ffn_chain_i8_nonorm_fwd(const int8_t* x_idx, const float* x_delta, const float* x_zero_float, int x_n_bits, float x_eps,
-                               const float* residual, const tq_ffn_stage* stages, uint64_t n_stages /* 1..4 */, void* y,
+                               const float* residual, const tq_ffn_stage* stages, uint64_t n_stages /* 2..4 */, void* y,
                                int8_t* y_idx, int y_dtype, uint64_t M, uint64_t K1, uint64_t N1, uint64_t N2,
                                tq_stream_t stream);
 

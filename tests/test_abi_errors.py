@@ -132,3 +132,59 @@ def test_staircase_entry_points(env):
     assert lib.tq_act_stair_build(2, C.byref(q), 2048, big.data_ptr(), big.numel(), st) == 0
     y_ref = y.clone()
     assert call(table=big.data_ptr(), nb=2048) == 0 and torch.equal(y, y_ref)
+
+
+def test_round5_entry_points(env):
+    """tq_attention_i8_strided_fwd, tq_linear_i8_nonorm_grouped_fwd, tq_ffn_chain_i8_nonorm_fwd: argument errors."""
+    _hip, be, lib, q, (d, z) = env
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(2, 64, 128, dtype=torch.int8, device='cuda')
+    ctx = torch.empty(2, 64, 128, device='cuda')
+    att = lambda vs: lib.tq_attention_i8_strided_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), ctx.data_ptr(), None, 2, 64, 2, 64, 0,
+                                                     vs, None, 8.0, C.byref(q), C.byref(q), C.byref(q), None, C.byref(q), None, st)
+    assert att(0) == 0 and att(128) == 0
+    assert att(100) == -1 and 'v_row_stride' in _err(lib)
+    # grouped Linear -> NoNorm chains
+    M, N, K = 64, 128, 128
+    xi = torch.zeros(M, K, dtype=torch.int8, device='cuda')
+    w = torch.zeros(2 * N, K, dtype=torch.int8, device='cuda')
+    rs = torch.zeros(2 * N, dtype=torch.int32, device='cuda')
+    wd = torch.full((2 * N,), 0.01, device='cuda')
+    nw, nb = torch.ones(2 * N, device='cuda'), torch.zeros(2 * N, device='cuda')
+    y = torch.empty(2, M, N, device='cuda')
+    QP = C.POINTER(_hip.tq_quantizer)
+    two = C.cast((QP * 2)(C.pointer(q), C.pointer(q)), C.POINTER(QP))
+    one = C.cast((QP * 2)(C.pointer(q), None), C.POINTER(QP))
+    grp = lambda **kw: lib.tq_linear_i8_nonorm_grouped_fwd(xi.data_ptr(), w.data_ptr(), rs.data_ptr(), None, nw.data_ptr(), nb.data_ptr(),
+                                                         y.data_ptr(), None, 0, M, kw.get('N', 2 * N), K, d.data_ptr(), z.data_ptr(), 8,
+                                                         1e-8, wd.data_ptr(), 1e-8, kw.get('G', 2), kw.get('qd', two), kw.get('qo', two), st)
+    assert grp() == 0
+    assert grp(G=4) == -1 and '2 or 3 groups' in _err(lib)
+    assert grp(N=2 * N - 64) == -1
+    assert grp(qd=one) == -1 and 'dense-output quantizer' in _err(lib)
+    assert grp(qo=one) == -1 and 'output quantizer' in _err(lib)
+    # chain of feed-forward blocks
+    w1 = torch.zeros(512, 128, dtype=torch.int8, device='cuda'); w2 = torch.zeros(128, 512, dtype=torch.int8, device='cuda')
+    rs1 = torch.zeros(512, dtype=torch.int32, device='cuda'); rs2 = torch.zeros(128, dtype=torch.int32, device='cuda')
+    s1 = torch.full((1,), 0.01, device='cuda')
+    n1, n0 = torch.ones(128, device='cuda'), torch.zeros(128, device='cuda')
+    xf = torch.zeros(32, 128, dtype=torch.int8, device='cuda'); res = torch.zeros(32, 128, device='cuda'); yo = torch.empty(32, 128, device='cuda')
+
+    def stage(**kw):
+        g = _hip.tq_ffn_stage()
+        g.w1_idx, g.w1_rowsum, g.w1_delta, g.w1_n_params, g.w1_eps = kw.get('w1', w1.data_ptr()), rs1.data_ptr(), s1.data_ptr(), 1, 1e-8
+        g.q_mid = C.pointer(q)
+        g.w2_idx, g.w2_rowsum, g.w2_delta, g.w2_n_params, g.w2_eps = w2.data_ptr(), rs2.data_ptr(), s1.data_ptr(), 1, 1e-8
+        g.nn_weight, g.nn_bias = n1.data_ptr(), n0.data_ptr()
+        g.q_out = kw.get('q_out', C.pointer(q))
+        return g
+    chain = lambda stages, n=None: lib.tq_ffn_chain_i8_nonorm_fwd(
+        xf.data_ptr(), d.data_ptr(), z.data_ptr(), 8, 1e-8, res.data_ptr(), C.cast((_hip.tq_ffn_stage * len(stages))(*stages), C.c_void_p),
+        len(stages) if n is None else n, yo.data_ptr(), None, 0, 32, 128, 512, 128, st)
+    assert chain([stage(), stage()]) == 0
+    assert chain([stage()]) == -1 and '2..4' in _err(lib)
+    assert chain([stage()] * 4, n=5) == -1 and '2..4' in _err(lib)
+    assert chain([stage(w1=None), stage()]) == -1 and 'NULL pointer in stage 0' in _err(lib)
+    assert chain([stage(q_out=None), stage()]) == -1 and 'stage 0 needs an asymmetric' in _err(lib)
+    assert chain([stage(), stage(q_out=None)]) == 0                      # the last block may go without output quantizer
+    torch.cuda.synchronize()

@@ -1,4 +1,4 @@
-"""Kernel durations of the MobileBERT feed-forward chain (tq_ffn_chain_i8_nonorm_fwd) for 1..4 blocks next to the
+"""Kernel durations of the MobileBERT feed-forward chain (tq_ffn_chain_i8_nonorm_fwd) for 2..4 blocks next to the
 single-block kernel, M = 1024:   rocprofv3 --kernel-trace --stats --output-format csv -d OUT -o t -- python tools/tuning/ffn_chain_time.py"""
 import sys
 sys.path.insert(0, '/root/repo/transformer-quantization_amd'); sys.path.insert(0, '/root/repo')
@@ -22,7 +22,7 @@ s0 = stages[0]
 for _ in range(30):
     be.ffn_i8_nonorm(x_i8, xq, s0['w1_idx'], s0['w1_rowsum'], s0['bias1'], s0['w1_delta'], 1e-8, s0['q_mid'], s0['w2_idx'], s0['w2_rowsum'],
                      s0['bias2'], s0['w2_delta'], 1e-8, res, s0['nn_w'], s0['nn_b'], s0['q_dense'], s0['q_sum'], s0['q_out'], torch.float32, want_idx=True)
-for n in (1, 2, 3, 4):
+for n in (2, 3, 4):
     for _ in range(30):
         be.ffn_chain_i8_nonorm(x_i8, xq, res, stages[:n], torch.float32, want_idx=True)
 torch.cuda.synchronize()

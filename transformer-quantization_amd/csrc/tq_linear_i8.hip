@@ -1636,7 +1636,7 @@ extern "C" int tq_ffn_chain_i8_nonorm_fwd(const int8_t* x_idx, const float* x_de
                                           tq_stream_t stream) {
   if (M == 0) return TQ_OK;
   TQ_REQUIRE(x_idx && x_delta && x_zero_float && residual && stages && y, "tq_ffn_chain_i8_nonorm_fwd: NULL pointer");
-  TQ_REQUIRE(n_stages >= 1 && n_stages <= (uint64_t)kMaxFfnChain, "tq_ffn_chain_i8_nonorm_fwd: 1..%d feed-forward blocks", kMaxFfnChain);
+  TQ_REQUIRE(n_stages >= 2 && n_stages <= (uint64_t)kMaxFfnChain, "tq_ffn_chain_i8_nonorm_fwd: 2..%d feed-forward blocks (one: tq_ffn_i8_nonorm_fwd)", kMaxFfnChain);
   TQ_REQUIRE(K1 == 128 && N1 == 512 && N2 == 128, "tq_ffn_chain_i8_nonorm_fwd: only the (128, 512, 128) feed-forward shape is built");
   TQ_REQUIRE(M % 16 == 0 && M < (1u << 31), "tq_ffn_chain_i8_nonorm_fwd: M must be a multiple of 16");
   TQ_REQUIRE(y_dtype == TQ_F32 || y_dtype == TQ_BF16, "tq_ffn_chain_i8_nonorm_fwd: y dtype must be fp32 or bf16");
