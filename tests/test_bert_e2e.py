@@ -69,6 +69,64 @@ def test_bert_base_w8a8_cpu_exact():
         torch.set_num_threads(1)
 
 
+@pytest.mark.default_route
+def test_bert_merged_launches_host_logic_cpu():
+    """Host logic of the default (integer) route's merged launches -- embedding block as one call, query | key | value as
+    one grouped index-only GEMM, the feed-forward pair with an index-only intermediate (quantization/fused.py) -- replayed
+    on the CPU through the oracle backend: bit-identical to the same route with those helpers switched off (one integer
+    Linear per call), and close to the layered route."""
+    from harness.bert import QLayer, build_bert_base
+    from quantization import _hip, fused, options
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from tests._oracle_backend import OracleBackend
+    from utils.utils import pass_data_for_range_estimation
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    model, _ = build_bert_base(seed=1000, num_layers=2, **qp)
+    model = model.eval()
+    ids = torch.randint(0, 30000, (2, 64), generator=torch.Generator().manual_seed(0))
+    be = OracleBackend()
+    prev = _hip.set_backend(be)
+    calls = {}
+    try:
+        for name in ('linear_i8_grouped', 'embeddings_layernorm_quant', 'linear_i8'):
+            orig = getattr(be, name)
+
+            def wrap(*a, _o=orig, _n=name, **k):
+                calls[_n] = calls.get(_n, 0) + 1
+                return _o(*a, **k)
+            setattr(be, name, wrap)
+        with torch.no_grad():
+            pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
+            model.fix_ranges()
+            assert options.INT8_LINEAR == 'auto'
+            merged = model(ids)
+            seen = dict(calls)
+            calls.clear()
+            keep = fused.quantized_self_attention, fused.embeddings_layernorm_quant
+            fused.quantized_self_attention = lambda *a, **k: None
+            fused.embeddings_layernorm_quant = lambda *a, **k: None
+            QLayer.fuse_ffn = False
+            try:
+                plain = model(ids)
+            finally:
+                fused.quantized_self_attention, fused.embeddings_layernorm_quant = keep
+                QLayer.fuse_ffn = None
+            options.INT8_LINEAR = False
+            try:
+                layered = model(ids)
+            finally:
+                options.INT8_LINEAR = 'auto'
+    finally:
+        _hip.set_backend(prev)
+    assert seen == {'embeddings_layernorm_quant': 1, 'linear_i8_grouped': 2, 'linear_i8': 6}, seen
+    assert calls == {'linear_i8': 12}, calls                       # Q, K, V, attention output, FFN1, FFN2 per layer
+    assert torch.equal(merged, plain)
+    span = float(layered.max() - layered.min())
+    assert float((merged - layered).abs().max()) <= 0.05 * span
+
+
 @pytest.mark.gpu
 def test_bert_base_w8a8_gpu():
     """End-to-end on the GPU.  CPU and hipBLASLt GEMMs differ in the last bits; through 12 quantized
