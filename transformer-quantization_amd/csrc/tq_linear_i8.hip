@@ -1083,11 +1083,12 @@ constexpr int kMaxFfnChain = 4;
 // input of the next, and NoNorm has no row statistics: everything is local to a token row, so the block of ffn_i8_k that
 // owns 16 rows can take them through ALL the blocks without leaving the CU.  Per stage the same steps as ffn_i8_k (same
 // integer contractions, same element arithmetic: bit-identical to n launches); between stages
-//   * the stage's output stays in registers as the next residual, and its int8 indices go straight into the x tile of
-//     LDS in the operand layout (every wave writes its 32 columns; the barrier that opens the next stage publishes them);
+//   * the stage's int8 output indices go straight into the x tile of LDS in the operand layout (every wave writes its
+//     own columns; the barrier that opens the next stage publishes them), and the next residual is rebuilt from them in
+//     registers: y = scale * (index - zp), the very value the tail computes from the index;
 //   * the weight slices are wave-private LDS regions, so a wave refills them by itself as soon as IT is done with them:
 //     W1 of the next stage right after this stage's GEMM 1, W2 right after its GEMM 2 -- each refill has about a stage
-//     to land -- with counted vmcnt waits (each slice is 16 LDS-DMA instructions per wave) and raw barriers;
+//     to land -- with counted vmcnt waits (a slice is N1 / NW / 8 LDS-DMA instructions per wave) and raw barriers;
 //   * the quantizer buffers and per-column constants of ALL stages are requested at kernel start and parked in registers;
 //     every wave writes the LDS constants of its OWN columns (no cross-wave hazard with their readers).
 // (One kernel argument per stage: as members -- or worse, an array -- of ONE 2.7 KB argument struct, clang's private copy of
