@@ -131,15 +131,18 @@ int tq_residual_nonorm_quant_fwd(const void* dense_out, const void* residual, vo
  * route):
  *     y = Q_out( LayerNorm( Q_sum2( Q_sum1( word[word_ids] + type[type_ids] ) + pos[pos_ids] ) ) )
  * The tables are fp32 [*_rows, d], already fake-quantized (the eval-mode parameter cache of QuantEmbedding); the ids are
- * int64 [rows] on the device and are clamped to their table (torch's F.embedding raises on an out-of-range id: validate
- * on the layered route).  Same element arithmetic and summation order as tq_residual_layernorm_quant_fwd with
+ * int64 [rows] on the device.  An id outside its table -- where torch's CPU F.embedding raises IndexError -- never reads
+ * out of bounds: the output row is NaN as a whole (its y_idx bytes unspecified) and, when bad_ids is given, *bad_ids is set
+ * to 1 (a 4-byte flag the kernel can write and the HOST can read without synchronising, e.g. pinned host memory; never
+ * cleared by the library).  Same element arithmetic and summation order as tq_residual_layernorm_quant_fwd with
  * dense_out = word + type (one fp32 addition) and residual = pos; d as there (fp32 rows).                              */
 int tq_embeddings_layernorm_quant_fwd(const float* word_table, uint64_t word_rows, const int64_t* word_ids,
                                       const float* type_table, uint64_t type_rows, const int64_t* type_ids,
                                       const float* pos_table, uint64_t pos_rows, const int64_t* pos_ids, float* y,
                                       int8_t* y_idx /* optional */, uint64_t rows, uint64_t d,
                                       const tq_quantizer* q_sum1, const tq_quantizer* q_sum2, const float* ln_weight,
-                                      const float* ln_bias, float ln_eps, const tq_quantizer* q_out, tq_stream_t stream);
+                                      const float* ln_bias, float ln_eps, const tq_quantizer* q_out,
+                                      int32_t* bad_ids /* optional */, tq_stream_t stream);
 
 /* (f3) Fused integer Linear + bias + activation + output quantizer on the i8 matrix cores.
  * Replaces QuantizationHijacker.forward for a Linear with fixed ranges (quantization/hijacker.py:

@@ -77,11 +77,12 @@ class OracleBackend:
 
     def embeddings_layernorm_quant(self, word, word_ids, typ, type_ids, pos, pos_ids, q_sum1, q_sum2, ln_weight, ln_bias, ln_eps,
                                    q_out, want_idx=False):
-        """BERT's embedding block through the oracle's element chain (ids clamped to their tables like the kernel;
-        LayerNorm statistics in torch's order, like residual_layernorm_quant above)"""
+        """BERT's embedding block through the oracle's element chain (an id outside its table raises IndexError, as torch's
+        CPU F.embedding does -- the kernel reports it through its flag; LayerNorm statistics in torch's order, like
+        residual_layernorm_quant above)"""
         def q(v, a):
             return v if a is None else self._quant(v, *a, 1, 1)[1]
-        pick = lambda table, ids: table.float()[ids.clamp(0, table.shape[0] - 1)]
+        pick = lambda table, ids: torch.nn.functional.embedding(ids, table.float())
         u = q(q(pick(word, word_ids) + pick(typ, type_ids), q_sum1) + pick(pos, pos_ids), q_sum2)
         v = torch.nn.functional.layer_norm(u, (u.shape[-1],), ln_weight.float(), ln_bias.float(), ln_eps)
         if want_idx:

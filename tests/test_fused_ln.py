@@ -264,8 +264,8 @@ def test_fused_tails_special_values(dtype):
 def test_fused_embeddings_equal_kernel_order_oracle(d):
     """BERT's embedding block as ONE launch (tq_embeddings_layernorm_quant_fwd: word + token-type look-up, Q1, + position
     look-up, Q2, LayerNorm, Q3; reference models/quantized_bert.py:75-111) against the oracle chain with the LayerNorm
-    statistics in the kernel's order: every output and int8 index equal, bit for bit -- incl. repeated ids, the clamped
-    out-of-range ids and the quantizer subsets."""
+    statistics in the kernel's order: every output and int8 index equal, bit for bit -- incl. repeated ids and the quantizer subsets; out-of-range
+    ids give NaN rows and a deferred IndexError."""
     from oracle.ln_sum import layer_norm_kernel_order
     from quantization import _hip
     be = _hip.backend()
@@ -297,16 +297,32 @@ def test_fused_embeddings_equal_kernel_order_oracle(d):
         assert torch.equal(y, ref), (use, float((y - ref).abs().max()))
         if q3 is not None:
             assert torch.equal(out[1].cpu().float() + 128, O.fake_quant(v, q3[0], q3[1], 8, False)[0]), use
-    # ids outside their table are clamped (the layered route's F.embedding raises): no fault, the edge rows are used
+    # ids outside their table (torch's CPU F.embedding raises IndexError): no out-of-bounds read, exactly the rows that
+    # carry one are NaN, every other row is untouched, and the error surfaces -- once -- at the next synchronisation point
+    be.raise_deferred(sync=True)
     bad = ids.clone()
     bad[1, 1], bad[2, 2] = V_ + 5, -3
+    y_ok = be.embeddings_layernorm_quant(word.cuda(), ids.cuda(), typ.cuda(), tok.cuda(), pos.cuda(), pid.cuda(), k(p1), k(p2),
+                                         w.cuda(), b.cuda(), 1e-12, k(p3)).cpu().view(*ids.shape, -1)
     y_bad = be.embeddings_layernorm_quant(word.cuda(), bad.cuda(), typ.cuda(), tok.cuda(), pos.cuda(), pid.cuda(), k(p1), k(p2),
-                                          w.cuda(), b.cuda(), 1e-12, k(p3)).cpu()
-    y_cl = be.embeddings_layernorm_quant(word.cuda(), bad.clamp(0, V_ - 1).cuda(), typ.cuda(), tok.cuda(), pos.cuda(), pid.cuda(),
-                                         k(p1), k(p2), w.cuda(), b.cuda(), 1e-12, k(p3)).cpu()
-    assert torch.equal(y_bad, y_cl)
+                                          w.cuda(), b.cuda(), 1e-12, k(p3)).cpu().view(*ids.shape, -1)
+    hit = torch.zeros(ids.shape, dtype=torch.bool)
+    hit[1, 1] = hit[2, 2] = True
+    assert torch.isnan(y_bad[hit]).all() and torch.equal(y_bad[~hit], y_ok[~hit])
+    with pytest.raises(IndexError):
+        be.raise_deferred(sync=True)
+    be.raise_deferred(sync=True)              # reported once
+    bad_pos = pid.clone()
+    bad_pos.view(-1)[0] = pos.shape[0]          # the position / token-type tables are checked too
+    be.embeddings_layernorm_quant(word.cuda(), ids.cuda(), typ.cuda(), tok.cuda(), pos.cuda(), bad_pos.cuda(), k(p1), k(p2),
+                                  w.cuda(), b.cuda(), 1e-12, k(p3))
+    with pytest.raises(IndexError):           # without an explicit check: at the next call
+        torch.cuda.synchronize()
+        be.embeddings_layernorm_quant(word.cuda(), ids.cuda(), typ.cuda(), tok.cuda(), pos.cuda(), pid.cuda(), k(p1), k(p2),
+                                      w.cuda(), b.cuda(), 1e-12, k(p3))
 
 
+@pytest.mark.layered_route
 def test_fused_embeddings_in_bert_harness():
     """QEmbeddings.fuse: the block of the harness model as one launch -- used (one backend call per forward), >= 99.9 %
     of the outputs identical to the layered modules (torch's LayerNorm sums in another order), the rest one step away; the

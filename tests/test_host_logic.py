@@ -585,3 +585,115 @@ def test_inference_mode_keeps_the_layered_route_and_never_raises():
     finally:
         options.INT8_LINEAR = before
         _hip.set_backend(prev)
+
+
+def test_harness_constants_cached_under_inference_mode_do_not_reach_a_training_forward():
+    """ADVICE r5: the per-shape helper tensors of the harness (position ids, token types, zero mask) are cached process-wide;
+    one created under torch.inference_mode() is an inference tensor and `F.embedding(position ids)` of a later training
+    forward with the same shape would refuse to save it for backward.  Inference-mode entries are kept apart."""
+    from harness import bert
+    bert._CONSTANTS.clear()
+    with torch.inference_mode():
+        p_inf = bert.constant('positions', 1, 7, 'cpu')
+        assert p_inf.is_inference()
+    p = bert.constant('positions', 1, 7, 'cpu')
+    assert not p.is_inference() and torch.equal(p, p_inf)
+    emb = torch.nn.Embedding(16, 4)
+    emb(p).sum().backward()                                    # raised 'Inference tensors cannot be saved for backward'
+    assert bert.constant('positions', 1, 7, 'cpu') is p         # still cached
+    with torch.inference_mode():
+        assert bert.constant('positions', 1, 7, 'cpu') is p_inf
+
+
+@pytest.mark.default_route
+def test_hooks_on_bypassed_containers_and_global_hooks_keep_the_layered_route():
+    """a merged launch of the default route bypasses the __call__ of the CONTAINERS it replaces (BERT: the
+    QResidualBlock `layer.output` and the Sequential around the intermediate Linear; MobileBERT: the two QBottleneckLayers,
+    every QFFN / its QResidualNoNorm / its Sequential) -- a forward hook on one of them, or a global module hook, has to
+    keep the modules that fire it.  Replayed on the CPU through the oracle backend."""
+    from harness.bert import build_bert_base
+    from harness.mobilebert import build_mobilebert
+    from quantization import _hip, options
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from tests._oracle_backend import OracleBackend
+    from utils.utils import pass_data_for_range_estimation
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    ids = torch.randint(0, 30000, (2, 64), generator=torch.Generator().manual_seed(0))
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        assert options.INT8_LINEAR == 'auto'
+        for build, picks in ((build_bert_base, lambda m: [m.layers[0].output, m.layers[0].intermediate]),
+                             (build_mobilebert, lambda m: [m.layers[0].bottleneck_attention, m.layers[0].ffn[1],
+                                                           m.layers[0].ffn[0].output, m.layers[0].ffn[2].intermediate,
+                                                           m.layers[0].output, m.layers[0].intermediate])):
+            model, _ = build(seed=1000, num_layers=1, **qp)
+            model = model.eval()
+            with torch.no_grad():
+                pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
+                model.fix_ranges()
+                model(ids)                                            # the merged launches: no container is called
+                for container in picks(model):
+                    fired = []
+                    h = container.register_forward_hook(lambda m, i, o: fired.append(1))
+                    try:
+                        model(ids)
+                    finally:
+                        h.remove()
+                    assert fired == [1], (type(model).__name__, type(container).__name__, fired)
+                seen = []
+                h = torch.nn.modules.module.register_module_forward_hook(lambda m, i, o: seen.append(type(m).__name__))
+                try:
+                    model(ids)
+                finally:
+                    h.remove()
+                # a global hook observes EVERY module call of the layered chain, e.g. each quantized Linear and each container
+                n_lin = sum(1 for m in model.modules() if type(m).__name__ == 'QuantLinear')
+                assert seen.count('QuantLinear') == n_lin, (seen.count('QuantLinear'), n_lin)
+                assert any(n in seen for n in ('QResidualBlock', 'QResidualNoNorm'))
+    finally:
+        _hip.set_backend(prev)
+
+
+@pytest.mark.default_route
+def test_stacked_operand_caches_follow_in_place_parameter_updates():
+    """the stacked NoNorm affine vectors of MobileBERT's grouped bottleneck launch and the stacked bias of the
+    grouped Q | K | V launch are cached on the modules; an in-place update that keeps the pointers (optimizer step,
+    load_state_dict's copy_) has to invalidate them.  CPU replay through the oracle backend: after the update the merged
+    forward equals the un-merged integer forward again."""
+    from harness.mobilebert import QMobileLayer, build_mobilebert
+    from quantization import _hip, fused, options
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    from tests._oracle_backend import OracleBackend
+    from utils.utils import pass_data_for_range_estimation
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    ids = torch.randint(0, 30000, (2, 64), generator=torch.Generator().manual_seed(1))
+    prev = _hip.set_backend(OracleBackend())
+    try:
+        model, _ = build_mobilebert(seed=1000, num_layers=1, **qp)
+        model = model.eval()
+        L = model.layers[0]
+        with torch.no_grad():
+            pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
+            model.fix_ranges()
+            for nn_ in (L.bottleneck_input.LayerNorm, L.bottleneck_attention.LayerNorm):
+                nn_._quant_w = False                                 # quantized_params() now returns the raw Parameters
+
+            def unmerged():
+                keep = fused.linear_nonorm_quant_pair, fused.quantized_self_attention, fused.quantized_ffn_chain
+                fused.linear_nonorm_quant_pair = fused.quantized_self_attention = fused.quantized_ffn_chain = lambda *a, **k: None
+                try:
+                    return model(ids)
+                finally:
+                    fused.linear_nonorm_quant_pair, fused.quantized_self_attention, fused.quantized_ffn_chain = keep
+            assert torch.equal(model(ids), unmerged())
+            L.bottleneck_input.LayerNorm.weight.mul_(1.5)             # same storage, new values
+            L.bottleneck_attention.LayerNorm.bias.add_(0.25)
+            L.attention_self.key.bias.add_(0.5)                       # grouped query | key launch: stacked bias
+            after = model(ids)
+            assert torch.equal(after, unmerged())
+    finally:
+        _hip.set_backend(prev)

@@ -93,11 +93,15 @@ __device__ __forceinline__ f32x2 apply_f2(f32x2 v, const FusedF& q) { return q.o
 // is the division path (scales outside [2^-100, 2^100], grids of 2^22+ steps); IDX also emits int8(index - 128).
 // BERT's embedding block through the same body (EMB): the "dense output" row is word[word_ids[row]] + type[type_ids[row]]
 // (one fp32 addition, like the reference's `inputs_embeds + token_type_embeddings`, models/quantized_bert.py:95-111), the
-// "residual" row is pos[pos_ids[row]]; ids are clamped to the tables (the layered route's F.embedding raises instead).
+// "residual" row is pos[pos_ids[row]].  An id outside its table (torch's CPU F.embedding raises IndexError there; a GPU
+// look-up would read out of bounds) reads the clamped row for memory safety, turns the WHOLE output row NaN (a corrupt
+// batch or a vocabulary mismatch must not produce plausible activations) and raises `*bad` (optional; host-visible
+// memory: the Python side turns it into the IndexError of the layered CPU route, quantization/_hip.py).
 struct EmbArgs {
   const int64_t *a_rows, *a2_rows, *r_rows;
   const u32x4* a2;
   uint64_t a_n, a2_n, r_n;        // rows of the three tables
+  int32_t* bad;                   // set to 1 by any row with an out-of-range id (nullptr: not reported)
 };
 
 // One row's 16-byte vectors of this lane (dense output, residual, and the token-type row in EMB mode) -> registers.
@@ -109,15 +113,24 @@ __device__ __forceinline__ void ln_load_row(const u32x4* __restrict__ a, const u
   constexpr int V = Store<DT>::kVec;
   constexpr uint32_t d = LPR * NV * V;
   if (EMB) {
-    auto pick = [](const int64_t* ids, uint64_t row_, uint64_t n) {
+    bool bad = false;
+    auto pick = [&bad](const int64_t* ids, uint64_t row_, uint64_t n) {
       const int64_t id = ids[row_];
-      return id < 0 ? (uint64_t)0 : ((uint64_t)id >= n ? n - 1 : (uint64_t)id);
+      const bool out = id < 0 || (uint64_t)id >= n;
+      bad = bad || out;
+      return out ? (uint64_t)0 : (uint64_t)id;
     };
     const uint64_t oa = pick(emb.a_rows, row, emb.a_n) * (d / V) + lane;
     const uint64_t o2 = pick(emb.a2_rows, row, emb.a2_n) * (d / V) + lane;
     const uint64_t orr = pick(emb.r_rows, row, emb.r_n) * (d / V) + lane;
 #pragma unroll
     for (int v = 0; v < NV; ++v) { pa[v] = a[oa + v * LPR]; pa2[v] = emb.a2[o2 + v * LPR]; pr[v] = r[orr + v * LPR]; }
+    if (bad) {                       // row-uniform and rare: poison the word row (NaN rule of the body: the row turns NaN)
+      const u32x4 nan4 = {0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u};
+#pragma unroll
+      for (int v = 0; v < NV; ++v) pa[v] = nan4;
+      if (lane == 0 && emb.bad) __hip_atomic_store(emb.bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;
   }
   const uint64_t o = row * (d / V) + lane;
@@ -658,7 +671,8 @@ extern "C" int tq_embeddings_layernorm_quant_fwd(const float* word_table, uint64
                                                  const float* pos_table, uint64_t pos_rows, const int64_t* pos_ids, float* y,
                                                  int8_t* y_idx, uint64_t rows, uint64_t d, const tq_quantizer* q_sum1,
                                                  const tq_quantizer* q_sum2, const float* ln_weight, const float* ln_bias,
-                                                 float ln_eps, const tq_quantizer* q_out, tq_stream_t stream) {
+                                                 float ln_eps, const tq_quantizer* q_out, int32_t* bad_ids,
+                                                 tq_stream_t stream) {
   const char* who = "tq_embeddings_layernorm_quant_fwd";
   if (rows == 0) return TQ_OK;
   TQ_REQUIRE(word_table && type_table && pos_table && word_ids && type_ids && pos_ids && y && ln_weight && ln_bias, "%s: NULL pointer", who);
@@ -672,7 +686,8 @@ extern "C" int tq_embeddings_layernorm_quant_fwd(const float* word_table, uint64
       if (int e = check_quantizer(q, rows * d, who)) return e;
       TQ_REQUIRE(q->n_params == 1, "%s: per-tensor quantizers only", who);
     }
-  const EmbArgs emb{word_ids, type_ids, pos_ids, reinterpret_cast<const u32x4*>(type_table), word_rows, type_rows, pos_rows};
+  TQ_REQUIRE(bad_ids == nullptr || (reinterpret_cast<uintptr_t>(bad_ids) & 3u) == 0, "%s: bad_ids must be 4-byte aligned", who);
+  const EmbArgs emb{word_ids, type_ids, pos_ids, reinterpret_cast<const u32x4*>(type_table), word_rows, type_rows, pos_rows, bad_ids};
   return launch_res_ln<TQ_F32>(word_table, pos_table, y, y_idx, rows, d, ln_weight, ln_bias, ln_eps, q_sum1, q_sum2, q_out, 0,
                                static_cast<hipStream_t>(stream), &emb);
 }

@@ -22,6 +22,7 @@ from quantization import options
 from quantization.autoquant_utils import quantize_model
 from quantization.base_quantized_classes import QuantizedActivation
 from quantization.base_quantized_model import QuantizedModel
+from quantization.fused import hooked as _hooked
 
 
 _CONSTANTS = {}
@@ -30,8 +31,10 @@ _CONSTANTS = {}
 def constant(kind, B, T, device):
     """Read-only helper tensors of a forward that depend on the batch shape only -- the all-visible additive attention
     mask, the all-zero token-type ids, the position ids 0 .. T-1 -- built once per (shape, device) instead of by a fill /
-    arange launch in every forward (three ~5 us launches of a 0.84 ms hipGraph forward).  Never modified in place."""
-    key = (kind, B, T, str(device))
+    arange launch in every forward (three ~5 us launches of a 0.84 ms hipGraph forward).  Never modified in place.
+    Tensors created under torch.inference_mode() are inference tensors and cannot be saved for a later backward
+    (F.embedding(position ids) of a training forward with the same shape would raise): they get cache entries of their own."""
+    key = (kind, B, T, str(device), torch.is_inference_mode_enabled())
     t = _CONSTANTS.get(key)
     if t is None:
         if len(_CONSTANTS) > 64:
@@ -160,7 +163,8 @@ class QLayer(QuantizedModel):
 
     def forward(self, h, mask):
         a = self.attention_output(self.attention_self(h, mask), h)
-        if options.fuse_on(self.fuse_ffn, self, self.output.res_act_quantizer):
+        # (the merged launch calls neither self.output nor the Sequential: forward hooks on those containers keep the layered route)
+        if options.fuse_on(self.fuse_ffn, self, self.output.res_act_quantizer) and not _hooked(self.output, self.intermediate):
             from quantization.fused import quantized_bert_ffn
             out = self.output
             return quantized_bert_ffn(self.intermediate[0], out.dense, out.res_act_quantizer, out.LayerNorm, a, a)

@@ -25,6 +25,7 @@ from quantization import options
 from quantization.autoquant_utils import QuantNoNorm, quantize_model
 from quantization.base_quantized_classes import FP32Acts, QuantizedActivation
 from quantization.base_quantized_model import QuantizedModel
+from quantization.fused import hooked as _hooked
 from quantization.range_estimators import OptMethod, RangeEstimators
 
 # per-site switches of the reference (DEFAULT_QUANT_DICT, models/quantized_mobilebert.py:31-49)
@@ -185,7 +186,8 @@ class QFFN(QuantizedModel):
     fuse = None    # set True: intermediate + output + NoNorm tail as one integer launch (quantization/fused.py quantized_ffn)
 
     def forward(self, h):
-        if options.fuse_on(self.fuse, self, self.output.LayerNorm):
+        # (the merged launch calls neither self.output nor the Sequential: forward hooks on those containers keep the layered route)
+        if options.fuse_on(self.fuse, self, self.output.LayerNorm) and not _hooked(self.output, self.intermediate):
             return _ffn(self.intermediate, self.output, h)
         return self.output(self.intermediate(h), h)
 
@@ -215,7 +217,11 @@ class QMobileLayer(QuantizedModel):
 
     def forward(self, h, mask):
         pair = None
-        if options.fuse_on(self.bottleneck_input.fuse, self.bottleneck_input, self.bottleneck_input.LayerNorm):
+        # Merged launches bypass the __call__ of the containers they replace (the two QBottleneckLayers; every QFFN, its
+        # QResidualNoNorm and the Sequential around its intermediate Linear): a forward hook on one of them keeps the
+        # un-merged modules, whose own helpers check the leaves.
+        if (options.fuse_on(self.bottleneck_input.fuse, self.bottleneck_input, self.bottleneck_input.LayerNorm)
+                and not _hooked(self.bottleneck_input, self.bottleneck_attention)):
             from quantization.fused import linear_nonorm_quant_pair     # both bottlenecks read h: one integer launch
             with_value = options.fuse_on(self.attention_self.fuse, self.attention_self, self.attention_self.attn_probs_act_quantizer)
             pair = linear_nonorm_quant_pair(self.bottleneck_input.dense, self.bottleneck_input.LayerNorm,
@@ -231,7 +237,9 @@ class QMobileLayer(QuantizedModel):
         a = self.attention_output(self.attention_self(shared, shared, h, mask, value_out=value_out), layer_input)
         o = None
         if (options.fuse_on(self.fuse_ffn, self, self.output.LayerNorm) and self.fuse_chain
-                and all(options.fuse_on(f.fuse, f, f.output.LayerNorm) for f in self.ffn)):
+                and all(options.fuse_on(f.fuse, f, f.output.LayerNorm) for f in self.ffn)
+                and not _hooked(self.intermediate, self.output, *self.ffn, *(f.output for f in self.ffn),
+                                *(f.intermediate for f in self.ffn))):
             from quantization.fused import quantized_ffn_chain       # the four feed-forward blocks as ONE integer launch
             o = quantized_ffn_chain([(f.intermediate[0], f.output.dense, f.output.res_act_quantizer, f.output.LayerNorm)
                                      for f in self.ffn] + [(self.intermediate[0], self.output.dense,
@@ -239,7 +247,10 @@ class QMobileLayer(QuantizedModel):
         if o is None:
             for f in self.ffn:
                 a = f(a)
-            o = _ffn(self.intermediate, self.output, a) if options.fuse_on(self.fuse_ffn, self, self.output.LayerNorm) else self.output(self.intermediate(a), a)
+            if options.fuse_on(self.fuse_ffn, self, self.output.LayerNorm) and not _hooked(self.intermediate, self.output):
+                o = _ffn(self.intermediate, self.output, a)
+            else:
+                o = self.output(self.intermediate(a), a)
         return self.output_bottleneck(o, h)                       # back to 512, residual = the layer's input
 
 

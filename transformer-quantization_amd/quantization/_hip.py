@@ -79,7 +79,7 @@ SIGNATURES = {
     'tq_residual_layernorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _f, _QP, _vp]),
     'tq_residual_nonorm_quant_fwd': (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _int, _QP, _QP, _vp, _vp, _QP, _vp]),
     'tq_embeddings_layernorm_quant_fwd': (_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _u64, _u64, _QP, _QP,
-                                                _vp, _vp, C.c_float, _QP, _vp]),
+                                                _vp, _vp, C.c_float, _QP, _vp, _vp]),
     'tq_attention_i8_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u64, _u64, _vp, _f, _QP, _QP, _QP, _QP, _QP, _QP, _vp]),
     'tq_attention_i8_strided_fwd': (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u64, _u64, _u64, _vp, _f, _QP, _QP, _QP, _QP,
                                            _QP, _QP, _vp]),
@@ -492,8 +492,11 @@ class HipBackend:
     def embeddings_layernorm_quant(self, word, word_ids, type_tab, type_ids, pos_tab, pos_ids, q_sum1, q_sum2, ln_weight,
                                    ln_bias, ln_eps, q_out, want_idx=False):
         """y [rows, d] = Q_out(LN(Q_sum2(Q_sum1(word[word_ids] + type[type_ids]) + pos[pos_ids]))); tables fp32 [n, d]
-        (already fake-quantized), ids int64 [rows]; each q_* None or a per-tensor 7-tuple.  -> y (, int8 indices)."""
+        (already fake-quantized), ids int64 [rows]; each q_* None or a per-tensor 7-tuple.  -> y (, int8 indices).
+        An id outside its table makes its output row NaN and raises IndexError (what torch's CPU F.embedding raises) at the
+        next call of this method or of `raise_deferred` -- the launch itself is asynchronous."""
         _need_device(word, 'embeddings_layernorm_quant')
+        self.raise_deferred()
         _need_f32('embeddings_layernorm_quant', word, type_tab, pos_tab)
         tabs = [t.detach().contiguous() for t in (word, type_tab, pos_tab)]
         ids = [i.reshape(-1).contiguous() for i in (word_ids, type_ids, pos_ids)]
@@ -508,9 +511,30 @@ class HipBackend:
         rc = self.lib.tq_embeddings_layernorm_quant_fwd(
             _ptr(tabs[0]), tabs[0].shape[0], _ptr(ids[0]), _ptr(tabs[1]), tabs[1].shape[0], _ptr(ids[1]), _ptr(tabs[2]),
             tabs[2].shape[0], _ptr(ids[2]), _ptr(y), _ptr(idx), rows, d, refs[0], refs[1], _ptr(w32), _ptr(b32), float(ln_eps),
-            refs[2], _stream())
+            refs[2], self._bad_ids_flag().data_ptr(), _stream())
         _check(rc, self.lib)
         return (y, idx) if want_idx else y
+
+    def _bad_ids_flag(self):
+        """4 bytes of pinned host memory (device-visible at the same address): kernels raise it, the host reads it without
+        synchronising.  One per process (one process per GPU)."""
+        f = self.__dict__.get('_bad_ids')
+        if f is None:
+            f = self.__dict__['_bad_ids'] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return f
+
+    def raise_deferred(self, sync=False):
+        """Errors that launches already queued could only report asynchronously (an embedding id outside its table):
+        raised here, once.  sync=True waits for the device first (use after the last forward of an evaluation)."""
+        f = self.__dict__.get('_bad_ids')
+        if f is None:
+            return
+        if sync and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()
+        if int(f[0]) != 0:
+            f.zero_()
+            raise IndexError('index out of range in self (an embedding id outside its table reached '
+                             'tq_embeddings_layernorm_quant_fwd; the rows it produced are NaN)')
 
     def attention_i8(self, q_idx, k_idx, v_idx, num_heads, mask, denom, q_q, q_k, q_v, q_scores, q_probs, q_ctx,
                      want_idx=False):
@@ -1294,6 +1318,14 @@ def backend():
     if _backend is None:
         _backend = HipBackend()
     return _backend
+
+
+def raise_deferred(sync=False):
+    """Raise what queued launches could only report asynchronously (HipBackend.raise_deferred); a no-op before the first
+    launch and for backend doubles."""
+    f = getattr(_backend, 'raise_deferred', None)
+    if f is not None:
+        f(sync)
 
 
 def on_device(t):

@@ -17,7 +17,7 @@ from quantization import options
 from quantization import provenance
 from quantization.base_quantized_classes import FP32Acts, QuantizedActivation, QuantizedModule
 from quantization.hijacker import QuantizationHijacker, activations_list
-from quantization.quantization_manager import QuantizationManager
+from quantization.quantization_manager import QuantizationManager, _GLOBAL_FWD_HOOKS, _GLOBAL_FWD_PRE_HOOKS
 
 
 # The integer path is switched on with quantization.options.INT8_LINEAR (see there).
@@ -29,7 +29,10 @@ _ACT_CODES = {type(None): _hip.ACT_NONE, nn.ReLU: _hip.ACT_RELU, nn.GELU: _hip.A
 
 def _hooked(*modules):
     """Does any of these modules carry forward (pre-)hooks?  The integer / fused routes evaluate whole module chains in
-    one launch without calling the modules, so a hook on any of them would silently stop firing."""
+    one launch without calling the modules, so a hook on any of them (or a global module hook) would silently stop
+    firing."""
+    if _GLOBAL_FWD_HOOKS or _GLOBAL_FWD_PRE_HOOKS:
+        return True
     return any(m is not None and isinstance(m, nn.Module) and (m._forward_hooks or m._forward_pre_hooks) for m in modules)
 
 

@@ -17,7 +17,7 @@ from quantization import _hip
 from quantization import options
 from quantization import provenance
 from quantization.base_quantized_classes import FP32Acts
-from quantization.quantization_manager import QuantizationManager, Qstates
+from quantization.quantization_manager import QuantizationManager, Qstates, _GLOBAL_FWD_HOOKS, _GLOBAL_FWD_PRE_HOOKS
 
 
 def _fixed_per_tensor(enabled, mgr):
@@ -36,9 +36,17 @@ def _fixed_per_tensor(enabled, mgr):
 
 
 def _hooked(*modules):
-    """forward (pre-)hooks on modules a fused launch would not call"""
+    """forward (pre-)hooks on modules a fused launch would not call -- leaf modules AND the containers whose __call__
+    a merged launch bypasses (the harness models pass those: QResidualBlock, QFFN, the Sequential around an intermediate
+    Linear, ...) -- or global module hooks (torch.nn.modules.module.register_module_forward_hook), which every bypassed
+    __call__ would have fired."""
+    if _GLOBAL_FWD_HOOKS or _GLOBAL_FWD_PRE_HOOKS:
+        return True
     return any(m is not None and isinstance(m, torch.nn.Module) and (m._forward_hooks or m._forward_pre_hooks)
                for m in modules)
+
+
+hooked = _hooked      # public name for the harness models (containers they bypass when they take a merged launch)
 
 
 def residual_layernorm_quant(dense, res_quantizer, layer_norm, x, residual, _gemm=None):
@@ -323,7 +331,10 @@ def linear_nonorm_quant_pair(dense_a, layer_norm_a, dense_b, layer_norm_b, x, va
     if ops is None:
         return None
     affine = [ln.quantized_params() for _, ln in pairs]    # cached with fixed ranges in inference
-    key = tuple((w.data_ptr(), b.data_ptr()) for w, b in affine) + (G,)
+    # quantized pairs: fresh tensors per (parameter versions, range state) from quantized_params' own cache; with
+    # _quant_w = False they ARE the raw Parameters, which an optimizer step / load_state_dict rewrites in place behind the
+    # same pointers: versions and CACHE_EPOCH (hipGraph replays of a training step) are part of the key
+    key = tuple((w.data_ptr(), w._version, b.data_ptr(), b._version) for w, b in affine) + (G, options.CACHE_EPOCH)
     hit = getattr(layer_norm_a, '_stacked_affine_cache', None)
     if hit is None or hit[0] != key:
         ws = [w.detach().float().reshape(-1) for w, _ in affine]
@@ -544,7 +555,8 @@ def quantized_attention(query, key, value, mask, num_heads, scores_quantizer, pr
 def _stacked_qkv(layers):
     """int8 weights / row sums / biases / per-row weight scales of several QuantLinears stacked along the
     output dimension, cached on the first layer until any weight or weight range changes."""
-    key = tuple((l.weight.data_ptr(), l.weight._version, l.weight_quantizer.quantizer.range_state_key()) for l in layers)
+    key = tuple((l.weight.data_ptr(), l.weight._version, l.weight_quantizer.quantizer.range_state_key(),
+                 None if l.bias is None else (l.bias.data_ptr(), l.bias._version)) for l in layers)
     cache = getattr(layers[0], '_stacked_i8_cache', None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -652,7 +664,7 @@ def quantized_self_attention(x, query, key, value, mask, num_heads, scores_quant
         w_idx, rowsum, bias, scales = packed
         x_idx, xq = srcs[g[0]]
         _, buf = be.linear_i8_grouped(x_idx, w_idx, rowsum, bias, (xq[0], xq[1], xq[3], xq[6]), scales,
-                                      query.weight_quantizer.quantizer.eps, 0, [outs[i] for i in g], want_y=False,
+                                      layers[g[0]].weight_quantizer.quantizer.eps, 0, [outs[i] for i in g], want_y=False,
                                       want_idx=True)
         for j, i in enumerate(g):
             cols[i] = buf[..., j * D:(j + 1) * D]

@@ -8,7 +8,7 @@ with the integer fast paths).
 """
 import torch
 
-from quantization import options
+from quantization import _hip, options
 
 
 class CaptureRefused(RuntimeError):
@@ -131,6 +131,7 @@ class GraphedForward:
                 raise ValueError(f'input shape / dtype changed: captured {tuple(dst.shape)} {dst.dtype}, '
                                  f'got {tuple(src.shape)} {src.dtype}')
             dst.copy_(src, non_blocking=True)
+        _hip.raise_deferred()          # what an EARLIER replay could only flag (token ids outside the vocabulary): no sync
         self.graph.replay()
         return self.static_outputs
 

@@ -345,6 +345,7 @@ def run(config, args):
                 noise += float(((ref - out).double() ** 2).sum())
                 agree += int((ref.argmax(-1) == out.argmax(-1)).sum())
                 total += ids.shape[0]
+            _hip.raise_deferred(sync=True)       # e.g. a token id outside the vocabulary (IndexError, like the CPU route)
         try:
             _, t = _timed(evaluate)
         finally:
