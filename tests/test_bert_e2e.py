@@ -44,6 +44,7 @@ def _check_weights_reproduced(hf, z):
     check_weights_reproduced(hf, z)
 
 
+@pytest.mark.layered_route
 def test_bert_base_w8a8_cpu_exact():
     from quantization import _hip
     from tests._oracle_backend import OracleBackend
@@ -227,6 +228,7 @@ def _calibrate_readme(model, ids, n_calib):
         return model(ids.to(next(model.parameters()).device))
 
 
+@pytest.mark.layered_route
 def test_bert_base_readme_recipe_cpu_exact():
     from quantization import _hip
     from tests._oracle_backend import OracleBackend

@@ -150,6 +150,7 @@ def test_ring_kernel_equals_the_double_buffered_kernel(shape, act):
         assert (ring[0].double() - exact).abs().max().item() <= 4e-7 * exact.abs().max().item() + 1e-7
 
 
+@pytest.mark.layered_route
 def test_bert_forward_with_integer_linears():
     """Whole BERT-base fixed-range forward with every eligible Linear on the i8 matrix cores (and the
     fused layer tails): logits stay within the same envelope as CPU-vs-GPU GEMM round-off."""

@@ -78,6 +78,7 @@ def _by_name(z, names_key, *value_keys):
     return {n: tuple(z[k][i] for k in value_keys) for i, n in enumerate(names)}
 
 
+@pytest.mark.layered_route
 def test_mobilebert_w4a4_cpu_exact():
     from quantization import _hip
     from tests._oracle_backend import OracleBackend
@@ -298,6 +299,7 @@ def test_mobilebert_integer_attention_core_in_harness():
     assert torch.isfinite(fast).all() and float((fast - layered).abs().max()) <= 0.05 * span
 
 
+@pytest.mark.layered_route
 @pytest.mark.gpu
 def test_mobilebert_linear_nonorm_tails_in_gemm_epilogue():
     """options.INT8_LINEAR with the NoNorm tails fused behind the integer GEMMs (tq_linear_i8_nonorm_fwd: the four
@@ -442,6 +444,7 @@ class _IntegerMode:
         return False
 
 
+@pytest.mark.layered_route
 @pytest.mark.gpu
 def test_mobilebert_w4a4_integer_path_divergence_is_published_per_layer():
     """VERDICT r3 weak #2 / next #7.  The opt-in integer path is exact against ITS specification (previous test), but the

@@ -60,6 +60,7 @@ def test_multi_tensor_launch_rejects_what_it_cannot_tile():
         be.fake_quant_multi([_items(torch.float32, 1, 1)[0], _items(torch.bfloat16, 1, 1)[0]])
 
 
+@pytest.mark.layered_route
 def test_prequantize_weights_fills_the_same_cache_as_the_lazy_path():
     from quantization.autoquant_utils import prequantize_weights
     from quantization.hijacker import QuantizationHijacker

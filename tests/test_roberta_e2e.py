@@ -57,6 +57,7 @@ def test_roberta_position_ids_follow_the_reference():
     assert int(pos[3, 5]) == 1 and int(pos[3, 4]) == 6 and int(pos[0, 0]) == 2      # pad keeps 1; tokens count from 2
 
 
+@pytest.mark.layered_route
 def test_roberta_2l_w8a8_cpu_exact():
     from harness.bert import quantizer_census
     from quantization import _hip
