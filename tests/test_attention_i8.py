@@ -384,3 +384,30 @@ def test_key_split_workgroups_match_the_two_wave_form(T, dh, monkeypatch):
     same = (a[0] == b[0]).float().mean()
     assert float(same) >= 0.999, float(same)
     assert int((a[1].int() - b[1].int()).abs().max()) <= 1
+
+
+@pytest.mark.parametrize('zq', [0.0, 1.0, 128.0, 255.0])
+@pytest.mark.parametrize('T,dh,split', [(128, 64, '1'), (128, 64, '0'), (256, 32, '0'), (64, 64, '0')])
+def test_query_zero_point_extremes_equal_the_integer_oracle(zq, T, dh, split, monkeypatch):
+    """Round 6: the zero-point correction c_q sum_d a'_k of the scores is an MFMA of the K tile against an operand whose
+    bytes are all c_q = 128 - z_q; c_q = 128 (z_q = 0: a one-sided query grid) does not fit a byte and runs as two passes
+    with 64.  Every z_q incl. the ends of the grid equals oracle/tq_int_oracle.c bit for bit."""
+    from oracle import int_oracle as IO
+    from quantization import _hip
+    be = _hip.backend()
+    B, H = 2, 2
+    g = torch.Generator().manual_seed(int(zq) * 7 + T + dh)
+    qi, ki, vi = (torch.randint(-128, 128, (B, T, H * dh), generator=g).to(torch.int8) for _ in range(3))
+    mask = torch.zeros(B, T)
+    mask[1, T - 9:] = -10000.0
+    mk = lambda d, z, nb=8: (torch.tensor(d), torch.tensor(z), None, nb, False, False, 1e-8)
+    q_q, q_k, q_v = mk(0.011, zq), mk(0.013, 131.0), mk(0.009, 128.0)
+    q_s, q_p, q_c = mk(0.35, 128.0), mk(1.0 / 255, 0.0), mk(0.012, 125.0)
+    f = lambda q: (float(q[0]), float(q[1]), None, q[3], False, False, q[6])
+    dev = lambda q: (q[0].cuda(), q[1].cuda(), None, q[3], False, False, q[6])
+    monkeypatch.setenv('TQ_ATTN_SPLIT', split)
+    denom = math.sqrt(dh)
+    ctx, ci = be.attention_i8(qi.cuda(), ki.cuda(), vi.cuda(), H, mask.cuda(), denom, dev(q_q), dev(q_k), dev(q_v), dev(q_s),
+                              dev(q_p), dev(q_c), want_idx=True)
+    ref, ri = IO.attention_i8(qi, ki, vi, H, mask, denom, f(q_q), f(q_k), f(q_v), f(q_s), f(q_p), f(q_c))
+    assert torch.equal(ci.cpu(), ri) and torch.equal(ctx.cpu(), ref)

@@ -8,11 +8,11 @@ import subprocess
 import sys
 
 sys.path.insert(0, 'transformer-quantization_amd')
-from build import FLAGS  # noqa: E402
+from build import flags_for  # noqa: E402
 
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ''
-out = subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', '/dev/null'],
+out = subprocess.run(['/opt/rocm/bin/hipcc'] + flags_for(src) + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', '/dev/null'],
                      capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():

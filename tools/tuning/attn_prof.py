@@ -19,7 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'build':
     import build as B
     os.makedirs(OUT, exist_ok=True)
     srcs = B._sources()
-    procs = [subprocess.Popen(['/opt/rocm/bin/hipcc'] + B.FLAGS + ['-DTQ_ATTN_PROF', '-c', s, '-o',
+    procs = [subprocess.Popen(['/opt/rocm/bin/hipcc'] + B.flags_for(s) + ['-DTQ_ATTN_PROF', '-c', s, '-o',
                                                                     os.path.join(OUT, os.path.basename(s)[:-4] + '.o')]) for s in srcs]
     assert all(p.wait() == 0 for p in procs)
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] +

@@ -21,6 +21,18 @@ FLAGS = [
     '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
 ]
 
+# Per-source additions.  tq_attention_i8.hip: MFMA results in VGPRs.  The register allocator otherwise parks the i32
+# accumulators of the attention core in AGPRs (36 per lane) and moves every one of them to a VGPR with its own
+# v_accvgpr_read before the VALU epilogue can touch it (~100 moves per wave) -- and VGPRs + AGPRs together cost an
+# occupancy step (T = 128: 147 -> 113 registers, 3 -> 4 waves per SIMD; key-split kernel 114 -> 78, 4 -> 5).
+PER_SOURCE_FLAGS = {
+    'tq_attention_i8.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
+}
+
+
+def flags_for(src):
+    return FLAGS + PER_SOURCE_FLAGS.get(os.path.basename(src), [])
+
 
 def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
@@ -50,7 +62,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + extra + ['-c', src, '-o', obj]
+            cmd = [hipcc] + flags_for(src) + extra + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

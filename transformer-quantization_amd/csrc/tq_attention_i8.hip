@@ -21,6 +21,7 @@
 // operand.  Nothing but Q, K, V indices (3 x 64 B per token and head) is read and only C is written:
 // the [B, H, T, T] score and probability tensors never exist in memory.
 #include <algorithm>
+#include <type_traits>
 
 #include "tq_device.h"
 #include "tq_host.h"
@@ -59,7 +60,7 @@ __device__ __forceinline__ uint32_t key_slot(uint32_t key) {
 // keep the live stage arrays small
 template <int N>
 __device__ __forceinline__ void quot2_n(f32x2* x, f32x2 r, f32x2 nb) {
-  constexpr int C = N < 8 ? N : 8;
+  constexpr int C = N < 4 ? N : 4;
   static_assert(N % C == 0, "pairs");
 #pragma unroll
   for (int c = 0; c < N; c += C) {
@@ -71,6 +72,62 @@ __device__ __forceinline__ void quot2_n(f32x2* x, f32x2 r, f32x2 nb) {
 #pragma unroll
     for (int i = 0; i < C; ++i) x[c + i] = __builtin_elementwise_fma(e[i], r, q0[i]);
   }
+}
+
+// exp_neg_ieee (tq_device.h) for N register pairs: the same single IEEE operations per element -- v_pk_mul / v_pk_fma /
+// v_pk_add ARE the scalar operations on two lanes -- so every result is bit-identical to the scalar function and to
+// tq_exp_neg of oracle/tq_int_oracle.c; 10.5 instead of 16 issue slots per element (round 6: the exponential was 30 % of the
+// VALU instructions of a launch, profiles/r06/attention_pmc_*.json).  Stage by stage over chunks of 8 pairs.
+template <int N>
+__device__ __forceinline__ void exp_neg_ieee2_n(f32x2* x) {
+  constexpr int C = N < 4 ? N : 4;
+  static_assert(N % C == 0, "pairs");
+  auto k2 = [](float c) { return f32x2{c, c}; };
+#pragma unroll
+  for (int c = 0; c < N; c += C) {
+    f32x2 k[C], r[C], y[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) k[i] = x[c + i] * k2(1.44269504088896341f);
+#pragma unroll
+    for (int i = 0; i < C; ++i) k[i] = f32x2{rintf(k[i].x), rintf(k[i].y)};
+#pragma unroll
+    for (int i = 0; i < C; ++i) r[i] = __builtin_elementwise_fma(k[i], k2(-0.693359375f), x[c + i]);
+#pragma unroll
+    for (int i = 0; i < C; ++i) r[i] = __builtin_elementwise_fma(k[i], k2(2.12194440e-4f), r[i]);
+#pragma unroll
+    for (int i = 0; i < C; ++i) y[i] = __builtin_elementwise_fma(k2(1.9875691500e-4f), r[i], k2(1.3981999507e-3f));
+#pragma unroll
+    for (int i = 0; i < C; ++i) y[i] = __builtin_elementwise_fma(y[i], r[i], k2(8.3334519073e-3f));
+#pragma unroll
+    for (int i = 0; i < C; ++i) y[i] = __builtin_elementwise_fma(y[i], r[i], k2(4.1665795894e-2f));
+#pragma unroll
+    for (int i = 0; i < C; ++i) y[i] = __builtin_elementwise_fma(y[i], r[i], k2(1.6666665459e-1f));
+#pragma unroll
+    for (int i = 0; i < C; ++i) y[i] = __builtin_elementwise_fma(y[i], r[i], k2(5.0000001201e-1f));
+#pragma unroll
+    for (int i = 0; i < C; ++i) y[i] = __builtin_elementwise_fma(y[i], r[i] * r[i], r[i]);
+#pragma unroll
+    for (int i = 0; i < C; ++i) y[i] = y[i] + k2(1.0f);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      const float ex = ldexpf(y[i].x, (int)k[i].x), ey = ldexpf(y[i].y, (int)k[i].y);
+      x[c + i].x = x[c + i].x < -86.0f ? 0.0f : ex;       // (NaN: see exp_neg_ieee)
+      x[c + i].y = x[c + i].y < -86.0f ? 0.0f : ey;
+    }
+  }
+}
+
+// 4 x 4 byte transpose of four dwords: o[e] = bytes e of (r0, r1, r2, r3), r0 in the low byte.  v_perm_b32 selects
+// bytes 0..3 from its SECOND source and 4..7 from its first: 8 instructions (shifts / masks / ors: ~24).
+__device__ __forceinline__ void transpose4x4_b8(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t (&o)[4]) {
+  const uint32_t t0 = __builtin_amdgcn_perm(r1, r0, 0x05010400u);      // r0.b0 r1.b0 r0.b1 r1.b1
+  const uint32_t t1 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);      // r0.b2 r1.b2 r0.b3 r1.b3
+  const uint32_t t2 = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+  const uint32_t t3 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+  o[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+  o[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+  o[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+  o[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
 
 #ifdef TQ_ATTN_PROF
@@ -96,8 +153,11 @@ __device__ __forceinline__ float pair_exchange(float (*slot)[16], float v, int w
 // ~2 waves per SIMD (BERT-base at batch 8: 0.75) the kernel is the latency of that one chain, so halving it pays for
 // the three exchanges through LDS (row max, row sum, the integer partial sums of the second GEMM -- all exact, the
 // float sum a + b is the same value in both waves).
+// (Round 6, measured and not kept -- profiles/r06/attn_qt_ab.txt: a wave taking TWO 16-query tiles one after the other, V^T
+// staging and parameter derivation paid once per 32 queries: 1561 -> 1415 instructions per tile but 165 registers, 3 waves
+// per SIMD instead of 4: -4 % at B = 64, +11 % at B = 128 and at T = 256.)
 template <int NT_ALL, int DH, bool SPLIT>   // NT_ALL = T / 16 key tiles, DH = head dim (32 or 64)
-__global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void attention_i8_k(AttnArgs p) {   // <= 512 VGPRs per lane
+__global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void attention_i8_k(AttnArgs p) {
   constexpr int T = NT_ALL * 16;
   constexpr int NT = SPLIT ? NT_ALL / 2 : NT_ALL;  // key tiles of this wave
   constexpr int KS = NT / 4;                       // its 64-key MFMA steps of the second GEMM
@@ -182,14 +242,12 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
       const uint32_t key4 = (c / PARTS) * 4, part = c % PARTS;
       const uint32_t slot = key_slot(key4);
 #pragma unroll
-      for (int w = 0; w < 4; ++w)
+      for (int w = 0; w < 4; ++w) {
+        uint32_t word[4];                              // word[e]: byte kk = head dim 4 w + e of key key4 + kk
+        transpose4x4_b8((uint32_t)raw[it][0][w], (uint32_t)raw[it][1][w], (uint32_t)raw[it][2][w], (uint32_t)raw[it][3][w], word);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          uint32_t word = 0;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) word |= (((uint32_t)raw[it][kk][w] >> (8 * e)) & 0xffu) << (8 * kk);
-          *reinterpret_cast<uint32_t*>(s_vt + (part * 16 + w * 4 + e) * PITCH + slot) = word;
-        }
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<uint32_t*>(s_vt + (part * 16 + w * 4 + e) * PITCH + slot) = word[e];
+      }
     }
   }
 
@@ -210,19 +268,49 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
   const QF fc = make_qf(pc);
   const bool fast_ctx = p.fast_ok && p.has_ctx && fc.ok;
 
+  // The zero-point corrections ride on the matrix cores (round 6: they were a v_mul_lo + v_add3 per score): the per-query
+  // constant is the accumulator's initial value, and c_q sum_d a'_k is one more MFMA of the K tile against an operand whose
+  // bytes are all c_q (c_q = 128 - z_q is in [-127, 128]; 128 = two passes with 64).  Same exact integers as before.
+  const int cq_b = cq == 128 ? 64 : cq;
+  const int cq_w = (int)((uint32_t)(cq_b & 0xff) * 0x01010101u);
+  const v4i cq4 = {cq_w, cq_w, cq_w, cq_w};
+  const v4i qc4 = {q_const, q_const, q_const, q_const};
   float sc[NT][4];
+  auto score_tiles = [&](auto wide) {                // (one wave-uniform branch around the loop, not one per tile)
+    if constexpr (K_EARLY) {
+      // register-resident K tiles: the NT accumulator chains side by side, pass by pass (a dependent MFMA waits for
+      // its predecessor's last pass: tile by tile the second MFMA of every tile stalled the wave)
+      v4i acc[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    v4i fk = zero4;
-    if (K_EARLY) fk = fk_all[t];
-    else if (kin) fk = *reinterpret_cast<const v4i*>(p.k + base + (size_t)((t0 + t) * 16 + r16) * row_stride + g * 16);
-    const v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq, zero4, 0, 0, 0);
-    const v4i rsk = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, ones, zero4, 0, 0, 0);    // sum_d a'_k of rows 4g + r
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk_all[t], fq, qc4, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sc[t][r] = (float)(acc[r] + cq * rsk[r] + q_const) * s_qk;
-    // pin the four scores: the scheduler otherwise keeps both integer accumulators of every tile (8 NT registers) alive
-    asm volatile("" : "+v"(sc[t][0]), "+v"(sc[t][1]), "+v"(sc[t][2]), "+v"(sc[t][3]));
-  }
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk_all[t], cq4, acc[t], 0, 0, 0);
+      if (decltype(wide)::value) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk_all[t], cq4, acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[t][r] = (float)acc[t][r] * s_qk;
+      return;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      v4i fk = zero4;
+      if (K_EARLY) fk = fk_all[t];
+      else if (kin) fk = *reinterpret_cast<const v4i*>(p.k + base + (size_t)((t0 + t) * 16 + r16) * row_stride + g * 16);
+      v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq, qc4, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, cq4, acc, 0, 0, 0);               // + c_q sum_d a'_k of rows 4g + r
+      if (decltype(wide)::value) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, cq4, acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[t][r] = (float)acc[r] * s_qk;
+      // pin the four scores: the scheduler otherwise keeps the integer accumulators of every tile alive
+      asm volatile("" : "+v"(sc[t][0]), "+v"(sc[t][1]), "+v"(sc[t][2]), "+v"(sc[t][3]));
+    }
+  };
+  if (cq == 128) score_tiles(std::true_type{});
+  else score_tiles(std::false_type{});
 
   TQ_STAMP(3);
   v4i fp[KS];
@@ -235,9 +323,9 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
     for (int t = 0; t < NT; ++t) { x[2 * t] = f32x2{sc[t][0], sc[t][1]}; x[2 * t + 1] = f32x2{sc[t][2], sc[t][3]}; }
     if (p.has_scores) {
 #pragma unroll
-      for (int c = 0; c < P; c += 8) {
-        f32x2 (&xc)[8] = *reinterpret_cast<f32x2(*)[8]>(&x[c]);
-        qf_fake_quant2_n<8>(xc, fs);
+      for (int c = 0; c < P; c += 4) {
+        f32x2 (&xc)[4] = *reinterpret_cast<f32x2(*)[4]>(&x[c]);
+        qf_fake_quant2_n<4>(xc, fs);
       }
     }
     if (denom_pow2) {
@@ -265,10 +353,14 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
     // a lane group adds its exponentials sequentially (tile-major), groups combine as (s0 + s1) + (s2 + s3), the two
     // halves are added last -- the same tree whether one wave owns the whole row or two waves own a half each.
     float sum = 0.f, sum_hi = 0.f;
+    {
+      const f32x2 nmx = {-mx, -mx};                    // x - mx == x + (-mx), bit for bit
+#pragma unroll
+      for (int i = 0; i < P; ++i) x[i] = x[i] + nmx;
+    }
+    exp_neg_ieee2_n<P>(x);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-      x[i].x = exp_neg_ieee(x[i].x - mx);
-      x[i].y = exp_neg_ieee(x[i].y - mx);
       if (SPLIT || i < P / 2) { sum += x[i].x; sum += x[i].y; }
       else { sum_hi += x[i].x; sum_hi += x[i].y; }
     }
@@ -286,10 +378,10 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
     quot2_n<P>(x, f32x2{rsv, rsv}, f32x2{-sum, -sum});
     f32x2 hq[P];
 #pragma unroll
-    for (int c = 0; c < P; c += 8) {                 // clamp(rne(p / scale) + zp, lo, hi) - zp
-      f32x2 (&xc)[8] = *reinterpret_cast<f32x2(*)[8]>(&x[c]);
-      f32x2 (&hc)[8] = *reinterpret_cast<f32x2(*)[8]>(&hq[c]);
-      qf_round2_n<8>(xc, fpq, hc);
+    for (int c = 0; c < P; c += 4) {                 // clamp(rne(p / scale) + zp, lo, hi) - zp
+      f32x2 (&xc)[4] = *reinterpret_cast<f32x2(*)[4]>(&x[c]);
+      f32x2 (&hc)[4] = *reinterpret_cast<f32x2(*)[4]>(&hq[c]);
+      qf_round2_n<4>(xc, fpq, hc);
     }
     const f32x2 zp2 = {pp.zp, pp.zp};
 #pragma unroll
