@@ -9,7 +9,8 @@ G=gpurun_out
 P=profiles/$R
 mkdir -p "$P"
 for f in bench_n1.json bench_rccl1.json bench_sweep.json config_bench.json int_vs_reference.json gpu_tests_full_suite.log \
-         py_overhead2.txt mx_probe.txt bert_default_route_layer_timeline.txt mobilebert_default_route_layer_timeline.txt; do
+         py_overhead2.txt mx_probe.txt bert_default_route_layer_timeline.txt mobilebert_default_route_layer_timeline.txt \
+         attn_phase_profile.txt attn_graph.txt attention_pmc_B64.json attention_pmc_B8.json; do
   [ -s "$G/$R/$f" ] && cp "$G/$R/$f" "$P/$f"
 done
 cp "$G/prof_$R/summary.txt" "$P/summary.txt"

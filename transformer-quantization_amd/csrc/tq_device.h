@@ -29,8 +29,22 @@ struct QP {
 };
 
 __device__ __forceinline__ float grid_top(int n_bits) {
-  // 2.0 ** n_bits - 1 evaluated in double like the python float, then narrowed to fp32
-  return (float)(ldexp(1.0, n_bits) - 1.0);
+  // 2.0 ** n_bits - 1 evaluated in double like the python float, then narrowed to fp32: 2^n - 1 exactly up to 24 bits,
+  // 2^n above (2^n - 1 is not an fp32 value there and rounds to nearest).  Integer arithmetic instead of three
+  // double-precision instructions (round 6: the prologue of a latency-bound fused launch derives up to six quantizers).
+  return n_bits <= 24 ? (float)((1u << (n_bits & 31)) - 1u) : ldexpf(1.0f, n_bits);
+}
+
+// scale = exp(delta) in the log domain, max(delta, eps) otherwise (quantizers.py:142-147).  log_domain is a wave-uniform
+// kernel argument: a REAL branch -- written as a select, expf (~15 VALU instructions) was evaluated speculatively by every
+// kernel for every quantizer.  (The volatile asm keeps the compiler from if-converting the block back.)
+__device__ __forceinline__ float effective_scale(int log_domain, float d, float eps) {
+  float s = d < eps ? eps : d;
+  if (log_domain) {
+    s = expf(d);
+    asm volatile("" : "+v"(s));
+  }
+  return s;
 }
 
 __device__ __forceinline__ float clamp_nanprop(float v, float lo, float hi) {
@@ -43,11 +57,11 @@ __device__ __forceinline__ float clamp_nanprop(float v, float lo, float hi) {
 __device__ __forceinline__ QP make_qp(const tq_quantizer& q, uint64_t p) {
   QP r;
   const float d = q.delta[p];
-  r.scale = q.log_domain ? expf(d) : (d < q.eps ? q.eps : d);    // quantizers.py:142-147
+  r.scale = effective_scale(q.log_domain, d, q.eps);             // quantizers.py:142-147
   if (q.symmetric) {
     const bool sgn = q.signed_flag != nullptr && q.signed_flag[0] != 0;
     r.zp = 0.0f;                                                  // :330-332
-    r.lo = sgn ? -(float)ldexp(1.0, q.n_bits - 1) : 0.0f;         // :321-323
+    r.lo = sgn ? -ldexpf(1.0f, q.n_bits - 1) : 0.0f;              // :321-323
     r.hi = grid_top(q.n_bits - (sgn ? 1 : 0));                    // :325-328
   } else {
     r.lo = 0.0f;                                                  // :132-135
@@ -118,11 +132,11 @@ __device__ __forceinline__ void qraw_arrived(QRaw& w) {
 
 __device__ __forceinline__ QP qp_from_raw(const tq_quantizer& q, const QRaw& w) {
   QP r;
-  r.scale = q.log_domain ? expf(w.d) : (w.d < q.eps ? q.eps : w.d);
+  r.scale = effective_scale(q.log_domain, w.d, q.eps);
   if (q.symmetric) {
     const bool sgn = q.signed_flag != nullptr && w.s != 0;
     r.zp = 0.0f;
-    r.lo = sgn ? -(float)ldexp(1.0, q.n_bits - 1) : 0.0f;
+    r.lo = sgn ? -ldexpf(1.0f, q.n_bits - 1) : 0.0f;
     r.hi = grid_top(q.n_bits - (sgn ? 1 : 0));
   } else {
     r.lo = 0.0f;
