@@ -386,6 +386,40 @@ def test_key_split_workgroups_match_the_two_wave_form(T, dh, monkeypatch):
     assert int((a[1].int() - b[1].int()).abs().max()) <= 1
 
 
+@pytest.mark.parametrize('T,dh', [(128, 64), (128, 32), (256, 64), (384, 32), (512, 64)])
+def test_eight_query_waves_per_workgroup_are_bit_identical(T, dh, monkeypatch):
+    """Large grids run the one-wave-per-row form with EIGHT query waves per workgroup (TQ_ATTN_QW=8: the V tile is fetched
+    and transposed once per 128 queries instead of once per 32): same per-wave code on the same data, so values, indices
+    and NaN rows are those of the two-wave workgroups, bit for bit -- with masks, without the scores quantizer, branch-free
+    and guarded chains."""
+    from quantization import _hip
+    be = _hip.backend()
+    B, H = 3, 2
+    g = torch.Generator().manual_seed(13 * T + dh)
+    qi, ki, vi = (torch.randint(-128, 128, (B, T, H * dh), generator=g, dtype=torch.int8).cuda() for _ in range(3))
+    mask = torch.zeros(B, T)
+    mask[1, T // 3:] = -10000.0
+    mask[2, :] = -float('inf')
+    pq, pk, pv = _params(-3.0, 2.5), _params(-2.0, 3.0), _params(-1.5, 1.0)
+    ps, pp, pc = _params(-60.0, 70.0), _params(0.0, 0.6), _params(-1.2, 0.9)
+    k7 = lambda p: None if p is None else (p[0].cuda(), p[1].cuda(), None, 8, False, False, 1e-8)
+    monkeypatch.setenv('TQ_ATTN_SPLIT', '0')
+    for use_s in (True, False):
+        for fast in ('1', '0'):
+            monkeypatch.setenv('TQ_ATTN_FAST', fast)
+            outs = []
+            for qw in ('2', '8'):
+                monkeypatch.setenv('TQ_ATTN_QW', qw)
+                ctx, idx = be.attention_i8(qi, ki, vi, H, mask.cuda(), math.sqrt(dh), k7(pq), k7(pk), k7(pv),
+                                           k7(ps) if use_s else None, k7(pp), k7(pc), want_idx=True)
+                outs.append((ctx.cpu(), idx.cpu()))
+            (c1, i1), (c2, i2) = outs
+            assert torch.isnan(c1[2]).all() and not torch.isnan(c1[:2]).any()
+            assert torch.equal(torch.isnan(c1), torch.isnan(c2))
+            ok = ~torch.isnan(c1)
+            assert torch.equal(c1[ok].view(torch.int32), c2[ok].view(torch.int32)) and torch.equal(i1[ok], i2[ok])
+
+
 @pytest.mark.parametrize('zq', [0.0, 1.0, 128.0, 255.0])
 @pytest.mark.parametrize('T,dh,split', [(128, 64, '1'), (128, 64, '0'), (256, 32, '0'), (64, 64, '0')])
 def test_query_zero_point_extremes_equal_the_integer_oracle(zq, T, dh, split, monkeypatch):

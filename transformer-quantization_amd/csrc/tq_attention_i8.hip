@@ -11,7 +11,8 @@
 // int8(index - 128):
 //     S[q,k] = s_q s_k ( sum_d a'_q a'_k + c_k sum_d a'_q + c_q sum_d a'_k + d c_q c_k ),   c = 128 - z
 //     C[q,d] = s_p s_v ( sum_k a'_p a'_v + c_v sum_k a'_p + c_p sum_k a'_v + T c_p c_v )
-// One workgroup (2 waves) owns 32 query rows of one (batch, head); each wave computes S^T = K Q^T for
+// One workgroup (2 waves, 8 on grids that are not key-split: round 6) owns 32 (128) query rows of one (batch, head); each
+// wave computes S^T = K Q^T for
 // its 16 queries with T/16 v_mfma_i32_16x16x64_i8 (d = 64 = one MFMA K step), keeps the 16 x T scores
 // in registers (lane = one query column, keys 16t + 4g + r), does the quantizers / mask / softmax
 // there, packs the probability indices straight into the B operand of the second MFMA (the MFMA K
@@ -156,12 +157,17 @@ __device__ __forceinline__ float pair_exchange(float (*slot)[16], float v, int w
 // (Round 6, measured and not kept -- profiles/r06/attn_qt_ab.txt: a wave taking TWO 16-query tiles one after the other, V^T
 // staging and parameter derivation paid once per 32 queries: 1561 -> 1415 instructions per tile but 165 registers, 3 waves
 // per SIMD instead of 4: -4 % at B = 64, +11 % at B = 128 and at T = 256.)
-template <int NT_ALL, int DH, bool SPLIT>   // NT_ALL = T / 16 key tiles, DH = head dim (32 or 64)
-__global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void attention_i8_k(AttnArgs p) {
+// QW = query waves per workgroup of the one-wave-per-row form (2, or 8 on large grids: round 6).  With 8 waves a workgroup
+// owns 128 queries of its (batch, head): the V tile is fetched and transposed into LDS once per 128 queries instead of
+// once per 32, and the K tiles of the eight waves come from the same CU's L1.  Same per-wave code and data: bit-identical.
+template <int NT_ALL, int DH, bool SPLIT, int QW = kAttnWaves>   // NT_ALL = T / 16 key tiles, DH = head dim (32 or 64)
+__global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : QW * kWave) void attention_i8_k(AttnArgs p) {
+  static_assert(QW == kAttnWaves || !SPLIT, "the key-split form has two query waves");
+  static_assert((NT_ALL * 16) % (16 * QW) == 0, "whole workgroups per row of queries");
   constexpr int T = NT_ALL * 16;
   constexpr int NT = SPLIT ? NT_ALL / 2 : NT_ALL;  // key tiles of this wave
   constexpr int KS = NT / 4;                       // its 64-key MFMA steps of the second GEMM
-  constexpr int THREADS = SPLIT ? 2 * kAttnThreads : kAttnThreads;
+  constexpr int THREADS = SPLIT ? 2 * kAttnThreads : QW * kWave;
   constexpr int PITCH = T + 32;                    // 32 * odd bytes: conflict-free ds_read_b128 (4 x 16 lane groups, 64 banks)
   constexpr int NPART = 1 + 8 * (DH / 16);         // integers per lane a kh = 1 wave hands to its kh = 0 partner
   static_assert(!SPLIT || NT_ALL % 8 == 0, "key split needs an even number of 64-key steps");
@@ -169,10 +175,10 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
   __shared__ float s_red[SPLIT ? 2 : 1][4][16];    // [max | sum][wave][query]
   __shared__ int s_part[SPLIT ? 2 : 1][SPLIT ? NPART : 1][64];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 1, kh = SPLIT ? tid >> 7 : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = SPLIT ? (tid >> 6) & 1 : tid >> 6, kh = SPLIT ? tid >> 7 : 0;
   const int r16 = lane & 15, g = lane >> 4;
   const int t0 = kh * NT;                          // first key tile of this wave
-  const uint32_t qblocks = T / (16 * kAttnWaves);
+  const uint32_t qblocks = T / (16 * QW);
   const uint32_t bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
   const uint32_t b = bh / p.H, h = bh % p.H;
   const size_t row_stride = p.in_stride;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : kAttnThreads) void atten
   // value) in flight together with the V tile
   const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
   const v4i zero4 = {0, 0, 0, 0};
-  const uint32_t qrow = qb * 16 * kAttnWaves + wave * 16 + r16;
+  const uint32_t qrow = qb * 16 * QW + wave * 16 + r16;
   const bool kin = g * 16 < DH;                     // lane groups beyond the head dim supply zeros
   v4i fq = zero4;
   if (kin) fq = *reinterpret_cast<const v4i*>(p.q + base + (size_t)qrow * row_stride + g * 16);
@@ -616,14 +622,27 @@ extern "C" int tq_attention_i8_strided_fwd(const int8_t* q_idx, const int8_t* k_
   // key split (4 waves per 32 queries) while the plain grid leaves the SIMDs under ~2 waves each: T % 128 == 0 only
   const int split_env = tuning("TQ_ATTN_SPLIT", -1);     // read per call: the tests flip it
   const bool split = T % 128 == 0 && (split_env >= 0 ? split_env != 0 : grid <= 1024);
+  // eight query waves per workgroup (one V^T staging per 128 queries) whenever the keys are not split: T % 128 == 0 only
+  // (profiles/r06/attn_qw_ab.txt: -3 % at B = 32, -7 % at B = 64, -9 % at B = 128, -10 % at T = 256, -20 % at T = 512)
+  const int qw_env = tuning("TQ_ATTN_QW", -1);           // read per call: the tests flip it
+  const bool wide = !split && T % 128 == 0 && (qw_env >= 0 ? qw_env == 8 : true);
 #define TQ_ATTN_LAUNCH(NTV, DHV, SP)                                                                             \
   hipLaunchKernelGGL((attention_i8_k<NTV, DHV, SP>), dim3(grid), dim3((SP) ? 2 * kAttnThreads : kAttnThreads), 0, st, a)
+#define TQ_ATTN_LAUNCH8(NTV, DHV)                                                                                \
+  hipLaunchKernelGGL((attention_i8_k<NTV, DHV, false, 8>), dim3(grid / 4), dim3(8 * kWave), 0, st, a)
 #define TQ_ATTN(NTV)                                                                                             \
   case NTV * 16:                                                                                                 \
     if constexpr ((NTV) % 8 == 0) {                                                                              \
       if (split) {                                                                                               \
         if (head_dim == 64) TQ_ATTN_LAUNCH(NTV, 64, true);                                                       \
         else TQ_ATTN_LAUNCH(NTV, 32, true);                                                                      \
+        break;                                                                                                   \
+      }                                                                                                          \
+    }                                                                                                            \
+    if constexpr ((NTV) % 8 == 0) {                                                                              \
+      if (wide) {                                                                                                \
+        if (head_dim == 64) TQ_ATTN_LAUNCH8(NTV, 64);                                                            \
+        else TQ_ATTN_LAUNCH8(NTV, 32);                                                                           \
         break;                                                                                                   \
       }                                                                                                          \
     }                                                                                                            \
@@ -635,6 +654,7 @@ extern "C" int tq_attention_i8_strided_fwd(const int8_t* q_idx, const int8_t* k_
     default: return set_error(TQ_EUNSUPPORTED, "tq_attention_i8_fwd: sequence length %llu", (unsigned long long)T);
   }
 #undef TQ_ATTN_LAUNCH
+#undef TQ_ATTN_LAUNCH8
 #undef TQ_ATTN
   return check_launch("attention_i8_k");
 }
