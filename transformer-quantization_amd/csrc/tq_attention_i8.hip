@@ -174,6 +174,13 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : QW * kWave) void attenti
   __shared__ __attribute__((aligned(16))) int8_t s_vt[DH * PITCH];
   __shared__ float s_red[SPLIT ? 2 : 1][4][16];    // [max | sum][wave][query]
   __shared__ int s_part[SPLIT ? 2 : 1][SPLIT ? NPART : 1][64];
+  // QW = 8: the K tile of the (batch, head) is fetched ONCE per workgroup (one 16-byte load per thread at T = 128) and read
+  // from LDS by the eight waves -- each wave fetching its own copy was 8 of the 13 loads per lane in front of the first
+  // instruction, on a launch whose longest phase is that fetch (profiles/r06/attn_phase_profile.txt).  Row pitch DH + 16:
+  // conflict-free ds_read_b128 of 16 rows x 16 bytes.
+  constexpr bool K_LDS = !SPLIT && QW == 8;
+  constexpr int KP = DH + 16;
+  __shared__ __attribute__((aligned(16))) int8_t s_k[K_LDS ? T * KP : 16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = SPLIT ? (tid >> 6) & 1 : tid >> 6, kh = SPLIT ? tid >> 7 : 0;
   const int r16 = lane & 15, g = lane >> 4;
@@ -210,8 +217,19 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : QW * kWave) void attenti
   v4i fq = zero4;
   if (kin) fq = *reinterpret_cast<const v4i*>(p.q + base + (size_t)qrow * row_stride + g * 16);
   // short rows: the K tiles too -- one exposed memory latency for V, Q, K and the parameters instead of two
-  constexpr bool K_EARLY = NT <= 8;
+  constexpr bool K_EARLY = NT <= 8 && !K_LDS;
   v4i fk_all[K_EARLY ? NT : 1];
+  constexpr uint32_t KCH = (uint32_t)T * PARTS;     // 16-byte chunks of the K tile (K_LDS)
+  constexpr int KIT = K_LDS ? (KCH + THREADS - 1) / THREADS : 1;
+  v4i kraw[KIT];
+  if (K_LDS) {
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const uint32_t c = tid + it * THREADS;
+      if (KCH % THREADS == 0 || c < KCH)
+        kraw[it] = *reinterpret_cast<const v4i*>(p.k + base + (size_t)(c / PARTS) * row_stride + (c % PARTS) * 16);
+    }
+  }
   if (K_EARLY) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -257,6 +275,14 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : QW * kWave) void attenti
     }
   }
 
+  if (K_LDS) {
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const uint32_t c = tid + it * THREADS;
+      if (KCH % THREADS == 0 || c < KCH) *reinterpret_cast<v4i*>(s_k + (c / PARTS) * KP + (c % PARTS) * 16) = kraw[it];
+    }
+    __syncthreads();                                 // K tile and V^T are in LDS
+  }
   TQ_STAMP(1);
   // ---- S^T = K Q^T for this wave's 16 queries --------------------------------------------------------
   const int rsq = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fq, zero4, 0, 0, 0)[0];   // sum_d a'_q of column r16
@@ -305,6 +331,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : QW * kWave) void attenti
     for (int t = 0; t < NT; ++t) {
       v4i fk = zero4;
       if (K_EARLY) fk = fk_all[t];
+      else if (K_LDS) { if (kin) fk = *reinterpret_cast<const v4i*>(s_k + ((t0 + t) * 16 + r16) * KP + g * 16); }
       else if (kin) fk = *reinterpret_cast<const v4i*>(p.k + base + (size_t)((t0 + t) * 16 + r16) * row_stride + g * 16);
       v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq, qc4, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, cq4, acc, 0, 0, 0);               // + c_q sum_d a'_k of rows 4g + r
@@ -467,7 +494,7 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : QW * kWave) void attenti
   }
 
   TQ_STAMP(4);
-  if (!SPLIT) __syncthreads();                       // V^T is in LDS
+  if (!SPLIT && !K_LDS) __syncthreads();             // V^T is in LDS
   TQ_STAMP(5);
 
   // ---- C^T = V^T P^T -------------------------------------------------------------------------------
