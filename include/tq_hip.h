@@ -37,7 +37,9 @@
 extern "C" {
 #endif
 
-#define TQ_ABI_VERSION 1
+/* 2 (round 6): tq_embeddings_layernorm_quant_fwd takes `bad_ids` (a signature change of an existing entry point; additions
+ * alone had not moved the number). */
+#define TQ_ABI_VERSION 2
 
 /* storage dtype of x / y */
 enum { TQ_F32 = 0, TQ_BF16 = 1, TQ_F16 = 2 };

@@ -45,7 +45,8 @@ def test_python_binding_covers_header(lib_path):
     from quantization import _hip
     assert sorted(_hip.SIGNATURES) == _declared()
     lib = _hip.load_library()
-    assert lib.tq_abi_version() == 1
+    header = open(os.path.join(ROOT, 'include', 'tq_hip.h')).read()
+    assert lib.tq_abi_version() == _hip.ABI_VERSION == int(re.search(r'#define TQ_ABI_VERSION (\d+)', header).group(1))
     assert lib.tq_last_error() is not None
 
 
@@ -116,7 +117,7 @@ def test_fastcall_stub_calls_the_same_library_through_raw_addresses():
     fc = _hip.fastcall()
     assert fc is not None, 'lib/_tq_fastcall*.so missing: python transformer-quantization_amd/build.py'
     lib = _hip.load_library()
-    assert fc.call_ptrs(_hip.entry_address(lib.tq_abi_version)) == lib.tq_abi_version() == 1
+    assert fc.call_ptrs(_hip.entry_address(lib.tq_abi_version)) == lib.tq_abi_version() == _hip.ABI_VERSION
     # tq_fake_quant_fwd(x = NULL, ...) is rejected by the library's own argument checks on both routes
     addr = _hip.entry_address(lib.tq_fake_quant_fwd)
     rc_fast = fc.fake_quant_fwd(addr, 0, 0, 0, 0, 16, 0, 0, 0)

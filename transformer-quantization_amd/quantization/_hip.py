@@ -60,6 +60,8 @@ _QPD = C.POINTER(tq_quantizer_f64)
 
 # name -> (restype, argtypes); must list every symbol include/tq_hip.h declares
 
+ABI_VERSION = 2          # == TQ_ABI_VERSION of include/tq_hip.h (tests/test_abi.py compares the header, the library and this)
+
 SIGNATURES = {
     'tq_fake_quant_fwd_f64': (_int, [_vp, _vp, _vp, _u64, _QPD, _vp]),
     'tq_fake_quant_bwd_f64_workspace_bytes': (_sz, [_u64, _u64, _u64]),
@@ -178,8 +180,9 @@ def load_library(path=None):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.tq_abi_version() != 1:
-        raise TQError('libtq_hip.so ABI version mismatch')
+    if lib.tq_abi_version() != ABI_VERSION:
+        raise TQError('libtq_hip.so ABI version mismatch: the library says %d, this binding is written for %d -- rebuild '
+                      '(python transformer-quantization_amd/build.py)' % (lib.tq_abi_version(), ABI_VERSION))
     if path is None:
         _lib = lib
     return lib
