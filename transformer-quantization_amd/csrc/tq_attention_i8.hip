@@ -169,11 +169,12 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : QW * kWave) void attenti
   constexpr int KS = NT / 4;                       // its 64-key MFMA steps of the second GEMM
   constexpr int THREADS = SPLIT ? 2 * kAttnThreads : QW * kWave;
   constexpr int PITCH = T + 32;                    // 32 * odd bytes: conflict-free ds_read_b128 (4 x 16 lane groups, 64 banks)
-  constexpr int NPART = 1 + 8 * (DH / 16);         // integers per lane a kh = 1 wave hands to its kh = 0 partner
+  constexpr int KSA = SPLIT ? 2 * KS : KS;         // 64-key steps of the wave that finishes the tile (all keys)
   static_assert(!SPLIT || NT_ALL % 8 == 0, "key split needs an even number of 64-key steps");
   __shared__ __attribute__((aligned(16))) int8_t s_vt[DH * PITCH];
   __shared__ float s_red[SPLIT ? 2 : 1][4][16];    // [max | sum][wave][query]
-  __shared__ int s_part[SPLIT ? 2 : 1][SPLIT ? NPART : 1][64];
+  // key-split form: the kh = 1 wave hands its probability indices (KS operands of 16 bytes per lane) to its kh = 0 partner
+  __shared__ __attribute__((aligned(16))) v4i s_fp[SPLIT ? 2 : 1][SPLIT ? KS : 1][64];
   // QW = 8: the K tile of the (batch, head) is fetched ONCE per workgroup (one 16-byte load per thread at T = 128) and read
   // from LDS by the eight waves -- each wave fetching its own copy was 8 of the 13 loads per lane in front of the first
   // instruction, on a launch whose longest phase is that fetch (profiles/r06/attn_phase_profile.txt).  Row pitch DH + 16:
@@ -498,45 +499,40 @@ __global__ __launch_bounds__(SPLIT ? 2 * kAttnThreads : QW * kWave) void attenti
   TQ_STAMP(5);
 
   // ---- C^T = V^T P^T -------------------------------------------------------------------------------
+  // Key-split form (round 6): the kh = 1 wave is done once its probability indices are in LDS; its partner runs the second
+  // GEMM over ALL keys.  (Before, both waves ran their half and the kh = 1 wave handed over 1 + 8 d / 16 integer partial
+  // sums per lane -- 33 LDS stores, 33 loads and 33 additions per lane against 1 + 1 here; the MFMAs are not the
+  // bottleneck.)  The same exact integers either way.
+  v4i fpa[KSA];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) fpa[s] = fp[s];
+  if (SPLIT) {
+    if (kh == 1) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) s_fp[wave][s][lane] = fp[s];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) fpa[KS + s] = s_fp[wave][s][lane];
+  }
   v4i rsp4 = zero4;
 #pragma unroll
-  for (int s = 0; s < KS; ++s) rsp4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fp[s], rsp4, 0, 0, 0);
+  for (int s = 0; s < KSA; ++s) rsp4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, fpa[s], rsp4, 0, 0, 0);
   v4i accs[DH / 16], csvs[DH / 16];
 #pragma unroll
   for (int j = 0; j < DH / 16; ++j) {
     v4i acc = zero4, csv = zero4;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const v4i fv = *reinterpret_cast<const v4i*>(s_vt + (j * 16 + r16) * PITCH + (kh * KS + s) * 64 + g * 16);
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv, fp[s], acc, 0, 0, 0);
+    for (int s = 0; s < KSA; ++s) {
+      const v4i fv = *reinterpret_cast<const v4i*>(s_vt + (j * 16 + r16) * PITCH + s * 64 + g * 16);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv, fpa[s], acc, 0, 0, 0);
       csv = __builtin_amdgcn_mfma_i32_16x16x64_i8(fv, ones, csv, 0, 0, 0);              // sum_k a'_v of rows 4g + r
     }
     accs[j] = acc;
     csvs[j] = csv;
   }
-  int rsp = rsp4[0];                                 // sum_k a'_p of column r16 (this wave's keys)
-  if (SPLIT) {                                       // integer partial sums of the upper key half -> the kh = 0 wave
-    if (kh == 1) {
-      s_part[wave][0][lane] = rsp;
-#pragma unroll
-      for (int j = 0; j < DH / 16; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s_part[wave][1 + 8 * j + r][lane] = accs[j][r];
-          s_part[wave][1 + 8 * j + 4 + r][lane] = csvs[j][r];
-        }
-    }
-    __syncthreads();
-    if (kh == 1) return;
-    rsp += s_part[wave][0][lane];
-#pragma unroll
-    for (int j = 0; j < DH / 16; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        accs[j][r] += s_part[wave][1 + 8 * j + r][lane];
-        csvs[j][r] += s_part[wave][1 + 8 * j + 4 + r][lane];
-      }
-  }
+  const int rsp = rsp4[0];                           // sum_k a'_p of column r16
   const int p_const = cv * rsp + T * cp * cv;
   const size_t out_row = ((size_t)b * T + qrow) * ((size_t)p.H * DH) + (size_t)h * DH;
 #pragma unroll
