@@ -413,11 +413,24 @@ def calibration_model_block(device, rank, world, use_dist, wd):
         for name, ids in legs.items():
             wd.stage = f'calibration_model: {name} eager'
             leg = {'per_rank_batch': list(ids.shape), 'global_batch': [ids.shape[0] * world if name == 'weak' else 128, 128]}
+            from quantization.autoquant_utils import INT8_STATS
+            i8_before = INT8_STATS['kernel_calls']
             model(ids)                   # untimed: the 102 weight quantizers estimate (and exchange) once, on the first forward
+            # options.INT8_CALIBRATION (product default): Linears whose GEMM reaches INT8_CALIBRATION_MIN_MACS run as exact
+            # integer GEMMs in a calibrating forward too -- none at [8,128], all 72 encoder Linears at [128,128] on one GPU
+            leg['integer_gemm_linears_per_forward'] = INT8_STATS['kernel_calls'] - i8_before
             before = tq_dist.stats()
             n_eager = 10
             eager = _wall_ms(lambda: model(ids), n_eager, 2, use_dist)
             after = tq_dist.stats()
+            if leg['integer_gemm_linears_per_forward']:
+                wd.stage = f'calibration_model: {name} eager, fp32 GEMMs'
+                keep_cal = options.INT8_CALIBRATION
+                options.INT8_CALIBRATION = False
+                try:
+                    leg['eager_ms_fp32_gemms'] = round(_max_over_ranks([_wall_ms(lambda: model(ids), 5, 1, use_dist)], device, use_dist)[0], 4)
+                finally:
+                    options.INT8_CALIBRATION = keep_cal
             leg['collectives_per_forward'] = (after['minmax_calls'] + after['sum_calls'] - before['minmax_calls']
                                               - before['sum_calls']) / (n_eager + 2)
             leg['exchanged_bytes_per_forward'] = (after['bytes'] - before['bytes']) / (n_eager + 2)

@@ -102,6 +102,9 @@ def test_bert_merged_launches_host_logic_cpu():
             pass_data_for_range_estimation([(ids,)], model, act_quant=True, weight_quant=True, max_num_batches=1)
             model.fix_ranges()
             assert options.INT8_LINEAR == 'auto'
+            # (options.INT8_CALIBRATION: the calibrating forward above ran its 12 Linears as integer GEMMs too, one call each)
+            assert calls == {'linear_i8': 12}, calls
+            calls.clear()
             merged = model(ids)
             seen = dict(calls)
             calls.clear()
@@ -347,3 +350,78 @@ def test_bert_base_default_route_is_the_integer_route_and_no_further_from_the_re
         before = INT8_STATS['kernel_calls']
         model(ids.cuda())
         assert INT8_STATS['kernel_calls'] == before
+
+
+@pytest.mark.gpu
+@pytest.mark.default_route
+def test_calibrating_forward_on_the_integer_route():
+    """options.INT8_CALIBRATION: with autograd off, the Linears of a CALIBRATING forward whose input quantizer has just set
+    its range run the exact integer GEMM (the fp32 result goes to the output quantizer's estimator as usual).  Against the
+    layered calibration of the same model on the same batches: the weight grids are bit-equal (they do not depend on the
+    route), every activation site estimates a range within the bar the layered GPU route itself is held to against the
+    reference (10 % of the site's span; a random-init quantized network amplifies the GEMMs' round-off), the calibrated
+    model's logits agree to 10 % of their span, and -- with in-place estimator state -- a recorded calibrating forward
+    replays to the bits of the eager one.  Small GEMMs (options.INT8_CALIBRATION_MIN_MACS) keep torch's fp32 GEMM."""
+    from harness.bert import build_bert_base, quantizer_census
+    from quantization import options
+    from quantization.autoquant_utils import INT8_STATS
+    from quantization.graphs import GraphedForward
+    from quantization.quantizers import QMethods
+    from quantization.range_estimators import RangeEstimators
+    qp = dict(method=QMethods.symmetric_uniform, act_method=QMethods.asymmetric_uniform, n_bits=8, n_bits_act=8,
+              weight_range_method=RangeEstimators.current_minmax, act_range_method=RangeEstimators.running_minmax)
+    g = torch.Generator().manual_seed(77)
+    batches = [torch.randint(1000, 30000, (16, 128), generator=g).cuda() for _ in range(3)]
+    keep = options.INT8_CALIBRATION, options.INT8_CALIBRATION_MIN_MACS, options.INPLACE_CALIBRATION_STATE
+    res = {}
+    try:
+        for on in (False, True):
+            options.INT8_CALIBRATION, options.INT8_CALIBRATION_MIN_MACS = on, 0
+            model, _ = build_bert_base(seed=1000, num_layers=3, **qp)
+            model = model.cuda().eval()
+            with torch.no_grad():
+                model.set_quant_state(True, True)
+                model.estimate_ranges()
+                before = INT8_STATS['kernel_calls']
+                for b in batches:
+                    model(b)
+                calls = INT8_STATS['kernel_calls'] - before
+                act, wts = quantizer_census(model)
+                res[on] = dict(calls=calls,
+                               act=torch.stack([torch.stack([m.quantizer.x_min.reshape(()), m.quantizer.x_max.reshape(())]) for _, m in act]).cpu(),
+                               wts=[m.quantizer._delta.clone().cpu() for _, m in wts])
+                model.fix_ranges()
+                res[on]['logits'] = model(batches[0]).cpu()
+        assert res[False]['calls'] == 0 and res[True]['calls'] == 3 * 3 * 6, (res[False]['calls'], res[True]['calls'])
+        assert all(torch.equal(a, b) for a, b in zip(res[False]['wts'], res[True]['wts']))
+        a, b = res[False]['act'], res[True]['act']
+        span = (a[:, 1] - a[:, 0]).abs().clamp_min(1e-12)
+        dev = (a - b).abs().max(dim=1).values / span
+        assert float(dev.max()) <= 0.10 and float(dev.median()) <= 0.01, (float(dev.max()), float(dev.median()))
+        assert float(dev[:3].max()) == 0.0                  # the embedding block's three sites sit in front of every GEMM
+        la, lb = res[False]['logits'], res[True]['logits']
+        assert float((la - lb).abs().max()) <= 0.10 * float(la.max() - la.min())
+        # the size rule: at [16,128] tokens none of BERT-base's GEMMs reaches the default threshold
+        options.INT8_CALIBRATION_MIN_MACS = keep[1]
+        model, _ = build_bert_base(seed=1000, num_layers=1, **qp)
+        model = model.cuda().eval()
+        with torch.no_grad():
+            model.set_quant_state(True, True)
+            model.estimate_ranges()
+            before = INT8_STATS['kernel_calls']
+            model(batches[0])
+            assert INT8_STATS['kernel_calls'] == before
+            # recorded == eager (in-place estimator state), integer GEMMs in both
+            options.INT8_CALIBRATION_MIN_MACS = 0
+            options.INPLACE_CALIBRATION_STATE = True
+            model(batches[0])
+            import copy
+            twin = copy.deepcopy(model)
+            gf = GraphedForward(model, batches[1])
+            y_graph = gf(batches[1]).clone()
+            y_eager = twin(batches[1])
+            assert torch.equal(y_graph, y_eager)
+            for (_, m1), (_, m2) in zip(quantizer_census(model)[0], quantizer_census(twin)[0]):
+                assert torch.equal(m1.quantizer._delta, m2.quantizer._delta) and torch.equal(m1.quantizer._zero_float, m2.quantizer._zero_float)
+    finally:
+        options.INT8_CALIBRATION, options.INT8_CALIBRATION_MIN_MACS, options.INPLACE_CALIBRATION_STATE = keep

@@ -158,10 +158,34 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
 
     def forward(self, x, offsets=None):
         if options.int8_active() and (options.INT8_LINEAR is True or not self.training):
-            y = self._int8_forward(x)
+            amgr = self._modules.get('activation_quantizer')
+            calibrating = self._quant_a and type(amgr) is QuantizationManager and amgr._estimating()
+            y = self._int8_calibrating_forward(x) if calibrating else self._int8_forward(x)
             if y is not None:
                 return y
         return super().forward(x, offsets)
+
+    def _int8_calibrating_forward(self, x):
+        """options.INT8_CALIBRATION: this layer's output quantizer is still ESTIMATING its range, but the input lies on
+        the grid its producer just set (provenance: the estimating quantizer tags what it returns) and the weight grid
+        is known -- so the GEMM is the same exact integer contraction as in a fixed-range forward (the fp32 simulation
+        of the layered route approximates this very value), with bias and activation function in the epilogue and the
+        un-quantized fp32 result handed to the estimator as usual.  None: not applicable, the layered modules run."""
+        amgr = self._modules.get('activation_quantizer')
+        if (not options.INT8_CALIBRATION or self.training or not self._quant_a or type(amgr) is not QuantizationManager
+                or not amgr._estimating() or torch.is_grad_enabled()):
+            return None
+        # small GEMMs stay with torch's fp32 GEMM: the integer path costs one more launch (the input's indices) and ~60 us
+        # more host time per layer than F.linear -- at [8,128] tokens an eager calibrating forward was 12.2 instead of 7.8 ms
+        if x.is_cuda and x.numel() // self.in_features * self.in_features * self.out_features < options.INT8_CALIBRATION_MIN_MACS:
+            return None
+        pre = self._int8_forward(x, with_output_quantizer=False)     # bias + activation function applied, no quantizer
+        if pre is None:
+            return None
+        self._save('', pre)
+        out = amgr.quantize(pre)
+        self._save('_Q', out)
+        return out
 
     # ---- integer path ---------------------------------------------------------------------------
     def _int8_weights(self):
@@ -194,12 +218,19 @@ class QuantLinear(QuantizationHijacker, nn.Linear):
         if _hooked(wmgr, getattr(wmgr, 'quantizer', None), self._modules.get('activation_quantizer'),
                    getattr(self._modules.get('activation_quantizer'), 'quantizer', None), self.activation_function):
             return False                 # somebody observes a stage the fused launch would skip: layered route
-        return bool(self._quant_w and self.activation_save_target is None
-                    and isinstance(wmgr, QuantizationManager) and wmgr.quantizer.is_initialized
+        if not (self._quant_w and self.activation_save_target is None and isinstance(wmgr, QuantizationManager)):
+            return False
+        if wmgr.state != Qstates.fix_ranges:
+            # calibrating forward (options.INT8_CALIBRATION): the weight range is whatever the layered route's first step
+            # -- get_params(): estimate, fake-quantize, cache in eval mode -- leaves behind; run exactly that step
+            if not (options.INT8_CALIBRATION and not self.training and wmgr._estimating() and not torch.is_grad_enabled()):
+                return False
+            self.get_params()
+        return bool(wmgr.quantizer.is_initialized
                     and wmgr.quantizer.symmetric and wmgr.quantizer.n_bits <= 8
                     and wmgr.quantizer.scale_domain == 'linear'
                     and wmgr.quantizer._delta.numel() in (1, self.out_features)
-                    and wmgr.state == Qstates.fix_ranges and not wmgr.quantizer._delta.requires_grad)
+                    and not wmgr.quantizer._delta.requires_grad)
 
     def _int8_plan(self, x, with_output_quantizer=True):
         """Arguments of the integer evaluation of this layer for input `x`, or None when the configuration does not

@@ -5,9 +5,11 @@ import torch
 # quantizer fused into the epilogue (tq_linear_i8_fwd); quantizers with a fixed per-tensor range then also emit their int8
 # grid indices in the same launch so that the GEMM can consume them directly, and the harness models run their fused
 # fixed-range tails / attention cores.
-#   'auto' (default): whenever autograd is off (torch.no_grad() / inference_mode) -- the fixed-range EVALUATION forward.
-#           Calibration (ranges not fixed: every plan declines), training and anything with forward hooks on the modules
-#           involved keep the layered route (one launch per quantizer around torch's fp32 GEMM, the reference's module chain).
+#   'auto' (default): whenever autograd is off (torch.no_grad()) -- the fixed-range EVALUATION forward (and, for large GEMMs,
+#           calibrating forwards: INT8_CALIBRATION below).
+#           Training and anything with forward hooks on the modules involved keep the layered route (one launch per
+#           quantizer around torch's fp32 GEMM, the reference's module chain); so do the fused tails / attention core / small
+#           GEMMs of a calibrating forward (their quantizers are still estimating).
 #   True:   also under autograd (QAT forward on the matrix cores, straight-through backward).
 #   False:  never -- the layered route everywhere.
 # Why 'auto' is the default (round 5, profiles/r05/int_vs_reference.json, tests/test_bert_e2e.py / test_mobilebert_e2e.py
@@ -18,6 +20,22 @@ import torch
 # deviation 1.283 vs 1.291 steps; first layer 99.80 % vs 99.20 %) -- while it is deterministic, exact arithmetic and 4x
 # faster (3.26 -> 0.80 ms).
 INT8_LINEAR = 'auto'
+
+# Calibrating forwards (ranges still being estimated, autograd off) on the integer route as well: a quantized Linear whose
+# INPUT was produced by a quantizer that has just set its range for this batch (per-tensor asymmetric <= 8 bit) and whose
+# weight grid is known runs the exact integer GEMM (bias + activation function in the epilogue, fp32 result to the output
+# quantizer's estimator) instead of the fp32 simulation -- the GEMMs are 2 of the 4.2 ms of a BERT-base calibrating forward
+# at [8,128] and 25 of 33 ms at [128,128].  The statistics each estimator sees are those of the EXACT products the fp32
+# GEMMs approximate (ranges differ from the layered GPU route's by its round-off, as the layered GPU route's differ from
+# the reference's CPU GEMMs); everything else -- estimators, state machine, exchanges of a sharded calibration -- is the
+# layered code.  Follows INT8_LINEAR: off where that is off (and under autograd / training mode / forward hooks).
+INT8_CALIBRATION = True
+# ... for GEMMs of at least this many multiply-accumulates (M x K x N; 2^33 = 16 384 tokens through a 768 x 768 Linear, 4 096
+# through BERT's feed-forward Linears).  Below, the ~45 us of extra host work + one more launch per layer (the input's
+# indices) cost an EAGER calibrating forward more than the fp32 GEMM they replace (profiles/r06/calib_int8_ab.txt: with
+# every Linear on the integer path [8,128] went 7.8 -> 12.2 ms eager while its hipGraph went 4.2 -> 3.2 ms; [128,128]:
+# 33.1 -> 19.1 ms either way).  The rule depends on the shapes only, so a recorded forward takes the route the eager one took.
+INT8_CALIBRATION_MIN_MACS = 1 << 33
 
 # Integer Linears with a GELU: evaluate activation + output quantizer through a staircase table built on the device from
 # the quantizer's range (csrc/tq_stair.hip, one extra launch per range state) instead of the erf fit + exact quotient in

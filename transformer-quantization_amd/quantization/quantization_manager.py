@@ -260,10 +260,19 @@ class QuantizationManager(nn.Module):
             if est is None:
                 raise RuntimeError('this manager was built with a fixed range: no estimator to run')
             y = self._fused_estimating_forward(x)
-            if y is not None:
-                return y
-            cur_xmin, cur_xmax = est(x)
-            self.set_quant_range(cur_xmin, cur_xmax)
+            if y is None:
+                cur_xmin, cur_xmax = est(x)
+                self.set_quant_range(cur_xmin, cur_xmax)
+                y = mods['quantizer'](x)
+            if options.INT8_CALIBRATION and options.int8_active():
+                # calibrating forward on the integer route: what this call returns lies on the grid it has just set -- the
+                # consuming integer Linear derives the int8 indices itself (one index-only launch: no estimator kernel
+                # emits them) and reads the parameters from the device buffers recorded here
+                q = mods['quantizer']
+                if (type(q) is AsymmetricUniformQuantizer and q.n_bits <= 8 and q.scale_domain == 'linear'
+                        and y.dtype is torch.float32 and q._delta is not None and q._delta.numel() == 1):
+                    provenance.tag(y, q)
+            return y
         return mods['quantizer'](x)
 
     def __getstate__(self):
