@@ -51,7 +51,38 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+RESOURCES = os.path.join(LIBDIR, 'kernel_resources.json')
+
+
+def _parse_resources(stderr_text):
+    """clang's -Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: {vgpr, agpr, scratch, occupancy, lds}};
+    everything else the compiler wrote to stderr (warnings, errors) is returned for printing."""
+    import re
+    res, cur, rest = {}, None, []
+    for line in stderr_text.splitlines():
+        m = re.search(r'remark:\s+(.*?)\s+\[-Rpass-analysis=kernel-resource-usage\]', line)
+        if not m:
+            if 'Rpass-analysis' not in line:
+                rest.append(line)
+            continue
+        t = m.group(1)
+        if t.startswith('Function Name:'):
+            cur = res.setdefault(t.split(':', 1)[1].strip(), {})
+        elif cur is not None and ':' in t:
+            k, v = (x.strip() for x in t.split(':', 1))
+            key = {'VGPRs': 'vgpr', 'AGPRs': 'agpr', 'ScratchSize [bytes/lane]': 'scratch', 'Occupancy [waves/SIMD]': 'occupancy',
+                   'LDS Size [bytes/block]': 'lds'}.get(k)
+            if key and v.isdigit():
+                cur[key] = int(v)
+    return res, '\n'.join(rest)
+
+
 def build(force=False, verbose=True):
+    """Compile stale sources, link lib/libtq_hip.so, and write lib/kernel_resources.json: registers, scratch bytes per lane,
+    occupancy and LDS of EVERY kernel as the compiler reports them (tests/test_abi.py asserts that no kernel uses scratch
+    memory: round 6 shipped, for two collections, a header change that made the register allocator spill the accumulators
+    of the 128 x 128 tile Linear -- 2.5x slower at M = 8192 -- and nothing but the kernel table showed it)."""
+    import json
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     extra = os.environ.get('TQ_EXTRA_HIPCC_FLAGS', '').split()      # e.g. -DTQ_I8_DBG_BUILD for tools/tuning/i8_dbg.py
     os.makedirs(LIBDIR, exist_ok=True)
@@ -61,19 +92,32 @@ def build(force=False, verbose=True):
     for src in _sources():
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + flags_for(src) + extra + ['-c', src, '-o', obj]
+        if force or _stale(obj, [src] + hdrs) or not os.path.exists(obj[:-2] + '.res.json'):
+            cmd = [hipcc] + flags_for(src) + extra + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
-        if p.wait() != 0:
+            procs.append((src, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    for src, obj, p in procs:
+        _, err = p.communicate()
+        res, rest = _parse_resources(err or '')
+        if rest.strip():
+            print(rest, file=sys.stderr, flush=True)
+        if p.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}')
-    if force or procs or _stale(LIB, objs):
+        with open(obj[:-2] + '.res.json', 'w') as f:
+            json.dump(res, f)
+    if force or procs or _stale(LIB, objs) or not os.path.exists(RESOURCES):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        merged = {}
+        for obj in objs:
+            with open(obj[:-2] + '.res.json') as f:
+                for k, v in json.load(f).items():
+                    merged[k] = dict(v, source=os.path.basename(obj)[:-2] + '.hip')
+        with open(RESOURCES, 'w') as f:
+            json.dump(merged, f, indent=0, sort_keys=True)
     return LIB
 
 

@@ -29,22 +29,34 @@ struct QP {
 };
 
 __device__ __forceinline__ float grid_top(int n_bits) {
-  // 2.0 ** n_bits - 1 evaluated in double like the python float, then narrowed to fp32: 2^n - 1 exactly up to 24 bits,
-  // 2^n above (2^n - 1 is not an fp32 value there and rounds to nearest).  Integer arithmetic instead of three
-  // double-precision instructions (round 6: the prologue of a latency-bound fused launch derives up to six quantizers).
-  return n_bits <= 24 ? (float)((1u << (n_bits & 31)) - 1u) : ldexpf(1.0f, n_bits);
+  // 2.0 ** n_bits - 1 evaluated in double like the python float, then narrowed to fp32
+  return (float)(ldexp(1.0, n_bits) - 1.0);
 }
 
+// The same value from integer arithmetic (n_bits <= 24: the ABI's range) for the quantizer derivations of kernel prologues
+// (round 6: three double-precision instructions per quantizer otherwise; a latency-bound fused launch derives up to six).
+// NOT used for the explicit grid_top() calls of the integer Linear: with them in integer form the register allocator spilt
+// the accumulators of its 128 x 128 tile kernel (272 bytes of scratch per lane, M = 8192: 45 -> 114 us).
+__device__ __forceinline__ float grid_top_small(int n_bits) { return (float)((1u << (n_bits & 31)) - 1u); }
+
 // scale = exp(delta) in the log domain, max(delta, eps) otherwise (quantizers.py:142-147).  log_domain is a wave-uniform
-// kernel argument: a REAL branch -- written as a select, expf (~15 VALU instructions) was evaluated speculatively by every
-// kernel for every quantizer.  (The volatile asm keeps the compiler from if-converting the block back.)
+// kernel argument: a REAL branch -- written as a select, expf (~15 VALU instructions and up to 30 registers: the fused
+// LayerNorm tails went from 3 to 4 waves per SIMD) is evaluated speculatively for every quantizer of every prologue.  The
+// volatile asm keeps the compiler from if-converting the block back.  TQ_SCALE_SELECT (defined by csrc/tq_linear_i8.hip
+// before this header): the select form -- the asm also stops the unrolling of the epilogue loops of the 128 x 128 tile
+// Linear, whose accumulators then live in scratch memory (272 bytes per lane; M = 8192: 45 -> 114 us, caught by
+// profiles/r06/kernel_table.md).
 __device__ __forceinline__ float effective_scale(int log_domain, float d, float eps) {
+#ifdef TQ_SCALE_SELECT
+  return log_domain ? expf(d) : (d < eps ? eps : d);
+#else
   float s = d < eps ? eps : d;
   if (log_domain) {
     s = expf(d);
     asm volatile("" : "+v"(s));
   }
   return s;
+#endif
 }
 
 __device__ __forceinline__ float clamp_nanprop(float v, float lo, float hi) {
@@ -61,11 +73,11 @@ __device__ __forceinline__ QP make_qp(const tq_quantizer& q, uint64_t p) {
   if (q.symmetric) {
     const bool sgn = q.signed_flag != nullptr && q.signed_flag[0] != 0;
     r.zp = 0.0f;                                                  // :330-332
-    r.lo = sgn ? -ldexpf(1.0f, q.n_bits - 1) : 0.0f;              // :321-323
-    r.hi = grid_top(q.n_bits - (sgn ? 1 : 0));                    // :325-328
+    r.lo = sgn ? -ldexpf(1.0f, q.n_bits - 1) : 0.0f;         // :321-323
+    r.hi = grid_top_small(q.n_bits - (sgn ? 1 : 0));                    // :325-328
   } else {
     r.lo = 0.0f;                                                  // :132-135
-    r.hi = grid_top(q.n_bits);                                    // :137-140
+    r.hi = grid_top_small(q.n_bits);                                    // :137-140
     r.zp = clamp_nanprop(rintf(q.zero_float[p]), r.lo, r.hi);     // :149-153
   }
   return r;
@@ -137,10 +149,10 @@ __device__ __forceinline__ QP qp_from_raw(const tq_quantizer& q, const QRaw& w) 
     const bool sgn = q.signed_flag != nullptr && w.s != 0;
     r.zp = 0.0f;
     r.lo = sgn ? -ldexpf(1.0f, q.n_bits - 1) : 0.0f;
-    r.hi = grid_top(q.n_bits - (sgn ? 1 : 0));
+    r.hi = grid_top_small(q.n_bits - (sgn ? 1 : 0));
   } else {
     r.lo = 0.0f;
-    r.hi = grid_top(q.n_bits);
+    r.hi = grid_top_small(q.n_bits);
     r.zp = clamp_nanprop(rintf(w.z), r.lo, r.hi);
   }
   return r;

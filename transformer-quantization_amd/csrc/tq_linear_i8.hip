@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#define TQ_SCALE_SELECT          // tq_device.h effective_scale: the select form (see there: scratch in the 128 x 128 tile kernel otherwise)
 #include "tq_device.h"
 #include "tq_host.h"
 
