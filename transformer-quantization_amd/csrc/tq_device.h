@@ -42,21 +42,19 @@ __device__ __forceinline__ float grid_top_small(int n_bits) { return (float)((1u
 // scale = exp(delta) in the log domain, max(delta, eps) otherwise (quantizers.py:142-147).  log_domain is a wave-uniform
 // kernel argument: a REAL branch -- written as a select, expf (~15 VALU instructions and up to 30 registers: the fused
 // LayerNorm tails went from 3 to 4 waves per SIMD) is evaluated speculatively for every quantizer of every prologue.  The
-// volatile asm keeps the compiler from if-converting the block back.  TQ_SCALE_SELECT (defined by csrc/tq_linear_i8.hip
-// before this header): the select form -- the asm also stops the unrolling of the epilogue loops of the 128 x 128 tile
-// Linear, whose accumulators then live in scratch memory (272 bytes per lane; M = 8192: 45 -> 114 us, caught by
-// profiles/r06/kernel_table.md).
+// volatile asm keeps the compiler from if-converting the block back.  SELECT = true: the select form, for the 128 x 128
+// tile integer Linear -- there the asm stops the unrolling of the epilogue loops and the accumulators end up in scratch
+// memory (272 bytes per lane; M = 8192: 45 -> 114 us, caught by profiles/r06/kernel_table.md; guarded since by
+// tests/test_abi.py::test_no_kernel_uses_scratch_memory).
+template <bool SELECT = false>
 __device__ __forceinline__ float effective_scale(int log_domain, float d, float eps) {
-#ifdef TQ_SCALE_SELECT
-  return log_domain ? expf(d) : (d < eps ? eps : d);
-#else
+  if (SELECT) return log_domain ? expf(d) : (d < eps ? eps : d);
   float s = d < eps ? eps : d;
   if (log_domain) {
     s = expf(d);
     asm volatile("" : "+v"(s));
   }
   return s;
-#endif
 }
 
 __device__ __forceinline__ float clamp_nanprop(float v, float lo, float hi) {
@@ -66,10 +64,11 @@ __device__ __forceinline__ float clamp_nanprop(float v, float lo, float hi) {
   return v;
 }
 
+template <bool SELECT = false>
 __device__ __forceinline__ QP make_qp(const tq_quantizer& q, uint64_t p) {
   QP r;
   const float d = q.delta[p];
-  r.scale = effective_scale(q.log_domain, d, q.eps);             // quantizers.py:142-147
+  r.scale = effective_scale<SELECT>(q.log_domain, d, q.eps);             // quantizers.py:142-147
   if (q.symmetric) {
     const bool sgn = q.signed_flag != nullptr && q.signed_flag[0] != 0;
     r.zp = 0.0f;                                                  // :330-332
@@ -142,9 +141,10 @@ __device__ __forceinline__ void qraw_arrived(QRaw& w) {
   w.s = s;
 }
 
+template <bool SELECT = false>
 __device__ __forceinline__ QP qp_from_raw(const tq_quantizer& q, const QRaw& w) {
   QP r;
-  r.scale = effective_scale(q.log_domain, w.d, q.eps);
+  r.scale = effective_scale<SELECT>(q.log_domain, w.d, q.eps);
   if (q.symmetric) {
     const bool sgn = q.signed_flag != nullptr && w.s != 0;
     r.zp = 0.0f;

@@ -20,7 +20,6 @@
 #include <algorithm>
 #include <type_traits>
 
-#define TQ_SCALE_SELECT          // tq_device.h effective_scale: the select form (see there: scratch in the 128 x 128 tile kernel otherwise)
 #include "tq_device.h"
 #include "tq_host.h"
 
@@ -408,6 +407,7 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
                                                      int kg, const QP& qo, int shift, float sx,
                                                      const f32x4 (*res_pre)[MI] = nullptr /* residual in registers */,
                                                      int8_t* keep = nullptr /* staging area: the indices stay there (MI == 1) */) {
+  constexpr bool BIG = NI * MI >= 16;          // the 128 x 128 tile kernel: tq_device.h effective_scale's select form (see there)
   const uint32_t og = out_group(p, n0);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -437,12 +437,12 @@ __device__ __forceinline__ void linear_epilogue_generic(const LinArgs& p, v4i (&
         }
         if (p.tail == 2) {
           v = v + (res_pre != nullptr ? res_pre[i][j][r] : p.residual[rat + r]);
-          if (p.on_t1) v = q_dequant(q_index(v, make_qp(p.q_t1, 0)), make_qp(p.q_t1, 0));
+          if (p.on_t1) v = q_dequant(q_index(v, make_qp<BIG>(p.q_t1, 0)), make_qp<BIG>(p.q_t1, 0));
         }
         if (p.tail >= 1) {
           v = v * p.nn_w[n + r] + p.nn_b[n + r];
           if (p.on_t2) {
-            const QP q2 = make_qp(og == 1 ? p.q_t2b : (og == 2 ? p.q_t2c : p.q_t2), 0);
+            const QP q2 = make_qp<BIG>(og == 1 ? p.q_t2b : (og == 2 ? p.q_t2c : p.q_t2), 0);
             const float xi = q_index(v, q2);
             oi4.e[r] = (int8_t)((int)xi - 128);
             v = q_dequant(xi, q2);
@@ -538,14 +538,15 @@ __device__ __forceinline__ void epilogue_arrived(EpiRaw& w) {
   }
 }
 
-template <bool WITH_TAIL>
+// SEL: tq_device.h effective_scale's select form (the 128 x 128 tile kernel: see there)
+template <bool WITH_TAIL, bool SEL = false>
 __device__ __forceinline__ EpiCtx epilogue_finish(const LinArgs& p, const EpiRaw& w) {
   EpiCtx c;
   c.sx = w.dx < p.x_eps ? p.x_eps : w.dx;
   const int zx = (int)clamp_nanprop(rintf(w.zx), 0.0f, grid_top(p.x_n_bits));
   c.shift = 128 - zx;
   c.qo = QP{1.f, 0.f, 0.f, 0.f};
-  if (p.has_q) c.qo = qp_from_raw(w.qsel, w.qo);
+  if (p.has_q) c.qo = qp_from_raw<SEL>(w.qsel, w.qo);
   c.qf = make_qf(c.qo);
   c.fast = p.act != ACT_TANH && (!p.has_q || c.qf.ok) && p.fast_epi != 0;
   c.stair = false;
@@ -556,8 +557,8 @@ __device__ __forceinline__ EpiCtx epilogue_finish(const LinArgs& p, const EpiRaw
   }
   c.qf1 = c.qf2 = c.qf;
   if (WITH_TAIL) {
-    c.qf1 = make_qf(p.on_t1 ? qp_from_raw(p.q_t1, w.q1) : QP{1.f, 0.f, 0.f, 1.f});
-    c.qf2 = make_qf(p.on_t2 ? qp_from_raw(w.t2sel, w.q2) : QP{1.f, 0.f, 0.f, 1.f});
+    c.qf1 = make_qf(p.on_t1 ? qp_from_raw<SEL>(p.q_t1, w.q1) : QP{1.f, 0.f, 0.f, 1.f});
+    c.qf2 = make_qf(p.on_t2 ? qp_from_raw<SEL>(w.t2sel, w.q2) : QP{1.f, 0.f, 0.f, 1.f});
     c.fast = c.fast && p.act == ACT_NONE && c.qf1.ok && c.qf2.ok;
   }
   return c;
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(kBlock, WT == 64 ? 2 : 4) void linear_i8_lds_k(LinA
     for (int s = 0; s < (NS == 2 ? 2 : NS - 2); ++s)
       if ((uint32_t)s < nk) issue(s, s * 128);
     epilogue_arrived<WITH_TAIL>(eraw);
-    const EpiCtx ectx = epilogue_finish<WITH_TAIL>(p, eraw);
+    const EpiCtx ectx = epilogue_finish<WITH_TAIL, WT == 64>(p, eraw);
     if (tid < BT) {
       cst[tid] = ectx.sx * (ld_dw < p.w_eps ? p.w_eps : ld_dw);
       cst[BT + tid] = ld_b;
