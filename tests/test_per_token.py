@@ -115,9 +115,14 @@ def test_per_token_and_dynamic_gpu_equals_reference(fused):
     ((4, 6, 4104), 1),                              # rows longer than the wave kernels take: the block-per-row kernels
     ((131, 500, 136), 1),                           # 17 / 34 vectors per row: the flat U-row batches with ragged last iteration
 ])
-def test_row_parameter_launch_shapes_vs_oracle(dtype, shape, axis):
+@pytest.mark.parametrize('rows_flat', [None, '2', '3'], ids=['by-size', 'flat-per-lane', 'flat-table'])
+def test_row_parameter_launch_shapes_vs_oracle(dtype, shape, axis, rows_flat, monkeypatch):
     """Statistics, parameters, indices and outputs for row-parameter layouts through the wave-per-(parameter, slice)
-    kernels and their neighbours, against the oracle on the same tensor."""
+    kernels and their neighbours, against the oracle on the same tensor.  TQ_ROWS_FLAT = 2 / 3: the same through the
+    flat-tile kernels that large launches take (fq_rows_flat: parameters per lane; fq_rows_tab: per tile into LDS, rows of
+    >= 4 vectors)."""
+    if rows_flat is not None:
+        monkeypatch.setenv('TQ_ROWS_FLAT', rows_flat)
     from oracle import tq_oracle as O
     from quantization import _hip
     be = _hip.backend()
@@ -227,3 +232,41 @@ def test_misaligned_and_odd_row_lengths_take_the_fallback_kernels(dtype):
         ya, ia = be.fake_quant(aligned, ref[2], ref[3], None, 8, False, False, 1e-8, T, inner, idx_dtype=torch.uint8)
         ys, is_ = be.fake_quant(skewed, ref[2], ref[3], None, 8, False, False, 1e-8, T, inner, idx_dtype=torch.uint8)
         assert torch.equal(ya, ys) and torch.equal(ia, is_) and torch.equal(ya, ref[5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_per_token_full_size_properties(dtype):
+    """BASELINE's full activation size with per-token ranges ([256,512,768]: 201 / 403 MB, above the size from which the
+    flat-tile kernel fq_rows_tab takes row-parameter launches): statistics == torch's reductions, idempotence on the fixed
+    grid, indices on the grid and consistent with the output, the wave-per-row route (TQ_ROWS_FLAT=0) bit-identical, and
+    slabs at both ends and in the middle of the tensor against the oracle."""
+    from oracle import tq_oracle as O
+    from quantization import _hip
+    be = _hip.backend()
+    B, T, D = 256, 512, 768
+    torch.manual_seed(77)
+    x = torch.randn(B, T, D, device='cuda', dtype=dtype)
+    x[..., 308] *= 20
+    x *= torch.linspace(0.5, 3.0, T, device='cuda', dtype=dtype).view(1, T, 1)
+    mn, mx = be.minmax(x, T, D)
+    xt = x.float().transpose(0, 1).reshape(T, -1)
+    assert torch.equal(mn, xt.amin(1)) and torch.equal(mx, xt.amax(1))
+    d, z = be.set_range_asym(mn, mx, 8, 1e-8, False)
+    y, idx = be.fake_quant(x, d, z, None, 8, False, False, 1e-8, T, D, idx_dtype=torch.uint8)
+    os.environ['TQ_ROWS_FLAT'] = '0'
+    try:
+        y0, idx0 = be.fake_quant(x, d, z, None, 8, False, False, 1e-8, T, D, idx_dtype=torch.uint8)
+    finally:
+        os.environ.pop('TQ_ROWS_FLAT')
+    assert torch.equal(y, y0) and torch.equal(idx, idx0)
+    y2, _ = be.fake_quant(y, d, z, None, 8, False, False, 1e-8, T, D)
+    assert torch.equal(y2, y)                                              # Q(Q(x)) == Q(x)
+    _, idx_only = be.fake_quant(x, d, z, None, 8, False, False, 1e-8, T, D, want_y=False, idx_dtype=torch.uint8)
+    assert torch.equal(idx_only, idx)
+    zp = torch.round(z).clamp(0, 255).view(1, T, 1)
+    deq = (d.view(1, T, 1) * (idx.float() - zp)).to(dtype)
+    assert torch.equal(deq, y)
+    for b in (0, B // 2 + 1, B - 1):
+        ref_idx, ref_y = O.fake_quant_lowp(x[b:b + 1].cpu(), d.cpu(), z.cpu(), 8, False, axis=1)
+        assert torch.equal(idx[b:b + 1].cpu().float(), ref_idx) and torch.equal(y[b:b + 1].cpu(), ref_y)

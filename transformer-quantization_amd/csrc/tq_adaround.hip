@@ -129,11 +129,14 @@ __global__ __launch_bounds__(kBlock) void ada_fwd_k(const float* __restrict__ w,
   const uint64_t nv = n / V;
   const float inv_temp = MODE == TQ_ADA_SIGMOID_TEMP ? 1.0f / temp : 1.0f;
   const bool one = q.n_params == 1;
-  QP p = make_qp(q, 0);                              // per-tensor grid: loop-invariant
+  // (make_qp's select form in this file: the parameters are also derived per vector inside the element loops, where the
+  // volatile asm of the branch form blocks hoisting; one box, ada_bwd_adam_k [30522,768]: 128.6 us against 136.1 us,
+  // profiles/r06/header_ab_same_box.txt)
+  QP p = make_qp<true>(q, 0);                              // per-tensor grid: loop-invariant
   float rcp = guarded_rcp(p.scale);
   for (uint64_t iv = (uint64_t)blockIdx.x * kBlock + threadIdx.x; iv < nv; iv += (uint64_t)gridDim.x * kBlock) {
     if (!one) {
-      p = make_qp(q, par_index(q, iv * V));
+      p = make_qp<true>(q, par_index(q, iv * V));
       rcp = guarded_rcp(p.scale);
     }
     const vec wv = reinterpret_cast<const vec*>(w)[iv], av = reinterpret_cast<const vec*>(alpha)[iv];
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void ada_fwd_k(const float* __restrict__ w,
 __global__ __launch_bounds__(kBlock) void ada_init_k(const float* __restrict__ w, float* __restrict__ alpha, uint64_t n,
                                                      tq_quantizer q, int mode, float temp) {
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    const QP p = make_qp(q, par_index(q, i));
+    const QP p = make_qp<true>(q, par_index(q, i));
     const float x = w[i] / p.scale;
     const float rest = x - floorf(x);
     float a;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void ada_bwd_k(const float* __restrict__ w,
                                                     const float* __restrict__ g_wq, float* __restrict__ g_alpha,
                                                     uint64_t n, tq_quantizer q, int mode, float temp) {
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    const QP p = make_qp(q, par_index(q, i));
+    const QP p = make_qp<true>(q, par_index(q, i));
     float dh;
     const float h = ada_h_fast(alpha[i], mode, mode == TQ_ADA_SIGMOID_TEMP ? 1.0f / temp : 1.0f, dh);
     float xi = floor_quot(w[i], p.scale, guarded_rcp(p.scale)) + h;
@@ -203,11 +206,11 @@ __global__ __launch_bounds__(kBlock) void ada_bwd_adam_k(const float* __restrict
   const bool reg_on = reg_w != 0.0f;
   const float reg_k = reg_on ? -2.0f * reg_w * beta : 0.0f, bm1 = reg_on ? beta - 1.0f : 1.0f;
   const bool one = q.n_params == 1;
-  QP p = make_qp(q, 0);                              // per-tensor grid: loop-invariant
+  QP p = make_qp<true>(q, 0);                              // per-tensor grid: loop-invariant
   float rcp = guarded_rcp(p.scale);
   for (uint64_t iv = (uint64_t)blockIdx.x * kBlock + threadIdx.x; iv < nv; iv += (uint64_t)gridDim.x * kBlock) {
     if (!one) {
-      p = make_qp(q, par_index(q, iv * V));
+      p = make_qp<true>(q, par_index(q, iv * V));
       rcp = guarded_rcp(p.scale);
     }
     const vec wv = reinterpret_cast<const vec*>(w)[iv], gv = reinterpret_cast<const vec*>(g_wq)[iv];

@@ -566,6 +566,121 @@ __global__ __launch_bounds__(kBlock) void fq_rows_wave(const u32x4* __restrict__
   else fq_rows_wave_body<DT, HAS_IDX, NT, false>(x, y, idx, idx_dtype, outer, vpr, n_params, S, p_at, s, p, qf);
 }
 
+// ------------------------------------------------------------------------------ per row, flat tile order (round 6)
+// The same quantizers as fq_rows_wave -- parameters constant along rows of `inner` contiguous elements: per-token
+// activations (reference main.py:359-376), per-channel weights -- in the tile order of fq_tensor: a workgroup owns
+// kBlock * U CONSECUTIVE 16-byte vectors, whatever rows they belong to, and every lane derives the parameters of the row
+// its vector lies in.  fq_rows_wave gives a wave one token position and walks the batch: four streams of 1.5-3 KB rows
+// that lie S x T rows apart (66 % of HBM at [1024,512,768] for bf16 AND for fp32, whose rows fill every lane); here the
+// resident blocks sweep one contiguous window like the per-tensor kernel, at the price of ~45 more instructions per
+// vector (two exact divisions by launch constants, three cached 4-byte parameter reads, make_qp + make_qf per lane),
+// which an HBM-bound kernel has room for (~200 issue slots per vector at 6 TB/s).
+//
+// row = floor(k / vpr), parameter = row mod n_params, both through a double-precision reciprocal: for a < 2^32 the
+// product a * RN(1 / d) is within a * 2^-52 < 2^-20 of a / d, so its truncation is floor(a / d) or -- only when d
+// divides a -- one less; one comparison of the remainder repairs that.
+__device__ __forceinline__ uint32_t div_exact_u32(uint32_t a, uint32_t d, double rd, uint32_t& rem) {
+  uint32_t qt = (uint32_t)((double)a * rd);
+  uint32_t r = a - qt * d;
+  if (r >= d) { r -= d; qt += 1; }
+  rem = r;
+  return qt;
+}
+
+template <int DT, bool HAS_IDX, bool NT, int U>
+__global__ __launch_bounds__(kBlock) void fq_rows_flat(const u32x4* __restrict__ x, u32x4* __restrict__ y,
+                                                       void* __restrict__ idx, int idx_dtype, uint64_t n_vec, uint32_t vpr,
+                                                       double rcp_vpr, double rcp_np, tq_quantizer q) {
+  constexpr int V = Store<DT>::kVec;
+  constexpr uint64_t TILE = (uint64_t)kBlock * U;
+  const uint32_t n_params = (uint32_t)q.n_params;
+  for (uint64_t t0 = (uint64_t)blockIdx.x * TILE; t0 < n_vec; t0 += (uint64_t)gridDim.x * TILE) {
+    const uint64_t i = t0 + threadIdx.x;
+    const bool full = t0 + TILE <= n_vec;
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t k = i + (uint64_t)u * kBlock;
+      if (full || k < n_vec) v[u] = NT ? ld_stream(x + k) : x[k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t k = i + (uint64_t)u * kBlock;
+      if (full || k < n_vec) {
+        uint32_t rem;
+        const uint32_t row = div_exact_u32((uint32_t)k, vpr, rcp_vpr, rem);
+        div_exact_u32(row, n_params, rcp_np, rem);
+        const QP p = make_qp<true>(q, rem);
+        const QF qf = make_qf(p);
+        u32x4 o;
+        if (qf.ok) o = fq_vec<DT, HAS_IDX, true>(v[u], p, idx, idx_dtype, k * V, &qf);
+        else o = fq_vec<DT, HAS_IDX, false>(v[u], p, idx, idx_dtype, k * V, &qf);
+        if (y) { if (NT) st_stream(y + k, o); else y[k] = o; }
+      }
+    }
+  }
+}
+
+// The same with the parameters of the rows a tile touches derived ONCE per tile into LDS (rows of >= 4 vectors: a tile of
+// kBlock * U vectors touches at most kBlock * U / 4 + 2 rows): per vector a local row number (one fma + truncation: exact for
+// offsets below 2^22, see the comment in the body), two broadcast LDS reads and the quantizer itself.  The per-lane form
+// above costs ~45 instructions per vector on top of the quantizer: 78 % of HBM for fp32 but 67 % for bf16 (8 elements per
+// vector) at [1024,512,768], and slower than the wave-per-row kernel on tensors of a few MB (profiles/r06/rows_flat_ab.txt).
+struct RowQ { float scale, rcp, ylo, yhi, zp, lo, hi, ok; };
+
+template <int DT, bool HAS_IDX, bool NT, int U>
+__global__ __launch_bounds__(kBlock) void fq_rows_tab(const u32x4* __restrict__ x, u32x4* __restrict__ y,
+                                                      void* __restrict__ idx, int idx_dtype, uint64_t n_vec, uint32_t vpr,
+                                                      double rcp_vpr, double rcp_np, float rcp_vpr_f, tq_quantizer q) {
+  constexpr int V = Store<DT>::kVec;
+  constexpr uint32_t TILE = kBlock * U;
+  __shared__ __attribute__((aligned(16))) RowQ s_q[TILE / 4 + 2];
+  const uint32_t n_params = (uint32_t)q.n_params;
+  const float half_rcp = 0.5f * rcp_vpr_f;
+  for (uint64_t t0 = (uint64_t)blockIdx.x * TILE; t0 < n_vec; t0 += (uint64_t)gridDim.x * TILE) {
+    const uint64_t i = t0 + threadIdx.x;
+    const bool full = t0 + TILE <= n_vec;
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t k = i + (uint64_t)u * kBlock;
+      if (full || k < n_vec) v[u] = NT ? ld_stream(x + k) : x[k];
+    }
+    uint32_t rem0;
+    const uint32_t row0 = div_exact_u32((uint32_t)t0, vpr, rcp_vpr, rem0);      // first row of the tile, offset inside it
+    for (uint32_t r = threadIdx.x; (uint64_t)r * vpr < (uint64_t)rem0 + TILE; r += kBlock) {
+      uint32_t pi;
+      div_exact_u32(row0 + r, n_params, rcp_np, pi);
+      const QP p = make_qp<true>(q, pi);
+      const QF qf = make_qf(p);
+      s_q[r] = RowQ{p.scale, qf.rcp.x, qf.ylo, qf.yhi, p.zp, p.lo, p.hi, qf.ok ? 1.0f : 0.0f};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t k = i + (uint64_t)u * kBlock;
+      if (full || k < n_vec) {
+        // local row = floor(j / vpr), j = offset from the start of the tile's first row (< vpr + TILE < 2^22):
+        // (j + 0.5) / vpr lies >= 0.5 / vpr away from every integer, the computed value within (j + 0.5) / vpr * 2^-23 of it
+        const uint32_t j = rem0 + (uint32_t)u * kBlock + threadIdx.x;
+        const uint32_t rl = (uint32_t)__builtin_fmaf((float)j, rcp_vpr_f, half_rcp);
+        const RowQ e = s_q[rl];
+        const QP p = {e.scale, e.zp, e.lo, e.hi};
+        QF qf;
+        qf.scale = f32x2{e.scale, e.scale};
+        qf.nscale = f32x2{-e.scale, -e.scale};
+        qf.rcp = f32x2{e.rcp, e.rcp};
+        qf.ylo = e.ylo; qf.yhi = e.yhi; qf.zp = e.zp; qf.ok = e.ok != 0.0f;
+        u32x4 o;
+        if (qf.ok) o = fq_vec<DT, HAS_IDX, true>(v[u], p, idx, idx_dtype, k * V, &qf);
+        else o = fq_vec<DT, HAS_IDX, false>(v[u], p, idx, idx_dtype, k * V, &qf);
+        if (y) { if (NT) st_stream(y + k, o); else y[k] = o; }
+      }
+    }
+    if (t0 + (uint64_t)gridDim.x * TILE < n_vec) __syncthreads();    // the table is rewritten by the next tile
+  }
+}
+
 // ------------------------------------------------------------------------------ fallback
 template <int DT, bool HAS_IDX>
 __global__ __launch_bounds__(kBlock) void fq_scalar(const void* __restrict__ x, void* __restrict__ y,
@@ -646,6 +761,37 @@ static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t 
     else     { if (nt) TQ_LAUNCH_AXIS(true, 1) else TQ_LAUNCH_AXIS(false, 1) }
 #undef TQ_LAUNCH_AXIS
     return check_launch("fq_axis");
+  }
+  // rows of `inner` elements sharing a parameter: the flat-tile kernels once the launch moves >= 192 MB (measured on one
+  // box, profiles/r06/rows_flat_ab.txt: [1024,512,768] 66 -> 73-76 % of HBM for bf16, 67-76 -> 77-78 % for fp32, ahead
+  // from [128,512,768] bf16 / [64,512,768] fp32 upwards; below that -- tensors that stay in the 256 MB infinity cache from
+  // one launch to the next -- the wave-per-row kernel is ahead, and for 16-bit index-only output at every size).
+  // TQ_ROWS_FLAT=0: never, 1: by size, 2: the per-lane form everywhere, 3: the table form everywhere.
+  const int rows_flat = tuning("TQ_ROWS_FLAT", 1);     // (read per launch: tests/test_per_token.py switches it)
+  const uint64_t moved = n * elem_size(DT) * (y != nullptr ? 2 : 1);
+  const bool flat_pays = rows_flat >= 2 || (moved >= (192ull << 20) && (y != nullptr || DT == TQ_F32));
+  if (rows_flat && flat_pays && vec_ok && q.n_params > 1 && q.inner > 1 && q.inner % V == 0 && n_vec_all < (1ull << 32) && n % V == 0 &&
+      q.n_params < (1ull << 32)) {
+    const uint32_t vpr = (uint32_t)(q.inner / V);
+    const double rcp_vpr = 1.0 / (double)vpr, rcp_np = 1.0 / (double)q.n_params;
+#define TQ_LAUNCH_ROWS_FLAT(NTV, UV)                                                                       \
+    hipLaunchKernelGGL((fq_rows_flat<DT, HAS_IDX, NTV, UV>),                                                \
+                       dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n_vec_all, kBlock * UV), 1), kMaxTiles)), \
+                       dim3(kBlock), 0, st, xv, yv, idx, idx_dtype, n_vec_all, vpr, rcp_vpr, rcp_np, q)
+#define TQ_LAUNCH_ROWS_TAB(NTV, UV)                                                                        \
+    hipLaunchKernelGGL((fq_rows_tab<DT, HAS_IDX, NTV, UV>),                                                 \
+                       dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n_vec_all, kBlock * UV), 1), kMaxTiles)), \
+                       dim3(kBlock), 0, st, xv, yv, idx, idx_dtype, n_vec_all, vpr, rcp_vpr, rcp_np, (float)rcp_vpr, q)
+    if (vpr >= 4 && vpr <= (1u << 20) && rows_flat != 2) {       // (TQ_ROWS_FLAT=2: the per-lane form everywhere)
+      if (big) { if (nt) TQ_LAUNCH_ROWS_TAB(true, 4); else TQ_LAUNCH_ROWS_TAB(false, 4); }
+      else     { if (nt) TQ_LAUNCH_ROWS_TAB(true, 1); else TQ_LAUNCH_ROWS_TAB(false, 1); }
+      return check_launch("fq_rows_tab");
+    }
+#undef TQ_LAUNCH_ROWS_TAB
+    if (big) { if (nt) TQ_LAUNCH_ROWS_FLAT(true, 4); else TQ_LAUNCH_ROWS_FLAT(false, 4); }
+    else     { if (nt) TQ_LAUNCH_ROWS_FLAT(true, 1); else TQ_LAUNCH_ROWS_FLAT(false, 1); }
+#undef TQ_LAUNCH_ROWS_FLAT
+    return check_launch("fq_rows_flat");
   }
   if (vec_ok && q.n_params > 1 && q.inner > 1 && q.inner % V == 0 && q.inner / V <= kWaveRowMaxVec &&
       q.n_params <= (1u << 24) && n % (q.n_params * q.inner) == 0) {
