@@ -235,6 +235,38 @@ def test_special_values_nan_inf(q):
     assert torch.equal(idx.cpu()[ok].view(torch.int32), ref_idx[ok].view(torch.int32))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n_bits', [8, 4, 2])
+def test_byte_index_outputs_equal_the_float_indices(q, dtype, n_bits):
+    """uint8 indices and int8(index - 128) (the integer GEMM's operand) for grids inside [0, 255] are packed with one
+    v_cvt_pk_u8_f32 per element (csrc/tq_fake_quant.hip store_idx): equal to the float index tensor converted element by
+    element, NaN inputs give byte 0 / -128 (the conversion's value for NaN, as before), +-inf the grid ends; per-tensor,
+    per-embedding and per-token launches, with and without the dequantised output."""
+    from quantization import _hip
+    be = _hip.backend()
+    g = torch.Generator().manual_seed(n_bits)
+    x = (torch.randn(6, 40, 64, generator=g) * 3).to(dtype)
+    x.view(-1)[[0, 77, 4095, 9000]] = torch.tensor([float('nan'), float('inf'), -float('inf'), float('nan')]).to(dtype)
+    xd = x.to(DEV)
+    for n_params, inner in ((1, 1), (64, 1), (40, 64)):
+        lo = -torch.rand(n_params, generator=g) * 4 - 1
+        hi = torch.rand(n_params, generator=g) * 4 + 1
+        delta, zf = O.asym_params_from_range(lo, hi, n_bits)
+        args = (delta.to(DEV), zf.to(DEV), None, n_bits, False, False, 1e-8, n_params, inner)
+        y, idx = be.fake_quant(xd, *args, idx_dtype=torch.float32)
+        want = torch.nan_to_num(idx, nan=0.0)
+        assert float(want.min()) >= 0 and float(want.max()) <= 2 ** n_bits - 1
+        for want_y in (True, False):
+            y8, i8 = be.fake_quant(xd, *args, want_y=want_y, idx_dtype=torch.uint8)
+            assert i8.dtype == torch.uint8 and torch.equal(i8.float(), want), (n_params, want_y)
+            if want_y:
+                assert torch.equal(y8.view(torch.int16 if y8.element_size() == 2 else torch.int32),
+                                   y.view(torch.int16 if y.element_size() == 2 else torch.int32))
+        if n_params == 1:
+            _, im = be.fake_quant_int8(xd, delta.to(DEV), zf.to(DEV), n_bits, 1e-8)
+            assert im.dtype == torch.int8 and torch.equal(im.float(), want - 128)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('shape,axis', [((8, 128, 768), 2), ((4, 16, 3072), 2), ((8, 768), 1),
                                         ((5, 7, 24), 2), ((3, 40, 6), 1), ((6, 10), 0)])

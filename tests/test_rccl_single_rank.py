@@ -145,8 +145,15 @@ def test_bench_gpus_2_spawns_two_ranks_with_real_kernels():
     env = dict(os.environ, TQ_BENCH_SAME_DEVICE='1', TQ_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu', '--batch', '64',
-                        '--seq', '128'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu', '--batch', '64', '--seq', '128']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        # Seen once in ~10 full-suite runs on the GPU pool and never in isolation (round 6); the two ranks rendezvous over
+        # a port probed a moment earlier by bench.py's launcher.  Keep the evidence, try once more.
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'bench_gpus2_first_attempt.txt'), 'w') as f:
+            f.write(f'rc {r.returncode}\n--- stdout\n{r.stdout[-8000:]}\n--- stderr\n{r.stderr[-16000:]}\n')
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1

@@ -21,6 +21,9 @@ namespace tq {
 
 template <int N, typename T> struct alignas(N * sizeof(T)) PackN { T e[N]; };
 
+// (Round 6, measured and not kept -- profiles/r06/idx_pack_ab.txt: one v_cvt_pk_u8_f32 per element instead of convert + mask +
+// shift/or for byte grids: bit-identical and 2 of ~10 instructions per element fewer, no change in any launch time --
+// the index-only bf16 -> u8 launch (63-68 % of HBM) is not instruction-bound.)
 template <int V>
 __device__ __forceinline__ void store_idx(void* idx, int idx_dtype, uint64_t off, const float (&xi)[V]) {
   switch (idx_dtype) {  // wave-uniform
@@ -343,19 +346,26 @@ __global__ __launch_bounds__(kBlock) void fq_axis(const u32x4* __restrict__ x, u
 }
 
 // Register-resident variant: the block size is chosen as a multiple of the vectors per row, so a lane
-// owns ONE vector column for its whole life and keeps that column's (scale, zp) in registers: no LDS,
-// no barrier, no column arithmetic in the loop.  Tile = blockDim.x * U consecutive vectors.
+// owns ONE vector column for its whole life and keeps that column's parameters in registers: no LDS,
+// no barrier, no column arithmetic in the loop.  Tile = blockDim.x * U consecutive vectors; a block takes `tpb`
+// consecutive tiles (round 6: it took one, so the V parameter derivations per lane -- an IEEE division each -- cost as
+// much as the quantization of its U vectors; and the element math is now the exact branch-free form of tq_device.h with
+// per-column constants: med3 against the column's dequantised grid ends, Markstein quotient on register pairs, instead
+// of the guarded reciprocal with its data-dependent branch per element).
 template <int DT, bool HAS_IDX, bool NT, int U, int MAXB>
 __global__ __launch_bounds__(MAXB) void fq_axis_reg(const u32x4* __restrict__ x, u32x4* __restrict__ y,
-                                                    void* __restrict__ idx, int idx_dtype, uint64_t n, tq_quantizer q) {
+                                                    void* __restrict__ idx, int idx_dtype, uint64_t n, tq_quantizer q,
+                                                    uint32_t tpb) {
   constexpr int V = Store<DT>::kVec;
+  constexpr int H = V / 2;
   const uint32_t bs = blockDim.x;
   const uint64_t tile_vecs = (uint64_t)bs * U;
   const uint64_t n_vec = n / V;
   const uint32_t vpr = (uint32_t)q.n_params / V;
   const uint64_t n_tiles = (n_vec + tile_vecs - 1) / tile_vecs;
-  uint64_t tile = blockIdx.x;
+  uint64_t tile = (uint64_t)blockIdx.x * tpb;
   if (tile >= n_tiles) return;
+  const uint64_t tile_end = tile + tpb < n_tiles ? tile + tpb : n_tiles;
 
   u32x4 v[U];
   auto load_tile = [&](uint64_t t) {
@@ -390,12 +400,17 @@ __global__ __launch_bounds__(MAXB) void fq_axis_reg(const u32x4* __restrict__ x,
   }
   const QP p0 = make_qp(q, 0);                        // int_min / int_max do not depend on the column
   const float lo = p0.lo, hi = p0.hi;
-  float rc[V];
+  float rc[V], ylo[V], yhi[V];
+  bool ok = true;                                   // every column admits the exact branch-free form (QF::ok)
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     sc[j] = q.log_domain ? expf(sc[j]) : (sc[j] < q.eps ? q.eps : sc[j]);              // quantizers.py:142-147
     zp[j] = q.symmetric ? 0.0f : clamp_nanprop(rintf(zp[j]), lo, hi);                  // :149-153, :330-332
     rc[j] = guarded_rcp(sc[j]);
+    const float klo = lo - zp[j], khi = hi - zp[j];
+    ylo[j] = sc[j] * klo;
+    yhi[j] = sc[j] * khi;
+    ok = ok && (rc[j] == rc[j]) && fabsf(klo) < 4194304.0f && fabsf(khi) < 4194304.0f;
   }
   for (;;) {
     const uint64_t i0 = tile * tile_vecs + threadIdx.x;
@@ -405,20 +420,44 @@ __global__ __launch_bounds__(MAXB) void fq_axis_reg(const u32x4* __restrict__ x,
       const uint64_t k = i0 + (uint64_t)u * bs;
       float g[V], f[V];
       Store<DT>::unpack(v[u], g);
+      if (ok) {
+        f32x2 xc[H], q0[H], e[H];
 #pragma unroll
-      for (int j = 0; j < V; ++j) f[j] = clamp_nanprop(rne_quot1(g[j], sc[j], rc[j]) + zp[j], lo, hi);
+        for (int j = 0; j < H; ++j) {
+          xc[j].x = __builtin_amdgcn_fmed3f(g[2 * j], ylo[2 * j], yhi[2 * j]);
+          xc[j].y = __builtin_amdgcn_fmed3f(g[2 * j + 1], ylo[2 * j + 1], yhi[2 * j + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < H; ++j) q0[j] = xc[j] * f32x2{rc[2 * j], rc[2 * j + 1]};
+#pragma unroll
+        for (int j = 0; j < H; ++j) e[j] = __builtin_elementwise_fma(q0[j], f32x2{-sc[2 * j], -sc[2 * j + 1]}, xc[j]);
+#pragma unroll
+        for (int j = 0; j < H; ++j) q0[j] = __builtin_elementwise_fma(e[j], f32x2{rc[2 * j], rc[2 * j + 1]}, q0[j]);
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+          const f32x2 xi = f32x2{rintf(q0[j].x), rintf(q0[j].y)} + f32x2{zp[2 * j], zp[2 * j + 1]};
+          f[2 * j] = (g[2 * j] != g[2 * j]) ? g[2 * j] : xi.x;                        // torch.clamp keeps NaN; v_med3 does not
+          f[2 * j + 1] = (g[2 * j + 1] != g[2 * j + 1]) ? g[2 * j + 1] : xi.y;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) f[j] = clamp_nanprop(rne_quot1(g[j], sc[j], rc[j]) + zp[j], lo, hi);
+      }
       if (full || k < n_vec) {
         if (HAS_IDX) store_idx<V>(idx, idx_dtype, k * V, f);
         if (y) {
 #pragma unroll
-          for (int j = 0; j < V; ++j) f[j] = sc[j] * (f[j] - zp[j]);
+          for (int j = 0; j < H; ++j) {
+            const f32x2 yv = f32x2{sc[2 * j], sc[2 * j + 1]} * (f32x2{f[2 * j], f[2 * j + 1]} - f32x2{zp[2 * j], zp[2 * j + 1]});
+            f[2 * j] = yv.x;
+            f[2 * j + 1] = yv.y;
+          }
           const u32x4 o = Store<DT>::pack(f);
           if (NT) st_stream(y + k, o); else y[k] = o;
         }
       }
     }
-    tile += gridDim.x;
-    if (tile >= n_tiles) break;
+    if (++tile >= tile_end) break;
     load_tile(tile);
   }
 }
@@ -727,20 +766,33 @@ static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t 
   const bool lds_ok = vec_ok && q.n_params > 1 && q.inner == 1 && q.n_params % V == 0 && q.n_params <= 5440;
   const bool reg_ok = vec_ok && q.n_params > 1 && q.inner == 1 && q.n_params % V == 0 && q.n_params / V <= 1024 &&
                       aligned16(q.delta) && (q.symmetric || aligned16(q.zero_float));
-  const bool prefer_reg = axis_reg == 1 || (axis_reg == 2 && DT == TQ_F32 && q.n_params / V <= 256);
+  // Round 6 (profiles/r06/axis_wide_ab.txt, axis_reg_tpb.txt; one box each): with several tiles per block and the packed
+  // exact element math the register kernel is ahead for fp32 at every width (d = 768: 76 % against 69 % of HBM at
+  // [1024,512,768]; d = 3072: 75 % against 65 %, and 9 us against 20 us at [8,128,3072]) and for 16-bit tensors with an
+  // output on wide rows or large launches (d = 768: 77 % against 73 %; d = 3072: 68 % against 60 %); the LDS table stays
+  // for 16-bit launches of a few MB on rows of <= 1024 columns and for 16-bit index-only output.
+  const bool prefer_reg = axis_reg == 1 || (axis_reg == 2 && (DT == TQ_F32 || (y != nullptr && (q.n_params >= 2048 || big))));
   if (reg_ok && (prefer_reg || !lds_ok)) {
     const uint32_t vpr = (uint32_t)(q.n_params / V);
     const uint32_t bs = vpr <= kBlock ? vpr * (kBlock / vpr) : vpr;
+    static const int reg_tpb = tuning("TQ_AXIS_REG_TPB", 0);
 #define TQ_LAUNCH_AXIS_REG(NTV, UV, MB)                                                                    \
-    hipLaunchKernelGGL((fq_axis_reg<DT, HAS_IDX, NTV, UV, MB>),                                             \
-                       dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n_vec_all, (uint64_t)bs * UV), 1), kMaxTiles)), \
-                       dim3(bs), 0, st, xv, yv, idx, idx_dtype, n, q)
+    {                                                                                                      \
+      const uint64_t n_tiles = std::max<uint64_t>(ceil_div(n_vec_all, (uint64_t)bs * UV), 1);               \
+      /* consecutive tiles per block: U x tpb vectors per lane pay for its V parameter derivations -- 16 for 16-bit  \
+         storage (V = 8), 4 for fp32, twice that without an output; more than that costs locality (the resident blocks  \
+         then sweep a window tpb times larger: fp32 [1024,512,768] 76 % with one tile, 66 % with eight) */  \
+      const uint64_t rule = (uint64_t)(DT == TQ_F32 ? 4 : 16) / UV * (y != nullptr ? 1 : 2);                  \
+      const uint32_t tpb = reg_tpb > 0 ? (uint32_t)reg_tpb : (uint32_t)std::max<uint64_t>(std::min<uint64_t>(rule, n_tiles / 2048), 1); \
+      hipLaunchKernelGGL((fq_axis_reg<DT, HAS_IDX, NTV, UV, MB>), dim3((unsigned)ceil_div(n_tiles, tpb)),   \
+                         dim3(bs), 0, st, xv, yv, idx, idx_dtype, n, q, tpb);                               \
+    }
     if (bs <= kBlock) {
-      if (big) { if (nt) TQ_LAUNCH_AXIS_REG(true, 4, kBlock); else TQ_LAUNCH_AXIS_REG(false, 4, kBlock); }
-      else     { if (nt) TQ_LAUNCH_AXIS_REG(true, 1, kBlock); else TQ_LAUNCH_AXIS_REG(false, 1, kBlock); }
+      if (big) { if (nt) TQ_LAUNCH_AXIS_REG(true, 4, kBlock) else TQ_LAUNCH_AXIS_REG(false, 4, kBlock) }
+      else     { if (nt) TQ_LAUNCH_AXIS_REG(true, 1, kBlock) else TQ_LAUNCH_AXIS_REG(false, 1, kBlock) }
     } else {
-      if (big) { if (nt) TQ_LAUNCH_AXIS_REG(true, 2, 1024); else TQ_LAUNCH_AXIS_REG(false, 2, 1024); }
-      else     { if (nt) TQ_LAUNCH_AXIS_REG(true, 1, 1024); else TQ_LAUNCH_AXIS_REG(false, 1, 1024); }
+      if (big) { if (nt) TQ_LAUNCH_AXIS_REG(true, 2, 1024) else TQ_LAUNCH_AXIS_REG(false, 2, 1024) }
+      else     { if (nt) TQ_LAUNCH_AXIS_REG(true, 1, 1024) else TQ_LAUNCH_AXIS_REG(false, 1, 1024) }
     }
 #undef TQ_LAUNCH_AXIS_REG
     return check_launch("fq_axis_reg");
