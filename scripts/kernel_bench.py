@@ -95,7 +95,7 @@ def fam_fq():
         del gy
         # per-token ranges (`--per-token`: axis = 1, reference main.py:359-376): one (scale, zero-point) per token position
         dT, zT = torch.full((S,), 0.03, device=dev), torch.full((S,), 128.0, device=dev)
-        run('fq', f'K2r fq_rows_wave per-token {name} [1024,512,768]', 'fq_rows_wave', lambda: be.fake_quant(
+        run('fq', f'K2r fq_rows_tab per-token {name} [1024,512,768]', 'fq_rows_tab', lambda: be.fake_quant(
             x, dT, zT, None, 8, False, False, 1e-8, S, D), 2 * es * n, 'hbm', note=f'dtype code {code}')
         run('stats', f'K4r mm_rows_wave per-token {name}', 'mm_rows_wave', lambda: be.minmax(x, S, D), es * n, 'hbm')
         # dynamic per-token step (`--dynamic --per-token`): statistics -> estimator -> parameters -> quantize, every call;
@@ -103,7 +103,7 @@ def fam_fq():
         # parameter-sized launches between them (mm_final, calib_update_k) show in the HIP-event column
         run('dyn', f'dynamic per-token estimate+quantize {name} [1024,512,768]', None, lambda: be.calibrate_minmax(
             x, S, D, _hip.EST_CURRENT, None, None, 0.9, 0, None, 8, False, 1e-8, False), 3 * es * n, 'hbm',
-            patterns=['mm_rows_wave', 'fq_rows_wave'], note='tq_calibrate_minmax: 4 launches')
+            patterns=['mm_rows_wave', 'fq_rows_tab'], note='tq_calibrate_minmax: 4 launches')
         run('dyn', f'dynamic per-tensor estimate+quantize {name} [1024,512,768]', None, lambda: be.calibrate_minmax(
             x, 1, 1, _hip.EST_CURRENT, None, None, 0.9, 0, None, 8, False, 1e-8, False), 3 * es * n, 'hbm',
             patterns=[f'mm_rows<{code}', f'fq_tensor<{code}, false, true'],

@@ -341,7 +341,9 @@ extern "C" int tq_adaround_fwd(const float* w, const float* alpha, float* w_q, u
   if (n == 0) return TQ_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool v4 = ada_vec4(n, q, {w, alpha, w_q});
-  const unsigned grid = ew_grid(v4 ? n / 4 : n);
+  // one-shot tiles like the step kernel (a 2048-block grid-stride loop left [3072,768] = 2304 tiles with a second round
+  // for 256 blocks)
+  const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(v4 ? n / 4 : n, kBlock), 1), 1u << 30);
 #define TQ_ADA_FWD(M)                                                                                                  \
   do {                                                                                                                 \
     if (v4 && soft) hipLaunchKernelGGL((ada_fwd_k<4, M, true>), dim3(grid), dim3(kBlock), 0, st, w, alpha, w_q, n, *q, temperature);       \
