@@ -18,14 +18,16 @@ def timeit(fn, reps=30):
     return s.elapsed_time(e) / reps * 1e3
 
 
-for shape in ((1024, 512, 768), (64, 128, 3072), (8, 128, 768)):
+K1 = len(sys.argv) > 1 and sys.argv[1] == 'k1'          # only the headline shape, with the plain fake-quant row
+for shape in ((1024, 512, 768),) if K1 else ((1024, 512, 768), (64, 128, 3072), (8, 128, 768)):
     D = shape[-1]
     for dt, es in ((torch.bfloat16, 2), (torch.float32, 4)):
         x = torch.randn(*shape, device=dev).to(dt)
         n = x.numel()
         d1, z1 = torch.tensor(0.03, device=dev), torch.tensor(128.0, device=dev)
         dv, zv = torch.full((D,), 0.03, device=dev), torch.full((D,), 128.0, device=dev)
-        rows = (('per-tensor index-only u8', lambda: be.fake_quant(x, d1, z1, None, 8, False, False, 1e-8, 1, 1, want_y=False, idx_dtype=torch.uint8), es + 1),
+        rows = (('per-tensor y (K1)', lambda: be.fake_quant(x, d1, z1, None, 8, False, False, 1e-8, 1, 1), 2 * es),
+                ('per-tensor index-only u8', lambda: be.fake_quant(x, d1, z1, None, 8, False, False, 1e-8, 1, 1, want_y=False, idx_dtype=torch.uint8), es + 1),
                 ('per-tensor y + int8(idx-128)', lambda: be.fake_quant_int8(x, d1, z1, 8, 1e-8), 2 * es + 1),
                 ('per-embedding index-only u8', lambda: be.fake_quant(x, dv, zv, None, 8, False, False, 1e-8, D, 1, want_y=False, idx_dtype=torch.uint8), es + 1))
         for name, fn, bpe in rows:

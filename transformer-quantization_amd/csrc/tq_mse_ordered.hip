@@ -169,10 +169,11 @@ __global__ __launch_bounds__(kBlock) void mse_ord_unit_k(const void* __restrict_
     const uint32_t n = (uint32_t)min((uint64_t)16, t1 - t);
     float xs[16];
     // padding with zeros is exact: 0 quantizes to 0 for every candidate, and s + 0 = s
-    // (round 6: written as `j < n ? load : 0` alone, each of the 16 loads sits in its own exec-mask branch -- ~80 of the ~260
-    // instructions of a two-candidate chunk; a full chunk in both half-waves is the usual case;
-    // a uniform-length variant for the short last chunk of 768-element rows changed nothing: [8,128,768] x 100 candidates 40.0 -> 37.0 us, [256,512,768] x 100 1.97 -> 1.89 ms on one box,
-    // profiles/r06/mse_uncond_ab.txt)
+    // (round 6: written as `j < n ? load : 0` alone, each of the 16 loads sits in its own exec-mask branch -- ~80 of the
+    // ~260 instructions of a two-candidate chunk.  A full chunk in both half-waves is the usual case and loads
+    // unconditionally: [8,128,768] x 100 candidates 40.0 -> 37.0 us, [256,512,768] x 100 1.97 -> 1.89 ms on one box,
+    // profiles/r06/mse_uncond_ab.txt; a uniform-length variant for the short last chunk of 768-element rows changed
+    // nothing, and requesting the next chunk before this one's arithmetic was slower: mse_prefetch_ab.txt.)
     if (__builtin_amdgcn_ballot_w64(n != 16) == 0) {      // a full chunk in both half-waves
 #pragma unroll
       for (int j = 0; j < 16; ++j) xs[j] = view((t + j) * 32 + col);
