@@ -119,13 +119,18 @@ __device__ __forceinline__ u32x4 fq_vec(const u32x4& in, const QP& p, void* idx,
 // when the tensor has more than kMaxTiles tiles.
 constexpr unsigned kMaxTiles = 1u << 20;
 
-template <int DT, bool HAS_IDX, bool NT, int U, bool FAST>
+// TPB consecutive tiles per block: 1 everywhere except 16-bit index-only output (2 B in, 1 B out per element), the one
+// layout that gains from two (one box, profiles/r06/fq_tpb_ab.txt: 65.9 -> 69.4 % of HBM; the headline bf16 -> bf16
+// launch loses: 76.9 -> 75.1 -> 71.0 % with 1 / 2 / 4).
+template <int DT, bool HAS_IDX, bool NT, int U, bool FAST, int TPB = 1>
 __device__ __forceinline__ void fq_tensor_tiles(const u32x4* __restrict__ x, u32x4* __restrict__ y,
                                                 void* __restrict__ idx, int idx_dtype, uint64_t n_vec, const QP& p,
                                                 const QF& qf) {
   constexpr int V = Store<DT>::kVec;
   constexpr uint64_t TILE = (uint64_t)kBlock * U;
-  for (uint64_t t0 = (uint64_t)blockIdx.x * TILE; t0 < n_vec; t0 += (uint64_t)gridDim.x * TILE) {
+  for (uint64_t tb = (uint64_t)blockIdx.x * (TILE * TPB); tb < n_vec; tb += (uint64_t)gridDim.x * (TILE * TPB))
+#pragma unroll 1
+  for (uint64_t t0 = tb; t0 < tb + TILE * TPB && t0 < n_vec; t0 += TILE) {
     const uint64_t i = t0 + threadIdx.x;
     if (t0 + TILE <= n_vec) {
       u32x4 v[U];
@@ -149,7 +154,7 @@ __device__ __forceinline__ void fq_tensor_tiles(const u32x4* __restrict__ x, u32
   }
 }
 
-template <int DT, bool HAS_IDX, bool NT, int U>
+template <int DT, bool HAS_IDX, bool NT, int U, int TPB = 1>
 __global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x, u32x4* __restrict__ y,
                                                     void* __restrict__ idx, int idx_dtype, uint64_t n,
                                                     tq_quantizer q) {
@@ -157,8 +162,8 @@ __global__ __launch_bounds__(kBlock) void fq_tensor(const u32x4* __restrict__ x,
   const QP p = make_qp(q, 0);
   const QF qf = make_qf(p);
   const uint64_t n_vec = n / V;
-  if (qf.ok) fq_tensor_tiles<DT, HAS_IDX, NT, U, true>(x, y, idx, idx_dtype, n_vec, p, qf);
-  else fq_tensor_tiles<DT, HAS_IDX, NT, U, false>(x, y, idx, idx_dtype, n_vec, p, qf);
+  if (qf.ok) fq_tensor_tiles<DT, HAS_IDX, NT, U, true, TPB>(x, y, idx, idx_dtype, n_vec, p, qf);
+  else fq_tensor_tiles<DT, HAS_IDX, NT, U, false, TPB>(x, y, idx, idx_dtype, n_vec, p, qf);
   // ragged tail (< V elements)
   const uint64_t tail0 = n_vec * V;
   if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
@@ -755,6 +760,12 @@ static int launch_fq(const void* x, void* y, void* idx, int idx_dtype, uint64_t 
     hipLaunchKernelGGL((fq_tensor<DT, HAS_IDX, NTV, UV>),                                                   \
                        dim3((unsigned)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n_vec_all, kBlock * UV), 1), kMaxTiles)), \
                        dim3(kBlock), 0, st, xv, yv, idx, idx_dtype, n, q)
+    if (HAS_IDX && DT != TQ_F32 && y == nullptr && big && nt) {     // 16-bit index-only at size: two tiles per block
+      hipLaunchKernelGGL((fq_tensor<DT, HAS_IDX, true, 4, HAS_IDX ? 2 : 1>),
+                         dim3((unsigned)std::min<uint64_t>(ceil_div(n_vec_all, kBlock * 4 * 2), kMaxTiles)), dim3(kBlock), 0, st, xv, yv,
+                         idx, idx_dtype, n, q);
+      return check_launch("fq_tensor");
+    }
     if (big) { if (nt) TQ_LAUNCH_TENSOR(true, 4); else TQ_LAUNCH_TENSOR(false, 4); }
     else     { if (nt) TQ_LAUNCH_TENSOR(true, 1); else TQ_LAUNCH_TENSOR(false, 1); }
 #undef TQ_LAUNCH_TENSOR
