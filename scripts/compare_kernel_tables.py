@@ -12,7 +12,8 @@ THRESH = 0.08      # boxes differ by +-5 %
 
 
 def load(path):
-    return {r['label']: r for r in json.load(open(path))}
+    # (round 6 renamed the per-token row with its kernel: fq_rows_wave -> fq_rows_tab)
+    return {r['label'].replace('fq_rows_wave', 'fq_rows_tab'): r for r in json.load(open(path))}
 
 
 def main():
