@@ -114,6 +114,7 @@ def test_per_token_and_dynamic_gpu_equals_reference(fused):
     ((3072, 768), 0),                               # per-channel weight layout (outer = 1)
     ((4, 6, 4104), 1),                              # rows longer than the wave kernels take: the block-per-row kernels
     ((131, 500, 136), 1),                           # 17 / 34 vectors per row: the flat U-row batches with ragged last iteration
+    ((19, 33, 1000), 1),                            # 125 / 250 vectors per row: the statistics walk 4 rows as one index space
 ])
 @pytest.mark.parametrize('rows_flat', [None, '2', '3'], ids=['by-size', 'flat-per-lane', 'flat-table'])
 def test_row_parameter_launch_shapes_vs_oracle(dtype, shape, axis, rows_flat, monkeypatch):

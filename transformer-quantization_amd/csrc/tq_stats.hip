@@ -158,6 +158,40 @@ __global__ __launch_bounds__(kBlock) void mm_rows_wave(const u32x4* __restrict__
   const u32x4* base = x + (uint64_t)p * vpr;
   MinMax acc;
   uint64_t o = s;
+  // Rows that are not a whole number of wave widths (d = 768 in 16-bit storage: 96 vectors, the second pass over a row had
+  // 32 of 64 lanes loading: 75 % of HBM against 86 % for fp32's 192 vectors): the U rows of a batch as ONE index space of
+  // U * vpr vectors -- 6 full passes instead of 8 half-empty ones.  A lane steps its (row, offset) pair by the wave width:
+  // at most one row boundary per step since vpr > 64; no division.  (Round 5 tried the same for the fake-quant kernel and
+  // found it slower; for the statistics, which do a quarter of the arithmetic per vector, it pays -- profiles/r06/mm_flat_ab.txt.)
+  if (vpr > kWave && vpr % kWave != 0) {
+    const uint64_t rs = (uint64_t)S * row_stride;                     // vectors between two rows of a batch
+    const uint32_t total = U * vpr;
+    for (; o + (uint64_t)(U - 1) * S < outer; o += (uint64_t)U * S) {
+      uint32_t i = lane;
+      uint64_t at = o * row_stride + lane;
+      for (uint32_t g0 = 0; g0 < total; g0 += U * kWave) {
+        u32x4 v[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          ok[u] = g0 + (uint32_t)u * kWave + lane < total;
+          if (ok[u]) v[u] = ld_stream(base + at);
+          i += kWave;
+          at += kWave;
+          if (i >= vpr) { i -= vpr; at += rs - vpr; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (ok[u]) {
+            float f[V];
+            Store<DT>::unpack(v[u], f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc.add(f[j]);
+          }
+        }
+      }
+    }
+  }
   for (; o + (uint64_t)(U - 1) * S < outer; o += (uint64_t)U * S) {
     for (uint32_t i = lane; i < vpr; i += kWave) {
       u32x4 v[U];
