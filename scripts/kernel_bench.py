@@ -85,6 +85,11 @@ def fam_fq():
             x, delta, zf, None, 8, False, False, 1e-8, 1, 1), 2 * es * n, 'hbm')
         run('fq', f'K2 fq_axis per-embedding {name} [1024,512,768]', f'fq_axis', lambda: be.fake_quant(
             x, dv, zv, None, 8, False, False, 1e-8, D, 1), 2 * es * n, 'hbm', note=f'dtype code {code}')
+        # the [B, T, 3072] feed-forward activations of config 2 (per-embedding ranges on wide rows)
+        xw = x.view(B, S // 4, 4 * D)
+        dw, zw = torch.full((4 * D,), 0.03, device=dev), torch.full((4 * D,), 128.0, device=dev)
+        run('fq', f'K2w fq_axis per-embedding {name} [1024,128,3072]', f'fq_axis', lambda: be.fake_quant(
+            xw, dw, zw, None, 8, False, False, 1e-8, 4 * D, 1), 2 * es * n, 'hbm', note=f'dtype code {code}')
         run('fq', f'K3 index-only u8 {name}', f'fq_tensor<{code}, true', lambda: be.fake_quant(
             x, delta, zf, None, 8, False, False, 1e-8, 1, 1, want_y=False, idx_dtype=torch.uint8), (es + 1) * n, 'hbm')
         gy = torch.randn(B, S, D, device=dev).to(dt)
