@@ -459,7 +459,9 @@ static int launch_res_ln(const void* a, const void* r, void* y, int8_t* y_idx, u
 // with a NaN sum are patched after the last quantizer.
 __device__ __forceinline__ bool softmax_fast_ok(const tq_quantizer& q1, const tq_quantizer& q2, int on1, int on2, float denom) {
   if (!on1 || !on2) return false;
-  const QP p1 = make_qp(q1, 0), p2 = make_qp(q2, 0);
+  // (make_qp's select form in the softmax chain: with the branch form of round 6 the [256,12,128,128] launch went from 75 to
+  // 82-86 us in the kernel table; 86 -> 80 us on one box with the select, profiles/r06/softmax_select_ab.txt)
+  const QP p1 = make_qp<true>(q1, 0), p2 = make_qp<true>(q2, 0);
   const float ad = fabsf(denom);
   return make_qf(p1).ok && make_qf(p2).ok && p1.scale >= 0x1p-60f && p1.scale <= 0x1p60f && p2.scale >= 0x1p-60f &&
          p2.scale <= 0x1p60f && ad >= 0x1p-20f && ad <= 0x1p20f;
@@ -472,7 +474,7 @@ __device__ __forceinline__ void softmax_fast_body(const f32x4* __restrict__ s, f
   constexpr int RPB = kBlock / LPR;
   constexpr uint32_t T4 = LPR * NV;
   constexpr int P = NV * 2;                      // pairs per lane and row
-  const QF f1 = make_qf(make_qp(q1, 0)), f2 = make_qf(make_qp(q2, 0));
+  const QF f1 = make_qf(make_qp<true>(q1, 0)), f2 = make_qf(make_qp<true>(q2, 0));
   const float rdv = 1.0f / denom;
   const f32x2 rd = {rdv, rdv}, nd = {-denom, -denom};
   const int lane = threadIdx.x % LPR, sub = threadIdx.x / LPR;
