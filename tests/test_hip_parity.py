@@ -856,6 +856,46 @@ def test_percentile_per_tensor_on_gpu_equals_numpy(q):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('rows', [400, 1100, 2600], ids=['400-partials', '1100-partials', '2600-partials'])
+def test_fused_calibration_step_at_sizes_across_its_launch_forms(rows, dtype):
+    """tq_calibrate_tensor picks its launch form by the number of block partials of the statistics pass: the ticket kernel /
+    two ticket-free launches up to 512, two ticket-free launches up to 2048 (round 6: sites of [128,128]-token calibrating
+    forwards), four launches beyond.  Three running-min/max batches (fresh and in-place state) against the separate calls
+    tq_minmax -> tq_range_update -> tq_set_range_asym -> tq_fake_quant_fwd: state, parameters and y bit-equal."""
+    from quantization import _hip
+    be = _hip.backend()
+    per_block = 256 * (4 if dtype == torch.float32 else 8) * 8
+    n = rows * per_block - 3 * (4 if dtype == torch.float32 else 8)
+    g = torch.Generator().manual_seed(rows)
+    xs = [(torch.randn(n, generator=g) * (1.0 + 0.5 * i)).to(dtype).to(DEV) for i in range(3)]
+    xs[2][n // 2] = 40.0
+    lo = hi = None
+    state = None
+    inplace = None
+    for i, x in enumerate(xs):
+        mn, mx = be.minmax(x, 1, 1)
+        if lo is None:
+            lo, hi = mn.clone(), mx.clone()
+        else:
+            lo, hi = be.range_update(_hip.EST_RUNNING, mn, mx, lo, hi, 0.9)
+        d, z = be.set_range_asym(lo, hi, 8, 1e-8, False)
+        y_ref, _ = be.fake_quant(x, d, z, None, 8, False, False, 1e-8, 1, 1)
+        r = be.calibrate_minmax(x, 1, 1, _hip.EST_RUNNING, None if state is None else state[0], None if state is None else state[1],
+                                0.9, 0, None, 8, False, 1e-8, False)
+        state = (r[0], r[1])
+        if inplace is None:
+            inplace = tuple(None if v is None else v.clone() for v in r[:5])
+            ri = r
+        else:
+            ri = be.calibrate_minmax(x, 1, 1, _hip.EST_RUNNING, inplace[0], inplace[1], 0.9, 0, None, 8, False, 1e-8, False, out=inplace)
+        for got in (r, ri):
+            assert torch.equal(got[0].reshape(()), lo.reshape(())) and torch.equal(got[1].reshape(()), hi.reshape(())), (rows, i)
+            assert torch.equal(got[2].reshape(()), d.reshape(())) and torch.equal(got[3].reshape(()), z.reshape(())), (rows, i)
+            assert torch.equal(got[5].view(torch.int16 if got[5].element_size() == 2 else torch.int32),
+                               y_ref.view(torch.int16 if y_ref.element_size() == 2 else torch.int32)), (rows, i)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
 @pytest.mark.parametrize('symmetric', [False, True], ids=['asym', 'sym'])
 @pytest.mark.parametrize('mode', [0, 1, 2], ids=['current', 'all', 'running'])
 def test_split_calibration_step_equals_the_single_gpu_step(mode, symmetric, dtype):

@@ -761,6 +761,7 @@ extern "C" int tq_calibrate_minmax(const void* x, uint64_t n, int dtype, uint64_
 }
 
 constexpr unsigned kTicketMaxBlocks = 512;
+constexpr unsigned kTicketFreeMaxBlocks = 2048;   // (TQ_CALIB_FREE_MAX overrides: A/B)   // partial pairs every quantizer block folds itself
 
 // Statistics half of the ticket-free single-GPU step: per-block (min, max) -> ws[2 b], ws[2 b + 1]; block 0 also copies
 // the previous estimator state behind the partials (ws[2 gridDim.x], ws[2 gridDim.x + 1]) so that the quantizer launch
@@ -837,17 +838,23 @@ extern "C" int tq_calibrate_tensor(const void* x, uint64_t n, int dtype, int mod
   // other) before it takes its ticket: ~3.5 us x blocks / resident blocks.  Worth it while launches dominate
   // (small tensors); a [1024,512,768] tensor has 16384 blocks and ran 930 us against 125 us for the separate
   // statistics + finalize + update launches, so large tensors take that path.
-  if (pl.gx > kTicketMaxBlocks)
-    return tq_calibrate_minmax(x, n, dtype, 1, 1, mode, prev_min, prev_max, cur_min, cur_max, momentum, 0, nullptr, n_bits,
-                               symmetric, eps, log_domain, delta, zero_float, signed_flag, y, workspace, workspace_bytes, stream);
-  TQ_REQUIRE(workspace && workspace_bytes >= (size_t)pl.gx * 2 * sizeof(float), "tq_calibrate_tensor: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
   const bool vec = aligned16(x);
   // ticket-free form when the quantized tensor is wanted too (the usual calibrating forward): block partials + copy of
-  // the previous state in launch 1, fold + update + parameters + quantize in launch 2 (fq_tensor_calib)
+  // the previous state in launch 1, fold + update + parameters + quantize in launch 2 (fq_tensor_calib).  Every block of
+  // launch 2 folds all partial pairs itself (8 bytes each, from L2): taken up to kTicketFreeMaxBlocks partials (round 6:
+  // was 512, so that a [16384,768] site of a [128,128] calibrating forward ran statistics -> finalize -> update -> quantize
+  // as four launches, ~9.5 us of which are the two parameter-sized ones: 159 sites per BERT-base forward).
   static const int ticket_free = tuning("TQ_CALIB_TICKET_FREE", 1);
-  if (ticket_free && y != nullptr && vec && aligned16(y) && workspace_bytes >= ((size_t)pl.gx * 2 + 2) * sizeof(float)) {
+  static const unsigned free_max = (unsigned)tuning("TQ_CALIB_FREE_MAX", (int)kTicketFreeMaxBlocks);
+  const bool free_ok = ticket_free && y != nullptr && vec && aligned16(y) && pl.gx <= free_max && workspace &&
+                       workspace_bytes >= ((size_t)pl.gx * 2 + 2) * sizeof(float);
+  if (pl.gx > kTicketMaxBlocks && !free_ok)
+    return tq_calibrate_minmax(x, n, dtype, 1, 1, mode, prev_min, prev_max, cur_min, cur_max, momentum, 0, nullptr, n_bits,
+                               symmetric, eps, log_domain, delta, zero_float, signed_flag, y, workspace, workspace_bytes, stream);
+  TQ_REQUIRE(workspace && workspace_bytes >= (size_t)pl.gx * 2 * sizeof(float), "tq_calibrate_tensor: workspace too small");
+  if (free_ok) {
     switch (dtype) {
       case TQ_F32: hipLaunchKernelGGL((calib_partials_k<TQ_F32, true>), dim3(pl.gx), dim3(kBlock), 0, st, x, n, ws, prev_min, prev_max); break;
       case TQ_BF16: hipLaunchKernelGGL((calib_partials_k<TQ_BF16, true>), dim3(pl.gx), dim3(kBlock), 0, st, x, n, ws, prev_min, prev_max); break;
