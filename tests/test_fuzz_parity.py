@@ -32,8 +32,13 @@ def _case(rs):
     return layout, dtype, shape, axis, per_channel, sym, n_bits
 
 
+@pytest.mark.parametrize('rows_flat', [None, '3'], ids=['by-size', 'flat-row-kernels'])
 @pytest.mark.parametrize('seed', range(6))
-def test_fake_quant_fuzz(seed):
+def test_fake_quant_fuzz(seed, rows_flat, monkeypatch):
+    # TQ_ROWS_FLAT=3: the inner-axis / per-channel layouts take the flat-tile kernels that only large launches reach by size
+    # (fq_rows_tab; fq_rows_flat for rows of fewer than 4 vectors)
+    if rows_flat is not None:
+        monkeypatch.setenv('TQ_ROWS_FLAT', rows_flat)
     from quantization import _hip
     from quantization.quantizers import param_layout
     be = _hip.backend()
