@@ -7,7 +7,7 @@ if len(sys.argv) == 1:
         subprocess.check_call([sys.executable, __file__, 'run'], env=dict(os.environ, TQ_AXIS_REG=v))
     sys.exit(0)
 if sys.argv[1] == 'tpb':                     # register kernel, tiles per block
-    for t in ('1', '2', '4', '8'):
+    for t in ('4', '8', '16', '32'):
         print(f'== TQ_AXIS_REG=1 TQ_AXIS_REG_TPB={t}', flush=True)
         subprocess.check_call([sys.executable, __file__, 'run', 'big'], env=dict(os.environ, TQ_AXIS_REG='1', TQ_AXIS_REG_TPB=t))
     sys.exit(0)
