@@ -1317,8 +1317,16 @@ __global__ __launch_bounds__(kBlock) void rowsum_i8_k(const int8_t* __restrict__
 template <int YDT, bool WITH_TAIL>
 static int launch_linear_t(const LinArgs& a, hipStream_t st) {
   if (a.K % 128 == 0 && a.M % 64 == 0 && a.N % 64 == 0 && tuning("TQ_I8_LDS", 1)) {
-    // 128 x 128 block tiles once they still give >= 4 blocks per CU, else 64 x 64
-    const bool big = a.M % 128 == 0 && a.N % 128 == 0 && (uint64_t)(a.M / 128) * (a.N / 128) >= (uint64_t)tuning("TQ_I8_BIG_MIN", 1024);
+    // 128 x 128 block tiles from 384 tiles on (1.5 per CU), else 64 x 64.  Round 6 (profiles/r06/i8_tile_ab.txt, one box, the
+    // four Linear shapes of a BERT-base layer as graph replays): the threshold was 1024 tiles, which kept K = 3072 -> 768
+    // on 64 x 64 tiles up to 16384 tokens -- 71.5 us against 49.1 us (27 -> 40 % of the i8 peak: with a long K the
+    // epilogue is amortised and the larger tile halves the LDS traffic per MFMA); at 8192 tokens 34.3 -> 27.7 us and
+    // 768 -> 768 12.0 -> 11.0 us.  Below 384 tiles the small tiles win (4096 tokens, 768 -> 768: 7.2 against 8.9 us).
+    // Default-route BERT-base forward [64,128] 2.41 -> 2.28 ms, [128,128] 4.33 -> 4.07 ms; [32,128] 1.35 -> 1.37 ms.
+    // (K >= 512 for the lower threshold: measured on BERT's K = 768 / 3072 only; short-K shapes keep the old rule)
+    const uint64_t tiles128 = (uint64_t)(a.M / 128) * (a.N / 128);
+    const bool big = a.M % 128 == 0 && a.N % 128 == 0 &&
+                     (tiles128 >= 1024 || (a.K >= 512 && tiles128 >= (uint64_t)tuning("TQ_I8_BIG_MIN", 384)));
     const uint64_t grid = big ? (uint64_t)(a.M / 128) * (a.N / 128) : (uint64_t)(a.M / 64) * (a.N / 64);   // one block per tile
     // the staircase entries sit behind the per-column constants; dropped when they would cost a resident block
     // (160 KB per CU: 2 blocks of 128 x 128 tiles, 4 of 64 x 64)
