@@ -96,6 +96,44 @@ def test_linear_i8_vs_fp32_simulation(shape, cfg):
     assert torch.equal(yb, y.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize('shape', [(8192, 768, 768), (8192, 768, 3072), (4096, 3072, 768), (2048, 768, 1024)])
+def test_block_tile_sizes_are_bit_identical(shape):
+    """128 x 128 block tiles are taken from 384 tiles on for K >= 512 (round 6; 1024 tiles before): the shapes a BERT-base
+    layer runs at 4096 / 8192 tokens on both sides of that rule, forced onto either tile size (TQ_I8_BIG_MIN = 1 / huge) --
+    pre-quantizer fp32 output, quantized output and int8 indices equal bit for bit (the contraction is exact integer
+    arithmetic and the epilogue is the same per output), and the default choice equals them."""
+    from quantization import _hip
+    be = _hip.backend()
+    M, N, K = shape
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    x_i8 = torch.randint(-128, 128, (M, K), dtype=torch.int8, device='cuda', generator=g)
+    w_i8 = torch.randint(-127, 128, (N, K), dtype=torch.int8, device='cuda', generator=g)
+    rs = be.rowsum_i8(w_i8)
+    b = torch.randn(N, device='cuda', generator=g)
+    xq = (torch.tensor(0.02, device='cuda'), torch.tensor(117.0, device='cuda'), 8, 1e-8)
+    wd = torch.tensor([0.001], device='cuda')
+    q_out = (torch.tensor(0.05, device='cuda'), torch.tensor(100.0, device='cuda'), None, 8, False, False, 1e-8)
+
+    def run():
+        y0 = be.linear_i8(x_i8, w_i8, rs, b, xq, wd, 1e-8, _hip.ACT_NONE, None, torch.float32)
+        y1, i1 = be.linear_i8(x_i8, w_i8, rs, b, xq, wd, 1e-8, _hip.ACT_GELU, q_out, torch.float32, want_idx=True)
+        return y0, y1, i1
+    base = run()
+    outs = []
+    for big_min in ('1', '100000000'):
+        os.environ['TQ_I8_BIG_MIN'] = big_min
+        try:
+            outs.append(run())
+        finally:
+            del os.environ['TQ_I8_BIG_MIN']
+    for a, c, d in zip(base, *outs):
+        assert torch.equal(a, c) and torch.equal(a, d)
+    # a slab against the exact integer contraction (fp32 epsilon of the exact value)
+    acc = x_i8[:64].double() @ w_i8.double().t()
+    exact = (acc - (117.0 - 128.0) * w_i8.double().sum(1)) * (0.02 * 0.001) + b.double()
+    assert (base[0][:64].double() - exact).abs().max().item() <= 4e-7 * exact.abs().max().item() + 1e-7
+
+
 @pytest.mark.parametrize('shape', [(1024, 768, 768), (1024, 768, 3072), (64, 64, 256), (128, 192, 512), (256, 256, 1024),
                                    (64, 128, 1280), (128, 64, 2048), (1024, 1024, 1792), (64, 64, 16384)])
 @pytest.mark.parametrize('act', ['none', 'gelu'])
